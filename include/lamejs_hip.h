@@ -1,0 +1,110 @@
+/*
+ * lamejs_hip.h -- C ABI of the MI355X-native MP3 frame-encode path (liblamejs_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of zhuker/lamejs: everything that
+ * `Mp3Encoder.encodeBuffer()/flush()` does after parameter resolution.  The entry points are
+ * what the reference's JavaScript front end would bind through a thin N-API addon
+ * (lamejs_amd/js/addon/lhip_napi.c); plain pointers and sizes only.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   lhip_create   <- new Mp3Encoder(channels, samplerate, kbps)      src/js/index.js:66-111
+ *                    (lame_init + lame_init_params; the resolved tables arrive as one blob built by
+ *                     the host-side JavaScript lamejs_amd/js/tables.js with the host's own Math.*)
+ *   lhip_encode   <- Mp3Encoder.encodeBuffer(left, right)            src/js/index.js:117-130
+ *                    -> Lame.lame_encode_buffer                      src/js/Lame.js:1490-1514
+ *                    -> lame_encode_buffer_sample                    src/js/Lame.js:1527-1667
+ *                    -> Encoder.lame_encode_mp3_frame (hot path)     src/js/Encoder.js:388-659
+ *   lhip_flush    <- Mp3Encoder.flush() -> Lame.lame_encode_flush    src/js/index.js:132-135, Lame.js:1381-1488
+ *   lhip_destroy  <- (garbage collection of the encoder object)
+ *
+ * Semantics preserved: any chunking of the same sample stream yields the same bytes; a call
+ * returns the bytes of all whole frames completed by that call (possibly 0); errors are negative
+ * return codes mirroring the reference (-1 output buffer too small, -3 bad handle, -4 internal/device
+ * error).  A stream handle is not thread-safe (same as the reference); distinct handles are independent.
+ * The library never retains caller pointers past the call.
+ *
+ * There is NO CPU fallback: if no HIP device is usable every entry point fails with -4 and
+ * lhip_last_error() explains why.
+ */
+#ifndef LAMEJS_HIP_H
+#define LAMEJS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lhip_stream lhip_stream;
+
+typedef struct lhip_config {
+    int32_t channels;     /* 1 or 2 (as passed to Mp3Encoder) */
+    int32_t samplerate;   /* Hz */
+    int32_t kbps;         /* CBR bitrate */
+    int32_t device;       /* HIP device ordinal; -1 = current device */
+} lhip_config;
+
+#define LHIP_ERR_BUFFER_TOO_SMALL (-1)
+#define LHIP_ERR_BAD_HANDLE       (-3)
+#define LHIP_ERR_INTERNAL         (-4)
+
+/* number of usable HIP devices (0 if none / runtime unavailable) */
+int lhip_device_count(void);
+
+/* Create an encoder stream.  `tables` is the LHTB blob produced by lamejs_amd/js/tables.js for
+ * (channels, samplerate, kbps); it is validated against cfg, uploaded to HBM (shared between
+ * streams with identical blobs) and may be freed by the caller on return.  Returns 0 or <0. */
+int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes, lhip_stream** out);
+
+/* Append nsamples Int16 samples per channel (right may be NULL for mono) and write the bytes of
+ * every MP3 frame completed by them to out.  Returns bytes written (>= 0) or a negative code. */
+int64_t lhip_encode(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples,
+                    uint8_t* out, size_t out_cap);
+
+/* Pad with zeros until all buffered samples are emitted (reference flush rules); a second call
+ * returns 0. */
+int64_t lhip_flush(lhip_stream* s, uint8_t* out, size_t out_cap);
+
+void lhip_destroy(lhip_stream* s);
+
+/* Upper bound of the bytes lhip_encode can return for nsamples more samples on this stream. */
+size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples);
+
+/* Batch extension (BASELINE config 5: many independent streams, one launch): stream i receives
+ * nsamples[i] samples from left[i]/right[i] and its frames are written to out[i] (capacity
+ * out_cap[i]); written[i] receives the byte count or a negative code.  All streams must share one
+ * configuration (same tables blob) and device.  Returns 0 or the first negative code. */
+int lhip_encode_batch(lhip_stream* const* streams, size_t nstreams, const int16_t* const* left,
+                      const int16_t* const* right, const size_t* nsamples, uint8_t* const* out,
+                      const size_t* out_cap, int64_t* written);
+int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* const* out,
+                     const size_t* out_cap, int64_t* written);
+
+/* Device-resident variants: the pointers are HBM addresses on the stream's device (e.g. a
+ * torch tensor's data_ptr()); nothing crosses PCIe except a few hundred bytes of descriptors.
+ * Work is enqueued on the HIP stream set by lhip_set_hip_stream (default: the null stream) and the
+ * call returns after enqueueing unless `sync` is non-zero. */
+int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const int16_t* const* d_left,
+                             const int16_t* const* d_right, const size_t* nsamples, uint8_t* const* d_out,
+                             const size_t* out_cap, int64_t* written, int sync);
+
+/* Use this hipStream_t (passed as void*) for all work of streams on `device` (-1 = current). */
+int lhip_set_hip_stream(int device, void* hip_stream);
+
+/* Statistics of the most recent batch on the calling thread: frames encoded, frames that needed
+ * the bin-search seed repair pass, repair iterations. */
+void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations);
+
+/* Debug/test taps (tests only): copy intermediate results of the most recent batch to the host.
+ * what: 0 xr [granule][ch][576] f32, 1 blocktype [granule][ch] i32, 2 E [granule][ch][122] f32 (thresholds
+ * handed to the quantizer for that granule), 3 ath_adjust [frame] f64, 4 side records (struct GrSide).
+ * Returns bytes copied or <0. */
+int64_t lhip_debug_read(int what, void* dst, size_t cap);
+
+const char* lhip_last_error(void);
+const char* lhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,226 @@
+// Bitstream formatter kernel: one wave per frame builds the complete, byte-aligned MP3 frame
+// (header, side info, scalefactors, Huffman data, ancillary stuffing) in LDS and copies it out.
+// Follows reference BitStream.js: encodeSideInfo2 (259-426), writeMainData (600-689),
+// Huffmancode (487-552), huffman_coder_count1 (428-482), drain_into_ancillary (175-213).
+// With the reservoir disabled every frame is self-contained (main_data_begin == 0), so the frame
+// is: sideinfo_len bytes | main data of gr0ch0, gr0ch1, gr1ch0, gr1ch1 | stuffing to the frame size.
+// Variable-length codes are placed with an integer prefix sum over code lengths (order-free).
+#pragma once
+#include "lhip_defs.h"
+#include "lhip_wave.h"
+#include "lhip_layout.h"
+#include "k_quant.h"   // frame_bits_of / frame_padding
+
+namespace lhip {
+
+struct BitsLds { uint32_t w[272]; };
+
+// write the low n bits of val at bit position pos (MSB-first stream); n <= 32
+LHIP_DEV void put_bits(uint32_t* w, int pos, uint32_t val, int n) {
+    if (n <= 0) return;
+    if (n < 32) val &= (1u << n) - 1u;
+    const int wi = pos >> 5, off = pos & 31;
+    if (off + n <= 32) lds_or(&w[wi], val << (32 - off - n));
+    else {
+        const int n2 = off + n - 32;
+        lds_or(&w[wi], val >> n2);
+        lds_or(&w[wi + 1], val << (32 - n2));
+    }
+}
+
+// Huffman-code the pairs [start, end) with table `t` starting at bit `pos`; returns bits written
+LHIP_DEV int huff_region(const Tables& T, uint32_t* w, int pos, int t, int start, int end, const int16_t* q, int lane) {
+    if (t == 0 || start >= end) return 0;
+    const int32_t* hl = T.ht_hlen + T.ht_off[t];
+    const int32_t* hc = T.ht_code + T.ht_off[t];
+    const int linbits = T.ht_xlen[t];
+    int total_all = 0;
+    for (int base = start; base < end; base += 2 * LHIP_NL) {
+        const int i = base + 2 * lane;
+        int cbits = 0, xbits = 0;
+        uint32_t code = 0, ext = 0;
+        if (i < end) {
+            int v1 = q[i], v2 = q[i + 1];
+            int x1 = v1 < 0 ? -v1 : v1, x2 = v2 < 0 ? -v2 : v2;
+            int xlen = linbits;
+            if (x1 != 0) { if (v1 < 0) ext++; cbits--; }
+            if (t > 15) {
+                if (x1 > 14) { ext |= (uint32_t)(x1 - 15) << 1; xbits = linbits; x1 = 15; }
+                if (x2 > 14) { ext <<= linbits; ext |= (uint32_t)(x2 - 15); xbits += linbits; x2 = 15; }
+                xlen = 16;
+            }
+            if (x2 != 0) { ext <<= 1; if (v2 < 0) ext++; cbits--; }
+            x1 = x1 * xlen + x2;
+            xbits -= cbits;
+            cbits += hl[x1];
+            code = (uint32_t)hc[x1];
+        }
+        int tot;
+        const int off = wave_excl_scan(cbits + xbits, lane, &tot);
+        if (i < end) {
+            put_bits(w, pos + off, code, cbits);
+            put_bits(w, pos + off + cbits, ext, xbits);
+        }
+        pos += tot;
+        total_all += tot;
+    }
+    return total_all;
+}
+
+LHIP_DEV int count1_region(const Tables& T, uint32_t* w, int pos, const GrSide& gi, const int16_t* q, int lane) {
+    const int t = gi.count1table_select + 32;
+    const int32_t* hl = T.ht_hlen + T.ht_off[t];
+    const int32_t* hc = T.ht_code + T.ht_off[t];
+    const int nquads = (gi.count1 - gi.big_values) / 4;
+    int total_all = 0;
+    for (int base = 0; base < nquads; base += LHIP_NL) {
+        const int k = base + lane;
+        int n = 0;
+        uint32_t val = 0;
+        if (k < nquads) {
+            const int ix = gi.big_values + 4 * k;
+            int huffbits = 0, p = 0;
+            int v;
+            v = q[ix + 0]; if (v != 0) { p += 8; if (v < 0) huffbits++; }
+            v = q[ix + 1]; if (v != 0) { p += 4; huffbits *= 2; if (v < 0) huffbits++; }
+            v = q[ix + 2]; if (v != 0) { p += 2; huffbits *= 2; if (v < 0) huffbits++; }
+            v = q[ix + 3]; if (v != 0) { p++; huffbits *= 2; if (v < 0) huffbits++; }
+            val = (uint32_t)(huffbits + hc[p]);
+            n = hl[p];
+        }
+        int tot;
+        const int off = wave_excl_scan(n, lane, &tot);
+        if (k < nquads) put_bits(w, pos + off, val, n);
+        pos += tot;
+        total_all += tot;
+    }
+    return total_all;
+}
+
+LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L) {
+    const int C = T.channels_out;
+    const int st = W.fslot_stream[fslot];
+    const StreamDesc sd = SD[st];
+    const int k = fslot - sd.fslot0 - 1;
+    if (k < 0) return;
+    const int fidx = sd.out_slot0 + k;
+    const int padding = frame_padding(T, sd, k);
+    const int frame_bits = frame_bits_of(T, padding);
+    const int nwords = (frame_bits + 31) >> 5;
+    for (int i = lane; i < nwords + 1; i += LHIP_NL) L.w[i] = 0;
+    wave_sync();
+    const GrSide* side = W.side + (int64_t)fidx * 2 * C;
+    int pos = 0;
+    if (lane == 0) {
+        uint32_t* w = L.w;
+#define PUT(v, n) { put_bits(w, pos, (uint32_t)(v), (n)); pos += (n); }
+        PUT(0xfff, 12) PUT(T.version, 1) PUT(4 - 3, 2) PUT(!T.error_protection ? 1 : 0, 1)
+        PUT(T.bitrate_index, 4) PUT(T.samplerate_index, 2) PUT(padding, 1) PUT(T.extension, 1)
+        PUT(T.mode, 2) PUT(0, 2) PUT(T.copyright, 1) PUT(T.original, 1) PUT(T.emphasis, 2)
+        PUT(0, 9)
+        PUT(0, C == 2 ? 3 : 5)
+        for (int ch = 0; ch < C; ch++) {
+            const int sc = side[(1 * C) + ch].scfsi;
+            for (int band = 0; band < 4; band++) PUT((sc >> band) & 1, 1)
+        }
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < C; ch++) {
+                const GrSide& gi = side[gr * C + ch];
+                PUT(gi.part2_3_length + gi.part2_length, 12)
+                PUT(gi.big_values / 2, 9)
+                PUT(gi.global_gain, 8)
+                PUT(gi.scalefac_compress, 4)
+                int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
+                if (ts0 == 14) ts0 = 16;
+                if (ts1 == 14) ts1 = 16;
+                if (ts2 == 14) ts2 = 16;
+                if (gi.block_type != NORM_TYPE) {
+                    PUT(1, 1) PUT(gi.block_type, 2) PUT(0, 1)
+                    PUT(ts0, 5) PUT(ts1, 5)
+                    PUT(gi.subblock_gain[0], 3) PUT(gi.subblock_gain[1], 3) PUT(gi.subblock_gain[2], 3)
+                } else {
+                    PUT(0, 1) PUT(ts0, 5) PUT(ts1, 5) PUT(ts2, 5)
+                    PUT(gi.region0_count, 4) PUT(gi.region1_count, 3)
+                }
+                PUT(gi.preflag, 1) PUT(gi.scalefac_scale, 1) PUT(gi.count1table_select, 1)
+            }
+#undef PUT
+    }
+    pos = 8 * T.sideinfo_len;
+    wave_sync();
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++) {
+            const GrSide& gi = side[gr * C + ch];
+            const int16_t* q = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+            const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];
+            // scalefactors: at most 36 short fields
+            {
+                int p2 = pos;
+                for (int sfb = 0; sfb < gi.sfbmax; sfb++) {
+                    const int v = gi.scalefac[sfb];
+                    if (v == -1) continue;
+                    const int n = sfb < gi.sfbdivide ? slen1 : slen2;
+                    if (lane == 0) put_bits(L.w, p2, (uint32_t)v, n);
+                    p2 += n;
+                }
+                pos = p2;
+            }
+            int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
+            if (ts0 == 14) ts0 = 16;
+            if (ts1 == 14) ts1 = 16;
+            if (ts2 == 14) ts2 = 16;
+            if (gi.block_type == SHORT_TYPE) {
+                int r1 = 3 * T.sfb_s[3];
+                if (r1 > gi.big_values) r1 = gi.big_values;
+                pos += huff_region(T, L.w, pos, ts0, 0, r1, q, lane);
+                pos += huff_region(T, L.w, pos, ts1, r1, gi.big_values, q, lane);
+            } else {
+                const int bigv = gi.big_values;
+                int i = gi.region0_count + 1;
+                int r1 = T.sfb_l[i];
+                i += gi.region1_count + 1;
+                int r2 = T.sfb_l[i];
+                if (r1 > bigv) r1 = bigv;
+                if (r2 > bigv) r2 = bigv;
+                pos += huff_region(T, L.w, pos, ts0, 0, r1, q, lane);
+                pos += huff_region(T, L.w, pos, ts1, r1, r2, q, lane);
+                pos += huff_region(T, L.w, pos, ts2, r2, bigv, q, lane);
+            }
+            pos += count1_region(T, L.w, pos, gi, q, lane);
+        }
+    // ancillary stuffing (drain_into_ancillary): "LAME", coerced version chars, then zero bits
+    if (lane == 0) {
+        int remaining = frame_bits - pos;
+        const uint32_t lame[4] = {0x4c, 0x41, 0x4d, 0x45};
+        int p2 = pos;
+        for (int i = 0; i < 4; i++) if (remaining >= 8) { put_bits(L.w, p2, lame[i], 8); p2 += 8; remaining -= 8; }
+        if (remaining >= 32)
+            for (int i = 0; i < T.n_version_bytes && remaining >= 8; ++i) { remaining -= 8; put_bits(L.w, p2, (uint32_t)T.version_bytes[i], 8); p2 += 8; }
+    }
+    wave_sync();
+    const int nbytes = frame_bits >> 3;
+    uint8_t* out = W.out + sd.out_off + (int64_t)0;
+    // frames of a stream are consecutive; frame k starts after the k frames before it (sizes differ by the padding slot)
+    int64_t start = 0;
+    {
+        // bytes of frames 0..k-1 = k * base + (number of padded frames among them)
+        const int base = frame_bits_of(T, 0) >> 3;
+        // count paddings in closed form: floor((lag0_shift + k*frac)/out_samplerate) style accumulation
+        // lag before frame j is (lag0 - j*frac) mod sr; a padding happens when that value < frac
+        int64_t npad = 0;
+        if (T.frac_SpF != 0) {
+            // number of wraps of the accumulator over k steps
+            const int64_t sr = T.out_samplerate;
+            int64_t m0 = (int64_t)sd.slot_lag % sr; if (m0 < 0) m0 += sr;
+            // after k decrements the unwrapped value is m0 - k*frac; each wrap adds sr; wraps = ceil((k*frac - m0)/sr) clipped at 0
+            const int64_t need = (int64_t)k * T.frac_SpF - m0;
+            npad = need > 0 ? (need + sr - 1) / sr : 0;
+        }
+        start = (int64_t)k * base + npad;
+    }
+    out += start;
+    for (int i = lane; i < nbytes; i += LHIP_NL) out[i] = (uint8_t)(L.w[i >> 2] >> (24 - 8 * (i & 3)));
+    if (lane == 0) W.frame_bytes[fidx] = nbytes;
+}
+
+}  // namespace lhip

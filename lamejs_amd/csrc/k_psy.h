@@ -1,0 +1,566 @@
+// Psychoacoustic model kernels (nspsytune), decomposed per SURVEY.md 3.4:
+//   kb_psyA  : per (psy call, channel) -- everything that is a pure function of the PCM window:
+//              fs/4 high-pass + sub-block peaks, 1024-pt and 3x256-pt windowed FHT, energies,
+//              loudness, partition energies / tonality index, short-block spreading.
+//   kb_scan  : per stream -- the two tiny recurrences (attack/block-type chain, ATH auto-adjust).
+//   kb_psyB  : per psy call -- thresholds that need the scan results (additive masking with the
+//              adjusted ATH, short-block limiting, sfb mapping, inter-channel masking).
+// Behaviour follows reference PsyModel.js:1000-1383 (L3psycho_anal_ns), FFT.js:31-224 and
+// Encoder.js:166-243 (adjust_ATH); line references are given at each step.
+#pragma once
+#include "lhip_defs.h"
+#include "lhip_wave.h"
+#include "lhip_math.h"
+#include "lhip_layout.h"
+
+namespace lhip {
+
+// ---------------------------------------------------------------------------------------------
+// kb_prep: Int16 -> scaled Float32 (Lame.js:1506-1560).  One element per thread, grid-stride.
+// ---------------------------------------------------------------------------------------------
+LHIP_DEV void kb_prep_elem(const Tables& T, float* dst, const int16_t* src, int64_t i) {
+    float v = (float)src[i];
+    if (!(T.scale == 0.0) && !(T.scale == 1.0)) v = (float)((double)v * T.scale);
+    dst[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FHT butterflies, one radix-4 pass over n points held in LDS (FFT.js:45-112).
+// Work item t in [0, n/8): block m = t / kx, index i = t % kx inside the block.
+// ---------------------------------------------------------------------------------------------
+LHIP_DEV void fht_item(float* fz, int k1, int kx, int t, const double* tw) {
+    const int k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
+    const int m = t / kx, i = t - m * kx;
+    float* fi = fz + m * k4 + i;
+    if (i == 0) {
+        float* gi = fi + kx;
+        double f0, f1, f2, f3;
+        f1 = (double)fi[0] - (double)fi[k1];
+        f0 = (double)fi[0] + (double)fi[k1];
+        f3 = (double)fi[k2] - (double)fi[k3];
+        f2 = (double)fi[k2] + (double)fi[k3];
+        fi[k2] = (float)(f0 - f2);
+        fi[0] = (float)(f0 + f2);
+        fi[k3] = (float)(f1 - f3);
+        fi[k1] = (float)(f1 + f3);
+        f1 = (double)gi[0] - (double)gi[k1];
+        f0 = (double)gi[0] + (double)gi[k1];
+        f3 = LHIP_SQRT2 * (double)gi[k3];
+        f2 = LHIP_SQRT2 * (double)gi[k2];
+        gi[k2] = (float)(f0 - f2);
+        gi[0] = (float)(f0 + f2);
+        gi[k3] = (float)(f1 - f3);
+        gi[k1] = (float)(f1 + f3);
+    } else {
+        float* gi = fz + m * k4 + k1 - i;
+        const double c1 = tw[4 * (i - 1) + 0], s1 = tw[4 * (i - 1) + 1], c2 = tw[4 * (i - 1) + 2], s2 = tw[4 * (i - 1) + 3];
+        double a, b, g0, f0, f1, g1, f2, g2, f3, g3;
+        b = s2 * (double)fi[k1] - c2 * (double)gi[k1];
+        a = c2 * (double)fi[k1] + s2 * (double)gi[k1];
+        f1 = (double)fi[0] - a;
+        f0 = (double)fi[0] + a;
+        g1 = (double)gi[0] - b;
+        g0 = (double)gi[0] + b;
+        b = s2 * (double)fi[k3] - c2 * (double)gi[k3];
+        a = c2 * (double)fi[k3] + s2 * (double)gi[k3];
+        f3 = (double)fi[k2] - a;
+        f2 = (double)fi[k2] + a;
+        g3 = (double)gi[k2] - b;
+        g2 = (double)gi[k2] + b;
+        b = s1 * f2 - c1 * g3;
+        a = c1 * f2 + s1 * g3;
+        fi[k2] = (float)(f0 - a);
+        fi[0] = (float)(f0 + a);
+        gi[k3] = (float)(g1 - b);
+        gi[k1] = (float)(g1 + b);
+        b = c1 * g2 - s1 * f3;
+        a = s1 * g2 + c1 * f3;
+        gi[k2] = (float)(g0 - a);
+        gi[0] = (float)(g0 + a);
+        fi[k3] = (float)(f1 - b);
+        fi[k1] = (float)(f1 + b);
+    }
+}
+
+struct PsyALds {
+    float fz[BLKSIZE];              // long FHT buffer
+    float fs[3][BLKSIZE_s];         // short FHT buffers
+    float fe[HBLKSIZE + 3];         // long energies
+    float fes[3][HBLKSIZE_s + 3];   // short energies
+    float eb[CBANDS], mx[CBANDS], av[CBANDS];
+    float ebs[3][CBANDS];
+};
+
+// one wave per (granule slot >= 1 of a stream, channel)
+LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int ch, int lane, PsyALds& L) {
+    const int C = T.channels_out;
+    const int st = W.gslot_stream[gslot];
+    const StreamDesc sd = SD[st];
+    const int q = gslot - sd.gslot0 - 1;              // local psy call index
+    if (q < 0) return;                                // carry slot: nothing to compute
+    const float* buf = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 304;
+    const int64_t o = (int64_t)gslot * C + ch;
+
+    // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
+    {
+        const float* fir = buf + 397;                 // 576 - 350 - 21 + 192
+        for (int sbk = 0; sbk < 9; sbk++) {
+            float m = 1.0f;
+            for (int l = lane; l < 64; l += LHIP_NL) {
+                const int i = sbk * 64 + l;
+                double sum1 = (double)fir[i + 10], sum2 = 0.0;
+                for (int j = 0; j < 9; j += 2) {
+                    sum1 += T.hpf_fircoef[j] * ((double)fir[i + j] + (double)fir[i + 21 - j]);
+                    sum2 += T.hpf_fircoef[j + 1] * ((double)fir[i + j + 1] + (double)fir[i + 21 - j - 1]);
+                }
+                float v = (float)(sum1 + sum2);
+                v = v < 0 ? -v : v;
+                if (m < v) m = v;
+            }
+            m = wave_maxf(m);
+            if (lane == 0) W.peaks[o * PK_STRIDE + sbk] = m;
+        }
+    }
+
+    // --- windowing + first radix-4 stage (FFT.js:185-221 long, 140-180 short) ---
+    for (int jj = lane; jj < BLKSIZE / 8; jj += LHIP_NL) {
+        const int i = T.fft_rv_tbl[jj] & 0xff;
+        float* x = L.fz + 4 * jj;
+        double f0, f1, f2, f3, w;
+        f0 = (double)T.window[i] * (double)buf[i];
+        w = (double)T.window[i + 0x200] * (double)buf[i + 0x200];
+        f1 = f0 - w; f0 = f0 + w;
+        f2 = (double)T.window[i + 0x100] * (double)buf[i + 0x100];
+        w = (double)T.window[i + 0x300] * (double)buf[i + 0x300];
+        f3 = f2 - w; f2 = f2 + w;
+        x[0] = (float)(f0 + f2); x[2] = (float)(f0 - f2); x[1] = (float)(f1 + f3); x[3] = (float)(f1 - f3);
+        f0 = (double)T.window[i + 0x001] * (double)buf[i + 0x001];
+        w = (double)T.window[i + 0x201] * (double)buf[i + 0x201];
+        f1 = f0 - w; f0 = f0 + w;
+        f2 = (double)T.window[i + 0x101] * (double)buf[i + 0x101];
+        w = (double)T.window[i + 0x301] * (double)buf[i + 0x301];
+        f3 = f2 - w; f2 = f2 + w;
+        x[BLKSIZE / 2 + 0] = (float)(f0 + f2); x[BLKSIZE / 2 + 2] = (float)(f0 - f2);
+        x[BLKSIZE / 2 + 1] = (float)(f1 + f3); x[BLKSIZE / 2 + 3] = (float)(f1 - f3);
+    }
+    for (int it = lane; it < 3 * (BLKSIZE_s / 8); it += LHIP_NL) {
+        const int b = it / (BLKSIZE_s / 8), j = it - b * (BLKSIZE_s / 8);
+        const int k = (576 / 3) * (b + 1);
+        const int i = T.fft_rv_tbl[j << 2] & 0xff;
+        float* x = L.fs[b] + 4 * j;
+        double f0, f1, f2, f3, w;
+        f0 = (double)T.window_s[i] * (double)buf[i + k];
+        w = (double)T.window_s[0x7f - i] * (double)buf[i + k + 0x80];
+        f1 = f0 - w; f0 = f0 + w;
+        f2 = (double)T.window_s[i + 0x40] * (double)buf[i + k + 0x40];
+        w = (double)T.window_s[0x3f - i] * (double)buf[i + k + 0xc0];
+        f3 = f2 - w; f2 = f2 + w;
+        x[0] = (float)(f0 + f2); x[2] = (float)(f0 - f2); x[1] = (float)(f1 + f3); x[3] = (float)(f1 - f3);
+        f0 = (double)T.window_s[i + 0x01] * (double)buf[i + k + 0x01];
+        w = (double)T.window_s[0x7e - i] * (double)buf[i + k + 0x81];
+        f1 = f0 - w; f0 = f0 + w;
+        f2 = (double)T.window_s[i + 0x41] * (double)buf[i + k + 0x41];
+        w = (double)T.window_s[0x3e - i] * (double)buf[i + k + 0xc1];
+        f3 = f2 - w; f2 = f2 + w;
+        x[BLKSIZE_s / 2 + 0] = (float)(f0 + f2); x[BLKSIZE_s / 2 + 2] = (float)(f0 - f2);
+        x[BLKSIZE_s / 2 + 1] = (float)(f1 + f3); x[BLKSIZE_s / 2 + 3] = (float)(f1 - f3);
+    }
+    wave_sync();
+
+    // --- remaining FHT passes; twiddle table offsets 0,1,8,39 (pass t has kx-1 entries) ---
+    {
+        int off = 0;
+        for (int k1 = 4, kx = 2; k1 < BLKSIZE; k1 <<= 2, kx <<= 2) {
+            for (int t = lane; t < BLKSIZE / 8; t += LHIP_NL) fht_item(L.fz, k1, kx, t, T.fht_twiddle + 4 * off);
+            if (k1 < BLKSIZE_s)
+                for (int t = lane; t < 3 * (BLKSIZE_s / 8); t += LHIP_NL) {
+                    const int b = t / (BLKSIZE_s / 8);
+                    fht_item(L.fs[b], k1, kx, t - b * (BLKSIZE_s / 8), T.fht_twiddle + 4 * off);
+                }
+            wave_sync();
+            off += kx - 1;
+        }
+    }
+
+    // --- energies (PsyModel.js:274-296) ---
+    for (int j = lane; j <= BLKSIZE / 2; j += LHIP_NL) {
+        if (j == 0) { float e0 = L.fz[0]; L.fe[0] = (float)((double)e0 * (double)e0); }
+        else {
+            const double re = L.fz[j], im = L.fz[BLKSIZE - j];
+            L.fe[j] = (float)((re * re + im * im) * 0.5);
+        }
+    }
+    for (int it = lane; it < 3 * (BLKSIZE_s / 2 + 1); it += LHIP_NL) {
+        const int b = it / (BLKSIZE_s / 2 + 1), j = it - b * (BLKSIZE_s / 2 + 1);
+        if (j == 0) { float e0 = L.fs[b][0]; L.fes[b][0] = (float)((double)e0 * (double)e0); }
+        else {
+            const double re = L.fs[b][j], im = L.fs[b][BLKSIZE_s - j];
+            L.fes[b][j] = (float)((re * re + im * im) * 0.5);
+        }
+    }
+    wave_sync();
+
+    // --- loudness: strictly sequential f64 sum (PsyModel.js:241-249); lane 0 only ---
+    if (lane == 0) {
+        double lp = 0.0;
+        for (int i = 0; i < BLKSIZE / 2; ++i) lp += (double)L.fe[i] * (double)T.eql_w[i];
+        lp *= T.VO_SCALE;
+        W.loud[o] = (float)lp;
+    }
+
+    // --- long partitions: energy, max, average (calc_energy, PsyModel.js:906-928) ---
+    for (int b = lane; b < T.npart_l; b += LHIP_NL) {
+        double ebb = 0, m = 0;
+        int j = T.lineoff_l[b];
+        for (int i = 0; i < T.numlines_l[b]; ++i, ++j) {
+            const double el = L.fe[j];
+            ebb += el;
+            if (m < el) m = el;
+        }
+        L.eb[b] = (float)ebb;
+        L.mx[b] = (float)m;
+        L.av[b] = (float)(ebb * (double)T.rnumlines_l[b]);
+    }
+    // --- short partitions: energy per sub-block (compute_masking_s first loop, 740-750) ---
+    for (int it = lane; it < 3 * T.npart_s; it += LHIP_NL) {
+        const int sblock = it / T.npart_s, b = it - sblock * T.npart_s;
+        double ebb = 0;
+        int j = T.lineoff_s[b];
+        for (int i = 0; i < T.numlines_s[b]; ++i, ++j) ebb += (double)L.fes[sblock][j];
+        L.ebs[sblock][b] = (float)ebb;
+    }
+    wave_sync();
+
+    // --- tonality index (calc_mask_index_l, PsyModel.js:930-992) ---
+    for (int b = lane; b < CBANDS; b += LHIP_NL) {
+        int k = 0;
+        float ebv = 0.f;
+        if (b < T.npart_l) {
+            const int last = T.npart_l - 1;
+            const int lo = b > 0 ? b - 1 : b, hi = b < last ? b + 1 : b;
+            double a, m;
+            int nl;
+            if (b == 0) { a = (double)L.av[0] + (double)L.av[1]; nl = T.numlines_l[0] + T.numlines_l[1] - 1; }
+            else if (b == last) { a = (double)L.av[b - 1] + (double)L.av[b]; nl = T.numlines_l[b - 1] + T.numlines_l[b] - 1; }
+            else { a = (double)L.av[b - 1] + (double)L.av[b] + (double)L.av[b + 1]; nl = T.numlines_l[b - 1] + T.numlines_l[b] + T.numlines_l[b + 1] - 1; }
+            if (a > 0.0) {
+                m = L.mx[lo];
+                for (int t = lo + 1; t <= hi; t++) if (m < (double)L.mx[t]) m = L.mx[t];
+                a = 20.0 * (m * (double)(hi - lo + 1) - a) / (a * nl);
+                k = js_toint32(a);
+                if (k > 8) k = 8;
+            }
+            ebv = L.eb[b];
+        }
+        W.eb_l[o * EBL_STRIDE + b] = ebv;
+        W.mask_idx[o * EBL_STRIDE + b] = k;
+    }
+    // --- short spreading (compute_masking_s second loop before limiting, 752-760) ---
+    for (int it = lane; it < 3 * CBANDS; it += LHIP_NL) {
+        const int sblock = it / CBANDS, b = it - sblock * CBANDS;
+        float ecbv = 0.f, ebv = 0.f;
+        if (b < T.npart_s) {
+            int kk = T.s3ind_s[2 * b], j = T.s3off_s[b];
+            double ecb = (double)T.s3_ss[j++] * (double)L.ebs[sblock][kk];
+            ++kk;
+            while (kk <= T.s3ind_s[2 * b + 1]) { ecb += (double)T.s3_ss[j] * (double)L.ebs[sblock][kk]; ++j; ++kk; }
+            ecbv = (float)ecb;
+            ebv = L.ebs[sblock][b];
+        }
+        W.ecb_s[o * EBS_STRIDE + it] = ecbv;
+        W.eb_s[o * EBS_STRIDE + it] = ebv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kb_scan: one wave per stream.  Phase 1 (parallel): raw attack flags per (psy call, channel).
+// Phase 2 (lane 0): attack clean-up / block-type chain and the ATH auto-adjust recurrence.
+// ---------------------------------------------------------------------------------------------
+LHIP_DEV int attack_flags_raw(const Tables& T, const float* cur, const float* prev, int chn) {
+    // PsyModel.js:1105-1181 under the fractional-index port bug: only i in {0,3,6,9}
+    const double thr = (chn == 3) ? T.attackthre_s : T.attackthre;
+    float ai[4];
+    ai[0] = (float)((double)prev[6] / (double)prev[4]);
+    const double refv[3] = {(double)prev[7], (double)cur[1], (double)cur[4]};
+    for (int t = 0; t < 3; t++) {
+        double p = cur[3 * t];
+        const double r = refv[t];
+        if (p > r) p = p / r;
+        else if (r > p * 10.0) p = r / (p * 10.0);
+        else p = 0.0;
+        ai[t + 1] = (float)p;
+    }
+    double en_short[4];
+    en_short[0] = 0.0;
+    for (int i = 0; i < 3; i++) en_short[0] += (double)prev[i + 6];
+    en_short[1] = 0.0 + (double)cur[0]; en_short[2] = 0.0 + (double)cur[3]; en_short[3] = 0.0 + (double)cur[6];
+    int a[4];
+    for (int j = 0; j < 4; j++) a[j] = ((double)ai[j] > thr) ? 1 : 0;
+    for (int i = 1; i < 4; i++) {
+        double ratio;
+        if (en_short[i - 1] > en_short[i]) ratio = en_short[i - 1] / en_short[i];
+        else ratio = en_short[i] / en_short[i - 1];
+        if (ratio < 1.7) { a[i] = 0; if (i == 1) a[0] = 0; }
+    }
+    return a[0] | (a[1] << 1) | (a[2] << 2) | (a[3] << 3);
+}
+
+LHIP_DEV void kb_scan(const Tables& T, const Workspace& W, const StreamDesc* SD, int st, int lane) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[st];
+    const int nq = 2 * sd.nframes;
+    for (int it = lane; it < nq * C; it += LHIP_NL) {
+        const int q = it / C, ch = it - q * C;
+        const int64_t o = (int64_t)(sd.gslot0 + 1 + q) * C + ch;
+        W.att_raw[o] = attack_flags_raw(T, W.peaks + o * PK_STRIDE, W.peaks + (o - C) * PK_STRIDE, ch);
+    }
+    wave_sync();
+    if (lane != 0) return;
+    int last[2], tent[2];
+    for (int ch = 0; ch < C; ch++) {
+        last[ch] = W.last_attack[(int64_t)sd.gslot0 * C + ch];
+        tent[ch] = W.tent[(int64_t)sd.gslot0 * C + ch];
+    }
+    double adj = W.ath_adjust[sd.fslot0], lim = W.ath_limit[sd.fslot0];
+    for (int k = 0; k < sd.nframes; k++) {
+        for (int gr = 0; gr < 2; gr++) {
+            const int gs = sd.gslot0 + 1 + 2 * k + gr;
+            int ul[2] = {1, 1};
+            for (int ch = 0; ch < C; ch++) {
+                const int raw = W.att_raw[(int64_t)gs * C + ch];
+                int a0 = raw & 1, a1 = (raw >> 1) & 1, a2 = (raw >> 2) & 1, a3 = (raw >> 3) & 1;
+                if (a0 != 0 && last[ch] != 0) a0 = 0;
+                if (last[ch] == 3 || (a0 + a1 + a2 + a3) != 0) {
+                    ul[ch] = 0;
+                    if (a1 != 0 && a0 != 0) a1 = 0;
+                    if (a2 != 0 && a1 != 0) a2 = 0;
+                    if (a3 != 0 && a2 != 0) a3 = 0;
+                }
+                last[ch] = a2;
+                W.last_attack[(int64_t)gs * C + ch] = a2;
+                W.prev_short[(int64_t)gs * C + ch] = (tent[ch] == SHORT_TYPE) ? 1 : 0;
+            }
+            // block_type_set (PsyModel.js:784-826)
+            if (T.short_blocks_coupled && !(ul[0] != 0 && ul[1] != 0)) ul[0] = ul[1] = 0;
+            for (int ch = 0; ch < C; ch++) {
+                int bt = NORM_TYPE, old = tent[ch];
+                if (ul[ch] != 0) { if (old == SHORT_TYPE) bt = STOP_TYPE; }
+                else {
+                    bt = SHORT_TYPE;
+                    if (old == NORM_TYPE) old = START_TYPE;
+                    if (old == STOP_TYPE) old = SHORT_TYPE;
+                }
+                W.blocktype[(int64_t)gs * C + ch] = old;   // value returned for the granule being coded
+                tent[ch] = bt;
+                W.tent[(int64_t)gs * C + ch] = bt;
+            }
+        }
+        // adjust_ATH (Encoder.js:166-243): loudness of the two psy calls *before* these granules
+        {
+            const int64_t g0 = (int64_t)(sd.gslot0 + 2 * k) * C, g1 = g0 + C;
+            double max_pow = W.loud[g0], gr2_max = W.loud[g1];
+            if (C == 2) { max_pow += (double)W.loud[g0 + 1]; gr2_max += (double)W.loud[g1 + 1]; }
+            else { max_pow += max_pow; gr2_max += gr2_max; }
+            max_pow = max_pow > gr2_max ? max_pow : gr2_max;
+            max_pow *= 0.5;
+            max_pow *= T.ATH_aaSensitivityP;
+            if (T.ATH_useAdjust == 0) adj = 1.0;
+            else if (max_pow > 0.03125) {
+                if (adj >= 1.0) adj = 1.0;
+                else if (adj < lim) adj = lim;
+                lim = 1.0;
+            } else {
+                const double adj_lim_new = 31.98 * max_pow + 0.000625;
+                if (adj >= adj_lim_new) {
+                    adj *= adj_lim_new * 0.075 + 0.925;
+                    if (adj < adj_lim_new) adj = adj_lim_new;
+                } else {
+                    if (lim >= adj_lim_new) adj = adj_lim_new;
+                    else if (adj < lim) adj = lim;
+                }
+                lim = adj_lim_new;
+            }
+            W.ath_adjust[sd.fslot0 + 1 + k] = adj;
+            W.ath_limit[sd.fslot0 + 1 + k] = lim;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kb_psyB: one wave per psy call (all channels).
+// ---------------------------------------------------------------------------------------------
+LHIP_DEV double mask_add_l(const Tables& T, double ath_adjust, double m1, double m2, int kk, int b) {
+    // PsyModel.js:403-473 (long blocks)
+    double ratio;
+    if (m2 > m1) {
+        if (m2 < (m1 * T.ma_max_i2)) ratio = m2 / m1;
+        else return (m1 + m2);
+    } else {
+        if (m1 >= (m2 * T.ma_max_i2)) return (m1 + m2);
+        ratio = m1 / m2;
+    }
+    m1 += m2;
+    if ((b + 3) <= 3 + 3) {
+        if (ratio >= T.ma_max_i1) return m1;
+        const int i = js_toint32(v8_log10(ratio) * 16.0);
+        return m1 * T.ma_table2[i];
+    }
+    const int i = js_toint32(v8_log10(ratio) * 16.0);
+    m2 = (double)T.ATH_cb_l[kk] * ath_adjust;
+    if (m1 < T.ma_max_m * m2) {
+        if (m1 > m2) {
+            double f = 1.0;
+            if (i <= 13) f = T.ma_table3[i];
+            const double r = v8_log10(m1 / m2) * (10.0 / 15.0);
+            return m1 * ((T.ma_table1[i] - f) * r + f);
+        }
+        if (i > 13) return m1;
+        return m1 * T.ma_table3[i];
+    }
+    return m1 * T.ma_table1[i];
+}
+
+struct PsyBLds {
+    float thr_l[2][CBANDS + 2];
+    float thr_s[2][3][CBANDS + 2];
+    float E[2][E_STRIDE];
+};
+
+LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLds& L) {
+    const int C = T.channels_out;
+    const int st = W.gslot_stream[gslot];
+    const StreamDesc sd = SD[st];
+    const int q = gslot - sd.gslot0 - 1;
+    if (q < 0) return;
+    const int fs = sd.fslot0 + (q >> 1);                 // ATH.adjust as left by the previous frame
+    const double ath_adjust = W.ath_adjust[fs];
+
+    for (int ch = 0; ch < C; ch++) {
+        const int64_t o = (int64_t)gslot * C + ch;
+        const float* eb_l = W.eb_l + o * EBL_STRIDE;
+        const int32_t* midx = W.mask_idx + o * EBL_STRIDE;
+        // long-block spreading with additive masking (PsyModel.js:1274-1320); thr = ecb (pcfact == 0)
+        for (int b = lane; b < T.npart_l; b += LHIP_NL) {
+            int kk = T.s3ind[2 * b], k = T.s3off_l[b];
+            double eb2 = (double)eb_l[kk] * T.ma_tab[midx[kk]];
+            double ecb = (double)T.s3_ll[k++] * eb2;
+            while (++kk <= T.s3ind[2 * b + 1]) {
+                eb2 = (double)eb_l[kk] * T.ma_tab[midx[kk]];
+                ecb = mask_add_l(T, ath_adjust, ecb, (double)T.s3_ll[k++] * eb2, kk, kk - b);
+            }
+            ecb *= 0.158489319246111;
+            L.thr_l[ch][b] = (float)ecb;
+        }
+        // short-block limiting by the two previous sub-blocks (compute_masking_s, 762-775)
+        const int pshort = W.prev_short[o];
+        for (int it = lane; it < 3 * T.npart_s; it += LHIP_NL) {
+            const int sblock = it / T.npart_s, b = it - sblock * T.npart_s;
+            const float* e0 = W.ecb_s + o * EBS_STRIDE;
+            const float* em = W.ecb_s + (o - C) * EBS_STRIDE;       // previous psy call (or carry)
+            const float ecb = e0[sblock * CBANDS + b];
+            const float nb1 = sblock >= 1 ? e0[(sblock - 1) * CBANDS + b] : em[2 * CBANDS + b];
+            const float nb2 = sblock >= 2 ? e0[(sblock - 2) * CBANDS + b] : em[(sblock + 1) * CBANDS + b];
+            double x = 2 * (double)nb1;
+            float thr = (float)((double)ecb < x ? (double)ecb : x);
+            if (pshort) {
+                x = 16 * (double)nb2;
+                const double y = thr;
+                thr = (float)(x < y ? x : y);
+            }
+            L.thr_s[ch][sblock][b] = thr;
+        }
+    }
+    wave_sync();
+
+    for (int ch = 0; ch < C; ch++) {
+        const int64_t o = (int64_t)gslot * C + ch;
+        const float* eb_l = W.eb_l + o * EBL_STRIDE;
+        float* Eo = L.E[ch];
+        // convert_partition2scalefac_l (PsyModel.js:692-734): lane per scalefactor band
+        for (int sb = lane; sb < SBMAX_l; sb += LHIP_NL) {
+            const int npart = T.npart_l;
+            const int bstart = sb == 0 ? 0 : T.bo_l[sb - 1];      // partition shared with the previous band
+            float en_f = 0.f, thm_f = 0.f;
+            // band sb exists only if the walk has not run past npart before reaching it
+            if (sb == 0 || bstart < npart) {
+                double enn = 0.0, thmm = 0.0;
+                int b = bstart;
+                if (sb > 0) {
+                    const double w_next = 1.0 - (double)T.bo_l_weight[sb - 1];
+                    enn = w_next * (double)eb_l[b];
+                    thmm = w_next * (double)L.thr_l[ch][b];
+                    b++;
+                }
+                const int bo = T.bo_l[sb];
+                const int b_lim = bo < npart ? bo : npart;
+                while (b < b_lim) { enn += (double)eb_l[b]; thmm += (double)L.thr_l[ch][b]; b++; }
+                en_f = (float)enn; thm_f = (float)thmm;
+                if (b < npart) {
+                    const double w_curr = T.bo_l_weight[sb];
+                    en_f = (float)((double)en_f + w_curr * (double)eb_l[b]);
+                    thm_f = (float)((double)thm_f + w_curr * (double)L.thr_l[ch][b]);
+                }
+            }
+            Eo[E_EN_L + sb] = en_f;
+            Eo[E_THM_L + sb] = thm_f;
+        }
+        // convert_partition2scalefac_s (644-687) + x0.8 and pulse halving (1226-1267)
+        const float* pk = W.peaks + o * PK_STRIDE;            // en_subshort[3..11]
+        for (int it = lane; it < 3 * SBMAX_s; it += LHIP_NL) {
+            const int sblock = it / SBMAX_s, sb = it - sblock * SBMAX_s;
+            const float* ebs = W.eb_s + o * EBS_STRIDE + sblock * CBANDS;
+            const float* thr = L.thr_s[ch][sblock];
+            const int npart = T.npart_s;
+            const int bstart = sb == 0 ? 0 : T.bo_s[sb - 1];
+            float en_f = 0.f, thm_f = 0.f;
+            if (sb == 0 || bstart < npart) {
+                double enn = 0.0, thmm = 0.0;
+                int b = bstart;
+                if (sb > 0) {
+                    const double w_next = 1.0 - (double)T.bo_s_weight[sb - 1];
+                    enn = w_next * (double)ebs[b];
+                    thmm = w_next * (double)thr[b];
+                    b++;
+                }
+                const int bo = T.bo_s[sb];
+                const int b_lim = bo < npart ? bo : npart;
+                while (b < b_lim) { enn += (double)ebs[b]; thmm += (double)thr[b]; b++; }
+                en_f = (float)enn; thm_f = (float)thmm;
+                if (b < npart) {
+                    const double w_curr = T.bo_s_weight[sb];
+                    en_f = (float)((double)en_f + w_curr * (double)ebs[b]);
+                    thm_f = (float)((double)thm_f + w_curr * (double)thr[b]);
+                }
+            }
+            double thmm = thm_f;
+            thmm *= 0.8;
+            const double e3 = pk[sblock * 3 + 0], e4 = pk[sblock * 3 + 1], e5 = pk[sblock * 3 + 2];
+            const double enn = e3 + e4 + e5;
+            if (e5 * 6 < enn) {
+                thmm *= 0.5;
+                if (e4 * 6 < enn) thmm *= 0.5;
+            }
+            Eo[E_EN_S + sb * 3 + sblock] = en_f;
+            Eo[E_THM_S + sb * 3 + sblock] = (float)thmm;
+        }
+    }
+    wave_sync();
+    // inter-channel masking (PsyModel.js:525-543): stereo mode with ratio > 0
+    if (T.mode == 0 && T.interChRatio > 0.0 && C > 1) {
+        const double r_ = T.interChRatio;
+        float nl[2] = {0.f, 0.f};
+        for (int i = lane; i < SBMAX_l + 3 * SBMAX_s; i += LHIP_NL) {
+            const int idx = E_THM_L + i;                       // thm.l then thm.s are contiguous
+            const double l = L.E[0][idx], r = L.E[1][idx];
+            nl[0] = (float)(l + r * r_);
+            nl[1] = (float)(r + l * r_);
+            L.E[0][idx] = nl[0];
+            L.E[1][idx] = nl[1];
+        }
+        wave_sync();
+    }
+    for (int ch = 0; ch < C; ch++)
+        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[((int64_t)gslot * C + ch) * E_STRIDE + i] = L.E[ch][i];
+}
+
+}  // namespace lhip

@@ -1,0 +1,738 @@
+// C-ABI implementation of include/lamejs_hip.h: stream objects, HBM workspace management and
+// the kernel pipeline for one batch of frames.  Compiled by hipcc for gfx950 (the product), and
+// by g++ with -DLHIP_HOSTSIM for the test-only CPU simulation of the kernel logic (tests/hostsim).
+//
+// Pipeline per batch:  load carried state -> psyA (parallel over granule-channels)
+// -> scan (per stream) -> psyB (parallel) -> polyphase -> MDCT -> quantize (parallel over frames,
+// speculative bin-search seed) -> validate seed chain [-> repair flagged frames]* -> bit-pack -> save state.
+#include "../../include/lamejs_hip.h"
+#include "lhip_defs.h"
+#include "lhip_wave.h"
+#include "lhip_math.h"
+#include "lhip_layout.h"
+#include "k_psy.h"
+#include "k_fb.h"
+#include "k_quant.h"
+#include "k_bits.h"
+
+#include <string>
+#include <vector>
+#include <map>
+#include <mutex>
+#include <memory>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+
+using namespace lhip;
+
+// ===========================================================================================
+// runtime shim
+// ===========================================================================================
+static thread_local std::string g_err;
+static thread_local int64_t g_stat_frames = 0, g_stat_repaired = 0, g_stat_iters = 0;
+static void set_err(const std::string& e) { g_err = e; }
+
+#ifdef LHIP_HOSTSIM
+namespace rt {
+static int device_count() { return 1; }
+static bool set_device(int) { return true; }
+static void* dmalloc(size_t n) { return calloc(1, n ? n : 1); }
+static void dfree(void* p) { free(p); }
+static bool h2d(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return true; }
+static bool d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return true; }
+static bool d2d(void* d, const void* s, size_t n, void*) { memmove(d, s, n); return true; }
+static bool dzero(void* d, size_t n, void*) { memset(d, 0, n); return true; }
+static bool sync(void*) { return true; }
+}  // namespace rt
+#else
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return false; } } while (0)
+namespace rt {
+static int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+static bool set_device(int d) { HIPCK(hipSetDevice(d)); return true; }
+static void* dmalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; return p; }
+static void dfree(void* p) { if (p) (void)hipFree(p); }
+static bool h2d(void* d, const void* s, size_t n, void* st) { if (n) HIPCK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); return true; }
+static bool d2h(void* d, const void* s, size_t n, void* st) { if (n) HIPCK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); return true; }
+static bool d2d(void* d, const void* s, size_t n, void* st) { if (n) HIPCK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); return true; }
+static bool dzero(void* d, size_t n, void* st) { if (n) HIPCK(hipMemsetAsync(d, 0, n, (hipStream_t)st)); return true; }
+static bool sync(void* st) { HIPCK(hipStreamSynchronize((hipStream_t)st)); return true; }
+}  // namespace rt
+#endif
+
+// ===========================================================================================
+// device-resident per-stream state (what the reference carries from frame to frame)
+// ===========================================================================================
+struct StreamState {
+    float pcm_tail[2][MF_NEEDED];
+    float sb[2][SB_STRIDE];
+    float E[2][E_STRIDE];
+    float ecb_s[2][EBS_STRIDE];
+    float peaks[2][PK_STRIDE];
+    float loud[2];
+    int32_t last_attack[2], tent[2];
+    double ath_adjust, ath_limit;
+    int32_t seed[2][2];
+};
+
+struct StreamIO {          // per stream, per launch (device array parallel to StreamDesc)
+    StreamState* state;
+    const int16_t* src[2]; // new samples (device addresses)
+    uint8_t* out;          // where this stream's frames go (device address)
+    int32_t n_new, mf_size;
+};
+
+// load carried state into the stream's carry slots and build its sample segment (tail + new samples)
+LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[st];
+    const StreamIO io = IO[st];
+    const StreamState* S = io.state;
+    for (int ch = 0; ch < C; ch++) {
+        float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
+        for (int i = lane; i < io.mf_size; i += LHIP_NL) seg[i] = S->pcm_tail[ch][i];
+        for (int i = lane; i < io.n_new; i += LHIP_NL) kb_prep_elem(T, seg + io.mf_size, io.src[ch], i);
+        const int64_t o = (int64_t)sd.gslot0 * C + ch;
+        for (int i = lane; i < SB_STRIDE; i += LHIP_NL) W.sb[o * SB_STRIDE + i] = S->sb[ch][i];
+        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[ch][i];
+        for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[ch][i];
+        for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[ch][i];
+        if (lane == 0) {
+            W.loud[o] = S->loud[ch];
+            W.last_attack[o] = S->last_attack[ch];
+            W.tent[o] = S->tent[ch];
+            W.seed[((int64_t)sd.fslot0 * C + ch) * 2 + 0] = S->seed[ch][0];
+            W.seed[((int64_t)sd.fslot0 * C + ch) * 2 + 1] = S->seed[ch][1];
+        }
+    }
+    if (lane == 0) { W.ath_adjust[sd.fslot0] = S->ath_adjust; W.ath_limit[sd.fslot0] = S->ath_limit; }
+}
+
+// new samples only (large batches: one element per thread over all streams is overkill; per stream grid-stride)
+LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[st];
+    const StreamIO io = IO[st];
+    StreamState* S = io.state;
+    const int F = sd.nframes;
+    const int total = io.mf_size + io.n_new, keep = total - FRAME * F;
+    for (int ch = 0; ch < C; ch++) {
+        const float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
+        for (int i = lane; i < keep; i += LHIP_NL) S->pcm_tail[ch][i] = seg[FRAME * F + i];
+        if (F == 0) continue;
+        const int64_t o = (int64_t)(sd.gslot0 + 2 * F) * C + ch;
+        for (int i = lane; i < SB_STRIDE; i += LHIP_NL) S->sb[ch][i] = W.sb[o * SB_STRIDE + i];
+        for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[ch][i] = W.E[o * E_STRIDE + i];
+        for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[ch][i] = W.ecb_s[o * EBS_STRIDE + i];
+        for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[ch][i] = W.peaks[o * PK_STRIDE + i];
+        if (lane == 0) {
+            S->loud[ch] = W.loud[o];
+            S->last_attack[ch] = W.last_attack[o];
+            S->tent[ch] = W.tent[o];
+            const Seed s = seed_before(W, sd, C, F, 0, ch);
+            S->seed[ch][0] = s.start; S->seed[ch][1] = s.step;
+        }
+    }
+    if (lane == 0 && F > 0) { S->ath_adjust = W.ath_adjust[sd.fslot0 + F]; S->ath_limit = W.ath_limit[sd.fslot0 + F]; }
+}
+
+// ===========================================================================================
+// kernel launch layer
+// ===========================================================================================
+#ifndef LHIP_HOSTSIM
+__global__ __launch_bounds__(64) void g_load(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_load(T, W, SD, IO, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void g_save(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_save(T, W, SD, IO, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD) {
+    __shared__ PsyALds L;
+    const int C = T.channels_out;
+    kb_psyA(T, W, SD, blockIdx.x / C, blockIdx.x % C, threadIdx.x, L);
+}
+__global__ __launch_bounds__(64) void g_scan(Tables T, Workspace W, const StreamDesc* SD) { kb_scan(T, W, SD, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const StreamDesc* SD) {
+    __shared__ PsyBLds L;
+    kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
+}
+__global__ __launch_bounds__(64) void g_poly(Tables T, Workspace W, const StreamDesc* SD) {
+    const int C = T.channels_out;
+    kb_polyphase(T, W, SD, blockIdx.x / C, blockIdx.x % C, threadIdx.x);
+}
+__global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const StreamDesc* SD) {
+    __shared__ MdctLds L;
+    kb_mdct(T, W, SD, blockIdx.x, threadIdx.x, L);
+}
+__global__ __launch_bounds__(64) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain) {
+    __shared__ QuantLds L;
+    kb_quant(T, pb, W, SD, blockIdx.x, chain, threadIdx.x, L);
+}
+__global__ __launch_bounds__(64) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD) {
+    __shared__ QuantLds L;
+    kb_validate(T, pb, W, SD, blockIdx.x, threadIdx.x, L);
+}
+__global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const StreamDesc* SD) {
+    __shared__ BitsLds L;
+    kb_bits(T, W, SD, blockIdx.x, threadIdx.x, L);
+}
+#define LAUNCH(kern, nblk, st, ...) do { if ((nblk) > 0) { hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); \
+    hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
+#endif
+
+// ===========================================================================================
+// tables (shared between streams with identical blobs)
+// ===========================================================================================
+struct lhtb_entry { char name[32]; uint32_t dtype, count, offset, pad; };
+
+struct TableSet {
+    Tables T;               // device pointers
+    PowBase pb10;
+    std::vector<uint8_t> blob;
+    void* d_blob = nullptr;
+    void* d_extra = nullptr;
+    int device = 0;
+    int refs = 0;
+    int base_frame_bytes = 0;
+    ~TableSet() { rt::dfree(d_blob); rt::dfree(d_extra); }
+};
+
+static const lhtb_entry* find_entry(const uint8_t* b, const char* name) {
+    uint32_t n; memcpy(&n, b + 8, 4);
+    const lhtb_entry* e = (const lhtb_entry*)(b + 16);
+    for (uint32_t i = 0; i < n; i++) if (strncmp(e[i].name, name, 32) == 0) return &e[i];
+    return nullptr;
+}
+
+static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lhip_config& cfg, void* stream) {
+    if (nbytes < 16) { set_err("tables blob too small"); return false; }
+    uint32_t magic, total;
+    memcpy(&magic, blob, 4); memcpy(&total, (const uint8_t*)blob + 12, 4);
+    if (magic != 0x4254484cu || total > nbytes) { set_err("tables blob: bad magic/size"); return false; }
+    ts.blob.assign((const uint8_t*)blob, (const uint8_t*)blob + total);
+    const uint8_t* b = ts.blob.data();
+    ts.d_blob = rt::dmalloc(total);
+    if (!ts.d_blob) { set_err("hipMalloc(tables) failed"); return false; }
+    if (!rt::h2d(ts.d_blob, b, total, stream)) return false;
+    Tables& T = ts.T;
+    memset(&T, 0, sizeof T);
+    bool ok = true;
+    auto arr = [&](const char* name, uint32_t dtype, int* count) -> const void* {
+        const lhtb_entry* e = find_entry(b, name);
+        if (!e || e->dtype != dtype) { set_err(std::string("tables blob: entry missing: ") + name); ok = false; return nullptr; }
+        if (count) *count = (int)e->count;
+        return (const uint8_t*)ts.d_blob + e->offset;
+    };
+    auto host_arr = [&](const char* name) -> const void* { const lhtb_entry* e = find_entry(b, name); return e ? b + e->offset : nullptr; };
+    auto named = [&](const char* names_key, const char* key) -> int {
+        const lhtb_entry* e = find_entry(b, names_key);
+        if (!e) { ok = false; return 0; }
+        const int32_t* chars = (const int32_t*)(b + e->offset);
+        std::string all;
+        for (uint32_t i = 0; i < e->count && chars[i]; i++) all.push_back((char)chars[i]);
+        size_t pos = 0; int idx = 0;
+        while (pos <= all.size()) {
+            size_t c = all.find(',', pos);
+            if (c == std::string::npos) c = all.size();
+            if (all.compare(pos, c - pos, key) == 0) return idx;
+            idx++; pos = c + 1;
+        }
+        set_err(std::string("tables blob: config key missing: ") + key); ok = false; return 0;
+    };
+    const int32_t* ci = (const int32_t*)host_arr("cfg_i");
+    const double* cd = (const double*)host_arr("cfg_d");
+    if (!ci || !cd) { set_err("tables blob: cfg arrays missing"); return false; }
+#define CI(f) T.f = ci[named("cfg_i_names", #f)]
+#define CD(f) T.f = cd[named("cfg_d_names", #f)]
+    CI(channels_out); CI(mode); CI(mode_gr); CI(version); CI(samplerate_index); CI(bitrate_index); CI(brate);
+    CI(out_samplerate); CI(sideinfo_len); CI(frac_SpF); CI(noise_shaping); CI(noise_shaping_amp);
+    CI(noise_shaping_stop); CI(subblock_gain); CI(use_best_huffman); CI(full_outer_loop); CI(substep_shaping);
+    CI(sfb21_extra); CI(quant_comp); CI(quant_comp_short); CI(short_blocks_coupled); CI(useTemporal);
+    CI(ATH_useAdjust); CI(athaa_loudapprox); CI(copyright); CI(original); CI(emphasis); CI(extension);
+    CI(error_protection); CI(npart_l); CI(npart_s);
+    CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
+    CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
+#undef CI
+#undef CD
+#define AF(f) T.f = (const float*)arr(#f, 2, nullptr)
+#define AI(f) T.f = (const int32_t*)arr(#f, 1, nullptr)
+#define AD(f) T.f = (const double*)arr(#f, 3, nullptr)
+    AF(amp_filter); AF(ATH_l); AF(ATH_s); AF(ATH_psfb21); AF(ATH_psfb12); AF(ATH_cb_l); AF(ATH_cb_s); AF(eql_w);
+    AF(pow43); AF(adj43); AF(ipow20); AF(pow20); AF(longfact); AF(shortfact); AF(rnumlines_l); AF(bo_l_weight);
+    AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s);
+    AI(sfb_l); AI(sfb_s); AI(psfb21); AI(psfb12); AI(bv_scf); AI(numlines_l); AI(numlines_s); AI(bo_l); AI(bm_l);
+    AI(bo_s); AI(bm_s); AI(s3ind); AI(s3ind_s); AI(fft_rv_tbl); AI(mdct_order); AI(pretab); AI(scfsi_band);
+    AI(slen1_n); AI(slen2_n); AI(slen1_tab); AI(slen2_tab); AI(scale_short); AI(scale_long); AI(huf_tbl_noESC);
+    AI(ht_xlen); AI(ht_linmax); AI(ht_off); AI(ht_code); AI(ht_hlen); AI(largetbl); AI(table23); AI(table56);
+    AI(t32l); AI(t33l);
+    T.version_bytes = (const int32_t*)arr("version_bytes", 1, &T.n_version_bytes);
+    AD(fht_twiddle); AD(fht_costab); AD(enwindow); AD(mdct_win); AD(ma_tab); AD(ma_table1); AD(ma_table2);
+    AD(ma_table3); AD(hpf_fircoef);
+#undef AF
+#undef AI
+#undef AD
+    if (!ok) return false;
+    // ---- envelope checks: fail loudly rather than produce different bytes than the reference ----
+    if (T.channels_out != (cfg.channels == 1 ? 1 : 2) || T.out_samplerate != cfg.samplerate || T.brate <= 0) { set_err("tables blob does not match the requested configuration"); return false; }
+    if (T.version != 1 || T.mode_gr != 2 || T.quant_comp != 9 || T.quant_comp_short != 9 || T.error_protection || T.sfb21_extra ||
+        T.substep_shaping != 0 || T.noise_shaping_amp > 2 || T.use_best_huffman > 1 || T.athaa_loudapprox != 2 || T.full_outer_loop != 0) {
+        set_err("configuration outside the supported envelope (MPEG-1 CBR, quality-3 switches)"); return false;
+    }
+    // ---- derived index tables ----
+    const int32_t* h_s3ind = (const int32_t*)host_arr("s3ind");
+    const int32_t* h_s3ind_s = (const int32_t*)host_arr("s3ind_s");
+    const int32_t* h_nl = (const int32_t*)host_arr("numlines_l");
+    const int32_t* h_ns = (const int32_t*)host_arr("numlines_s");
+    const int32_t* h_bo_l = (const int32_t*)host_arr("bo_l");
+    const int32_t* h_bo_s = (const int32_t*)host_arr("bo_s");
+    std::vector<int32_t> extra(4 * CBANDS, 0);
+    int k = 0, j = 0;
+    for (int p = 0; p < T.npart_l; p++) { extra[p] = k; k += h_s3ind[2 * p + 1] - h_s3ind[2 * p] + 1; extra[2 * CBANDS + p] = j; j += h_nl[p]; }
+    if (j != HBLKSIZE) { set_err("long partitions do not cover 513 lines"); return false; }
+    k = 0; j = 0;
+    for (int p = 0; p < T.npart_s; p++) { extra[CBANDS + p] = k; k += h_s3ind_s[2 * p + 1] - h_s3ind_s[2 * p] + 1; extra[3 * CBANDS + p] = j; j += h_ns[p]; }
+    if (j != HBLKSIZE_s) { set_err("short partitions do not cover 129 lines"); return false; }
+    for (int sb = 1; sb < SBMAX_l; sb++) if (!(h_bo_l[sb] > h_bo_l[sb - 1] || h_bo_l[sb - 1] + 1 >= T.npart_l)) { set_err("unsupported partition/sfb layout (long)"); return false; }
+    for (int sb = 1; sb < SBMAX_s; sb++) if (!(h_bo_s[sb] > h_bo_s[sb - 1] || h_bo_s[sb - 1] + 1 >= T.npart_s)) { set_err("unsupported partition/sfb layout (short)"); return false; }
+    ts.d_extra = rt::dmalloc(extra.size() * 4);
+    if (!ts.d_extra) { set_err("hipMalloc failed"); return false; }
+    if (!rt::h2d(ts.d_extra, extra.data(), extra.size() * 4, stream)) return false;
+    if (!rt::sync(stream)) return false;
+    T.s3off_l = (const int32_t*)ts.d_extra; T.s3off_s = T.s3off_l + CBANDS; T.lineoff_l = T.s3off_l + 2 * CBANDS; T.lineoff_s = T.s3off_l + 3 * CBANDS;
+    ts.pb10 = pow_log2_parts(10.0);
+    ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
+    return true;
+}
+
+// ===========================================================================================
+// per-device context: HIP stream + grow-only workspace
+// ===========================================================================================
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        rt::dfree(p);
+        cap = n + n / 4 + 4096;
+        p = rt::dmalloc(cap);
+        if (!p) { cap = 0; set_err("hipMalloc(workspace) failed"); return false; }
+        return true;
+    }
+    ~DevBuf() { rt::dfree(p); }
+};
+
+struct Context {
+    int device = 0;
+    void* stream = nullptr;
+    std::mutex mu;
+    std::map<std::string, std::shared_ptr<TableSet>> tables;
+    DevBuf pcm, fmap, gmap, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, last_attack, tent, prev_short, blocktype,
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, frame_bytes, sd, io, in16, out8;
+    // last batch (for debug taps)
+    Workspace lastW; int lastC = 0; bool have_last = false;
+};
+
+static std::mutex g_ctx_mu;
+static std::map<int, std::unique_ptr<Context>> g_ctx;
+
+static Context* get_context(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) return it->second.get();
+    std::unique_ptr<Context> c(new Context());
+    c->device = device;
+    Context* r = c.get();
+    g_ctx[device] = std::move(c);
+    return r;
+}
+
+struct lhip_stream {
+    uint32_t magic = 0x4c484950;
+    Context* ctx = nullptr;
+    std::shared_ptr<TableSet> ts;
+    StreamState* d_state = nullptr;
+    int mf_size = MF_INIT;
+    int mf_samples_to_encode = 576 + 1152;
+    int slot_lag = 0;
+    int64_t frame_num = 0;
+    ~lhip_stream() { rt::dfree(d_state); magic = 0; }
+};
+
+// ===========================================================================================
+// batch encode
+// ===========================================================================================
+struct Job {
+    lhip_stream* s; const int16_t* l; const int16_t* r; size_t n; uint8_t* out; size_t cap; int64_t written;
+    int F; int64_t bytes;
+};
+
+static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
+    int64_t npad = 0;
+    const Tables& T = ts.T;
+    if (T.frac_SpF != 0 && F > 0) {
+        const int64_t sr = T.out_samplerate;
+        int64_t m0 = slot_lag % sr; if (m0 < 0) m0 += sr;
+        const int64_t need = (int64_t)F * T.frac_SpF - m0;
+        npad = need > 0 ? (need + sr - 1) / sr : 0;
+    }
+    return (int64_t)F * ts.base_frame_bytes + npad;
+}
+
+static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
+    if (jobs.empty()) return true;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!rt::set_device(ctx->device)) return false;
+    void* st = ctx->stream;
+    TableSet& ts = *jobs[0].s->ts;
+    const Tables& T = ts.T;
+    const int C = T.channels_out;
+    const int S = (int)jobs.size();
+    // ---- plan ----
+    std::vector<StreamDesc> sd(S);
+    std::vector<StreamIO> io(S);
+    int nfs = 0, ngs = 0, nfr = 0;
+    int64_t pcm_plane = 0, in_total = 0, out_total = 0;
+    for (int i = 0; i < S; i++) {
+        Job& j = jobs[i];
+        lhip_stream* s = j.s;
+        if (s->ts.get() != &ts) { set_err("batch: all streams must share one configuration"); return false; }
+        const int64_t total = (int64_t)s->mf_size + (int64_t)j.n;
+        if (total > 0x7fffffff) { set_err("too many samples in one call"); return false; }
+        j.F = total >= MF_NEEDED ? (int)((total - MF_NEEDED) / FRAME) + 1 : 0;
+        j.bytes = batch_bytes(ts, s->slot_lag, j.F);
+        if ((size_t)j.bytes > j.cap) { j.written = LHIP_ERR_BUFFER_TOO_SMALL; set_err("output buffer too small"); return false; }
+        StreamDesc& d = sd[i];
+        memset(&d, 0, sizeof d);
+        d.nframes = j.F; d.fslot0 = nfs; d.gslot0 = ngs; d.out_slot0 = nfr;
+        d.pcm_off = pcm_plane; d.out_off = out_total; d.seg_len = (int)total; d.first_call = s->frame_num == 0;
+        d.slot_lag = s->slot_lag; d.frame_num0 = s->frame_num;
+        nfs += j.F + 1; ngs += 2 * j.F + 1; nfr += j.F;
+        pcm_plane += (total + 63) & ~(int64_t)63;
+        in_total += (int64_t)j.n; out_total += (j.bytes + 15) & ~(int64_t)15;
+    }
+    // ---- workspace ----
+    Workspace W;
+    memset(&W, 0, sizeof W);
+    W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
+    const size_t GC = (size_t)ngs * C, FR = (size_t)(nfr > 0 ? nfr : 1);
+#define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
+    ENS(pcm, (size_t)pcm_plane * C * 4 + 64); ENS(fmap, (size_t)nfs * 4); ENS(gmap, (size_t)ngs * 4);
+    ENS(peaks, GC * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GC * EBL_STRIDE * 4); ENS(mask_idx, GC * EBL_STRIDE * 4);
+    ENS(eb_s, GC * EBS_STRIDE * 4); ENS(ecb_s, GC * EBS_STRIDE * 4); ENS(att_raw, GC * 4); ENS(last_attack, GC * 4);
+    ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
+    ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
+    ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
+    ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(frame_bytes, FR * 4); ENS(sd, (size_t)S * sizeof(StreamDesc));
+    ENS(io, (size_t)S * sizeof(StreamIO));
+    if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
+#undef ENS
+    W.pcm = (float*)ctx->pcm.p; W.fslot_stream = (const int32_t*)ctx->fmap.p; W.gslot_stream = (const int32_t*)ctx->gmap.p;
+    W.peaks = (float*)ctx->peaks.p; W.loud = (float*)ctx->loud.p; W.eb_l = (float*)ctx->eb_l.p; W.mask_idx = (int32_t*)ctx->mask_idx.p;
+    W.eb_s = (float*)ctx->eb_s.p; W.ecb_s = (float*)ctx->ecb_s.p; W.att_raw = (int32_t*)ctx->att_raw.p;
+    W.last_attack = (int32_t*)ctx->last_attack.p; W.tent = (int32_t*)ctx->tent.p; W.prev_short = (int32_t*)ctx->prev_short.p;
+    W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
+    W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
+    W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
+    W.nflagged = (int32_t*)ctx->nflagged.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr;
+
+    // ---- descriptors / inputs ----
+    std::vector<int32_t> fmap(nfs), gmap(ngs);
+    int64_t in_off = 0;
+    for (int i = 0; i < S; i++) {
+        Job& j = jobs[i];
+        for (int k = 0; k <= j.F; k++) fmap[sd[i].fslot0 + k] = i;
+        for (int k = 0; k <= 2 * j.F; k++) gmap[sd[i].gslot0 + k] = i;
+        StreamIO& o = io[i];
+        o.state = j.s->d_state; o.n_new = (int)j.n; o.mf_size = j.s->mf_size;
+        if (dev_io) {
+            o.src[0] = j.l; o.src[1] = (C == 2 && j.r) ? j.r : j.l; o.out = j.out;
+        } else {
+            int16_t* base = (int16_t*)ctx->in16.p;
+            o.src[0] = base + in_off;
+            if (!rt::h2d((void*)o.src[0], j.l, j.n * 2, st)) return false;
+            in_off += (int64_t)j.n;
+            if (C == 2) {
+                o.src[1] = base + in_off;
+                if (!rt::h2d((void*)o.src[1], j.r ? j.r : j.l, j.n * 2, st)) return false;
+                in_off += (int64_t)j.n;
+            } else o.src[1] = o.src[0];
+            o.out = (uint8_t*)ctx->out8.p + sd[i].out_off;
+        }
+    }
+    if (!rt::h2d(ctx->fmap.p, fmap.data(), fmap.size() * 4, st)) return false;
+    if (!rt::h2d(ctx->gmap.p, gmap.data(), gmap.size() * 4, st)) return false;
+    if (!rt::h2d(ctx->sd.p, sd.data(), sd.size() * sizeof(StreamDesc), st)) return false;
+    if (!rt::h2d(ctx->io.p, io.data(), io.size() * sizeof(StreamIO), st)) return false;
+    if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
+    if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
+    const StreamDesc* dSD = (const StreamDesc*)ctx->sd.p;
+    const StreamIO* dIO = (const StreamIO*)ctx->io.p;
+
+    int64_t repaired = 0, iters = 0;
+    // out pointer per stream is carried in StreamIO; kb_bits reads W.out + sd.out_off, so give it a zero base
+    // and put the absolute address into out_off (device address space is 64-bit)
+    {
+        std::vector<StreamDesc> sd2 = sd;
+        for (int i = 0; i < S; i++) sd2[i].out_off = (int64_t)(uintptr_t)io[i].out;
+        if (!rt::h2d(ctx->sd.p, sd2.data(), sd2.size() * sizeof(StreamDesc), st)) return false;
+    }
+#ifdef LHIP_HOSTSIM
+    {
+        static PsyALds LA; static PsyBLds LB; static MdctLds LM; static QuantLds LQ; static BitsLds LBi;
+        for (int s = 0; s < S; s++) kb_load(T, W, dSD, dIO, s, 0);
+        for (int b = 0; b < ngs * C; b++) kb_psyA(T, W, dSD, b / C, b % C, 0, LA);
+        for (int s = 0; s < S; s++) kb_scan(T, W, dSD, s, 0);
+        for (int b = 0; b < ngs; b++) kb_psyB(T, W, dSD, b, 0, LB);
+        for (int b = 0; b < ngs * C; b++) kb_polyphase(T, W, dSD, b / C, b % C, 0);
+        for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
+        for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ);
+        for (;;) {
+            W.nflagged[0] = 0;
+            for (int b = 0; b < nfs; b++) kb_validate(T, ts.pb10, W, dSD, b, 0, LQ);
+            const int nf = W.nflagged[0];
+            if (nf == 0) break;
+            repaired += nf; iters++;
+            for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 1, 0, LQ);
+            if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
+        }
+        for (int b = 0; b < nfs; b++) kb_bits(T, W, dSD, b, 0, LBi);
+        for (int s = 0; s < S; s++) kb_save(T, W, dSD, dIO, s, 0);
+    }
+#else
+    LAUNCH(g_load, S, st, T, W, dSD, dIO);
+    LAUNCH(g_psyA, ngs * C, st, T, W, dSD);
+    LAUNCH(g_scan, S, st, T, W, dSD);
+    LAUNCH(g_psyB, ngs, st, T, W, dSD);
+    LAUNCH(g_poly, ngs * C, st, T, W, dSD);
+    LAUNCH(g_mdct, ngs, st, T, W, dSD);
+    LAUNCH(g_quant, nfs, st, T, ts.pb10, W, dSD, 0);
+    if (nfr > 0) {
+        for (;;) {
+            LAUNCH(g_validate, nfs, st, T, ts.pb10, W, dSD);
+            int32_t nf = 0;
+            if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
+            if (!rt::sync(st)) return false;
+            if (nf == 0) break;
+            repaired += nf; iters++;
+            if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
+            LAUNCH(g_quant, nfs, st, T, ts.pb10, W, dSD, 1);
+            if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
+        }
+    }
+    LAUNCH(g_bits, nfs, st, T, W, dSD);
+    LAUNCH(g_save, S, st, T, W, dSD, dIO);
+#endif
+    // ---- outputs ----
+    if (!dev_io) {
+        for (int i = 0; i < S; i++)
+            if (jobs[i].bytes > 0 && !rt::d2h(jobs[i].out, io[i].out, (size_t)jobs[i].bytes, st)) return false;
+        if (!rt::sync(st)) return false;
+    } else if (want_sync) {
+        if (!rt::sync(st)) return false;
+    }
+    // ---- host-side stream bookkeeping (Lame.js:1629-1661) ----
+    for (int i = 0; i < S; i++) {
+        Job& j = jobs[i];
+        lhip_stream* s = j.s;
+        const int64_t total = (int64_t)s->mf_size + (int64_t)j.n;
+        if (j.n > 0) {
+            if (s->mf_samples_to_encode < 1) s->mf_samples_to_encode = 576 + 1152;
+            s->mf_samples_to_encode += (int)j.n;
+        }
+        s->mf_samples_to_encode -= FRAME * j.F;
+        s->mf_size = (int)(total - (int64_t)FRAME * j.F);
+        if (T.frac_SpF != 0 && j.F > 0) {
+            int64_t m = ((int64_t)s->slot_lag - (int64_t)j.F * T.frac_SpF) % T.out_samplerate;
+            if (m < 0) m += T.out_samplerate;
+            s->slot_lag = (int)m;
+        }
+        s->frame_num += j.F;
+        j.written = j.bytes;
+    }
+    g_stat_frames = nfr; g_stat_repaired = repaired; g_stat_iters = iters;
+    ctx->lastW = W; ctx->lastC = C; ctx->have_last = true;
+    return true;
+}
+
+// ===========================================================================================
+// C ABI
+// ===========================================================================================
+extern "C" {
+
+int lhip_device_count(void) { return rt::device_count(); }
+
+const char* lhip_last_error(void) { return g_err.c_str(); }
+const char* lhip_version(void) {
+#ifdef LHIP_HOSTSIM
+    return "lamejs_amd 0.1 (HOST SIMULATION - tests only)";
+#else
+    return "lamejs_amd 0.1 (HIP gfx950)";
+#endif
+}
+
+int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes, lhip_stream** out) {
+    if (!cfg || !tables || !out) { set_err("null argument"); return LHIP_ERR_INTERNAL; }
+    *out = nullptr;
+    if (rt::device_count() <= 0) { set_err("no HIP device available (this library has no CPU fallback)"); return LHIP_ERR_INTERNAL; }
+    int dev = cfg->device;
+#ifndef LHIP_HOSTSIM
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) { set_err("hipGetDevice failed"); return LHIP_ERR_INTERNAL; } }
+#else
+    if (dev < 0) dev = 0;
+#endif
+    Context* ctx = get_context(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!rt::set_device(dev)) return LHIP_ERR_INTERNAL;
+    std::string key((const char*)tables, tables_bytes);
+    std::shared_ptr<TableSet> ts;
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) ts = it->second;
+    else {
+        ts = std::make_shared<TableSet>();
+        ts->device = dev;
+        if (!build_tables(*ts, tables, tables_bytes, *cfg, ctx->stream)) return LHIP_ERR_INTERNAL;
+        ctx->tables[key] = ts;
+    }
+    std::unique_ptr<lhip_stream> s(new lhip_stream());
+    s->ctx = ctx; s->ts = ts;
+    s->slot_lag = ts->T.frac_SpF;
+    // initial carried state (PsyModel.js:2566-2596 psymodel_init, Lame.js:168-171 lame_init_old)
+    std::unique_ptr<StreamState> h(new StreamState());
+    memset(h.get(), 0, sizeof(StreamState));
+    for (int ch = 0; ch < 2; ch++) {
+        for (int i = 0; i < E_STRIDE; i++) h->E[ch][i] = 1e20f;
+        for (int i = 0; i < EBS_STRIDE; i++) h->ecb_s[ch][i] = 1.0f;
+        for (int i = 0; i < 9; i++) h->peaks[ch][i] = 10.f;
+        h->tent[ch] = NORM_TYPE;
+        h->seed[ch][0] = 180; h->seed[ch][1] = 4;
+    }
+    h->ath_adjust = 0.01; h->ath_limit = 1.0;
+    s->d_state = (StreamState*)rt::dmalloc(sizeof(StreamState));
+    if (!s->d_state) { set_err("hipMalloc(stream state) failed"); return LHIP_ERR_INTERNAL; }
+    if (!rt::h2d(s->d_state, h.get(), sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    *out = s.release();
+    return 0;
+}
+
+void lhip_destroy(lhip_stream* s) {
+    if (!s || s->magic != 0x4c484950) return;
+    rt::set_device(s->ctx->device);
+    delete s;
+}
+
+size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples) {
+    if (!s || s->magic != 0x4c484950) return 0;
+    return (nsamples / FRAME + 3) * (size_t)(s->ts->base_frame_bytes + 1);
+}
+
+static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,
+                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync) {
+    if (n == 0) return 0;
+    std::vector<Job> jobs(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!streams[i] || streams[i]->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+        if (streams[i]->ctx != streams[0]->ctx) { set_err("batch: streams on different devices"); return LHIP_ERR_INTERNAL; }
+        jobs[i] = Job{streams[i], l[i], r ? r[i] : nullptr, ns[i], out[i], cap[i], 0, 0, 0};
+    }
+    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync);
+    for (size_t i = 0; i < n; i++) if (written) written[i] = ok ? jobs[i].written : (jobs[i].written < 0 ? jobs[i].written : LHIP_ERR_INTERNAL);
+    if (!ok) { for (auto& j : jobs) if (j.written < 0) return (int)j.written; return LHIP_ERR_INTERNAL; }
+    return 0;
+}
+
+int64_t lhip_encode(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    if (nsamples == 0) return 0;
+    if (!left) { set_err("null input"); return LHIP_ERR_INTERNAL; }
+    int64_t w = 0;
+    const int rc = encode_many(&s, 1, &left, &right, &nsamples, &out, &out_cap, &w, false, true);
+    return rc < 0 ? rc : w;
+}
+
+static size_t flush_zeros(lhip_stream* s) {
+    // Lame.js:1381-1443: how many zero samples make the remaining frames come out
+    if (s->mf_samples_to_encode < 1) return 0;
+    const int samples_to_encode = s->mf_samples_to_encode - 1152;
+    int end_padding = FRAME - (samples_to_encode % FRAME);
+    if (end_padding < 576) end_padding += FRAME;
+    const int frames_left = (samples_to_encode + end_padding) / FRAME;
+    if (frames_left <= 0) return 0;
+    return (size_t)(MF_NEEDED + FRAME * (frames_left - 1) - s->mf_size);
+}
+
+int64_t lhip_flush(lhip_stream* s, uint8_t* out, size_t out_cap) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    const size_t z = flush_zeros(s);
+    if (z == 0) { s->mf_samples_to_encode = 0; return 0; }
+    std::vector<int16_t> zeros(z, 0);
+    const int16_t* l = zeros.data();
+    const int16_t* r = zeros.data();
+    int64_t w = 0;
+    const int rc = encode_many(&s, 1, &l, &r, &z, &out, &out_cap, &w, false, true);
+    s->mf_samples_to_encode = 0;
+    return rc < 0 ? rc : w;
+}
+
+int lhip_encode_batch(lhip_stream* const* streams, size_t nstreams, const int16_t* const* left, const int16_t* const* right,
+                      const size_t* nsamples, uint8_t* const* out, const size_t* out_cap, int64_t* written) {
+    return encode_many(streams, nstreams, left, right, nsamples, out, out_cap, written, false, true);
+}
+
+int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* const* out, const size_t* out_cap, int64_t* written) {
+    std::vector<std::vector<int16_t>> zs(nstreams);
+    std::vector<const int16_t*> l(nstreams);
+    std::vector<size_t> ns(nstreams);
+    for (size_t i = 0; i < nstreams; i++) {
+        if (!streams[i] || streams[i]->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+        ns[i] = flush_zeros(streams[i]);
+        zs[i].assign(ns[i] ? ns[i] : 1, 0);
+        l[i] = zs[i].data();
+    }
+    const int rc = encode_many(streams, nstreams, l.data(), l.data(), ns.data(), out, out_cap, written, false, true);
+    for (size_t i = 0; i < nstreams; i++) streams[i]->mf_samples_to_encode = 0;
+    return rc;
+}
+
+int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const int16_t* const* d_left, const int16_t* const* d_right,
+                             const size_t* nsamples, uint8_t* const* d_out, const size_t* out_cap, int64_t* written, int sync) {
+    return encode_many(streams, nstreams, d_left, d_right, nsamples, d_out, out_cap, written, true, sync != 0);
+}
+
+int lhip_set_hip_stream(int device, void* hip_stream) {
+#ifndef LHIP_HOSTSIM
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return LHIP_ERR_INTERNAL; }
+#else
+    if (device < 0) device = 0;
+#endif
+    Context* ctx = get_context(device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stream = hip_stream;
+    return 0;
+}
+
+void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations) {
+    if (frames) *frames = g_stat_frames;
+    if (repaired_frames) *repaired_frames = g_stat_repaired;
+    if (repair_iterations) *repair_iterations = g_stat_iters;
+}
+
+int64_t lhip_debug_read(int what, void* dst, size_t cap) {
+    Context* ctx = nullptr;
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto& kv : g_ctx) if (kv.second->have_last) ctx = kv.second.get(); }
+    if (!ctx) { set_err("no batch has run"); return LHIP_ERR_INTERNAL; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    rt::set_device(ctx->device);
+    const Workspace& W = ctx->lastW;
+    const size_t GC = (size_t)W.ngslots * ctx->lastC;
+    const void* src = nullptr; size_t n = 0;
+    switch (what) {
+        case 0: src = W.xr; n = GC * 576 * 4; break;
+        case 1: src = W.blocktype; n = GC * 4; break;
+        case 2: src = W.E; n = GC * E_STRIDE * 4; break;
+        case 3: src = W.ath_adjust; n = (size_t)W.nfslots * 8; break;
+        case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ctx->lastC * sizeof(GrSide); break;
+        case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;
+        case 6: src = W.peaks; n = GC * PK_STRIDE * 4; break;
+        default: set_err("unknown tap"); return LHIP_ERR_INTERNAL;
+    }
+    if (n > cap) n = cap;
+    if (!rt::d2h(dst, src, n, ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    return (int64_t)n;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// lamejs_amd -- MI355X-native MP3 frame-encode path: shared definitions.
+//
+// Number model (the bit-exactness contract): every arithmetic expression is
+// IEEE f64; values the reference keeps in Float32Array are `float` here and are rounded
+// exactly at the reference's store points; Int32Array stores truncate (js_toint32).
+// All device code is compiled with -ffp-contract=off (no FMA may ever be formed).
+//
+// The kernel bodies in this directory are written as *wave programs*: NL lanes execute the
+// same uniform control flow, `for (i = lane; i < n; i += NL)` loops have independent
+// iterations, and cross-lane traffic goes through LDS or the wave_* helpers.  NL is 64 on
+// gfx950.  A test-only build (tests/hostsim, -DLHIP_HOSTSIM) compiles the same bodies with
+// NL = 1 for logic checks on a CPU; the product library contains the HIP build only.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef LHIP_HOSTSIM
+#include <math.h>
+#include <string.h>
+#define LHIP_DEV static inline
+#define LHIP_NL 1
+#else
+#include <hip/hip_runtime.h>
+#define LHIP_DEV static __device__ __forceinline__
+#define LHIP_NL 64
+#endif
+
+namespace lhip {
+
+enum {
+    SBMAX_l = 22, SBMAX_s = 13, SBPSY_l = 21, SBPSY_s = 12, PSFB21 = 6, PSFB12 = 6,
+    CBANDS = 64, BLKSIZE = 1024, HBLKSIZE = 513, BLKSIZE_s = 256, HBLKSIZE_s = 129, SFBMAX = 39,
+    NORM_TYPE = 0, START_TYPE = 1, SHORT_TYPE = 2, STOP_TYPE = 3,
+    IXMAX_VAL = 8206, PRECALC_SIZE = IXMAX_VAL + 2, Q_MAX = 257, Q_MAX2 = 116, LARGE_BITS = 100000,
+    MAX_BITS_PER_CHANNEL = 4095, MAX_BITS_PER_GRANULE = 7680,
+    FRAME = 1152, GRAN = 576, MF_NEEDED = 1904, MF_INIT = 528
+};
+
+#define LHIP_SQRT2 1.41421356237309504880
+
+// Read-only configuration + lookup tables, resident in HBM; built once per stream
+// configuration from the LHTB blob of lamejs_amd/js/tables.js.  Plain pointers only.
+struct Tables {
+    // scalars (ints)
+    int channels_out, mode, mode_gr, version, samplerate_index, bitrate_index, brate, out_samplerate,
+        sideinfo_len, frac_SpF, noise_shaping, noise_shaping_amp, noise_shaping_stop, subblock_gain,
+        use_best_huffman, full_outer_loop, substep_shaping, sfb21_extra, quant_comp, quant_comp_short,
+        short_blocks_coupled, useTemporal, ATH_useAdjust, athaa_loudapprox, copyright, original, emphasis,
+        extension, error_protection, npart_l, npart_s, n_version_bytes;
+    // scalars (doubles)
+    double scale, attackthre, attackthre_s, interChRatio, masking_lower_long, masking_lower_short,
+        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE;
+    // arrays
+    const float *amp_filter, *ATH_l, *ATH_s, *ATH_psfb21, *ATH_psfb12, *ATH_cb_l, *ATH_cb_s, *eql_w,
+        *pow43, *adj43, *ipow20, *pow20, *longfact, *shortfact, *rnumlines_l, *bo_l_weight, *bo_s_weight,
+        *s3_ll, *s3_ss, *window, *window_s;
+    const int32_t *sfb_l, *sfb_s, *psfb21, *psfb12, *bv_scf, *numlines_l, *numlines_s, *bo_l, *bm_l, *bo_s,
+        *bm_s, *s3ind, *s3ind_s, *fft_rv_tbl, *mdct_order, *pretab, *scfsi_band, *slen1_n, *slen2_n,
+        *slen1_tab, *slen2_tab, *scale_short, *scale_long, *huf_tbl_noESC, *version_bytes, *ht_xlen,
+        *ht_linmax, *ht_off, *ht_code, *ht_hlen, *largetbl, *table23, *table56, *t32l, *t33l;
+    const double *fht_twiddle, *fht_costab, *enwindow, *mdct_win, *ma_tab, *ma_table1, *ma_table2, *ma_table3,
+        *hpf_fircoef;
+    // derived on the host at create time (device pointers)
+    const int32_t *s3off_l, *s3off_s;       // start offset of partition b inside s3_ll / s3_ss
+    const int32_t *lineoff_l, *lineoff_s;   // first FFT line of partition b
+};
+
+// Per-granule-channel side information produced by the quantization kernel and consumed by the
+// bit-packing kernel (the subset of the reference's GrInfo that reaches the bitstream).
+struct GrSide {
+    int32_t part2_3_length, part2_length, big_values, count1, global_gain, scalefac_compress, block_type;
+    int32_t table_select[3], subblock_gain[3];
+    int32_t region0_count, region1_count, preflag, scalefac_scale, count1table_select;
+    int32_t sfbmax, sfbdivide;
+    int32_t active;                          // 1 if the granule had energy (bin search / outer loop ran)
+    int32_t bs_start, bs_step_in, bs_gain;   // bin-search seed used + resulting gain (seed-chain validation)
+    int32_t targ_bits;
+    int32_t scfsi;                           // gr1 only: bit i = scfsi[ch][i]
+    int32_t scalefac[SFBMAX];
+};
+
+}  // namespace lhip

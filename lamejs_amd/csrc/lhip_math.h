@@ -1,0 +1,229 @@
+// Device math that must agree bit-for-bit with the reference's host engine (V8 7.8 `Math.*`,
+// v8/src/base/ieee754.cc, fdlibm lineage -- third party, not part of /root/reference):
+//   Math.log10(x)       -> v8_log10()   used by mask_add, calc_noise, athAdjust
+//   Math.pow(10, y)     -> v8_pow10()   used by athAdjust
+//   Math.pow(x, 0.5)    -> sqrt(x)      (fdlibm/V8 shortcut for y == 0.5)
+//   (0 | x), Int32Array -> js_toint32()
+// Only f64 +,-,*,/ and integer bit manipulation are used; no FMA (-ffp-contract=off).
+// v8_pow10 exploits that the base is the constant 10: the first half of the fdlibm pow
+// algorithm (log2(x) as a hi/lo pair) depends on x alone, so it is evaluated once on the
+// host (pow_log2_parts) and the device only runs the y-dependent half.
+#pragma once
+#include "lhip_defs.h"
+
+namespace lhip {
+
+#ifdef LHIP_HOSTSIM
+LHIP_DEV uint32_t d_hi(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
+LHIP_DEV uint32_t d_lo(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; }
+LHIP_DEV double d_make(uint32_t hi, uint32_t lo) { uint64_t u = ((uint64_t)hi << 32) | lo; double x; memcpy(&x, &u, 8); return x; }
+LHIP_DEV double d_sqrt(double x) { return sqrt(x); }
+LHIP_DEV double d_abs(double x) { return fabs(x); }
+#else
+LHIP_DEV uint32_t d_hi(double x) { return (uint32_t)__double2hiint(x); }
+LHIP_DEV uint32_t d_lo(double x) { return (uint32_t)__double2loint(x); }
+LHIP_DEV double d_make(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
+LHIP_DEV double d_sqrt(double x) { return __builtin_sqrt(x); }   // correctly rounded f64 sqrt
+LHIP_DEV double d_abs(double x) { return __builtin_fabs(x); }
+#endif
+LHIP_DEV double d_with_hi(double x, uint32_t hi) { return d_make(hi, d_lo(x)); }
+LHIP_DEV double d_trunc_lo(double x) { return d_make(d_hi(x), 0u); }
+
+// ECMAScript ToInt32 for the values this path produces (finite, |x| < 2^31 in practice).
+LHIP_DEV int32_t js_toint32(double d) {
+    if (!(d == d)) return 0;
+    if (d >= -2147483648.0 && d <= 2147483647.0) return (int32_t)d;
+    // out-of-range: wrap modulo 2^32 (never reached by in-envelope inputs; kept for fidelity)
+    if (d_abs(d) > 1.0e300) return 0;
+    double t = (d < 0) ? -(double)(uint64_t)(-d) : (double)(uint64_t)d;
+    double q = t / 4294967296.0;
+    double fl = (double)(int64_t)q; if (fl > q) fl -= 1.0;
+    double m = t - fl * 4294967296.0;
+    return (int32_t)(uint32_t)m;
+}
+
+// natural logarithm, fdlibm method: x = 2^k (1+f); log(1+f) = f - s*(f - R(s^2)) ..., Remez poly
+LHIP_DEV double v8_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 two54 = 1.80143985094819840000e+16;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int32_t hx = (int32_t)d_hi(x);
+    uint32_t lx = d_lo(x);
+    int32_t k = 0;
+    if (hx < 0x00100000) {
+        if (((hx & 0x7fffffff) | lx) == 0) return -two54 / 0.0;
+        if (hx < 0) return (x - x) / 0.0;
+        k -= 54;
+        x *= two54;
+        hx = (int32_t)d_hi(x);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = d_with_hi(x, (uint32_t)(hx | (i ^ 0x3ff00000)));
+    k += (i >> 20);
+    double f = x - 1.0;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            double dk = (double)k;
+            return dk * ln2_hi + dk * ln2_lo;
+        }
+        double R = f * f * (0.5 - 0.33333333333333333 * f);
+        if (k == 0) return f - R;
+        double dk = (double)k;
+        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    double s = f / (2.0 + f);
+    double dk = (double)k;
+    double z = s * s;
+    i = hx - 0x6147a;
+    double w = z * z;
+    int32_t j = 0x6b851 - hx;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    double R = t2 + t1;
+    if (i > 0) {
+        double hfsq = 0.5 * f * f;
+        if (k == 0) return f - (hfsq - s * (hfsq + R));
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+LHIP_DEV double v8_log10(double x) {
+    const double two54 = 1.80143985094819840000e+16, ivln10 = 4.34294481903251816668e-01,
+                 log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+    int32_t hx = (int32_t)d_hi(x);
+    uint32_t lx = d_lo(x);
+    int32_t k = 0;
+    if (hx < 0x00100000) {
+        if (((hx & 0x7fffffff) | lx) == 0) return -two54 / 0.0;
+        if (hx < 0) return (x - x) / 0.0;
+        k -= 54;
+        x *= two54;
+        hx = (int32_t)d_hi(x);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    int32_t i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+    hx = (hx & 0x000fffff) | ((0x3ff - i) << 20);
+    double y = (double)(k + i);
+    x = d_with_hi(x, (uint32_t)hx);
+    double z = y * log10_2lo + ivln10 * v8_log(x);
+    return z + y * log10_2hi;
+}
+
+// ---- pow(x, y), x > 0 finite normal (x == 10 on this path), |y| < 2^31 ----
+struct PowBase { double t1, t2; };   // log2(x) = t1 + t2, t1 with a zeroed low word
+
+// x-dependent half (host side, once per table set).  Valid for positive normal x, any y with |y| <= 2^31.
+static inline PowBase pow_log2_parts(double x) {
+    const double bp[2] = {1.0, 1.5}, dp_h[2] = {0.0, 5.84962487220764160156e-01},
+                 dp_l[2] = {0.0, 1.35003920212974897128e-08};
+    const double L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01, L3 = 3.33333329818377432918e-01,
+                 L4 = 2.72728123808534006489e-01, L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01,
+                 cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01, cp_l = -7.02846165095275826516e-09;
+    uint64_t ub; __builtin_memcpy(&ub, &x, 8);
+    int32_t ix = (int32_t)(ub >> 32) & 0x7fffffff;
+    int32_t n = (ix >> 20) - 0x3ff, k;
+    int32_t j = ix & 0x000fffff;
+    ix = j | 0x3ff00000;
+    if (j <= 0x3988E) k = 0;
+    else if (j < 0xBB67A) k = 1;
+    else { k = 0; n += 1; ix -= 0x00100000; }
+    auto mk = [](uint32_t hi, uint32_t lo) { uint64_t u = ((uint64_t)hi << 32) | lo; double d; __builtin_memcpy(&d, &u, 8); return d; };
+    auto lo_of = [](double d) { uint64_t u; __builtin_memcpy(&u, &d, 8); return (uint32_t)u; };
+    auto hi_of = [](double d) { uint64_t u; __builtin_memcpy(&u, &d, 8); return (uint32_t)(u >> 32); };
+    double ax = mk((uint32_t)ix, (uint32_t)ub);
+    double u = ax - bp[k];
+    double v = 1.0 / (ax + bp[k]);
+    double ss = u * v;
+    double s_h = mk(hi_of(ss), 0);
+    double t_h = mk((uint32_t)(((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18)), 0);
+    double t_l = ax - (t_h - bp[k]);
+    double s_l = v * ((u - s_h * t_h) - s_h * t_l);
+    double s2 = ss * ss;
+    double r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+    r += s_l * (s_h + ss);
+    s2 = s_h * s_h;
+    t_h = 3.0 + s2 + r;
+    t_h = mk(hi_of(t_h), 0);
+    t_l = r - ((t_h - 3.0) - s2);
+    u = s_h * t_h;
+    v = s_l * t_h + t_l * ss;
+    double p_h = u + v;
+    p_h = mk(hi_of(p_h), 0);
+    double p_l = v - (p_h - u);
+    double z_h = cp_h * p_h;
+    double z_l = cp_l * p_h + p_l * cp + dp_l[k];
+    double t = (double)n;
+    PowBase pb;
+    pb.t1 = (((z_h + z_l) + dp_h[k]) + t);
+    pb.t1 = mk(hi_of(pb.t1), 0);
+    pb.t2 = z_l - (((pb.t1 - t) - dp_h[k]) - z_h);
+    (void)lo_of;
+    return pb;
+}
+
+// y-dependent half: 2^(y * (t1 + t2)) with the engine's exact operation order (including its
+// divisor grouping in the final rational step, which differs from Sun's fdlibm).
+LHIP_DEV double v8_pow_from_parts(double y, double t1, double t2) {
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+                 lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01, lg2_l = -1.90465429995776804525e-09,
+                 ovt = 8.0085662595372944372e-0017, huge = 1.0e300, tiny = 1.0e-300;
+    if (y == 0.0) return 1.0;
+    double y1 = d_trunc_lo(y);
+    double p_l = (y - y1) * t1 + y * t2;
+    double p_h = y1 * t1;
+    double z = p_l + p_h;
+    int32_t j = (int32_t)d_hi(z), i = (int32_t)d_lo(z);
+    if (j >= 0x40900000) {
+        if (((j - 0x40900000) | i) != 0) return huge * huge;
+        if (p_l + ovt > z - p_h) return huge * huge;
+    } else if ((j & 0x7fffffff) >= 0x4090cc00) {
+        if (((j - (int32_t)0xc090cc00) | i) != 0) return tiny * tiny;
+        if (p_l <= z - p_h) return tiny * tiny;
+    }
+    i = j & 0x7fffffff;
+    int32_t k = (i >> 20) - 0x3ff;
+    int32_t n = 0;
+    if (i > 0x3fe00000) {
+        n = j + (0x00100000 >> (k + 1));
+        k = ((n & 0x7fffffff) >> 20) - 0x3ff;
+        double t = d_make((uint32_t)(n & ~(0x000fffff >> k)), 0);
+        n = ((n & 0x000fffff) | 0x00100000) >> (20 - k);
+        if (j < 0) n = -n;
+        p_h -= t;
+    }
+    double t = d_trunc_lo(p_l + p_h);
+    double u = t * lg2_h;
+    double v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+    z = u + v;
+    double w = v - (z - u);
+    t = z * z;
+    double tt1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double r = (z * tt1) / ((tt1 - 2.0) - (w + z * w));
+    z = 1.0 - (r - z);
+    j = (int32_t)d_hi(z);
+    j += (n << 20);
+    if ((j >> 20) <= 0) {
+        // subnormal result: scale by 2^n in two exact steps (scalbn)
+        const double twom54 = 5.55111512312578270212e-17;
+        int32_t hz = (int32_t)d_hi(z);
+        int32_t kk = ((hz & 0x7ff00000) >> 20) + n;
+        if (kk <= -54) return tiny * tiny;
+        kk += 54;
+        z = d_with_hi(z, (uint32_t)((hz & 0x800fffff) | (kk << 20)));
+        return z * twom54;
+    }
+    return d_with_hi(z, (uint32_t)j);
+}
+
+}  // namespace lhip

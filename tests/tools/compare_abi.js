@@ -1,0 +1,69 @@
+/*
+ * TEST TOOL (needs /root/reference): encode a corpus with the unmodified reference and with the
+ * CPU oracle (tests/hostsim/_build/abi_cli_hostsim) and byte-compare.
+ * usage: node tests/tools/compare_oracle.js <corpus> <channels> <kbps> [nframes] [chunk]
+ *   corpus: wav | sine | bursts
+ */
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const cp = require('child_process');
+const { refPublic, REF } = require('./ref_harness.js');
+const gen = require('./pcm_gen.js');
+const tables = require('../../lamejs_amd/js/tables.js');
+
+const [corpus, chS, kbS, nfS, chunkS] = process.argv.slice(2);
+const ch = +chS, kbps = +kbS, nframes = +(nfS || 300), chunk = +(chunkS || 1152);
+let L, R;
+if (corpus == 'wav') {
+    L = gen.readWav(fs.readFileSync(path.join(REF, 'testdata/Left44100.wav'))).samples;
+    R = ch == 2 ? gen.readWav(fs.readFileSync(path.join(REF, 'testdata/Right44100.wav'))).samples : null;
+    /* the reference's own test feeds only whole 1152-sample chunks (Tests.js:27-33) */
+    const n = Math.floor(L.length / 1152) * 1152;
+    L = L.subarray(0, n); if (R) R = R.subarray(0, n);
+} else {
+    [L, R] = gen[corpus](nframes * 1152, ch);
+}
+
+function encodeRef() {
+    const lamejs = refPublic();
+    const enc = new lamejs.Mp3Encoder(ch, 44100, kbps);
+    const parts = [];
+    for (let i = 0; i < L.length; i += chunk) {
+        const l = L.subarray(i, i + chunk), r = R ? R.subarray(i, i + chunk) : undefined;
+        const b = ch == 2 ? enc.encodeBuffer(l, r) : enc.encodeBuffer(l);
+        if (b.length) parts.push(Buffer.from(b.buffer, b.byteOffset, b.length));
+    }
+    const f = enc.flush();
+    if (f.length) parts.push(Buffer.from(f.buffer, f.byteOffset, f.length));
+    return Buffer.concat(parts);
+}
+
+const tmp = fs.mkdtempSync('/tmp/lo_cmp_');
+const blob = tables.buildBlob(ch, 44100, kbps).blob;
+fs.writeFileSync(path.join(tmp, 't.bin'), blob);
+const inter = new Int16Array(L.length * ch);
+for (let i = 0; i < L.length; i++) { inter[i * ch] = L[i]; if (ch == 2) inter[i * ch + 1] = R[i]; }
+fs.writeFileSync(path.join(tmp, 'in.pcm'), Buffer.from(inter.buffer));
+const t0 = Date.now();
+const ref = encodeRef();
+const tRef = Date.now() - t0;
+const cli = path.join(__dirname, '../../tests/hostsim/_build/abi_cli_hostsim');
+const r = cp.spawnSync(process.env.LHIP_CLI || cli, [path.join(tmp, 't.bin'), path.join(tmp, 'in.pcm'), path.join(tmp, 'out.mp3'), '' + ch, '44100', '' + kbps].concat(process.env.LHIP_CHUNK ? [process.env.LHIP_CHUNK] : []), { encoding: 'utf8' });
+if (r.status !== 0) { console.log('oracle failed:', r.stderr); process.exit(2); }
+const mine = fs.readFileSync(path.join(tmp, 'out.mp3'));
+const md5 = (b) => require('crypto').createHash('md5').update(b).digest('hex');
+console.log('ref   :', ref.length, 'bytes md5', md5(ref), tRef, 'ms');
+console.log('abi   :', mine.length, 'bytes md5', md5(mine), r.stderr.trim());
+if (ref.equals(mine)) { console.log('IDENTICAL'); process.exit(0); }
+let d = 0; while (d < Math.min(ref.length, mine.length) && ref[d] == mine[d]) d++;
+/* locate the frame: walk frame sizes from the headers */
+let pos = 0, fr = 0;
+while (pos < ref.length) {
+    const pad = (ref[pos + 2] >> 1) & 1;
+    const len = Math.floor(144000 * kbps / 44100) + pad;
+    if (d < pos + len) break;
+    pos += len; fr++;
+}
+console.log('FIRST DIFF at byte', d, '= frame', fr, 'offset', d - pos, '(bit ~' + (d - pos) * 8 + ')');
+process.exit(1);
