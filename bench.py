@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- 1152-sample frames/s of the MI355X-native lamejs encode path (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch: the BASELINE config-2 workload (mono 44.1 kHz,
+128 kbps CBR, 1e5 synthetic sine+noise frames in ONE stream) per GPU, Int16 PCM resident in HBM when
+the timed region starts, MP3 bytes left in HBM.  With N > 1 GPUs every rank encodes its own stream
+(seed 12345 + rank): independent streams, no data-path collective ("weak" scaling); RCCL is used once,
+untimed, to broadcast the table blob and to gather output digests.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, algorithmic
+bytes / measured kernel time vs HBM peak) and `cpu_baseline` (the CPU oracle -- a plain-C port of the
+reference -- timed on one host core on a bounded sample).
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CH, SR, KBPS = 1, 44100, 128
+ALG_BYTES_PER_FRAME = 1152 * CH * 2 + 417.96   # Int16 PCM in + MP3 bytes out: 2722 B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=100000, help="frames per step per GPU (BASELINE: 1e5)")
+    ap.add_argument("--cpu-frames", type=int, default=40000, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--check-frames", type=int, default=2000, help="prefix checked against the CPU oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import lamejs_amd
+    import pcm
+
+    lib = lamejs_amd.load_library()
+    nfr = args.frames
+    nsamp = 1152 * nfr
+
+    # table blob: rank 0 builds it with the host JavaScript, everyone receives it over RCCL (setup, untimed)
+    if world > 1:
+        if rank == 0:
+            blob = lamejs_amd.tables_blob(CH, SR, KBPS)
+            n = torch.tensor([len(blob)], device=dev, dtype=torch.int64)
+        else:
+            n = torch.zeros(1, device=dev, dtype=torch.int64)
+        dist.broadcast(n, 0)
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev) if rank == 0 else torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        blob = bytes(t.cpu().numpy().tobytes())
+    else:
+        blob = lamejs_amd.tables_blob(CH, SR, KBPS)
+
+    L, _ = pcm.sine(nsamp, CH, seed=12345 + rank)
+    d_pcm = torch.from_numpy(L).to(dev)                      # Int16 PCM resident in HBM
+    cap = lib.lhip_max_output_bytes.__call__  # noqa
+    out_cap = (nfr + 4) * 419
+    d_out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
+
+    cfg = lamejs_amd._Config(CH, SR, KBPS, local_rank)
+    bbuf = ctypes.create_string_buffer(blob, len(blob))
+
+    def new_stream():
+        h = ctypes.c_void_p()
+        rc = lib.lhip_create(ctypes.byref(cfg), bbuf, len(blob), ctypes.byref(h))
+        assert rc == 0, lib.lhip_last_error()
+        return h
+
+    lib.lhip_set_hip_stream(local_rank, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    H1 = ctypes.c_void_p * 1
+    S1 = ctypes.c_size_t * 1
+    wr = (ctypes.c_int64 * 1)()
+
+    def step(h):
+        rc = lib.lhip_encode_batch_device(H1(h), 1, H1(d_pcm.data_ptr()), H1(d_pcm.data_ptr()), S1(nsamp), H1(d_out.data_ptr()), S1(out_cap), wr, 0)
+        assert rc == 0, lib.lhip_last_error()
+        return wr[0]
+
+    streams = [new_stream() for _ in range(args.warmup + args.steps)]
+    for w in range(args.warmup):
+        step(streams[w])
+    torch.cuda.synchronize()
+    lib.lhip_kernel_timing(0)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbytes = 0
+    for s in range(args.steps):
+        nbytes = step(streams[args.warmup + s])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    lib.lhip_last_batch_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    frames_per_step = a.value
+    mp3 = d_out[:nbytes].cpu().numpy().tobytes()
+
+    # parity spot check against the CPU oracle on a prefix (bit-exact) -- checker only, outside the timed region
+    parity = None
+    if args.check_frames > 0:
+        from oracle_py import oracle_encode
+        k = min(args.check_frames, nfr - 2)
+        ref = oracle_encode(CH, SR, KBPS, L[: 1152 * k], flush=False)
+        parity = bool(mp3[: len(ref)] == ref)
+
+    # per-kernel timing pass (untimed extra step with HIP events on the launch stream)
+    kern = {}
+    extra = new_stream()
+    nk = lib.lhip_kernel_timing(1)
+    step(extra)
+    torch.cuda.synchronize()
+    for i in range(nk):
+        name = ctypes.c_char_p(); ms = ctypes.c_double(); cnt = ctypes.c_int64()
+        lib.lhip_kernel_times.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+        lib.lhip_kernel_times(i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(cnt))
+        if cnt.value:
+            kern[name.value.decode()] = {"ms": round(ms.value, 4), "launches": cnt.value}
+    lib.lhip_kernel_timing(0)
+    dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+
+    digests = [hashlib.md5(mp3).hexdigest()]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, digests[0])
+        digests = gathered
+
+    if rank == 0:
+        total_frames = frames_per_step * args.steps * world
+        value = total_frames / dt
+        line = {
+            "metric": "1152-sample frames/s encoded (44.1kHz 128kbps CBR); bit-exact",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: mono 44.1kHz 128kbps CBR, 1e5 synthetic sine+noise frames, one stream per GPU",
+                       "frames_per_step_per_gpu": frames_per_step, "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
+                       "bit_exact_prefix_vs_oracle": parity, "seed_repaired_frames": b.value, "output_md5_per_rank": digests},
+            "kernels_ms": kern,
+        }
+        if dom:
+            kt = kern[dom]["ms"] / max(kern[dom]["launches"], 1) / 1000.0
+            alg = ALG_BYTES_PER_FRAME * frames_per_step
+            ach = alg / kt / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                                "note": "path is latency/ALU bound (SURVEY.md 8d): HBM fraction is small by construction"}
+        if args.cpu_frames > 0:
+            from oracle_py import oracle_encode
+            k = min(args.cpu_frames, nfr)
+            t1 = time.perf_counter()
+            oracle_encode(CH, SR, KBPS, L[: 1152 * k])
+            cdt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(k / cdt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": f"first {k} frames of the same stream, plain-C oracle (oracle/), 1 thread"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,16 @@ void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* r
  * Returns bytes copied or <0. */
 int64_t lhip_debug_read(int what, void* dst, size_t cap);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline
+ * line).  lhip_kernel_timing(1) resets and enables, returns the number of kernels; lhip_kernel_times(i)
+ * reports name / accumulated milliseconds / launches of kernel i. */
+int lhip_kernel_timing(int enable);
+int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* launches);
+
+/* Test hook: evaluate the device math used by the path on n doubles.  op: 0 log10, 1 pow(10,x), 2 sqrt,
+ * 3 1/x, 4 (double)(float)x, 5 ToInt32, 6 x/3 + x*0.1 (must not fuse). */
+int lhip_debug_math(int op, const double* in, double* out, size_t n);
+
 const char* lhip_last_error(void);
 const char* lhip_version(void);
 

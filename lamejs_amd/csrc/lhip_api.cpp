@@ -172,8 +172,51 @@ __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const Stream
     __shared__ BitsLds L;
     kb_bits(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-#define LAUNCH(kern, nblk, st, ...) do { if ((nblk) > 0) { hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); \
+// optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
+enum { KT_LOAD, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
+static const char* const g_kt_names[KT_N] = {"load", "psyA", "scan", "psyB", "polyphase", "mdct", "quant", "validate", "repair", "bits", "save"};
+static bool g_kt_on = false;
+static double g_kt_ms[KT_N];
+static int64_t g_kt_calls[KT_N];
+struct KtPending { int id; hipEvent_t a, b; };
+static std::vector<KtPending> g_kt_pending;
+static void kt_begin(int id, void* st) {
+    if (!g_kt_on) return;
+    KtPending p; p.id = id;
+    hipEventCreate(&p.a); hipEventCreate(&p.b);
+    hipEventRecord(p.a, (hipStream_t)st);
+    g_kt_pending.push_back(p);
+}
+static void kt_end(void* st) { if (g_kt_on && !g_kt_pending.empty()) hipEventRecord(g_kt_pending.back().b, (hipStream_t)st); }
+static void kt_collect() {
+    for (auto& p : g_kt_pending) {
+        float ms = 0.f;
+        hipEventSynchronize(p.b);
+        hipEventElapsedTime(&ms, p.a, p.b);
+        g_kt_ms[p.id] += ms; g_kt_calls[p.id]++;
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    g_kt_pending.clear();
+}
+#define LAUNCH(id, kern, nblk, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); \
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
+
+__global__ void g_math(int op, const double* in, double* out, size_t n, PowBase pb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    double r = 0;
+    switch (op) {
+        case 0: r = v8_log10(x); break;
+        case 1: r = v8_pow_from_parts(x, pb.t1, pb.t2); break;
+        case 2: r = d_sqrt(x); break;
+        case 3: r = 1.0 / x; break;
+        case 4: r = (double)(float)x; break;
+        case 5: r = (double)js_toint32(x); break;
+        case 6: r = x / 3.0 + x * 0.1; break;
+    }
+    out[i] = r;
+}
 #endif
 
 // ===========================================================================================
@@ -494,28 +537,28 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int s = 0; s < S; s++) kb_save(T, W, dSD, dIO, s, 0);
     }
 #else
-    LAUNCH(g_load, S, st, T, W, dSD, dIO);
-    LAUNCH(g_psyA, ngs * C, st, T, W, dSD);
-    LAUNCH(g_scan, S, st, T, W, dSD);
-    LAUNCH(g_psyB, ngs, st, T, W, dSD);
-    LAUNCH(g_poly, ngs * C, st, T, W, dSD);
-    LAUNCH(g_mdct, ngs, st, T, W, dSD);
-    LAUNCH(g_quant, nfs, st, T, ts.pb10, W, dSD, 0);
+    LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);
+    LAUNCH(KT_PSYA, g_psyA, ngs * C, st, T, W, dSD);
+    LAUNCH(KT_SCAN, g_scan, S, st, T, W, dSD);
+    LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
+    LAUNCH(KT_POLY, g_poly, ngs * C, st, T, W, dSD);
+    LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
+    LAUNCH(KT_QUANT, g_quant, nfs, st, T, ts.pb10, W, dSD, 0);
     if (nfr > 0) {
         for (;;) {
-            LAUNCH(g_validate, nfs, st, T, ts.pb10, W, dSD);
+            LAUNCH(KT_VALIDATE, g_validate, nfs, st, T, ts.pb10, W, dSD);
             int32_t nf = 0;
             if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
             if (!rt::sync(st)) return false;
             if (nf == 0) break;
             repaired += nf; iters++;
             if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
-            LAUNCH(g_quant, nfs, st, T, ts.pb10, W, dSD, 1);
+            LAUNCH(KT_REPAIR, g_quant, nfs, st, T, ts.pb10, W, dSD, 1);
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
     }
-    LAUNCH(g_bits, nfs, st, T, W, dSD);
-    LAUNCH(g_save, S, st, T, W, dSD, dIO);
+    LAUNCH(KT_BITS, g_bits, nfs, st, T, W, dSD);
+    LAUNCH(KT_SAVE, g_save, S, st, T, W, dSD, dIO);
 #endif
     // ---- outputs ----
     if (!dev_io) {
@@ -525,6 +568,9 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     } else if (want_sync) {
         if (!rt::sync(st)) return false;
     }
+#ifndef LHIP_HOSTSIM
+    if (g_kt_on) { if (!rt::sync(st)) return false; kt_collect(); }
+#endif
     // ---- host-side stream bookkeeping (Lame.js:1629-1661) ----
     for (int i = 0; i < S; i++) {
         Job& j = jobs[i];
@@ -733,6 +779,56 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
     if (n > cap) n = cap;
     if (!rt::d2h(dst, src, n, ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
     return (int64_t)n;
+}
+
+int lhip_kernel_timing(int enable) {
+#ifndef LHIP_HOSTSIM
+    g_kt_on = enable != 0;
+    for (int i = 0; i < KT_N; i++) { g_kt_ms[i] = 0; g_kt_calls[i] = 0; }
+    return KT_N;
+#else
+    (void)enable; return 0;
+#endif
+}
+
+int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* launches) {
+#ifndef LHIP_HOSTSIM
+    if (idx < 0 || idx >= KT_N) return -1;
+    if (name) *name = g_kt_names[idx];
+    if (total_ms) *total_ms = g_kt_ms[idx];
+    if (launches) *launches = g_kt_calls[idx];
+    return 0;
+#else
+    (void)idx; (void)name; (void)total_ms; (void)launches; return -1;
+#endif
+}
+
+int lhip_debug_math(int op, const double* in, double* out, size_t n) {
+#ifndef LHIP_HOSTSIM
+    double *din = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&din, n * 8) != hipSuccess || hipMalloc((void**)&dout, n * 8) != hipSuccess) { set_err("hipMalloc failed"); return LHIP_ERR_INTERNAL; }
+    hipMemcpy(din, in, n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(g_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, din, dout, n, pow_log2_parts(10.0));
+    hipError_t e = hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost);
+    hipFree(din); hipFree(dout);
+    if (e != hipSuccess) { set_err(hipGetErrorString(e)); return LHIP_ERR_INTERNAL; }
+    return 0;
+#else
+    const PowBase pb = pow_log2_parts(10.0);
+    for (size_t i = 0; i < n; i++) {
+        const double x = in[i];
+        switch (op) {
+            case 0: out[i] = v8_log10(x); break;
+            case 1: out[i] = v8_pow_from_parts(x, pb.t1, pb.t2); break;
+            case 2: out[i] = d_sqrt(x); break;
+            case 3: out[i] = 1.0 / x; break;
+            case 4: out[i] = (double)(float)x; break;
+            case 5: out[i] = (double)js_toint32(x); break;
+            default: out[i] = x / 3.0 + x * 0.1; break;
+        }
+    }
+    return 0;
+#endif
 }
 
 }  // extern "C"

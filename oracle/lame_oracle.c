@@ -438,3 +438,19 @@ long lo_flush(lo_enc* e, uint8_t* out, size_t cap) {
 void lo_enable_tap(lo_enc* e) { if (!e->tap) e->tap = (lo_tap*)calloc(1, sizeof(lo_tap)); }
 const void* lo_get_tap(const lo_enc* e) { return e->tap; }
 size_t lo_tap_size(void) { return sizeof(lo_tap); }
+
+/* test hook mirroring lhip_debug_math: the oracle's V8-exact math on n doubles */
+void lo_math(int op, const double* in, double* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        const double x = in[i];
+        switch (op) {
+            case 0: out[i] = v8_log10(x); break;
+            case 1: out[i] = v8_pow(10.0, x); break;
+            case 2: out[i] = sqrt(x); break;
+            case 3: out[i] = 1.0 / x; break;
+            case 4: out[i] = (double)(float)x; break;
+            case 5: out[i] = (double)js_toint32(x); break;
+            default: out[i] = x / 3.0 + x * 0.1; break;
+        }
+    }
+}

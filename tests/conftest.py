@@ -1,0 +1,38 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return json.loads((ROOT / "tests" / "golden" / "golden.json").read_text())["cases"]
+
+
+def load_case_pcm(case):
+    """PCM of a golden case: committed excerpt for the reference's fixtures, regenerated for synthetic corpora."""
+    import hashlib
+    import pcm
+
+    ch, n = case["channels"], case["nsamples"]
+    if case["corpus"] == "wavexcerpt":
+        L = np.fromfile(ROOT / "tests" / "golden" / "left44100_excerpt.s16", dtype="<i2")[:n]
+        R = np.fromfile(ROOT / "tests" / "golden" / "right44100_excerpt.s16", dtype="<i2")[:n] if ch == 2 else None
+    else:
+        L, R = pcm.CORPORA[case["corpus"]](n, ch)
+    h = hashlib.md5()
+    h.update(L.tobytes())
+    if R is not None:
+        h.update(R.tobytes())
+    assert h.hexdigest() == case["pcm_md5"], "PCM generator drifted from the fixture generator"
+    return L, R

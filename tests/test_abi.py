@@ -1,0 +1,36 @@
+"""The C-ABI library must load without a GPU and export every symbol include/lamejs_hip.h declares."""
+import ctypes
+import re
+
+from conftest import ROOT
+
+
+def test_hip_library_exports_declared_symbols():
+    import lamejs_amd
+    lib = lamejs_amd.load_library()
+    hdr = (ROOT / "include" / "lamejs_hip.h").read_text()
+    names = set(re.findall(r"\b(lhip_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"missing export {n}"
+    assert b"HIP gfx950" in lib.lhip_version()
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a HIP device creation must fail loudly (never silently fall back)."""
+    import lamejs_amd
+    lib = lamejs_amd.load_library()
+    if lib.lhip_device_count() > 0:
+        return
+    try:
+        lamejs_amd.Mp3Encoder(1, 44100, 128)
+    except lamejs_amd.LhipError as e:
+        assert "no HIP device" in str(e) or "failed" in str(e)
+    else:
+        raise AssertionError("encoder creation succeeded without a HIP device")
+
+
+def test_product_does_not_reference_oracle():
+    for p in list((ROOT / "lamejs_amd").rglob("*.h")) + list((ROOT / "lamejs_amd").rglob("*.cpp")) + list((ROOT / "lamejs_amd").rglob("*.py")) + list((ROOT / "lamejs_amd").rglob("*.js")):
+        txt = p.read_text(errors="ignore")
+        assert "oracle/" not in txt and "lame_oracle" not in txt and "oracle_py" not in txt, p
