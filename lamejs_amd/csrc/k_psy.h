@@ -305,84 +305,142 @@ LHIP_DEV int attack_flags_raw(const Tables& T, const float* cur, const float* pr
     return a[0] | (a[1] << 1) | (a[2] << 2) | (a[3] << 3);
 }
 
-LHIP_DEV void kb_scan(const Tables& T, const Workspace& W, const StreamDesc* SD, int st, int lane) {
+// raw attack flags of one psy call, all channels (parallel over granule slots)
+LHIP_DEV void kb_scan_raw(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot) {
     const int C = T.channels_out;
-    const StreamDesc sd = SD[st];
-    const int nq = 2 * sd.nframes;
-    for (int it = lane; it < nq * C; it += LHIP_NL) {
-        const int q = it / C, ch = it - q * C;
-        const int64_t o = (int64_t)(sd.gslot0 + 1 + q) * C + ch;
+    const StreamDesc sd = SD[W.gslot_stream[gslot]];
+    if (gslot - sd.gslot0 - 1 < 0) return;
+    for (int ch = 0; ch < C; ch++) {
+        const int64_t o = (int64_t)gslot * C + ch;
         W.att_raw[o] = attack_flags_raw(T, W.peaks + o * PK_STRIDE, W.peaks + (o - C) * PK_STRIDE, ch);
     }
-    wave_sync();
-    if (lane != 0) return;
-    int last[2], tent[2];
-    for (int ch = 0; ch < C; ch++) {
-        last[ch] = W.last_attack[(int64_t)sd.gslot0 * C + ch];
-        tent[ch] = W.tent[(int64_t)sd.gslot0 * C + ch];
+}
+
+// lastAttacks after the psy call in `gslot` (PsyModel.js:1183-1196, 1268), resolved by looking back:
+// a0' = a0 & !last, a1' = a1 & !a0', a2' = a2 & !a1'  ->  the value only depends on the previous call
+// when a0 = a1 = a2 = 1, so the walk almost always stops at once.
+LHIP_DEV int last_attack_after(const Workspace& W, int C, int gcarry, int gslot, int ch) {
+    int flips = 0, g = gslot;
+    for (;;) {
+        if (g == gcarry) { const int v = W.last_attack[(int64_t)g * C + ch] != 0; return flips ? !v : v; }
+        const int raw = W.att_raw[(int64_t)g * C + ch];
+        const int a0 = raw & 1, a1 = (raw >> 1) & 1, a2 = (raw >> 2) & 1;
+        int v;
+        if (!a2) v = 0;
+        else if (!a1) v = 1;
+        else if (!a0) v = 0;
+        else { flips ^= 1; g--; continue; }        // a2' = !last(g-1)
+        return flips ? !v : v;
     }
+}
+
+// per granule slot: attack clean-up -> uselongblock (coupled), lastAttacks (parallel over granule slots)
+LHIP_DEV void kb_scan_attack(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[W.gslot_stream[gslot]];
+    if (gslot - sd.gslot0 - 1 < 0) return;
+    int ul[2] = {1, 1};
+    for (int ch = 0; ch < C; ch++) {
+        const int last = last_attack_after(W, C, sd.gslot0, gslot - 1, ch);
+        const int raw = W.att_raw[(int64_t)gslot * C + ch];
+        int a0 = raw & 1, a1 = (raw >> 1) & 1, a2 = (raw >> 2) & 1, a3 = (raw >> 3) & 1;
+        if (a0 != 0 && last != 0) a0 = 0;
+        if ((a0 + a1 + a2 + a3) != 0) {            // lastAttacks == 3 never happens
+            ul[ch] = 0;
+            if (a1 != 0 && a0 != 0) a1 = 0;
+            if (a2 != 0 && a1 != 0) a2 = 0;
+        }
+        W.ul_tmp[(int64_t)gslot * C + ch] = a2;    // lastAttacks after this call (published below)
+    }
+    if (T.short_blocks_coupled && !(ul[0] != 0 && ul[1] != 0)) ul[0] = ul[1] = 0;
+    for (int ch = 0; ch < C; ch++) W.uselong[(int64_t)gslot * C + ch] = ul[ch];
+}
+
+// per granule slot: block_type_set chain from the (coupled) uselongblock flags of this and the two
+// previous calls (PsyModel.js:784-826) (parallel over granule slots)
+LHIP_DEV void kb_scan_blocktype(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[W.gslot_stream[gslot]];
+    const int q = gslot - sd.gslot0 - 1;
+    if (q < 0) return;
+    for (int ch = 0; ch < C; ch++) {
+        // tentative type left by the previous call
+        int old;
+        if (q == 0) old = W.tent[(int64_t)sd.gslot0 * C + ch];
+        else {
+            const int ul1 = W.uselong[(int64_t)(gslot - 1) * C + ch];
+            int pshort;
+            if (q == 1) pshort = W.tent[(int64_t)sd.gslot0 * C + ch] == SHORT_TYPE;
+            else pshort = W.uselong[(int64_t)(gslot - 2) * C + ch] == 0;
+            old = ul1 ? (pshort ? STOP_TYPE : NORM_TYPE) : SHORT_TYPE;
+        }
+        const int ul = W.uselong[(int64_t)gslot * C + ch];
+        W.prev_short[(int64_t)gslot * C + ch] = (old == SHORT_TYPE) ? 1 : 0;
+        int bt = NORM_TYPE;
+        if (ul != 0) { if (old == SHORT_TYPE) bt = STOP_TYPE; }
+        else {
+            bt = SHORT_TYPE;
+            if (old == NORM_TYPE) old = START_TYPE;
+            if (old == STOP_TYPE) old = SHORT_TYPE;
+        }
+        W.blocktype[(int64_t)gslot * C + ch] = old;
+        W.tent[(int64_t)gslot * C + ch] = bt;
+        W.last_attack[(int64_t)gslot * C + ch] = W.ul_tmp[(int64_t)gslot * C + ch];
+    }
+}
+
+// ATH auto-adjust recurrence (Encoder.js:166-243): one wave per stream; loudness values are staged
+// through LDS in chunks so that the strictly serial chain (lane 0) never waits on HBM.
+struct AthLds { float loud[4 * 512]; double adj[512], lim[512]; };
+
+LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc* SD, int st, int lane, AthLds& L) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[st];
     double adj = W.ath_adjust[sd.fslot0], lim = W.ath_limit[sd.fslot0];
-    for (int k = 0; k < sd.nframes; k++) {
-        for (int gr = 0; gr < 2; gr++) {
-            const int gs = sd.gslot0 + 1 + 2 * k + gr;
-            int ul[2] = {1, 1};
-            for (int ch = 0; ch < C; ch++) {
-                const int raw = W.att_raw[(int64_t)gs * C + ch];
-                int a0 = raw & 1, a1 = (raw >> 1) & 1, a2 = (raw >> 2) & 1, a3 = (raw >> 3) & 1;
-                if (a0 != 0 && last[ch] != 0) a0 = 0;
-                if (last[ch] == 3 || (a0 + a1 + a2 + a3) != 0) {
-                    ul[ch] = 0;
-                    if (a1 != 0 && a0 != 0) a1 = 0;
-                    if (a2 != 0 && a1 != 0) a2 = 0;
-                    if (a3 != 0 && a2 != 0) a3 = 0;
-                }
-                last[ch] = a2;
-                W.last_attack[(int64_t)gs * C + ch] = a2;
-                W.prev_short[(int64_t)gs * C + ch] = (tent[ch] == SHORT_TYPE) ? 1 : 0;
-            }
-            // block_type_set (PsyModel.js:784-826)
-            if (T.short_blocks_coupled && !(ul[0] != 0 && ul[1] != 0)) ul[0] = ul[1] = 0;
-            for (int ch = 0; ch < C; ch++) {
-                int bt = NORM_TYPE, old = tent[ch];
-                if (ul[ch] != 0) { if (old == SHORT_TYPE) bt = STOP_TYPE; }
-                else {
-                    bt = SHORT_TYPE;
-                    if (old == NORM_TYPE) old = START_TYPE;
-                    if (old == STOP_TYPE) old = SHORT_TYPE;
-                }
-                W.blocktype[(int64_t)gs * C + ch] = old;   // value returned for the granule being coded
-                tent[ch] = bt;
-                W.tent[(int64_t)gs * C + ch] = bt;
-            }
+    for (int k0 = 0; k0 < sd.nframes; k0 += 512) {
+        const int n = (sd.nframes - k0) < 512 ? (sd.nframes - k0) : 512;
+        // frame k uses the loudness of the two psy calls before its granules: slots gslot0+2k and gslot0+2k+1
+        for (int i = lane; i < n * 2 * C; i += LHIP_NL) {
+            const int k = i / (2 * C), r = i - k * 2 * C;
+            L.loud[4 * k + r] = W.loud[(int64_t)(sd.gslot0 + 2 * (k0 + k)) * C + r];
         }
-        // adjust_ATH (Encoder.js:166-243): loudness of the two psy calls *before* these granules
-        {
-            const int64_t g0 = (int64_t)(sd.gslot0 + 2 * k) * C, g1 = g0 + C;
-            double max_pow = W.loud[g0], gr2_max = W.loud[g1];
-            if (C == 2) { max_pow += (double)W.loud[g0 + 1]; gr2_max += (double)W.loud[g1 + 1]; }
-            else { max_pow += max_pow; gr2_max += gr2_max; }
-            max_pow = max_pow > gr2_max ? max_pow : gr2_max;
-            max_pow *= 0.5;
-            max_pow *= T.ATH_aaSensitivityP;
-            if (T.ATH_useAdjust == 0) adj = 1.0;
-            else if (max_pow > 0.03125) {
-                if (adj >= 1.0) adj = 1.0;
-                else if (adj < lim) adj = lim;
-                lim = 1.0;
-            } else {
-                const double adj_lim_new = 31.98 * max_pow + 0.000625;
-                if (adj >= adj_lim_new) {
-                    adj *= adj_lim_new * 0.075 + 0.925;
-                    if (adj < adj_lim_new) adj = adj_lim_new;
-                } else {
-                    if (lim >= adj_lim_new) adj = adj_lim_new;
+        wave_sync();
+        if (lane == 0) {
+            for (int k = 0; k < n; k++) {
+                double max_pow, gr2_max;
+                if (C == 2) { max_pow = (double)L.loud[4 * k] + (double)L.loud[4 * k + 1]; gr2_max = (double)L.loud[4 * k + 2] + (double)L.loud[4 * k + 3]; }
+                else { max_pow = L.loud[4 * k]; gr2_max = L.loud[4 * k + 1]; max_pow += max_pow; gr2_max += gr2_max; }
+                max_pow = max_pow > gr2_max ? max_pow : gr2_max;
+                max_pow *= 0.5;
+                max_pow *= T.ATH_aaSensitivityP;
+                if (T.ATH_useAdjust == 0) adj = 1.0;
+                else if (max_pow > 0.03125) {
+                    if (adj >= 1.0) adj = 1.0;
                     else if (adj < lim) adj = lim;
+                    lim = 1.0;
+                } else {
+                    const double adj_lim_new = 31.98 * max_pow + 0.000625;
+                    if (adj >= adj_lim_new) {
+                        adj *= adj_lim_new * 0.075 + 0.925;
+                        if (adj < adj_lim_new) adj = adj_lim_new;
+                    } else {
+                        if (lim >= adj_lim_new) adj = adj_lim_new;
+                        else if (adj < lim) adj = lim;
+                    }
+                    lim = adj_lim_new;
                 }
-                lim = adj_lim_new;
+                L.adj[k] = adj; L.lim[k] = lim;
             }
-            W.ath_adjust[sd.fslot0 + 1 + k] = adj;
-            W.ath_limit[sd.fslot0 + 1 + k] = lim;
         }
+        wave_sync();
+        for (int k = lane; k < n; k += LHIP_NL) {
+            W.ath_adjust[sd.fslot0 + 1 + k0 + k] = L.adj[k];
+            W.ath_limit[sd.fslot0 + 1 + k0 + k] = L.lim[k];
+        }
+        wave_sync();
+#ifndef LHIP_HOSTSIM
+        adj = __shfl(adj, 0); lim = __shfl(lim, 0);
+#endif
     }
 }
 

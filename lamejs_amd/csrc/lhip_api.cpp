@@ -91,7 +91,6 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
     for (int ch = 0; ch < C; ch++) {
         float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
         for (int i = lane; i < io.mf_size; i += LHIP_NL) seg[i] = S->pcm_tail[ch][i];
-        for (int i = lane; i < io.n_new; i += LHIP_NL) kb_prep_elem(T, seg + io.mf_size, io.src[ch], i);
         const int64_t o = (int64_t)sd.gslot0 * C + ch;
         for (int i = lane; i < SB_STRIDE; i += LHIP_NL) W.sb[o * SB_STRIDE + i] = S->sb[ch][i];
         for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[ch][i];
@@ -108,7 +107,19 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
     if (lane == 0) { W.ath_adjust[sd.fslot0] = S->ath_adjust; W.ath_limit[sd.fslot0] = S->ath_limit; }
 }
 
-// new samples only (large batches: one element per thread over all streams is overkill; per stream grid-stride)
+// Int16 -> scaled f32 for the new samples of every stream: grid-stride over (stream, channel, sample)
+LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int nstreams, int64_t tid, int64_t nthreads) {
+    const int C = T.channels_out;
+    for (int st = 0; st < nstreams; st++) {
+        const StreamIO io = IO[st];
+        const int64_t off = SD[st].pcm_off + io.mf_size;
+        for (int ch = 0; ch < C; ch++) {
+            float* dst = W.pcm + (int64_t)ch * W.pcm_plane + off;
+            for (int64_t i = tid; i < io.n_new; i += nthreads) kb_prep_elem(T, dst, io.src[ch], i);
+        }
+    }
+}
+
 LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
     const int C = T.channels_out;
     const StreamDesc sd = SD[st];
@@ -147,7 +158,13 @@ __global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const Stream
     const int C = T.channels_out;
     kb_psyA(T, W, SD, blockIdx.x / C, blockIdx.x % C, threadIdx.x, L);
 }
-__global__ __launch_bounds__(64) void g_scan(Tables T, Workspace W, const StreamDesc* SD) { kb_scan(T, W, SD, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(256) void g_prep(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nstreams) {
+    kb_prep(T, W, SD, IO, nstreams, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+__global__ __launch_bounds__(64) void g_scan_raw(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_raw(T, W, SD, g); }
+__global__ __launch_bounds__(64) void g_scan_attack(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_attack(T, W, SD, g); }
+__global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_blocktype(T, W, SD, g); }
+__global__ __launch_bounds__(64) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
 __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ PsyBLds L;
     kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
@@ -173,8 +190,8 @@ __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const Stream
     kb_bits(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
-enum { KT_LOAD, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
-static const char* const g_kt_names[KT_N] = {"load", "psyA", "scan", "psyB", "polyphase", "mdct", "quant", "validate", "repair", "bits", "save"};
+enum { KT_LOAD, KT_PREP, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
+static const char* const g_kt_names[KT_N] = {"load", "prep", "psyA", "scan", "psyB", "polyphase", "mdct", "quant", "validate", "repair", "bits", "save"};
 static bool g_kt_on = false;
 static double g_kt_ms[KT_N];
 static int64_t g_kt_calls[KT_N];
@@ -198,6 +215,8 @@ static void kt_collect() {
     }
     g_kt_pending.clear();
 }
+#define LAUNCHB(id, kern, nblk, nthr, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); \
+    hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
 #define LAUNCH(id, kern, nblk, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); \
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
 
@@ -364,7 +383,7 @@ struct Context {
     void* stream = nullptr;
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
-    DevBuf pcm, fmap, gmap, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, last_attack, tent, prev_short, blocktype,
+    DevBuf pcm, fmap, gmap, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
         ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, frame_bytes, sd, io, in16, out8;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0; bool have_last = false;
@@ -456,7 +475,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
     ENS(pcm, (size_t)pcm_plane * C * 4 + 64); ENS(fmap, (size_t)nfs * 4); ENS(gmap, (size_t)ngs * 4);
     ENS(peaks, GC * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GC * EBL_STRIDE * 4); ENS(mask_idx, GC * EBL_STRIDE * 4);
-    ENS(eb_s, GC * EBS_STRIDE * 4); ENS(ecb_s, GC * EBS_STRIDE * 4); ENS(att_raw, GC * 4); ENS(last_attack, GC * 4);
+    ENS(eb_s, GC * EBS_STRIDE * 4); ENS(ecb_s, GC * EBS_STRIDE * 4); ENS(att_raw, GC * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GC * 4); ENS(last_attack, GC * 4);
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
@@ -466,7 +485,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #undef ENS
     W.pcm = (float*)ctx->pcm.p; W.fslot_stream = (const int32_t*)ctx->fmap.p; W.gslot_stream = (const int32_t*)ctx->gmap.p;
     W.peaks = (float*)ctx->peaks.p; W.loud = (float*)ctx->loud.p; W.eb_l = (float*)ctx->eb_l.p; W.mask_idx = (int32_t*)ctx->mask_idx.p;
-    W.eb_s = (float*)ctx->eb_s.p; W.ecb_s = (float*)ctx->ecb_s.p; W.att_raw = (int32_t*)ctx->att_raw.p;
+    W.eb_s = (float*)ctx->eb_s.p; W.ecb_s = (float*)ctx->ecb_s.p; W.att_raw = (int32_t*)ctx->att_raw.p; W.uselong = (int32_t*)ctx->uselong.p; W.ul_tmp = (int32_t*)ctx->ul_tmp.p;
     W.last_attack = (int32_t*)ctx->last_attack.p; W.tent = (int32_t*)ctx->tent.p; W.prev_short = (int32_t*)ctx->prev_short.p;
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
@@ -518,8 +537,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     {
         static PsyALds LA; static PsyBLds LB; static MdctLds LM; static QuantLds LQ; static BitsLds LBi;
         for (int s = 0; s < S; s++) kb_load(T, W, dSD, dIO, s, 0);
+        kb_prep(T, W, dSD, dIO, S, 0, 1);
         for (int b = 0; b < ngs * C; b++) kb_psyA(T, W, dSD, b / C, b % C, 0, LA);
-        for (int s = 0; s < S; s++) kb_scan(T, W, dSD, s, 0);
+        for (int b = 0; b < ngs; b++) kb_scan_raw(T, W, dSD, b);
+        for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
+        for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
+        { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
         for (int b = 0; b < ngs; b++) kb_psyB(T, W, dSD, b, 0, LB);
         for (int b = 0; b < ngs * C; b++) kb_polyphase(T, W, dSD, b / C, b % C, 0);
         for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
@@ -538,8 +561,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
 #else
     LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);
+    {
+        int64_t nb = (in_total / C + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        if (nb < 1) nb = 1;
+        LAUNCHB(KT_PREP, g_prep, (int)nb, 256, st, T, W, dSD, dIO, S);
+    }
     LAUNCH(KT_PSYA, g_psyA, ngs * C, st, T, W, dSD);
-    LAUNCH(KT_SCAN, g_scan, S, st, T, W, dSD);
+    LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
+    LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
+    LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
+    LAUNCH(KT_SCAN, g_scan_ath, S, st, T, W, dSD);
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, ngs * C, st, T, W, dSD);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);

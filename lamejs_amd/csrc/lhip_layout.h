@@ -50,6 +50,8 @@ struct Workspace {
     float* ecb_s;               // [ngslots][C][3][64]   (carry slot: sblock 1 = nb_s2, sblock 2 = nb_s1)
     // scan outputs
     int32_t* att_raw;           // [ngslots][C]  bit j = raw ns_attacks[j]
+    int32_t* uselong;           // [ngslots][C]  coupled uselongblock flag of that call
+    int32_t* ul_tmp;            // [ngslots][C]  scratch: lastAttacks before publication
     int32_t* last_attack;       // [ngslots][C]  lastAttacks after that call
     int32_t* tent;              // [ngslots][C]  blocktype_old after that call (tentative type)
     int32_t* prev_short;        // [ngslots][C]  blocktype_old == SHORT as seen by that call's thresholds
