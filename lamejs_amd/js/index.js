@@ -1,0 +1,67 @@
+/*
+ * Drop-in replacement for the encode path of zhuker/lamejs:
+ *     const { Mp3Encoder, WavHeader } = require('lamejs_amd/js');
+ *     const enc = new Mp3Encoder(channels, sampleRate, kbps);
+ *     const bytes = enc.encodeBuffer(left[, right]);   // Int8Array, possibly empty
+ *     const tail  = enc.flush();
+ * Same constructor arguments, same return types and the same byte stream as the reference
+ * (src/js/index.js:66-136, 138-196).  Parameter resolution and every lookup table are computed here,
+ * in JavaScript (tables.js), with the engine's own Math.*; the per-frame hot path -- psychoacoustic
+ * model, polyphase + MDCT, CBR iteration loop, bitstream formatting -- runs as hand-written HIP
+ * kernels on an MI355X behind the C ABI of include/lamejs_hip.h, reached through a thin N-API addon.
+ * GPU efficiency comes from batching: pass many frames per encodeBuffer() call (the reference API
+ * already allows any length).  There is no CPU fallback.
+ */
+'use strict';
+const path = require('path');
+const tables = require('./tables.js');
+
+let addon = null;
+function loadAddon() {
+    if (!addon) addon = require(path.join(__dirname, 'addon', 'lhip_napi.node'));
+    return addon;
+}
+
+function Mp3Encoder(channels, samplerate, kbps) {
+    if (arguments.length != 3) {
+        console.error('WARN: Mp3Encoder(channels, samplerate, kbps) not specified');
+        channels = 1; samplerate = 44100; kbps = 128;
+    }
+    const native = loadAddon();
+    const blob = tables.buildBlob(channels, samplerate, kbps).blob;
+    const handle = native.create(blob, channels, samplerate, kbps);
+
+    this.encodeBuffer = function (left, right) {
+        if (channels == 1) right = null;
+        if (!(left instanceof Int16Array)) left = Int16Array.from(left);
+        if (right && !(right instanceof Int16Array)) right = Int16Array.from(right);
+        return native.encode(handle, left, right || null);
+    };
+    this.flush = function () { return native.flush(handle); };
+}
+
+/* RIFF/WAVE header reader with the reference's field names (index.js:138-193) */
+function WavHeader() { this.dataOffset = 0; this.dataLen = 0; this.channels = 0; this.sampleRate = 0; }
+WavHeader.readHeader = function (dataView) {
+    const tag = (o) => String.fromCharCode(dataView.getUint8(o), dataView.getUint8(o + 1), dataView.getUint8(o + 2), dataView.getUint8(o + 3));
+    const w = new WavHeader();
+    if (tag(0) != 'RIFF' || tag(8) != 'WAVE' || tag(12) != 'fmt ') return;
+    const fmtLen = dataView.getUint32(16, true);
+    if (fmtLen != 16 && fmtLen != 18) throw 'extended fmt chunk not implemented';
+    w.channels = dataView.getUint16(22, true);
+    w.sampleRate = dataView.getUint32(24, true);
+    let pos = 20 + fmtLen, len = 0;
+    for (;;) {
+        const id = tag(pos);
+        len = dataView.getUint32(pos + 4, true);
+        if (id == 'data') break;
+        pos += len + 8;
+    }
+    w.dataLen = len;
+    w.dataOffset = pos + 8;
+    return w;
+};
+
+module.exports.Mp3Encoder = Mp3Encoder;
+module.exports.WavHeader = WavHeader;
+module.exports.deviceCount = function () { return loadAddon().deviceCount(); };

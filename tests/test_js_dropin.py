@@ -1,0 +1,44 @@
+"""The JavaScript host (lamejs_amd/js: Mp3Encoder + N-API addon) must be a drop-in for the reference API:
+same calls as the reference's Tests.js, same bytes as the goldens.  CPU run uses the host-simulation
+library (logic only); the GPU run uses the real HIP library."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+NODE = shutil.which("node")
+ADDON = ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node"
+
+
+def _run(env_lib, corpus, ch, kbps, nfr, chunk):
+    env = dict(os.environ)
+    if env_lib:
+        env["LAMEJS_HIP_LIB"] = str(env_lib)
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk)],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _cases(golden):
+    return [c for c in golden if c["corpus"] in ("sine", "bursts") and c["nsamples"] <= 1152 * 400 and c["nsamples"] >= 1152 * 200]
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_dropin_hostsim(golden):
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    for c in _cases(golden)[:3]:
+        got = _run(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"])
+        assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_dropin_gpu(golden):
+    for c in _cases(golden):
+        got = _run(None, c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"])
+        assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
