@@ -389,58 +389,103 @@ LHIP_DEV void kb_scan_blocktype(const Tables& T, const Workspace& W, const Strea
     }
 }
 
-// ATH auto-adjust recurrence (Encoder.js:166-243): one wave per stream; loudness values are staged
-// through LDS in chunks so that the strictly serial chain (lane 0) never waits on HBM.
-struct AthLds { float loud[4 * 512]; double adj[512], lim[512]; };
+// ATH auto-adjust recurrence (Encoder.js:166-243), one wave per stream.
+// The recurrence (adjust, adjustLimit) <- F_k(adjust, adjustLimit) is serial in general (repeated f64
+// multiplications during a loudness descent cannot be re-associated), but two consecutive "loud" frames
+// (max_pow > 0.03125) force the state to (1, 1) whatever came before.  Frames are processed in chunks of
+// ATH_CHUNK; inside a chunk every lane owns a contiguous segment: pass A evaluates each segment from its
+// first such reset point onwards (no dependence on other lanes), then the segment prefixes are filled in
+// as soon as the state at the end of the previous segment is known (at most NL rounds, 1 in the common case).
+enum { ATH_CHUNK = 2048 };
+struct AthLds { double mp[ATH_CHUNK], adj[ATH_CHUNK], lim[ATH_CHUNK]; double e_adj[LHIP_NL + 1], e_lim[LHIP_NL + 1]; int known[LHIP_NL + 1], first_reset[LHIP_NL + 1]; };
+
+LHIP_DEV void ath_step(const Tables& T, double max_pow, double& adj, double& lim) {
+    if (T.ATH_useAdjust == 0) { adj = 1.0; return; }
+    if (max_pow > 0.03125) {
+        if (adj >= 1.0) adj = 1.0;
+        else if (adj < lim) adj = lim;
+        lim = 1.0;
+    } else {
+        const double adj_lim_new = 31.98 * max_pow + 0.000625;
+        if (adj >= adj_lim_new) {
+            adj *= adj_lim_new * 0.075 + 0.925;
+            if (adj < adj_lim_new) adj = adj_lim_new;
+        } else {
+            if (lim >= adj_lim_new) adj = adj_lim_new;
+            else if (adj < lim) adj = lim;
+        }
+        lim = adj_lim_new;
+    }
+}
 
 LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc* SD, int st, int lane, AthLds& L) {
     const int C = T.channels_out;
     const StreamDesc sd = SD[st];
-    double adj = W.ath_adjust[sd.fslot0], lim = W.ath_limit[sd.fslot0];
-    for (int k0 = 0; k0 < sd.nframes; k0 += 512) {
-        const int n = (sd.nframes - k0) < 512 ? (sd.nframes - k0) : 512;
-        // frame k uses the loudness of the two psy calls before its granules: slots gslot0+2k and gslot0+2k+1
-        for (int i = lane; i < n * 2 * C; i += LHIP_NL) {
-            const int k = i / (2 * C), r = i - k * 2 * C;
-            L.loud[4 * k + r] = W.loud[(int64_t)(sd.gslot0 + 2 * (k0 + k)) * C + r];
+    double cadj = W.ath_adjust[sd.fslot0], clim = W.ath_limit[sd.fslot0];   // state carried into the chunk
+    double prev_mp = 0.0;                                                    // max_pow of the frame before the chunk (0: unknown/not loud)
+    for (int k0 = 0; k0 < sd.nframes; k0 += ATH_CHUNK) {
+        const int n = (sd.nframes - k0) < ATH_CHUNK ? (sd.nframes - k0) : ATH_CHUNK;
+        // max_pow per frame (parallel): loudness of the two psy calls before the frame's granules
+        for (int k = lane; k < n; k += LHIP_NL) {
+            const int64_t g0 = (int64_t)(sd.gslot0 + 2 * (k0 + k)) * C, g1 = g0 + C;
+            double max_pow = W.loud[g0], gr2_max = W.loud[g1];
+            if (C == 2) { max_pow += (double)W.loud[g0 + 1]; gr2_max += (double)W.loud[g1 + 1]; }
+            else { max_pow += max_pow; gr2_max += gr2_max; }
+            max_pow = max_pow > gr2_max ? max_pow : gr2_max;
+            max_pow *= 0.5;
+            max_pow *= T.ATH_aaSensitivityP;
+            L.mp[k] = max_pow;
         }
         wave_sync();
-        if (lane == 0) {
-            for (int k = 0; k < n; k++) {
-                double max_pow, gr2_max;
-                if (C == 2) { max_pow = (double)L.loud[4 * k] + (double)L.loud[4 * k + 1]; gr2_max = (double)L.loud[4 * k + 2] + (double)L.loud[4 * k + 3]; }
-                else { max_pow = L.loud[4 * k]; gr2_max = L.loud[4 * k + 1]; max_pow += max_pow; gr2_max += gr2_max; }
-                max_pow = max_pow > gr2_max ? max_pow : gr2_max;
-                max_pow *= 0.5;
-                max_pow *= T.ATH_aaSensitivityP;
-                if (T.ATH_useAdjust == 0) adj = 1.0;
-                else if (max_pow > 0.03125) {
-                    if (adj >= 1.0) adj = 1.0;
-                    else if (adj < lim) adj = lim;
-                    lim = 1.0;
-                } else {
-                    const double adj_lim_new = 31.98 * max_pow + 0.000625;
-                    if (adj >= adj_lim_new) {
-                        adj *= adj_lim_new * 0.075 + 0.925;
-                        if (adj < adj_lim_new) adj = adj_lim_new;
-                    } else {
-                        if (lim >= adj_lim_new) adj = adj_lim_new;
-                        else if (adj < lim) adj = lim;
-                    }
-                    lim = adj_lim_new;
+        const int seglen = (n + LHIP_NL - 1) / LHIP_NL;
+        const int s0 = lane * seglen < n ? lane * seglen : n, s1 = (lane + 1) * seglen < n ? (lane + 1) * seglen : n;
+        // pass A: from the first reset point of the segment to its end
+        {
+            int fr = -1;
+            if (T.ATH_useAdjust != 0)
+                for (int k = s0; k < s1; k++) {
+                    const double pm = k > 0 ? L.mp[k - 1] : prev_mp;
+                    if (pm > 0.03125 && L.mp[k] > 0.03125) { fr = k; break; }
                 }
-                L.adj[k] = adj; L.lim[k] = lim;
+            else if (s0 < s1) fr = s0;
+            double a = 1.0, l = 1.0;
+            if (fr >= 0) {
+                L.adj[fr] = 1.0; L.lim[fr] = (T.ATH_useAdjust != 0) ? 1.0 : clim;
+                l = L.lim[fr];
+                for (int k = fr + 1; k < s1; k++) { ath_step(T, L.mp[k], a, l); L.adj[k] = a; L.lim[k] = l; }
             }
+            L.first_reset[lane] = fr;
+            L.known[lane + 1] = (fr >= 0) || (s0 >= s1 && false);
+            L.e_adj[lane + 1] = a; L.e_lim[lane + 1] = l;
+            if (lane == 0) { L.known[0] = 1; L.e_adj[0] = cadj; L.e_lim[0] = clim; }
         }
         wave_sync();
+        // prefix rounds: a segment's frames before its first reset need the state at the end of the previous segment
+        int done = (s0 >= s1);
+        for (int round = 0; round < LHIP_NL + 1; round++) {
+            int progressed = 0;
+            if (!done && L.known[lane]) {
+                double a = L.e_adj[lane], l = L.e_lim[lane];
+                const int fr = L.first_reset[lane];
+                const int stop = fr >= 0 ? fr : s1;
+                for (int k = s0; k < stop; k++) { ath_step(T, L.mp[k], a, l); L.adj[k] = a; L.lim[k] = l; }
+                if (fr < 0) { L.e_adj[lane + 1] = a; L.e_lim[lane + 1] = l; }
+                done = 1; progressed = 1;
+            }
+            wave_sync();
+            if (progressed && L.first_reset[lane] < 0) L.known[lane + 1] = 1;
+            // empty segments simply forward the state
+            if (s0 >= s1 && L.known[lane] && !L.known[lane + 1]) { L.e_adj[lane + 1] = L.e_adj[lane]; L.e_lim[lane + 1] = L.e_lim[lane]; L.known[lane + 1] = 1; }
+            wave_sync();
+            if (!wave_any(!done) && !wave_any(!L.known[lane + 1])) break;
+        }
         for (int k = lane; k < n; k += LHIP_NL) {
             W.ath_adjust[sd.fslot0 + 1 + k0 + k] = L.adj[k];
             W.ath_limit[sd.fslot0 + 1 + k0 + k] = L.lim[k];
         }
         wave_sync();
-#ifndef LHIP_HOSTSIM
-        adj = __shfl(adj, 0); lim = __shfl(lim, 0);
-#endif
+        cadj = L.adj[n - 1]; clim = L.lim[n - 1]; prev_mp = L.mp[n - 1];
+        wave_sync();
     }
 }
 

@@ -29,6 +29,16 @@ struct GI {   // wave-uniform scalar part of the reference's GrInfo
 
 struct NoiseRes { double max_noise; int over_count, over_SSD, bits; };
 
+// optional phase profiling (build with -DLHIP_PHASE_PROF; never in the product library)
+#if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
+#define PH_BEGIN() const unsigned long long ph_t0_ = __builtin_amdgcn_s_memtime()
+#define PH_END(L, id) do { if (lane == 0) { (L).prof[id] += __builtin_amdgcn_s_memtime() - ph_t0_; (L).prof[16 + id] += 1; } } while (0)
+#else
+#define PH_BEGIN() do {} while (0)
+#define PH_END(L, id) do {} while (0)
+#endif
+enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL, PH_N };
+
 struct QuantLds {
     float xr[576];
     float xrpow[576];
@@ -46,6 +56,9 @@ struct QuantLds {
     int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24];
     uint8_t line2sfb[576];
     double ath_pseudo[6];
+#ifdef LHIP_PHASE_PROF
+    unsigned long long prof[32];
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -435,15 +448,18 @@ struct PrevNoise { int gain, sfb_count1; };   // scalar part of CalcNoiseData (a
 LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int32_t* ix, PrevNoise* pn, int lane, QuantLds& L) {
     const double w = (double)IXMAX_VAL / ipow20(T, g.global_gain);
     if (g.xrpow_max > w) return LARGE_BITS;
-    q_quantize(T, g, scalefac, ix, pn != nullptr, pn ? pn->gain : 0, pn ? pn->sfb_count1 : 0, lane, L);
+    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, pn != nullptr, pn ? pn->gain : 0, pn ? pn->sfb_count1 : 0, lane, L); PH_END(L, PH_QUANTIZE); }
     int dummy = 0;
-    return q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane);
+    PH_BEGIN();
+    const int r = q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane);
+    PH_END(L, PH_COUNT);
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
 // calc_noise (QuantizePVT.js:784-878); distort -> L.distort, cache -> L.pn_*
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int32_t* ix, NoiseRes* res,
+LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int32_t* ix, NoiseRes* res,
                            PrevNoise* pn, int lane, QuantLds& L) {
     // 1) the (sequential) start-line walk: where each band begins and how many pairs it sums
     if (lane == 0) {
@@ -512,6 +528,13 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
     res->over_SSD = wave_sum(ssd);
     res->max_noise = wave_maxd(max_noise);
     wave_sync();
+}
+
+LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int32_t* ix, NoiseRes* res,
+                           PrevNoise* pn, int lane, QuantLds& L) {
+    PH_BEGIN();
+    q_calc_noise_(T, g, scalefac, ix, res, pn, lane, L);
+    PH_END(L, PH_NOISE);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -752,7 +775,9 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         NoiseRes ni;
         const int search_limit = 3;
         int maxggain = 255;
-        if (!q_balance_noise(T, w, L.sfw, lane, L)) break;
+        int bal_;
+        { PH_BEGIN(); bal_ = q_balance_noise(T, w, L.sfw, lane, L); PH_END(L, PH_BALANCE); }
+        if (!bal_) break;
         if (w.scalefac_scale != 0) maxggain = 254;
         const int huff_bits = targ_bits - w.part2_length;
         if (huff_bits <= 0) break;
@@ -1075,6 +1100,10 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     if (k < 0) return;
     const int fidx = sd.out_slot0 + k;                    // dense frame index
     if (chain && !W.seed_flag[fidx]) return;
+#ifdef LHIP_PHASE_PROF
+    if (lane == 0) for (int i = 0; i < 32; i++) L.prof[i] = 0;
+    const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();
+#endif
     const double ath_adjust = W.ath_adjust[fslot];        // after adjust_ATH of this frame
     const int padding = frame_padding(T, sd, k);
     const int mean_bits = (frame_bits_of(T, padding) - T.sideinfo_len * 8) / T.mode_gr;
@@ -1094,12 +1123,12 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             const int bt = W.blocktype[(int64_t)gslot * C + ch];
             const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
             const float* ratio = W.E + ((int64_t)(gslot - 1) * C + ch) * E_STRIDE;   // thresholds of the previous psy call
-            q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, lane, L);
+            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, lane, L); PH_END(L, PH_INIT); }
             int active = 0, bs_gain = 0;
             const Seed used = seed[ch];
             if (q_init_xrpow(g, lane, L)) {
                 active = 1;
-                q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L);
+                { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L); PH_END(L, PH_XMIN); }
                 q_outer_loop(T, g, targ[ch], used.start, used.step, &bs_gain, lane, L);
                 seed[ch].step = (used.start - bs_gain >= 4) ? 4 : 2;
                 seed[ch].start = bs_gain;
@@ -1108,8 +1137,8 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 wave_sync();
             }
             int scfsi[4];
-            q_best_scalefac_store(T, g, gr, ch, gr0_bt[ch], scfsi, lane, L);
-            if (T.use_best_huffman == 1) q_best_huffman_divide(T, g, lane, L);
+            { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt[ch], scfsi, lane, L); PH_END(L, PH_SFSTORE); }
+            if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L); PH_END(L, PH_HUFFDIV); }
             ResvSize -= g.part2_3_length + g.part2_length;
             if (gr == 0) {
                 gr0_bt[ch] = g.block_type;
@@ -1139,6 +1168,12 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         }
     }
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
+#ifdef LHIP_PHASE_PROF
+    if (lane == 0) {
+        L.prof[PH_TOTAL] = __builtin_amdgcn_s_memtime() - ph_total0_; L.prof[16 + PH_TOTAL] = 1;
+        for (int i = 0; i < 32; i++) atomicAdd((unsigned long long*)W.prof + i, L.prof[i]);
+    }
+#endif
 }
 
 // Re-run the bin searches of a frame with the chain-implied seeds; flag the frame if any result differs.

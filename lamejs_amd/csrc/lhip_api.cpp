@@ -384,7 +384,7 @@ struct Context {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     DevBuf pcm, fmap, gmap, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, frame_bytes, sd, io, in16, out8;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, frame_bytes, sd, io, in16, out8, prof;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0; bool have_last = false;
 };
@@ -480,7 +480,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
     ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(frame_bytes, FR * 4); ENS(sd, (size_t)S * sizeof(StreamDesc));
-    ENS(io, (size_t)S * sizeof(StreamIO));
+    ENS(io, (size_t)S * sizeof(StreamIO)); ENS(prof, 512);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
     W.pcm = (float*)ctx->pcm.p; W.fslot_stream = (const int32_t*)ctx->fmap.p; W.gslot_stream = (const int32_t*)ctx->gmap.p;
@@ -490,7 +490,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
-    W.nflagged = (int32_t*)ctx->nflagged.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr;
+    W.nflagged = (int32_t*)ctx->nflagged.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
@@ -522,6 +522,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (!rt::h2d(ctx->io.p, io.data(), io.size() * sizeof(StreamIO), st)) return false;
     if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
     if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
+    if (!rt::dzero(ctx->prof.p, 512, st)) return false;
     const StreamDesc* dSD = (const StreamDesc*)ctx->sd.p;
     const StreamIO* dIO = (const StreamIO*)ctx->io.p;
 
@@ -806,6 +807,7 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
         case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ctx->lastC * sizeof(GrSide); break;
         case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;
         case 6: src = W.peaks; n = GC * PK_STRIDE * 4; break;
+        case 7: src = W.prof; n = 256; break;
         default: set_err("unknown tap"); return LHIP_ERR_INTERNAL;
     }
     if (n > cap) n = cap;

@@ -71,6 +71,7 @@ struct Workspace {
     int32_t* nflagged;          // [1]
     uint8_t* out;               // output MP3 bytes
     int32_t* frame_bytes;       // [nframes_total]
+    unsigned long long* prof;   // [32] phase-profiling accumulators (profiling builds only)
 };
 
 }  // namespace lhip
