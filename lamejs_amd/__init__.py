@@ -42,7 +42,7 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else _LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("LAMEJS_HIP_LIB", _LIB_PATH))
     if not p.exists():
         raise LhipError(f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                         "lamejs_amd has no CPU fallback.")

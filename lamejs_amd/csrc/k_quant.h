@@ -39,11 +39,64 @@ struct NoiseRes { double max_noise; int over_count, over_SSD, bits; };
 #endif
 enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL, PH_N };
 
+// Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
+// inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
+enum { QT_N = 512 };
+struct QuantTabs {
+    float pow43[QT_N], adj43[QT_N];
+    float ipow20[Q_MAX], pow20[Q_MAX + Q_MAX2 + 1];
+    int32_t largetbl[256], table23[9], table56[16];
+    int32_t sfb_l[SBMAX_l + 1], sfb_s[SBMAX_s + 1], pretab[SBMAX_l];
+    uint16_t hoff[16];
+    uint16_t reorder_s[576];
+    uint8_t hlen[1088];          // code lengths of tables 1, 7..15 (offsets in hoff)
+    uint8_t t32l[16], t33l[16];
+    uint8_t l2s_long[576], l2s_short[576];
+};
+
+LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
+    for (int i = tid; i < QT_N; i += nthr) { Q.pow43[i] = T.pow43[i]; Q.adj43[i] = T.adj43[i]; }
+    for (int i = tid; i < Q_MAX; i += nthr) Q.ipow20[i] = T.ipow20[i];
+    for (int i = tid; i < Q_MAX + Q_MAX2 + 1; i += nthr) Q.pow20[i] = T.pow20[i];
+    for (int i = tid; i < 256; i += nthr) Q.largetbl[i] = T.largetbl[i];
+    for (int i = tid; i < 9; i += nthr) Q.table23[i] = T.table23[i];
+    for (int i = tid; i < 16; i += nthr) { Q.table56[i] = T.table56[i]; Q.t32l[i] = (uint8_t)T.t32l[i]; Q.t33l[i] = (uint8_t)T.t33l[i]; }
+    for (int i = tid; i < SBMAX_l + 1; i += nthr) Q.sfb_l[i] = T.sfb_l[i];
+    for (int i = tid; i < SBMAX_s + 1; i += nthr) Q.sfb_s[i] = T.sfb_s[i];
+    for (int i = tid; i < SBMAX_l; i += nthr) Q.pretab[i] = T.pretab[i];
+    // Huffman length pool: table 1 (4 entries), 7-9 (36), 10-12 (64), 13-15 (256)
+    {
+        int off = 0;
+        for (int t = 1; t < 16; t++) {
+            const int xl = T.ht_xlen[t];
+            const int n = (t == 1 || t >= 7) ? (t == 14 ? 256 : xl * xl) : 0;
+            if (tid == 0) Q.hoff[t] = (uint16_t)off;
+            for (int i = tid; i < n; i += nthr) Q.hlen[off + i] = (uint8_t)T.ht_hlen[T.ht_off[t] + i];
+            off += n;
+        }
+    }
+    for (int d = tid; d < 576; d += nthr) {
+        int sfb = 0;
+        while (T.sfb_l[sfb + 1] <= d) sfb++;
+        Q.l2s_long[d] = (uint8_t)sfb;
+        sfb = 0;
+        while (3 * T.sfb_s[sfb + 1] <= d) sfb++;
+        const int st = T.sfb_s[sfb], w = T.sfb_s[sfb + 1] - st;
+        const int r = d - 3 * st, win = r / w, l = st + (r - win * w);
+        Q.l2s_short[d] = (uint8_t)(3 * sfb + win);
+        Q.reorder_s[d] = (uint16_t)(3 * l + win);
+    }
+}
+
 struct QuantLds {
+    const QuantTabs* tabs;
     float xr[576];
-    float xrpow[576];
-    int32_t ixw[576];            // l3_enc of the working copy (cod_info_w)
-    int32_t ixb[576];            // l3_enc of the best/kept copy (cod_info)
+    union {                      // xrpow is dead once the outer loop has finished; the Huffman-split scratch reuses it
+        float xrpow[576];
+        struct { int32_t bstat[16][SBMAX_l + 2]; int32_t cand[21][16]; } hd;
+    };
+    int16_t ixw[576];            // l3_enc of the working copy (cod_info_w)
+    int16_t ixb[576];            // l3_enc of the best/kept copy (cod_info)
     int32_t sfw[SFBMAX + 1], sfb[SFBMAX + 1];     // scalefac working / kept
     int32_t width[SFBMAX + 1], window[SFBMAX + 1], start[SFBMAX + 2];
     float xmin[SFBMAX + 1], distort[SFBMAX + 1];
@@ -52,9 +105,7 @@ struct QuantLds {
     int32_t qmode[SFBMAX + 1], qlen[SFBMAX + 1];
     int32_t nstart[SFBMAX + 1], npairs[SFBMAX + 1], ncached[SFBMAX + 1];
     int32_t sf_gr0[2][SFBMAX + 1];                // final gr0 scalefactors per channel (for scfsi)
-    int32_t bstat[16][SBMAX_l + 2];               // per-band Huffman statistics (best_huffman_divide)
     int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24];
-    uint8_t line2sfb[576];
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
     unsigned long long prof[32];
@@ -64,8 +115,12 @@ struct QuantLds {
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV double ipow20(const Tables& T, int x) { return (double)T.ipow20[x]; }
-LHIP_DEV double pow20(const Tables& T, int x) { return (double)T.pow20[x + Q_MAX2]; }
+LHIP_DEV double ipow20(const QuantLds& L, int x) { return (double)L.tabs->ipow20[x]; }
+LHIP_DEV double pow20(const QuantLds& L, int x) { return (double)L.tabs->pow20[x + Q_MAX2]; }
+LHIP_DEV double pow43v(const Tables& T, const QuantLds& L, int i) { return (double)(i < QT_N ? L.tabs->pow43[i] : T.pow43[i]); }
+LHIP_DEV double adj43v(const Tables& T, const QuantLds& L, int i) { return (double)(i < QT_N ? L.tabs->adj43[i] : T.adj43[i]); }
+LHIP_DEV const uint8_t* line2sfb(const QuantLds& L, int block_type) { return block_type == SHORT_TYPE ? L.tabs->l2s_short : L.tabs->l2s_long; }
+LHIP_DEV const uint8_t* hlen_of(const QuantLds& L, int t) { return L.tabs->hlen + L.tabs->hoff[t]; }
 
 // QuantizePVT.js:541-561
 LHIP_DEV double athAdjust(const Tables& T, const PowBase& pb10, double a, double x, double athFloor) {
@@ -85,8 +140,8 @@ LHIP_DEV int sbgain(const GI& g, int w) {   // subblock_gain[w] without a dynami
     return w == 0 ? g.subblock_gain[0] : w == 1 ? g.subblock_gain[1] : w == 2 ? g.subblock_gain[2] : g.subblock_gain[3];
 }
 
-LHIP_DEV int sf_step(const Tables& T, const GI& g, const int32_t* scalefac, const int32_t* window, int sfb) {
-    return g.global_gain - ((scalefac[sfb] + (g.preflag != 0 ? T.pretab[sfb] : 0)) << (g.scalefac_scale + 1))
+LHIP_DEV int sf_step(const QuantLds& L, const GI& g, const int32_t* scalefac, const int32_t* window, int sfb) {
+    return g.global_gain - ((scalefac[sfb] + (g.preflag != 0 ? L.tabs->pretab[sfb] : 0)) << (g.scalefac_scale + 1))
            - sbgain(g, window[sfb]) * 8;
 }
 
@@ -120,26 +175,14 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         }
         if (lane == 0) L.start[nsfb] = 576;
         // re-order: within each short sfb the three windows become consecutive runs
-        for (int d = lane; d < 576; d += LHIP_NL) {
-            int sfb = 0;
-            while (3 * T.sfb_s[sfb + 1] <= d) sfb++;
-            const int st = T.sfb_s[sfb], w = T.sfb_s[sfb + 1] - st;
-            const int r = d - 3 * st, win = r / w, l = st + (r - win * w);
-            L.xr[d] = xr_g[3 * l + win];
-            L.line2sfb[d] = (uint8_t)(3 * sfb + win);
-        }
+        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[L.tabs->reorder_s[d]];
     } else {
         nsfb = SBMAX_l;
         for (int i = lane; i < SBMAX_l; i += LHIP_NL) {
             L.width[i] = T.sfb_l[i + 1] - T.sfb_l[i]; L.window[i] = 3; L.start[i] = T.sfb_l[i];
         }
         if (lane == 0) L.start[SBMAX_l] = 576;
-        for (int d = lane; d < 576; d += LHIP_NL) {
-            int sfb = 0;
-            while (T.sfb_l[sfb + 1] <= d) sfb++;
-            L.xr[d] = xr_g[d];
-            L.line2sfb[d] = (uint8_t)sfb;
-        }
+        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[d];
     }
     for (int i = lane; i <= SFBMAX; i += LHIP_NL) { L.sfw[i] = 0; L.sfb[i] = 0; }
     wave_sync();
@@ -252,11 +295,11 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
 }
 
 // ---------------------------------------------------------------------------------------------
-// quantize_xrpow (Takehiro.js:171-314) -> ix ; `prev` = use the prev_noise cache (pn_* in LDS)
+// quantize_xrpow (Takehiro.js:171-314) -> ix ; `use_prev` = the prev_noise cache (pn_* in LDS) is live
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, int32_t* ix, int use_prev,
+LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, int16_t* ix, int use_prev,
                          int pn_gain, int pn_sfb_count1, int lane, QuantLds& L) {
-    const double istep = ipow20(T, g.global_gain);
+    const double istep = ipow20(L, g.global_gain);
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
     const int mnz = g.max_nonzero_coeff;
@@ -264,13 +307,13 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     int cand = 99;
     for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
         int step = -1;
-        if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(T, g, scalefac, L.window, sfb);
+        if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(L, g, scalefac, L.window, sfb);
         int mode;
         if (prev_data_use && L.pn_step[sfb] == step) mode = 0;
         else {
             mode = 1;
             if (use_prev && pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) mode = 2;
-            if (L.start[sfb] + L.width[sfb] > mnz) cand = sfb;   // first such band ends the walk
+            if (L.start[sfb] + L.width[sfb] > mnz && sfb < cand) cand = sfb;   // first such band ends the walk
         }
         L.qmode[sfb] = mode;
         L.qlen[sfb] = L.width[sfb];
@@ -286,8 +329,9 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     }
     wave_sync();
     const double compareval0 = (1.0 - 0.4054) / istep;
+    const uint8_t* l2s = line2sfb(L, g.block_type);
     for (int i = lane; i < 576; i += LHIP_NL) {
-        const int sfb = L.line2sfb[i];
+        const int sfb = l2s[i];
         int have = 0, v = 0;
         if (i >= fill_from) { have = 1; v = 0; }
         if (sfb <= sfbmax && sfb <= sstar) {
@@ -299,88 +343,82 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
                 else {
                     double x = xv * istep;
                     const int rx = js_toint32(x);
-                    x += (double)T.adj43[rx];
+                    x += adj43v(T, L, rx);
                     v = js_toint32(x);
                 }
             }
         }
-        if (have) ix[i] = v;
+        if (have) ix[i] = (int16_t)v;
     }
     wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
-// choose_table over pairs [a, b) (Takehiro.js:465-516): cooperative; adds to *bits, returns table
+// Huffman table choice for a set of pairs (Takehiro.js:336-516).  Region description for the one-pass counter.
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV int q_choose_table(const Tables& T, const int32_t* ix, int a, int b, int* bits, int lane) {
-    int mx = 0;
-    for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) {
-        const int x1 = ix[p], x2 = ix[p + 1];
-        if (mx < x1) mx = x1;
-        if (mx < x2) mx = x2;
-    }
-    mx = wave_max(mx);
-    if (mx == 0) return 0;
-    if (mx == 1) {
-        const int32_t* h1 = T.ht_hlen + T.ht_off[1];
-        int s = 0;
-        for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) s += h1[ix[p] * 2 + ix[p + 1]];
-        *bits += wave_sum(s);
-        return 1;
-    }
-    if (mx <= 3) {
-        int t1 = T.huf_tbl_noESC[mx - 1];
-        const int xlen = T.ht_xlen[t1];
-        const int32_t* hl = (t1 == 2) ? T.table23 : T.table56;
-        int s = 0;
-        for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) s += hl[ix[p] * xlen + ix[p + 1]];   // two 16-bit sums, no carry (<= 288*19)
-        s = wave_sum(s);
-        int s2 = s & 0xffff;
-        s >>= 16;
-        if (s > s2) { s = s2; t1++; }
-        *bits += s;
-        return t1;
-    }
-    if (mx <= 15) {
-        const int t1 = T.huf_tbl_noESC[mx - 1];
-        const int xlen = T.ht_xlen[t1];
-        const int32_t *h1 = T.ht_hlen + T.ht_off[t1], *h2 = T.ht_hlen + T.ht_off[t1 + 1], *h3 = T.ht_hlen + T.ht_off[t1 + 2];
-        int s1 = 0, s2 = 0, s3 = 0;
-        for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) {
-            const int x = ix[p] * xlen + ix[p + 1];
-            s1 += h1[x]; s2 += h2[x]; s3 += h3[x];
-        }
-        s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
-        int t = t1;
-        if (s1 > s2) { s1 = s2; t++; }
-        if (s1 > s3) { s1 = s3; t = t1 + 2; }
-        *bits += s1;
-        return t;
-    }
-    if (mx > IXMAX_VAL) { *bits = LARGE_BITS; return -1; }
+struct RegionPlan { int kind, t1, xlen, lb1, lb2, choice, choice2; };   // kind 0 empty/zero, 1 t1, 2 table23/56, 4 triple, 5 ESC, 6 overflow
+
+LHIP_DEV RegionPlan plan_region(const Tables& T, int mx) {
+    RegionPlan r; r.kind = 0; r.t1 = 0; r.xlen = 0; r.lb1 = r.lb2 = 0; r.choice = r.choice2 = 0;
+    if (mx == 0) return r;
+    if (mx == 1) { r.kind = 1; r.t1 = 1; r.xlen = 2; return r; }
+    if (mx <= 3) { r.kind = 2; r.t1 = T.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 2) ? 3 : 4; return r; }
+    if (mx <= 15) { r.kind = 4; r.t1 = T.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 7) ? 6 : (r.t1 == 10) ? 8 : 16; return r; }
+    if (mx > IXMAX_VAL) { r.kind = 6; return r; }
     mx -= 15;
     int choice2, choice;
     for (choice2 = 24; choice2 < 32; choice2++) if (T.ht_linmax[choice2] >= mx) break;
     for (choice = choice2 - 8; choice < 24; choice++) if (T.ht_linmax[choice] >= mx) break;
-    const int lb1 = T.ht_xlen[choice], lb2 = T.ht_xlen[choice2];
-    int sa = 0, sb2 = 0;        // the two halves of the reference's packed sum, kept apart
-    for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) {
-        int x = ix[p], y = ix[p + 1], n = 0;
-        if (x != 0) { if (x > 14) { x = 15; n++; } x *= 16; }
-        if (y != 0) { if (y > 14) { y = 15; n++; } x += y; }
-        const int lt = T.largetbl[x];
-        sa += (lt >> 16) + n * lb1;
-        sb2 += (lt & 0xffff) + n * lb2;
+    r.kind = 5; r.choice = choice; r.choice2 = choice2; r.lb1 = T.ht_xlen[choice]; r.lb2 = T.ht_xlen[choice2];
+    return r;
+}
+
+// contribution of one pair to the (up to three) length sums of its region
+LHIP_DEV void pair_bits(const QuantLds& L, const RegionPlan& r, int x, int y, int& s0, int& s1, int& s2) {
+    switch (r.kind) {
+        case 1: s0 += hlen_of(L, 1)[x * 2 + y]; break;
+        case 2: s0 += (r.t1 == 2) ? L.tabs->table23[x * 3 + y] : L.tabs->table56[x * 4 + y]; break;   // packed hi|lo
+        case 4: { const int q = x * r.xlen + y; s0 += hlen_of(L, r.t1)[q]; s1 += hlen_of(L, r.t1 + 1)[q]; s2 += hlen_of(L, r.t1 + 2)[q]; } break;
+        case 5: {
+            int n = 0;
+            if (x != 0) { if (x > 14) { x = 15; n++; } x *= 16; }
+            if (y != 0) { if (y > 14) { y = 15; n++; } x += y; }
+            const int lt = L.tabs->largetbl[x];
+            s0 += (lt >> 16) + n * r.lb1; s1 += (lt & 0xffff) + n * r.lb2;
+        } break;
+        default: break;
     }
-    sa = wave_sum(sa); sb2 = wave_sum(sb2);
-    // reference: sum = sa*65536 + sb2 packed; sum2 = sum & 0xffff; sum >>= 16  (sb2 < 65536 on this path)
-    if (sa > sb2) { sa = sb2; choice = choice2; }
-    *bits += sa;
-    return choice;
+}
+
+// final table + bits from the wave-reduced sums (same tie-breaking as count_bit_* in the reference)
+LHIP_DEV int finish_region(const RegionPlan& r, int s0, int s1, int s2, int* bits) {
+    switch (r.kind) {
+        case 0: return 0;
+        case 1: *bits += s0; return 1;
+        case 2: { int t1 = r.t1, sum2 = s0 & 0xffff, sum = s0 >> 16; if (sum > sum2) { sum = sum2; t1++; } *bits += sum; return t1; }
+        case 4: { int t = r.t1; if (s0 > s1) { s0 = s1; t++; } if (s0 > s2) { s0 = s2; t = r.t1 + 2; } *bits += s0; return t; }
+        case 5: { int c = r.choice; if (s0 > s1) { s0 = s1; c = r.choice2; } *bits += s0; return c; }
+        default: *bits = LARGE_BITS; return -1;
+    }
+}
+
+// choose_table over pairs [a, b): cooperative; adds to *bits, returns table
+LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, int* bits, int lane, const QuantLds& L) {
+    int mx = 0;
+    for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) { const int x1 = ix[p], x2 = ix[p + 1]; if (mx < x1) mx = x1; if (mx < x2) mx = x2; }
+    mx = wave_max(mx);
+    const RegionPlan r = plan_region(T, mx);
+    int s0 = 0, s1 = 0, s2 = 0;
+    if (r.kind >= 1 && r.kind <= 5)
+        for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) pair_bits(L, r, ix[p], ix[p + 1], s0, s1, s2);
+    s0 = wave_sum(s0);
+    if (r.kind >= 4) s1 = wave_sum(s1);
+    if (r.kind == 4) s2 = wave_sum(s2);
+    return finish_region(r, s0, s1, s2, bits);
 }
 
 // noquant_count_bits (Takehiro.js:521-628); updates g, returns bits.  pn_sfb_count1 as in/out.
-LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int32_t* ix, int use_prev, int* pn_sfb_count1, int lane) {
+LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int use_prev, int* pn_sfb_count1, int lane, const QuantLds& L) {
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
     if (i > 576) i = 576;
     if (use_prev) *pn_sfb_count1 = 0;
@@ -389,23 +427,22 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int32_t* ix, int
     for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) if ((ix[p] | ix[p + 1]) != 0) top = p + 2;
     i = wave_max(top);
     g.count1 = i;
-    // quadruples (walking down from count1 in steps of 4) with all |v| <= 1
-    int a1 = 0, a2 = 0;
     // quad k covers lines [i-4(k+1), i-4k); the scan stops at the first quad holding a value > 1, or at i <= 3
     const int nq = i >> 2;
-    int firstbig = nq;                                   // index of the first (topmost) quad that breaks the scan
+    int firstbig = nq;
     for (int k = lane; k < nq; k += LHIP_NL) {
         const int e = i - 4 * k;
-        if (((ix[e - 1] | ix[e - 2] | ix[e - 3] | ix[e - 4]) & 0x7fffffff) > 1) { if (k < firstbig) firstbig = k; }
+        if (((ix[e - 1] | ix[e - 2] | ix[e - 3] | ix[e - 4]) & 0x7fff) > 1) { if (k < firstbig) firstbig = k; }
     }
     firstbig = wave_min(firstbig);
+    int a12 = 0;
     for (int k = lane; k < firstbig; k += LHIP_NL) {
         const int e = i - 4 * k;
         const int p = ((ix[e - 4] * 2 + ix[e - 3]) * 2 + ix[e - 2]) * 2 + ix[e - 1];
-        a1 += T.t32l[p];
-        a2 += T.t33l[p];
+        a12 += L.tabs->t32l[p] + (L.tabs->t33l[p] << 16);
     }
-    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    a12 = wave_sum(a12);
+    int a1 = a12 & 0xffff, a2 = a12 >> 16;
     i -= 4 * firstbig;
     int bits = a1;
     g.count1table_select = 0;
@@ -413,30 +450,56 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int32_t* ix, int
     g.count1bits = bits;
     g.big_values = i;
     if (i == 0) return bits;
+    int use2 = 0;
     if (g.block_type == SHORT_TYPE) {
-        a1 = 3 * T.sfb_s[3];
+        a1 = 3 * L.tabs->sfb_s[3];
         if (a1 > g.big_values) a1 = g.big_values;
         a2 = g.big_values;
     } else if (g.block_type == NORM_TYPE) {
         a1 = g.region0_count = T.bv_scf[i - 2];
         a2 = g.region1_count = T.bv_scf[i - 1];
-        a2 = T.sfb_l[a1 + a2 + 2];
-        a1 = T.sfb_l[a1 + 1];
-        if (a2 < i) g.table_select[2] = q_choose_table(T, ix, a2, i, &bits, lane);
+        a2 = L.tabs->sfb_l[a1 + a2 + 2];
+        a1 = L.tabs->sfb_l[a1 + 1];
+        if (a2 < i) use2 = 1;
     } else {
         g.region0_count = 7;
         g.region1_count = SBMAX_l - 1 - 7 - 1;
-        a1 = T.sfb_l[7 + 1];
+        a1 = L.tabs->sfb_l[7 + 1];
         a2 = i;
         if (a1 > a2) a1 = a2;
     }
     if (a1 > i) a1 = i;
     if (a2 > i) a2 = i;
-    if (0 < a1) g.table_select[0] = q_choose_table(T, ix, 0, a1, &bits, lane);
-    if (a1 < a2) g.table_select[1] = q_choose_table(T, ix, a1, a2, &bits, lane);
+    // one pass over the big-value pairs: region maxima ...
+    int m0 = 0, m1 = 0, m2 = 0;
+    for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) {
+        const int x = ix[p], y = ix[p + 1], m = x > y ? x : y;
+        if (p < a1) { if (m0 < m) m0 = m; } else if (p < a2) { if (m1 < m) m1 = m; } else { if (m2 < m) m2 = m; }
+    }
+    m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
+    const RegionPlan r0 = plan_region(T, m0), r1 = plan_region(T, m1), r2 = plan_region(T, m2);
+    // ... and the candidate-table length sums of all three regions
+    int s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
+    for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) {
+        const int x = ix[p], y = ix[p + 1];
+        if (p < a1) pair_bits(L, r0, x, y, s00, s01, s02);
+        else if (p < a2) pair_bits(L, r1, x, y, s10, s11, s12);
+        else pair_bits(L, r2, x, y, s20, s21, s22);
+    }
+    s00 = wave_sum(s00); s10 = wave_sum(s10); s20 = wave_sum(s20);
+    if (r0.kind >= 4) s01 = wave_sum(s01);
+    if (r1.kind >= 4) s11 = wave_sum(s11);
+    if (r2.kind >= 4) s21 = wave_sum(s21);
+    if (r0.kind == 4) s02 = wave_sum(s02);
+    if (r1.kind == 4) s12 = wave_sum(s12);
+    if (r2.kind == 4) s22 = wave_sum(s22);
+    // the reference evaluates region 2 first (NORM only), then 0, then 1; an overflowing region *sets* bits
+    if (use2) g.table_select[2] = finish_region(r2, s20, s21, s22, &bits);
+    if (0 < a1) g.table_select[0] = finish_region(r0, s00, s01, s02, &bits);
+    if (a1 < a2) g.table_select[1] = finish_region(r1, s10, s11, s12, &bits);
     if (use_prev && g.block_type == NORM_TYPE) {
         int sfb = 0;
-        while (T.sfb_l[sfb] < g.big_values) sfb++;
+        while (L.tabs->sfb_l[sfb] < g.big_values) sfb++;
         *pn_sfb_count1 = sfb;
     }
     return bits;
@@ -445,29 +508,30 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int32_t* ix, int
 struct PrevNoise { int gain, sfb_count1; };   // scalar part of CalcNoiseData (arrays are L.pn_*)
 
 // count_bits (Takehiro.js:630-660)
-LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int32_t* ix, PrevNoise* pn, int lane, QuantLds& L) {
-    const double w = (double)IXMAX_VAL / ipow20(T, g.global_gain);
+LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, PrevNoise* pn, int lane, QuantLds& L) {
+    const double w = (double)IXMAX_VAL / ipow20(L, g.global_gain);
     if (g.xrpow_max > w) return LARGE_BITS;
     { PH_BEGIN(); q_quantize(T, g, scalefac, ix, pn != nullptr, pn ? pn->gain : 0, pn ? pn->sfb_count1 : 0, lane, L); PH_END(L, PH_QUANTIZE); }
     int dummy = 0;
     PH_BEGIN();
-    const int r = q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane);
+    const int r = q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane, L);
     PH_END(L, PH_COUNT);
     return r;
 }
 
 // ---------------------------------------------------------------------------------------------
 // calc_noise (QuantizePVT.js:784-878); distort -> L.distort, cache -> L.pn_*
+// One lane per band sums its lines in the reference's order (f64 sums are order-sensitive); all gathers hit LDS.
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int32_t* ix, NoiseRes* res,
+LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
                            PrevNoise* pn, int lane, QuantLds& L) {
     // 1) the (sequential) start-line walk: where each band begins and how many pairs it sums
     if (lane == 0) {
         int j = 0;
         for (int sfb = 0; sfb < g.psymax; sfb++) {
-            const int s = sf_step(T, g, scalefac, L.window, sfb);
+            const int s = sf_step(L, g, scalefac, L.window, sfb);
             if (pn != nullptr && L.pn_step[sfb] == s) {
-                L.ncached[sfb] = 1;
+                L.ncached[sfb] = 1; L.nstart[sfb] = j; L.npairs[sfb] = 0;
                 j += L.width[sfb];
             } else {
                 int l = L.width[sfb] >> 1;
@@ -481,33 +545,28 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         }
     }
     wave_sync();
-    // 2) per band: noise sum in line order, distortion ratio, log10
+    // 2) per band (one lane each): noise summed in the reference's line order, distortion ratio, log10
     int over = 0, ssd = 0;
     double max_noise = -20.0;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
-        const int s = sf_step(T, g, scalefac, L.window, sfb);
         double noise;
         if (L.ncached[sfb]) {
             noise = L.pn_noise[sfb];
             L.distort[sfb] = (float)(noise / (double)L.xmin[sfb]);
             noise = L.pn_noise_log[sfb];
         } else {
-            const double step = pow20(T, s);
-            int j = L.nstart[sfb], l = L.npairs[sfb];
+            const int s = sf_step(L, g, scalefac, L.window, sfb);
+            const double step = pow20(L, s);
+            int j = L.nstart[sfb];
+            const int n = 2 * L.npairs[sfb];
             noise = 0;
             if (j > g.count1) {
-                for (int t = 0; t < 2 * l; t++, j++) { const double x = L.xr[j]; noise += x * x; }
+                for (int t = 0; t < n; t++, j++) { const double x = L.xr[j]; noise += x * x; }
             } else if (j > g.big_values) {
-                const float ix01_1 = (float)step;
-                for (int t = 0; t < 2 * l; t++, j++) {
-                    const double x = d_abs((double)L.xr[j]) - (ix[j] == 0 ? 0.0 : (double)ix01_1);
-                    noise += x * x;
-                }
+                const double s1 = (double)(float)step;
+                for (int t = 0; t < n; t++, j++) { const double x = d_abs((double)L.xr[j]) - (ix[j] == 0 ? 0.0 : s1); noise += x * x; }
             } else {
-                for (int t = 0; t < 2 * l; t++, j++) {
-                    const double x = d_abs((double)L.xr[j]) - (double)T.pow43[ix[j]] * step;
-                    noise += x * x;
-                }
+                for (int t = 0; t < n; t++, j++) { const double x = d_abs((double)L.xr[j]) - pow43v(T, L, ix[j]) * step; noise += x * x; }
             }
             if (pn != nullptr) { L.pn_step[sfb] = s; L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
@@ -530,7 +589,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     wave_sync();
 }
 
-LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int32_t* ix, NoiseRes* res,
+LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
                            PrevNoise* pn, int lane, QuantLds& L) {
     PH_BEGIN();
     q_calc_noise_(T, g, scalefac, ix, res, pn, lane, L);
@@ -582,7 +641,7 @@ LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantL
 LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L) {
     float m = 0.f;
     for (int i = lane; i < 576; i += LHIP_NL) {
-        const int sfb = L.line2sfb[i];
+        const int sfb = line2sfb(L, g.block_type)[i];
         if (L.qmode[sfb]) {
             const float v = (float)((double)L.xrpow[i] * amp);
             L.xrpow[i] = v;
@@ -667,10 +726,10 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
                 if (s >= 0) { if (lane == 0) scalefac[sfb] = s; }
                 else {
                     if (lane == 0) scalefac[sfb] = 0;
-                    amp = ipow20(T, 210 + (s << (g.scalefac_scale + 1)));
+                    amp = ipow20(L, 210 + (s << (g.scalefac_scale + 1)));
                     doamp = 1;
                 }
-            } else { amp = ipow20(T, 202); doamp = 1; }
+            } else { amp = ipow20(L, 202); doamp = 1; }
             wave_sync();
             if (doamp) {
                 float m = 0.f;
@@ -874,26 +933,28 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     if (recalc != 0) q_scale_bitcount(T, g, sf, lane);
 }
 
-// Huffman statistics of scalefactor band `band` over pairs below `limit`:
-// row 0 max, 1 t1, 2 table23(packed), 3 table56(packed), 4..6 t7-9, 7..9 t10-12, 10..12 t13-15, 13 largetbl hi, 14 lo, 15 #esc
-LHIP_DEV void q_band_stats(const Tables& T, const int32_t* ix, int limit, int lane, QuantLds& L) {
+// Huffman statistics per scalefactor band over the pairs below `limit`, then turned into prefix sums over
+// bands so that any union of whole bands [b0, b1) costs O(1):
+// row 0 max (kept per band), 1 t1, 2 table23 (packed), 3 table56 (packed), 4..6 t7-9, 7..9 t10-12, 10..12 t13-15,
+// 13 largetbl hi, 14 largetbl lo, 15 number of escaped values.  A row is only meaningful for regions whose
+// maximum admits the table group, which is exactly when the reference would look at it.
+LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int lane, QuantLds& L) {
     for (int band = lane; band < SBMAX_l; band += LHIP_NL) {
-        int a = T.sfb_l[band], b = T.sfb_l[band + 1];
+        const int a = L.tabs->sfb_l[band];
+        int b = L.tabs->sfb_l[band + 1];
         if (b > limit) b = limit;
         int mx = 0;
         for (int p = a; p < b; p++) if (mx < ix[p]) mx = ix[p];
         int s[16];
         for (int k = 0; k < 16; k++) s[k] = 0;
         s[0] = mx;
-        const int32_t *h1 = T.ht_hlen + T.ht_off[1];
-        const int32_t *h7 = T.ht_hlen + T.ht_off[7], *h8 = T.ht_hlen + T.ht_off[8], *h9 = T.ht_hlen + T.ht_off[9];
-        const int32_t *h10 = T.ht_hlen + T.ht_off[10], *h11 = T.ht_hlen + T.ht_off[11], *h12 = T.ht_hlen + T.ht_off[12];
-        const int32_t *h13 = T.ht_hlen + T.ht_off[13], *h14 = T.ht_hlen + T.ht_off[14], *h15 = T.ht_hlen + T.ht_off[15];
+        const uint8_t *h1 = hlen_of(L, 1), *h7 = hlen_of(L, 7), *h8 = hlen_of(L, 8), *h9 = hlen_of(L, 9), *h10 = hlen_of(L, 10),
+                      *h11 = hlen_of(L, 11), *h12 = hlen_of(L, 12), *h13 = hlen_of(L, 13), *h14 = hlen_of(L, 14), *h15 = hlen_of(L, 15);
         for (int p = a; p < b; p += 2) {
             const int x = ix[p], y = ix[p + 1];
             if (mx <= 1) s[1] += h1[x * 2 + y];
-            if (mx <= 2) s[2] += T.table23[x * 3 + y];
-            if (mx <= 3) s[3] += T.table56[x * 4 + y];
+            if (mx <= 2) s[2] += L.tabs->table23[x * 3 + y];
+            if (mx <= 3) s[3] += L.tabs->table56[x * 4 + y];
             if (mx <= 5) { const int q = x * 6 + y; s[4] += h7[q]; s[5] += h8[q]; s[6] += h9[q]; }
             if (mx <= 7) { const int q = x * 8 + y; s[7] += h10[q]; s[8] += h11[q]; s[9] += h12[q]; }
             if (mx <= 15) { const int q = x * 16 + y; s[10] += h13[q]; s[11] += h14[q]; s[12] += h15[q]; }
@@ -901,62 +962,48 @@ LHIP_DEV void q_band_stats(const Tables& T, const int32_t* ix, int limit, int la
                 int xx = x, yy = y, n = 0;
                 if (xx != 0) { if (xx > 14) { xx = 15; n++; } xx *= 16; }
                 if (yy != 0) { if (yy > 14) { yy = 15; n++; } xx += yy; }
-                const int lt = T.largetbl[xx];
+                const int lt = L.tabs->largetbl[xx];
                 s[13] += lt >> 16; s[14] += lt & 0xffff; s[15] += n;
             }
         }
-        for (int k = 0; k < 16; k++) L.bstat[k][band] = s[k];
+        for (int k = 0; k < 16; k++) L.hd.bstat[k][band + 1] = s[k];
+    }
+    wave_sync();
+    // prefix over bands: bstat[k][b] becomes the sum over bands < b (row 0: running maximum is NOT a prefix -- kept per band)
+    for (int k = 1 + lane; k < 16; k += LHIP_NL) {
+        int acc = 0;
+        L.hd.bstat[k][0] = 0;
+        for (int b = 1; b <= SBMAX_l; b++) { acc += L.hd.bstat[k][b]; L.hd.bstat[k][b] = acc; }
     }
     wave_sync();
 }
 
-// choose_table for the union of whole bands [b0, b1) from the statistics above
+// choose_table for the union of whole bands [b0, b1) from the statistics above (bits are added to *bits)
 LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, const QuantLds& L) {
-    int mx = 0, s[16];
-    for (int k = 1; k < 16; k++) s[k] = 0;
-    for (int b = b0; b < b1; b++) {
-        if (mx < L.bstat[0][b]) mx = L.bstat[0][b];
-        for (int k = 1; k < 16; k++) s[k] += L.bstat[k][b];
+    int mx = 0;
+    for (int b = b0; b < b1; b++) if (mx < L.hd.bstat[0][b + 1]) mx = L.hd.bstat[0][b + 1];
+    const RegionPlan r = plan_region(T, mx);
+#define SUMROW(k) (L.hd.bstat[k][b1] - L.hd.bstat[k][b0])
+    switch (r.kind) {
+        case 0: return 0;
+        case 1: return finish_region(r, SUMROW(1), 0, 0, bits);
+        case 2: return finish_region(r, (r.t1 == 2) ? SUMROW(2) : SUMROW(3), 0, 0, bits);
+        case 4: { const int o = (r.t1 == 7) ? 4 : (r.t1 == 10) ? 7 : 10; return finish_region(r, SUMROW(o), SUMROW(o + 1), SUMROW(o + 2), bits); }
+        case 5: { const int n = SUMROW(15); return finish_region(r, SUMROW(13) + n * r.lb1, SUMROW(14) + n * r.lb2, 0, bits); }
+        default: return finish_region(r, 0, 0, 0, bits);
     }
-    if (mx == 0) return 0;
-    if (mx == 1) { *bits += s[1]; return 1; }
-    if (mx <= 3) {
-        int t1 = T.huf_tbl_noESC[mx - 1];
-        int sum = (mx == 2) ? s[2] : s[3];
-        int sum2 = sum & 0xffff;
-        sum >>= 16;
-        if (sum > sum2) { sum = sum2; t1++; }
-        *bits += sum;
-        return t1;
-    }
-    if (mx <= 15) {
-        const int t1 = T.huf_tbl_noESC[mx - 1];
-        const int o = (t1 == 7) ? 4 : (t1 == 10) ? 7 : 10;
-        int s1 = s[o], s2 = s[o + 1], s3 = s[o + 2], t = t1;
-        if (s1 > s2) { s1 = s2; t++; }
-        if (s1 > s3) { s1 = s3; t = t1 + 2; }
-        *bits += s1;
-        return t;
-    }
-    if (mx > IXMAX_VAL) { *bits = LARGE_BITS; return -1; }
-    mx -= 15;
-    int choice2, choice;
-    for (choice2 = 24; choice2 < 32; choice2++) if (T.ht_linmax[choice2] >= mx) break;
-    for (choice = choice2 - 8; choice < 24; choice++) if (T.ht_linmax[choice] >= mx) break;
-    int sa = s[13] + s[15] * T.ht_xlen[choice], sb = s[14] + s[15] * T.ht_xlen[choice2];
-    if (sa > sb) { sa = sb; choice = choice2; }
-    *bits += sa;
-    return choice;
+#undef SUMROW
 }
 
-LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const int32_t* ix, int lane, const QuantLds& L) {
+// recalc_divide_sub (Takehiro.js:698-725); region 2 = bands r2.. up to big_values, from the band statistics
+LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const QuantLds& L) {
     const int bigv = c2.big_values;
     for (int r2 = 2; r2 < SBMAX_l + 1; r2++) {
-        const int a2 = T.sfb_l[r2];
+        const int a2 = L.tabs->sfb_l[r2];
         if (a2 >= bigv) break;
         int bits = L.r01_bits[r2 - 2] + c2.count1bits;
         if (g.part2_3_length <= bits) break;
-        const int r2t = q_choose_table(T, ix, a2, bigv, &bits, lane);
+        const int r2t = q_choose_from_stats(T, r2, SBMAX_l, &bits, L);
         if (g.part2_3_length <= bits) continue;
         g = c2;
         g.part2_3_length = bits;
@@ -969,34 +1016,40 @@ LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const in
 }
 
 LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L) {
-    const int32_t* ix = L.ixb;
+    const int16_t* ix = L.ixb;
     GI c2 = g;
     if (g.block_type == NORM_TYPE) {
-        // recalc_divide_init: every (region0, region1) split evaluated from per-band statistics
+        // recalc_divide_init: every (region0, region1) split evaluated from the per-band statistics
         q_band_stats(T, ix, g.big_values, lane, L);
         const int bigv = g.big_values;
         for (int s = lane; s < 24; s += LHIP_NL) { L.r01_bits[s] = LARGE_BITS; L.r01_div[s] = 0; L.r0_tbl[s] = 0; L.r1_tbl[s] = 0; }
-        wave_sync();
-        // lane s owns the sum index s = r0 + r1 (the only slots recalc_divide_sub can read are 0..20)
-        for (int s = lane; s <= 20; s += LHIP_NL) {
-            int bb = LARGE_BITS, bd = 0, bt0 = 0, bt1 = 0;
-            for (int r0 = 0; r0 < 16 && r0 <= s; r0++) {
-                const int r1 = s - r0;
-                if (r1 >= 8) continue;
-                const int a1 = T.sfb_l[r0 + 1];
-                if (a1 >= bigv) break;
-                const int a2 = T.sfb_l[r0 + r1 + 2];
-                if (a2 >= bigv) continue;            // the r1 loop of the reference has ended for this r0
-                int r0bits = 0;
-                const int r0t = q_choose_from_stats(T, 0, r0 + 1, &r0bits, L);
-                int bits = r0bits;
-                const int r1t = q_choose_from_stats(T, r0 + 1, r0 + r1 + 2, &bits, L);
-                if (bb > bits) { bb = bits; bd = r0; bt0 = r0t; bt1 = r1t; }
+        // all 16 x 8 splits in parallel; candidate bits go to cand[r0 + r1][r0]
+        for (int c = lane; c < 128; c += LHIP_NL) {
+            const int r0 = c >> 3, r1 = c & 7, sidx = r0 + r1;
+            if (sidx > 20) continue;
+            int bits = LARGE_BITS;
+            if (L.tabs->sfb_l[r0 + 1] < bigv && L.tabs->sfb_l[r0 + r1 + 2] < bigv) {
+                bits = 0;
+                q_choose_from_stats(T, 0, r0 + 1, &bits, L);
+                q_choose_from_stats(T, r0 + 1, r0 + r1 + 2, &bits, L);
             }
-            L.r01_bits[s] = bb; L.r01_div[s] = bd; L.r0_tbl[s] = bt0; L.r1_tbl[s] = bt1;
+            L.hd.cand[sidx][r0] = bits;
         }
         wave_sync();
-        q_recalc_divide_sub(T, c2, g, ix, lane, L);
+        // lane s: the first r0 (ascending) with the strictly smallest bits wins, as in the reference's loop order
+        for (int sidx = lane; sidx <= 20; sidx += LHIP_NL) {
+            int bb = LARGE_BITS, bd = -1;
+            for (int r0 = (sidx > 7 ? sidx - 7 : 0); r0 < 16 && r0 <= sidx; r0++)
+                if (bb > L.hd.cand[sidx][r0]) { bb = L.hd.cand[sidx][r0]; bd = r0; }
+            if (bd >= 0) {
+                int dummy = 0;
+                L.r01_bits[sidx] = bb; L.r01_div[sidx] = bd;
+                L.r0_tbl[sidx] = q_choose_from_stats(T, 0, bd + 1, &dummy, L);
+                L.r1_tbl[sidx] = q_choose_from_stats(T, bd + 1, sidx + 2, &dummy, L);
+            }
+        }
+        wave_sync();
+        q_recalc_divide_sub(T, c2, g, L);
     }
     int i = c2.big_values;
     if (i == 0 || (ix[i - 2] | ix[i - 1]) > 1) return;
@@ -1004,23 +1057,30 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
     if (i > 576) return;
     c2 = g;
     c2.count1 = i;
-    int a1 = 0, a2 = 0;
-    for (; i > c2.big_values; i -= 4) {
-        const int p = ((ix[i - 4] * 2 + ix[i - 3]) * 2 + ix[i - 2]) * 2 + ix[i - 1];
-        a1 += T.t32l[p];
-        a2 += T.t33l[p];
+    // quads from count1 + 2 down to the old big_values (all values <= 1 there)
+    const int nq = (i - c2.big_values + 3) >> 2;
+    int a12 = 0;
+    for (int k = lane; k < nq; k += LHIP_NL) {
+        const int e = i - 4 * k;
+        const int p = ((ix[e - 4] * 2 + ix[e - 3]) * 2 + ix[e - 2]) * 2 + ix[e - 1];
+        a12 += L.tabs->t32l[p] + (L.tabs->t33l[p] << 16);
     }
+    a12 = wave_sum(a12);
+    int a1 = a12 & 0xffff, a2 = a12 >> 16;
+    i -= 4 * nq;
     c2.big_values = i;
     c2.count1table_select = 0;
     if (a1 > a2) { a1 = a2; c2.count1table_select = 1; }
     c2.count1bits = a1;
-    if (c2.block_type == NORM_TYPE) q_recalc_divide_sub(T, c2, g, ix, lane, L);
-    else {
+    if (c2.block_type == NORM_TYPE) {
+        if (c2.big_values != g.big_values) q_band_stats(T, ix, c2.big_values, lane, L);   // statistics must honour the new limit
+        q_recalc_divide_sub(T, c2, g, L);
+    } else {
         c2.part2_3_length = a1;
-        a1 = T.sfb_l[7 + 1];
+        a1 = L.tabs->sfb_l[7 + 1];
         if (a1 > i) a1 = i;
-        if (a1 > 0) c2.table_select[0] = q_choose_table(T, ix, 0, a1, &c2.part2_3_length, lane);
-        if (i > a1) c2.table_select[1] = q_choose_table(T, ix, a1, i, &c2.part2_3_length, lane);
+        if (a1 > 0) c2.table_select[0] = q_choose_table(T, ix, 0, a1, &c2.part2_3_length, lane, L);
+        if (i > a1) c2.table_select[1] = q_choose_table(T, ix, a1, i, &c2.part2_3_length, lane, L);
         if (g.part2_3_length > c2.part2_3_length) g = c2;
     }
 }

@@ -177,13 +177,32 @@ __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const Stream
     __shared__ MdctLds L;
     kb_mdct(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-__global__ __launch_bounds__(64) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain) {
-    __shared__ QuantLds L;
-    kb_quant(T, pb, W, SD, blockIdx.x, chain, threadIdx.x, L);
+// quantization kernels: 4 waves (= 4 frames) per workgroup share one copy of the lookup tables in LDS
+enum { QWAVES = 4 };
+#ifndef LHIP_QOCC
+#define LHIP_QOCC 3     /* waves per SIMD the quantization kernel is register-budgeted for */
+#endif
+__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain, int nfs) {
+    __shared__ QuantTabs Q;
+    __shared__ QuantLds L[QWAVES];
+    q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, fslot = blockIdx.x * QWAVES + wv;
+    if (fslot >= nfs) return;
+    if ((threadIdx.x & 63) == 0) L[wv].tabs = &Q;
+    wave_sync();
+    kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv]);
 }
-__global__ __launch_bounds__(64) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD) {
-    __shared__ QuantLds L;
-    kb_validate(T, pb, W, SD, blockIdx.x, threadIdx.x, L);
+__global__ __launch_bounds__(64 * QWAVES) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
+    __shared__ QuantTabs Q;
+    __shared__ QuantLds L[QWAVES];
+    q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, fslot = blockIdx.x * QWAVES + wv;
+    if (fslot >= nfs) return;
+    if ((threadIdx.x & 63) == 0) L[wv].tabs = &Q;
+    wave_sync();
+    kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv]);
 }
 __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ BitsLds L;
@@ -536,7 +555,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
 #ifdef LHIP_HOSTSIM
     {
-        static PsyALds LA; static PsyBLds LB; static MdctLds LM; static QuantLds LQ; static BitsLds LBi;
+        static PsyALds LA; static PsyBLds LB; static MdctLds LM; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
+        q_load_tabs(T, QT, 0, 1); LQ.tabs = &QT;
         for (int s = 0; s < S; s++) kb_load(T, W, dSD, dIO, s, 0);
         kb_prep(T, W, dSD, dIO, S, 0, 1);
         for (int b = 0; b < ngs * C; b++) kb_psyA(T, W, dSD, b / C, b % C, 0, LA);
@@ -576,17 +596,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, ngs * C, st, T, W, dSD);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
-    LAUNCH(KT_QUANT, g_quant, nfs, st, T, ts.pb10, W, dSD, 0);
+    LAUNCHB(KT_QUANT, g_quant, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, 0, nfs);
     if (nfr > 0) {
         for (;;) {
-            LAUNCH(KT_VALIDATE, g_validate, nfs, st, T, ts.pb10, W, dSD);
+            LAUNCHB(KT_VALIDATE, g_validate, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, nfs);
             int32_t nf = 0;
             if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
             if (!rt::sync(st)) return false;
             if (nf == 0) break;
             repaired += nf; iters++;
             if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
-            LAUNCH(KT_REPAIR, g_quant, nfs, st, T, ts.pb10, W, dSD, 1);
+            LAUNCHB(KT_REPAIR, g_quant, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, 1, nfs);
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
     }
