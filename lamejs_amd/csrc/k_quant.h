@@ -52,6 +52,9 @@ struct QuantTabs {
     uint8_t hlen[1088];          // code lengths of tables 1, 7..15 (offsets in hoff)
     uint8_t t32l[16], t33l[16];
     uint8_t l2s_long[576], l2s_short[576];
+    uint8_t bv_scf[576];
+    uint8_t huf_tbl_noESC[16], ht_xlen[34];
+    uint16_t ht_linmax[34];
 };
 
 LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
@@ -64,6 +67,9 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int i = tid; i < SBMAX_l + 1; i += nthr) Q.sfb_l[i] = T.sfb_l[i];
     for (int i = tid; i < SBMAX_s + 1; i += nthr) Q.sfb_s[i] = T.sfb_s[i];
     for (int i = tid; i < SBMAX_l; i += nthr) Q.pretab[i] = T.pretab[i];
+    for (int i = tid; i < 576; i += nthr) Q.bv_scf[i] = (uint8_t)T.bv_scf[i];
+    for (int i = tid; i < 15; i += nthr) Q.huf_tbl_noESC[i] = (uint8_t)T.huf_tbl_noESC[i];
+    for (int i = tid; i < 34; i += nthr) { Q.ht_xlen[i] = (uint8_t)T.ht_xlen[i]; Q.ht_linmax[i] = (uint16_t)T.ht_linmax[i]; }
     // Huffman length pool: table 1 (4 entries), 7-9 (36), 10-12 (64), 13-15 (256)
     {
         int off = 0;
@@ -117,8 +123,16 @@ struct QuantLds {
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV double ipow20(const QuantLds& L, int x) { return (double)L.tabs->ipow20[x]; }
 LHIP_DEV double pow20(const QuantLds& L, int x) { return (double)L.tabs->pow20[x + Q_MAX2]; }
-LHIP_DEV double pow43v(const Tables& T, const QuantLds& L, int i) { return (double)(i < QT_N ? L.tabs->pow43[i] : T.pow43[i]); }
-LHIP_DEV double adj43v(const Tables& T, const QuantLds& L, int i) { return (double)(i < QT_N ? L.tabs->adj43[i] : T.adj43[i]); }
+LHIP_DEV double pow43v(const Tables& T, const QuantLds& L, int i) {
+    float v = L.tabs->pow43[i < QT_N ? i : QT_N - 1];
+    if (i >= QT_N) v = T.pow43[i];          // rare: large quantized values
+    return (double)v;
+}
+LHIP_DEV double adj43v(const Tables& T, const QuantLds& L, int i) {
+    float v = L.tabs->adj43[i < QT_N ? i : QT_N - 1];
+    if (i >= QT_N) v = T.adj43[i];
+    return (double)v;
+}
 LHIP_DEV const uint8_t* line2sfb(const QuantLds& L, int block_type) { return block_type == SHORT_TYPE ? L.tabs->l2s_short : L.tabs->l2s_long; }
 LHIP_DEV const uint8_t* hlen_of(const QuantLds& L, int t) { return L.tabs->hlen + L.tabs->hoff[t]; }
 
@@ -303,52 +317,46 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
     const int mnz = g.max_nonzero_coeff;
-    // per-band decision: 0 keep cached values, 1 full quantization, 2 the 0/1 shortcut
+    // per-band decision as wave-uniform bit masks: cached (keep old values) / 0-1 shortcut; the first
+    // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
+    uint64_t m_cached = 0, m_zo = 0;
     int cand = 99;
     for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
         int step = -1;
         if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(L, g, scalefac, L.window, sfb);
-        int mode;
-        if (prev_data_use && L.pn_step[sfb] == step) mode = 0;
+        if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
         else {
-            mode = 1;
-            if (use_prev && pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) mode = 2;
-            if (L.start[sfb] + L.width[sfb] > mnz && sfb < cand) cand = sfb;   // first such band ends the walk
+            if (use_prev && pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) m_zo |= 1ull << sfb;
+            if (L.start[sfb] + L.width[sfb] > mnz && sfb < cand) cand = sfb;
         }
-        L.qmode[sfb] = mode;
-        L.qlen[sfb] = L.width[sfb];
     }
+    m_cached = wave_or64(m_cached); m_zo = wave_or64(m_zo);
     const int sstar = wave_min(cand);
-    wave_sync();
-    int fill_from = 576;
+    int fill_from = 576, last_line = 576;       // lines >= last_line are not quantized (bands after sstar, tail of sstar)
     if (sstar <= sfbmax) {
         int l = mnz - L.start[sstar] + 1;
         if (l < 0) l = 0;
         fill_from = mnz;
-        if (lane == 0) { L.qmode[sstar] = 1; L.qlen[sstar] = l & ~1; }
+        last_line = L.start[sstar] + (l & ~1);
+        m_zo &= ~(1ull << sstar);                // the partial band is always quantized in full
     }
-    wave_sync();
     const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(L, g.block_type);
     for (int i = lane; i < 576; i += LHIP_NL) {
         const int sfb = l2s[i];
-        int have = 0, v = 0;
-        if (i >= fill_from) { have = 1; v = 0; }
-        if (sfb <= sfbmax && sfb <= sstar) {
-            const int mode = L.qmode[sfb];
-            if (mode != 0 && (i - L.start[sfb]) < L.qlen[sfb]) {
-                have = 1;
-                const double xv = L.xrpow[i];
-                if (mode == 2) v = (compareval0 > xv) ? 0 : 1;
-                else {
-                    double x = xv * istep;
-                    const int rx = js_toint32(x);
-                    x += adj43v(T, L, rx);
-                    v = js_toint32(x);
-                }
+        const int proc = (i < last_line) && !((m_cached >> sfb) & 1);
+        if (proc) {
+            const double xv = L.xrpow[i];
+            int v;
+            if ((m_zo >> sfb) & 1) v = (compareval0 > xv) ? 0 : 1;
+            else {
+                double x = xv * istep;                 // 0 <= x <= 8206 (guarded by count_bits): plain truncation == ToInt32
+                const int rx = (int)x;
+                x += adj43v(T, L, rx);
+                v = (int)x;
             }
-        }
-        if (have) ix[i] = (int16_t)v;
+            ix[i] = (int16_t)v;
+        } else if (i >= fill_from) ix[i] = 0;
     }
     wave_sync();
 }
@@ -358,18 +366,18 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
 // ---------------------------------------------------------------------------------------------
 struct RegionPlan { int kind, t1, xlen, lb1, lb2, choice, choice2; };   // kind 0 empty/zero, 1 t1, 2 table23/56, 4 triple, 5 ESC, 6 overflow
 
-LHIP_DEV RegionPlan plan_region(const Tables& T, int mx) {
+LHIP_DEV RegionPlan plan_region_(const QuantTabs& Q, int mx) {
     RegionPlan r; r.kind = 0; r.t1 = 0; r.xlen = 0; r.lb1 = r.lb2 = 0; r.choice = r.choice2 = 0;
     if (mx == 0) return r;
     if (mx == 1) { r.kind = 1; r.t1 = 1; r.xlen = 2; return r; }
-    if (mx <= 3) { r.kind = 2; r.t1 = T.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 2) ? 3 : 4; return r; }
-    if (mx <= 15) { r.kind = 4; r.t1 = T.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 7) ? 6 : (r.t1 == 10) ? 8 : 16; return r; }
+    if (mx <= 3) { r.kind = 2; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 2) ? 3 : 4; return r; }
+    if (mx <= 15) { r.kind = 4; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 7) ? 6 : (r.t1 == 10) ? 8 : 16; return r; }
     if (mx > IXMAX_VAL) { r.kind = 6; return r; }
     mx -= 15;
     int choice2, choice;
-    for (choice2 = 24; choice2 < 32; choice2++) if (T.ht_linmax[choice2] >= mx) break;
-    for (choice = choice2 - 8; choice < 24; choice++) if (T.ht_linmax[choice] >= mx) break;
-    r.kind = 5; r.choice = choice; r.choice2 = choice2; r.lb1 = T.ht_xlen[choice]; r.lb2 = T.ht_xlen[choice2];
+    for (choice2 = 24; choice2 < 32; choice2++) if (Q.ht_linmax[choice2] >= mx) break;
+    for (choice = choice2 - 8; choice < 24; choice++) if (Q.ht_linmax[choice] >= mx) break;
+    r.kind = 5; r.choice = choice; r.choice2 = choice2; r.lb1 = Q.ht_xlen[choice]; r.lb2 = Q.ht_xlen[choice2];
     return r;
 }
 
@@ -407,7 +415,7 @@ LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, in
     int mx = 0;
     for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) { const int x1 = ix[p], x2 = ix[p + 1]; if (mx < x1) mx = x1; if (mx < x2) mx = x2; }
     mx = wave_max(mx);
-    const RegionPlan r = plan_region(T, mx);
+    const RegionPlan r = plan_region_(*L.tabs, mx);
     int s0 = 0, s1 = 0, s2 = 0;
     if (r.kind >= 1 && r.kind <= 5)
         for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) pair_bits(L, r, ix[p], ix[p + 1], s0, s1, s2);
@@ -456,8 +464,8 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         if (a1 > g.big_values) a1 = g.big_values;
         a2 = g.big_values;
     } else if (g.block_type == NORM_TYPE) {
-        a1 = g.region0_count = T.bv_scf[i - 2];
-        a2 = g.region1_count = T.bv_scf[i - 1];
+        a1 = g.region0_count = L.tabs->bv_scf[i - 2];
+        a2 = g.region1_count = L.tabs->bv_scf[i - 1];
         a2 = L.tabs->sfb_l[a1 + a2 + 2];
         a1 = L.tabs->sfb_l[a1 + 1];
         if (a2 < i) use2 = 1;
@@ -477,7 +485,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         if (p < a1) { if (m0 < m) m0 = m; } else if (p < a2) { if (m1 < m) m1 = m; } else { if (m2 < m) m2 = m; }
     }
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
-    const RegionPlan r0 = plan_region(T, m0), r1 = plan_region(T, m1), r2 = plan_region(T, m2);
+    const RegionPlan r0 = plan_region_(*L.tabs, m0), r1 = plan_region_(*L.tabs, m1), r2 = plan_region_(*L.tabs, m2);
     // ... and the candidate-table length sums of all three regions
     int s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
     for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) {
@@ -982,7 +990,7 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
 LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, const QuantLds& L) {
     int mx = 0;
     for (int b = b0; b < b1; b++) if (mx < L.hd.bstat[0][b + 1]) mx = L.hd.bstat[0][b + 1];
-    const RegionPlan r = plan_region(T, mx);
+    const RegionPlan r = plan_region_(*L.tabs, mx);
 #define SUMROW(k) (L.hd.bstat[k][b1] - L.hd.bstat[k][b0])
     switch (r.kind) {
         case 0: return 0;

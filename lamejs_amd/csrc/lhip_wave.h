@@ -12,6 +12,7 @@ LHIP_DEV int wave_sum(int v) { return v; }
 LHIP_DEV int wave_max(int v) { return v; }
 LHIP_DEV int wave_min(int v) { return v; }
 LHIP_DEV int wave_or(int v) { return v; }
+LHIP_DEV uint64_t wave_or64(uint64_t v) { return v; }
 LHIP_DEV float wave_maxf(float v) { return v; }
 LHIP_DEV double wave_maxd(double v) { return v; }
 LHIP_DEV double wave_sumd(double v) { return v; }
@@ -33,6 +34,10 @@ LHIP_DEV int wave_sum(int v) { return __reduce_add_sync(~0ull, v); }
 LHIP_DEV int wave_max(int v) { return __reduce_max_sync(~0ull, v); }
 LHIP_DEV int wave_min(int v) { return __reduce_min_sync(~0ull, v); }
 LHIP_DEV int wave_or(int v) { return (int)__reduce_or_sync(~0ull, (unsigned)v); }
+LHIP_DEV uint64_t wave_or64(uint64_t v) {
+    const unsigned lo = __reduce_or_sync(~0ull, (unsigned)v), hi = __reduce_or_sync(~0ull, (unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 LHIP_DEV float wave_maxf(float v) {
     // max is exact and associative for non-NaN operands: any reduction order gives the same bits
     for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o); v = (t > v) ? t : v; }
