@@ -97,6 +97,7 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
 struct QuantLds {
     const QuantTabs* tabs;
     float xr[576];
+    double term[576];            // per-line squared-error terms (calc_noise)
     union {                      // xrpow is dead once the outer loop has finished; the Huffman-split scratch reuses it
         float xrpow[576];
         struct { int32_t bstat[16][SBMAX_l + 2]; int32_t cand[21][16]; } hd;
@@ -430,9 +431,19 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
     if (i > 576) i = 576;
     if (use_prev) *pn_sfb_count1 = 0;
+    // each lane keeps its pairs (lines 2(lane + NL j), +1) in registers for all passes
+    enum { NPL = (288 + LHIP_NL - 1) / LHIP_NL };
+    int vx[NPL], vy[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        vx[j] = 0; vy[j] = 0;
+        if (p < i) { vx[j] = ix[p]; vy[j] = ix[p + 1]; }
+    }
     // count1 boundary: highest pair with a non-zero value
     int top = 0;
-    for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) if ((ix[p] | ix[p + 1]) != 0) top = p + 2;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) if ((vx[j] | vy[j]) != 0) top = 2 * (lane + LHIP_NL * j) + 2;
     i = wave_max(top);
     g.count1 = i;
     // quad k covers lines [i-4(k+1), i-4k); the scan stops at the first quad holding a value > 1, or at i <= 3
@@ -478,21 +489,26 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     }
     if (a1 > i) a1 = i;
     if (a2 > i) a2 = i;
-    // one pass over the big-value pairs: region maxima ...
+    // region maxima ...
     int m0 = 0, m1 = 0, m2 = 0;
-    for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) {
-        const int x = ix[p], y = ix[p + 1], m = x > y ? x : y;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        const int m = (p < i) ? (vx[j] > vy[j] ? vx[j] : vy[j]) : 0;
         if (p < a1) { if (m0 < m) m0 = m; } else if (p < a2) { if (m1 < m) m1 = m; } else { if (m2 < m) m2 = m; }
     }
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
     const RegionPlan r0 = plan_region_(*L.tabs, m0), r1 = plan_region_(*L.tabs, m1), r2 = plan_region_(*L.tabs, m2);
     // ... and the candidate-table length sums of all three regions
     int s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
-    for (int p = 2 * lane; p < i; p += 2 * LHIP_NL) {
-        const int x = ix[p], y = ix[p + 1];
-        if (p < a1) pair_bits(L, r0, x, y, s00, s01, s02);
-        else if (p < a2) pair_bits(L, r1, x, y, s10, s11, s12);
-        else pair_bits(L, r2, x, y, s20, s21, s22);
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        if (p < i) {
+            if (p < a1) pair_bits(L, r0, vx[j], vy[j], s00, s01, s02);
+            else if (p < a2) pair_bits(L, r1, vx[j], vy[j], s10, s11, s12);
+            else pair_bits(L, r2, vx[j], vy[j], s20, s21, s22);
+        }
     }
     s00 = wave_sum(s00); s10 = wave_sum(s10); s20 = wave_sum(s20);
     if (r0.kind >= 4) s01 = wave_sum(s01);
@@ -553,7 +569,30 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         }
     }
     wave_sync();
-    // 2) per band (one lane each): noise summed in the reference's line order, distortion ratio, log10
+    // 2) squared-error term of every line, in parallel.  A line belongs to the band whose summing range
+    //    [nstart, nstart + 2 npairs) contains it; ranges are ordered and disjoint and coincide with the
+    //    natural bands except after a max_nonzero_coeff cut (where they slide down).
+    {
+        const uint8_t* l2s = line2sfb(L, g.block_type);
+        for (int j = lane; j < 576; j += LHIP_NL) {
+            int sfb = l2s[j];
+            if (sfb >= g.psymax) sfb = g.psymax - 1;
+            while (sfb + 1 < g.psymax && j >= L.nstart[sfb + 1]) sfb++;
+            double t = 0.0;
+            const int js = L.nstart[sfb];
+            if (!L.ncached[sfb] && j >= js && j < js + 2 * L.npairs[sfb]) {
+                const double step = pow20(L, sf_step(L, g, scalefac, L.window, sfb));
+                double x;
+                if (js > g.count1) x = L.xr[j];
+                else if (js > g.big_values) x = d_abs((double)L.xr[j]) - (ix[j] == 0 ? 0.0 : (double)(float)step);
+                else x = d_abs((double)L.xr[j]) - pow43v(T, L, ix[j]) * step;
+                t = x * x;
+            }
+            L.term[j] = t;
+        }
+    }
+    wave_sync();
+    // 3) per band (one lane each): ordered f64 sum of its terms, distortion ratio, log10
     int over = 0, ssd = 0;
     double max_noise = -20.0;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
@@ -563,27 +602,17 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             L.distort[sfb] = (float)(noise / (double)L.xmin[sfb]);
             noise = L.pn_noise_log[sfb];
         } else {
-            const int s = sf_step(L, g, scalefac, L.window, sfb);
-            const double step = pow20(L, s);
-            int j = L.nstart[sfb];
-            const int n = 2 * L.npairs[sfb];
+            const int js = L.nstart[sfb], n = 2 * L.npairs[sfb];
             noise = 0;
-            if (j > g.count1) {
-                for (int t = 0; t < n; t++, j++) { const double x = L.xr[j]; noise += x * x; }
-            } else if (j > g.big_values) {
-                const double s1 = (double)(float)step;
-                for (int t = 0; t < n; t++, j++) { const double x = d_abs((double)L.xr[j]) - (ix[j] == 0 ? 0.0 : s1); noise += x * x; }
-            } else {
-                for (int t = 0; t < n; t++, j++) { const double x = d_abs((double)L.xr[j]) - pow43v(T, L, ix[j]) * step; noise += x * x; }
-            }
-            if (pn != nullptr) { L.pn_step[sfb] = s; L.pn_noise[sfb] = (float)noise; }
+            for (int t = 0; t < n; t++) noise += L.term[js + t];
+            if (pn != nullptr) { L.pn_step[sfb] = sf_step(L, g, scalefac, L.window, sfb); L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
             L.distort[sfb] = (float)noise;
             noise = v8_log10(noise > 1E-20 ? noise : 1E-20);
             if (pn != nullptr) L.pn_noise_log[sfb] = (float)noise;
         }
         if (noise > 0.0) {
-            int tmp = js_toint32(noise * 10 + .5);
+            int tmp = (int)(noise * 10 + .5);          // 0 < noise < ~300: truncation == ToInt32
             if (tmp < 1) tmp = 1;
             ssd += tmp * tmp;
             over++;
