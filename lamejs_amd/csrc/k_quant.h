@@ -32,12 +32,17 @@ struct NoiseRes { double max_noise; int over_count, over_SSD, bits; };
 // optional phase profiling (build with -DLHIP_PHASE_PROF; never in the product library)
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
 #define PH_BEGIN() const unsigned long long ph_t0_ = __builtin_amdgcn_s_memtime()
-#define PH_END(L, id) do { if (lane == 0) { (L).prof[id] += __builtin_amdgcn_s_memtime() - ph_t0_; (L).prof[16 + id] += 1; } } while (0)
+#define PH_END(L, id) do { if (lane == 0) { (L).prof[id] += __builtin_amdgcn_s_memtime() - ph_t0_; (L).prof[32 + id] += 1; } } while (0)
+#define PH_MARK(L, id, t) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) { (L).prof[id] += n_ - (t); (L).prof[32 + id] += 1; } (t) = n_; } while (0)
+#define PH_NOW() __builtin_amdgcn_s_memtime()
 #else
 #define PH_BEGIN() do {} while (0)
 #define PH_END(L, id) do {} while (0)
+#define PH_MARK(L, id, t) do {} while (0)
+#define PH_NOW() 0ull
 #endif
-enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL, PH_N };
+enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL,
+       PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N };
 
 // Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
 // inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
@@ -95,7 +100,6 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
 }
 
 struct QuantLds {
-    const QuantTabs* tabs;
     float xr[576];
     double term[576];            // per-line squared-error terms (calc_noise)
     union {                      // xrpow is dead once the outer loop has finished; the Huffman-split scratch reuses it
@@ -115,27 +119,27 @@ struct QuantLds {
     int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24];
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
-    unsigned long long prof[32];
+    unsigned long long prof[64];
 #endif
 };
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV double ipow20(const QuantLds& L, int x) { return (double)L.tabs->ipow20[x]; }
-LHIP_DEV double pow20(const QuantLds& L, int x) { return (double)L.tabs->pow20[x + Q_MAX2]; }
-LHIP_DEV double pow43v(const Tables& T, const QuantLds& L, int i) {
-    float v = L.tabs->pow43[i < QT_N ? i : QT_N - 1];
+LHIP_DEV double ipow20(const QuantTabs& Q, int x) { return (double)Q.ipow20[x]; }
+LHIP_DEV double pow20(const QuantTabs& Q, int x) { return (double)Q.pow20[x + Q_MAX2]; }
+LHIP_DEV double pow43v(const Tables& T, const QuantTabs& Q, int i) {
+    float v = Q.pow43[i < QT_N ? i : QT_N - 1];
     if (i >= QT_N) v = T.pow43[i];          // rare: large quantized values
     return (double)v;
 }
-LHIP_DEV double adj43v(const Tables& T, const QuantLds& L, int i) {
-    float v = L.tabs->adj43[i < QT_N ? i : QT_N - 1];
+LHIP_DEV double adj43v(const Tables& T, const QuantTabs& Q, int i) {
+    float v = Q.adj43[i < QT_N ? i : QT_N - 1];
     if (i >= QT_N) v = T.adj43[i];
     return (double)v;
 }
-LHIP_DEV const uint8_t* line2sfb(const QuantLds& L, int block_type) { return block_type == SHORT_TYPE ? L.tabs->l2s_short : L.tabs->l2s_long; }
-LHIP_DEV const uint8_t* hlen_of(const QuantLds& L, int t) { return L.tabs->hlen + L.tabs->hoff[t]; }
+LHIP_DEV const uint8_t* line2sfb(const QuantTabs& Q, int block_type) { return block_type == SHORT_TYPE ? Q.l2s_short : Q.l2s_long; }
+LHIP_DEV const uint8_t* hlen_of(const QuantTabs& Q, int t) { return Q.hlen + Q.hoff[t]; }
 
 // QuantizePVT.js:541-561
 LHIP_DEV double athAdjust(const Tables& T, const PowBase& pb10, double a, double x, double athFloor) {
@@ -155,8 +159,8 @@ LHIP_DEV int sbgain(const GI& g, int w) {   // subblock_gain[w] without a dynami
     return w == 0 ? g.subblock_gain[0] : w == 1 ? g.subblock_gain[1] : w == 2 ? g.subblock_gain[2] : g.subblock_gain[3];
 }
 
-LHIP_DEV int sf_step(const QuantLds& L, const GI& g, const int32_t* scalefac, const int32_t* window, int sfb) {
-    return g.global_gain - ((scalefac[sfb] + (g.preflag != 0 ? L.tabs->pretab[sfb] : 0)) << (g.scalefac_scale + 1))
+LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, const int32_t* window, int sfb) {
+    return g.global_gain - ((scalefac[sfb] + (g.preflag != 0 ? Q.pretab[sfb] : 0)) << (g.scalefac_scale + 1))
            - sbgain(g, window[sfb]) * 8;
 }
 
@@ -165,7 +169,7 @@ LHIP_DEV int sf_step(const QuantLds& L, const GI& g, const int32_t* scalefac, co
 // xr_g: this granule-channel's MDCT output in HBM (natural order)
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath_adjust, GI& g, int block_type,
-                                const float* xr_g, int lane, QuantLds& L) {
+                                const float* xr_g, int lane, QuantLds& L, const QuantTabs& Q) {
     g.part2_3_length = 0; g.big_values = 0; g.count1 = 0; g.global_gain = 210; g.scalefac_compress = 0;
     g.block_type = block_type;
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
@@ -190,7 +194,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         }
         if (lane == 0) L.start[nsfb] = 576;
         // re-order: within each short sfb the three windows become consecutive runs
-        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[L.tabs->reorder_s[d]];
+        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[Q.reorder_s[d]];
     } else {
         nsfb = SBMAX_l;
         for (int i = lane; i < SBMAX_l; i += LHIP_NL) {
@@ -244,7 +248,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
 }
 
 // init_xrpow (Quantize.js:92-138); returns 1 if the granule has energy
-LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L) {
+LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     float m = 0.f;
     double sum = 0;
     for (int i = lane; i < 576; i += LHIP_NL) {
@@ -265,7 +269,7 @@ LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L) {
 
 // calc_xmin (QuantizePVT.js:569-719), CBR flavour
 LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_lower, const float* ratio /*E layout*/,
-                          GI& g, int lane, QuantLds& L) {
+                          GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     if (g.block_type != SHORT_TYPE) {
         for (int gsfb = lane; gsfb < g.psy_lmax; gsfb += LHIP_NL) {
             double xmin = ath_adjust * (double)T.ATH_l[gsfb];
@@ -313,18 +317,19 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
 // quantize_xrpow (Takehiro.js:171-314) -> ix ; `use_prev` = the prev_noise cache (pn_* in LDS) is live
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, int16_t* ix, int use_prev,
-                         int pn_gain, int pn_sfb_count1, int lane, QuantLds& L) {
-    const double istep = ipow20(L, g.global_gain);
+                         int pn_gain, int pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+    const double istep = ipow20(Q, g.global_gain);
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
     const int mnz = g.max_nonzero_coeff;
     // per-band decision as wave-uniform bit masks: cached (keep old values) / 0-1 shortcut; the first
     // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
+    unsigned long long tm_ = PH_NOW(); (void)tm_;
     uint64_t m_cached = 0, m_zo = 0;
     int cand = 99;
     for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
         int step = -1;
-        if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(L, g, scalefac, L.window, sfb);
+        if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
         if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
         else {
             if (use_prev && pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) m_zo |= 1ull << sfb;
@@ -341,8 +346,9 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
         last_line = L.start[sstar] + (l & ~1);
         m_zo &= ~(1ull << sstar);                // the partial band is always quantized in full
     }
+    PH_MARK(L, PH_Q_MASK, tm_);
     const double compareval0 = (1.0 - 0.4054) / istep;
-    const uint8_t* l2s = line2sfb(L, g.block_type);
+    const uint8_t* l2s = line2sfb(Q, g.block_type);
     for (int i = lane; i < 576; i += LHIP_NL) {
         const int sfb = l2s[i];
         const int proc = (i < last_line) && !((m_cached >> sfb) & 1);
@@ -353,26 +359,31 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
             else {
                 double x = xv * istep;                 // 0 <= x <= 8206 (guarded by count_bits): plain truncation == ToInt32
                 const int rx = (int)x;
-                x += adj43v(T, L, rx);
+                x += adj43v(T, Q, rx);
                 v = (int)x;
             }
             ix[i] = (int16_t)v;
         } else if (i >= fill_from) ix[i] = 0;
     }
     wave_sync();
+    PH_MARK(L, PH_Q_LINES, tm_);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Huffman table choice for a set of pairs (Takehiro.js:336-516).  Region description for the one-pass counter.
 // ---------------------------------------------------------------------------------------------
-struct RegionPlan { int kind, t1, xlen, lb1, lb2, choice, choice2; };   // kind 0 empty/zero, 1 t1, 2 table23/56, 4 triple, 5 ESC, 6 overflow
+struct RegionPlan { int kind, t1, xlen, lb1, lb2, choice, choice2, o0, o1, o2; };   // kind 0 empty/zero, 1 t1, 2 table23/56, 4 triple, 5 ESC, 6 overflow
 
 LHIP_DEV RegionPlan plan_region_(const QuantTabs& Q, int mx) {
-    RegionPlan r; r.kind = 0; r.t1 = 0; r.xlen = 0; r.lb1 = r.lb2 = 0; r.choice = r.choice2 = 0;
+    RegionPlan r; r.kind = 0; r.t1 = 0; r.xlen = 0; r.lb1 = r.lb2 = 0; r.choice = r.choice2 = 0; r.o0 = r.o1 = r.o2 = 0;
     if (mx == 0) return r;
-    if (mx == 1) { r.kind = 1; r.t1 = 1; r.xlen = 2; return r; }
+    if (mx == 1) { r.kind = 1; r.t1 = 1; r.xlen = 2; r.o0 = Q.hoff[1]; return r; }
     if (mx <= 3) { r.kind = 2; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 2) ? 3 : 4; return r; }
-    if (mx <= 15) { r.kind = 4; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 7) ? 6 : (r.t1 == 10) ? 8 : 16; return r; }
+    if (mx <= 15) {
+        r.kind = 4; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 7) ? 6 : (r.t1 == 10) ? 8 : 16;
+        r.o0 = Q.hoff[r.t1]; r.o1 = Q.hoff[r.t1 + 1]; r.o2 = Q.hoff[r.t1 + 2];
+        return r;
+    }
     if (mx > IXMAX_VAL) { r.kind = 6; return r; }
     mx -= 15;
     int choice2, choice;
@@ -383,16 +394,16 @@ LHIP_DEV RegionPlan plan_region_(const QuantTabs& Q, int mx) {
 }
 
 // contribution of one pair to the (up to three) length sums of its region
-LHIP_DEV void pair_bits(const QuantLds& L, const RegionPlan& r, int x, int y, int& s0, int& s1, int& s2) {
+LHIP_DEV void pair_bits(const QuantTabs& Q, const RegionPlan& r, int x, int y, int& s0, int& s1, int& s2) {
     switch (r.kind) {
-        case 1: s0 += hlen_of(L, 1)[x * 2 + y]; break;
-        case 2: s0 += (r.t1 == 2) ? L.tabs->table23[x * 3 + y] : L.tabs->table56[x * 4 + y]; break;   // packed hi|lo
-        case 4: { const int q = x * r.xlen + y; s0 += hlen_of(L, r.t1)[q]; s1 += hlen_of(L, r.t1 + 1)[q]; s2 += hlen_of(L, r.t1 + 2)[q]; } break;
+        case 1: s0 += Q.hlen[r.o0 + x * 2 + y]; break;
+        case 2: s0 += (r.t1 == 2) ? Q.table23[x * 3 + y] : Q.table56[x * 4 + y]; break;   // packed hi|lo
+        case 4: { const int q = x * r.xlen + y; s0 += Q.hlen[r.o0 + q]; s1 += Q.hlen[r.o1 + q]; s2 += Q.hlen[r.o2 + q]; } break;
         case 5: {
             int n = 0;
             if (x != 0) { if (x > 14) { x = 15; n++; } x *= 16; }
             if (y != 0) { if (y > 14) { y = 15; n++; } x += y; }
-            const int lt = L.tabs->largetbl[x];
+            const int lt = Q.largetbl[x];
             s0 += (lt >> 16) + n * r.lb1; s1 += (lt & 0xffff) + n * r.lb2;
         } break;
         default: break;
@@ -412,14 +423,14 @@ LHIP_DEV int finish_region(const RegionPlan& r, int s0, int s1, int s2, int* bit
 }
 
 // choose_table over pairs [a, b): cooperative; adds to *bits, returns table
-LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, int* bits, int lane, const QuantLds& L) {
+LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, int* bits, int lane, const QuantLds& L, const QuantTabs& Q) {
     int mx = 0;
     for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) { const int x1 = ix[p], x2 = ix[p + 1]; if (mx < x1) mx = x1; if (mx < x2) mx = x2; }
     mx = wave_max(mx);
-    const RegionPlan r = plan_region_(*L.tabs, mx);
+    const RegionPlan r = plan_region_(Q, mx);
     int s0 = 0, s1 = 0, s2 = 0;
     if (r.kind >= 1 && r.kind <= 5)
-        for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) pair_bits(L, r, ix[p], ix[p + 1], s0, s1, s2);
+        for (int p = a + 2 * lane; p < b; p += 2 * LHIP_NL) pair_bits(Q, r, ix[p], ix[p + 1], s0, s1, s2);
     s0 = wave_sum(s0);
     if (r.kind >= 4) s1 = wave_sum(s1);
     if (r.kind == 4) s2 = wave_sum(s2);
@@ -427,7 +438,8 @@ LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, in
 }
 
 // noquant_count_bits (Takehiro.js:521-628); updates g, returns bits.  pn_sfb_count1 as in/out.
-LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int use_prev, int* pn_sfb_count1, int lane, const QuantLds& L) {
+LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int use_prev, int* pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+    unsigned long long tm_ = PH_NOW(); (void)tm_;
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
     if (i > 576) i = 576;
     if (use_prev) *pn_sfb_count1 = 0;
@@ -446,6 +458,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     for (int j = 0; j < NPL; j++) if ((vx[j] | vy[j]) != 0) top = 2 * (lane + LHIP_NL * j) + 2;
     i = wave_max(top);
     g.count1 = i;
+    PH_MARK(L, PH_C_LOAD, tm_);
     // quad k covers lines [i-4(k+1), i-4k); the scan stops at the first quad holding a value > 1, or at i <= 3
     const int nq = i >> 2;
     int firstbig = nq;
@@ -458,7 +471,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     for (int k = lane; k < firstbig; k += LHIP_NL) {
         const int e = i - 4 * k;
         const int p = ((ix[e - 4] * 2 + ix[e - 3]) * 2 + ix[e - 2]) * 2 + ix[e - 1];
-        a12 += L.tabs->t32l[p] + (L.tabs->t33l[p] << 16);
+        a12 += Q.t32l[p] + (Q.t33l[p] << 16);
     }
     a12 = wave_sum(a12);
     int a1 = a12 & 0xffff, a2 = a12 >> 16;
@@ -468,22 +481,23 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     if (a1 > a2) { bits = a2; g.count1table_select = 1; }
     g.count1bits = bits;
     g.big_values = i;
+    PH_MARK(L, PH_C_QUADS, tm_);
     if (i == 0) return bits;
     int use2 = 0;
     if (g.block_type == SHORT_TYPE) {
-        a1 = 3 * L.tabs->sfb_s[3];
+        a1 = 3 * Q.sfb_s[3];
         if (a1 > g.big_values) a1 = g.big_values;
         a2 = g.big_values;
     } else if (g.block_type == NORM_TYPE) {
-        a1 = g.region0_count = L.tabs->bv_scf[i - 2];
-        a2 = g.region1_count = L.tabs->bv_scf[i - 1];
-        a2 = L.tabs->sfb_l[a1 + a2 + 2];
-        a1 = L.tabs->sfb_l[a1 + 1];
+        a1 = g.region0_count = Q.bv_scf[i - 2];
+        a2 = g.region1_count = Q.bv_scf[i - 1];
+        a2 = Q.sfb_l[a1 + a2 + 2];
+        a1 = Q.sfb_l[a1 + 1];
         if (a2 < i) use2 = 1;
     } else {
         g.region0_count = 7;
         g.region1_count = SBMAX_l - 1 - 7 - 1;
-        a1 = L.tabs->sfb_l[7 + 1];
+        a1 = Q.sfb_l[7 + 1];
         a2 = i;
         if (a1 > a2) a1 = a2;
     }
@@ -498,16 +512,17 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         if (p < a1) { if (m0 < m) m0 = m; } else if (p < a2) { if (m1 < m) m1 = m; } else { if (m2 < m) m2 = m; }
     }
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
-    const RegionPlan r0 = plan_region_(*L.tabs, m0), r1 = plan_region_(*L.tabs, m1), r2 = plan_region_(*L.tabs, m2);
+    const RegionPlan r0 = plan_region_(Q, m0), r1 = plan_region_(Q, m1), r2 = plan_region_(Q, m2);
+    PH_MARK(L, PH_C_MAX, tm_);
     // ... and the candidate-table length sums of all three regions
     int s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const int p = 2 * (lane + LHIP_NL * j);
         if (p < i) {
-            if (p < a1) pair_bits(L, r0, vx[j], vy[j], s00, s01, s02);
-            else if (p < a2) pair_bits(L, r1, vx[j], vy[j], s10, s11, s12);
-            else pair_bits(L, r2, vx[j], vy[j], s20, s21, s22);
+            if (p < a1) pair_bits(Q, r0, vx[j], vy[j], s00, s01, s02);
+            else if (p < a2) pair_bits(Q, r1, vx[j], vy[j], s10, s11, s12);
+            else pair_bits(Q, r2, vx[j], vy[j], s20, s21, s22);
         }
     }
     s00 = wave_sum(s00); s10 = wave_sum(s10); s20 = wave_sum(s20);
@@ -517,28 +532,27 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     if (r0.kind == 4) s02 = wave_sum(s02);
     if (r1.kind == 4) s12 = wave_sum(s12);
     if (r2.kind == 4) s22 = wave_sum(s22);
+    PH_MARK(L, PH_C_SUMS, tm_);
     // the reference evaluates region 2 first (NORM only), then 0, then 1; an overflowing region *sets* bits
     if (use2) g.table_select[2] = finish_region(r2, s20, s21, s22, &bits);
     if (0 < a1) g.table_select[0] = finish_region(r0, s00, s01, s02, &bits);
     if (a1 < a2) g.table_select[1] = finish_region(r1, s10, s11, s12, &bits);
-    if (use_prev && g.block_type == NORM_TYPE) {
-        int sfb = 0;
-        while (L.tabs->sfb_l[sfb] < g.big_values) sfb++;
-        *pn_sfb_count1 = sfb;
-    }
+    // first band whose start is >= big_values (PrevNoise.sfb_count1): one table look-up instead of a walk
+    if (use_prev && g.block_type == NORM_TYPE) *pn_sfb_count1 = g.big_values > 0 ? Q.l2s_long[g.big_values - 1] + 1 : 0;
+    PH_MARK(L, PH_C_FIN, tm_);
     return bits;
 }
 
 struct PrevNoise { int gain, sfb_count1; };   // scalar part of CalcNoiseData (arrays are L.pn_*)
 
 // count_bits (Takehiro.js:630-660)
-LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, PrevNoise* pn, int lane, QuantLds& L) {
-    const double w = (double)IXMAX_VAL / ipow20(L, g.global_gain);
+LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, PrevNoise* pn, int lane, QuantLds& L, const QuantTabs& Q) {
+    const double w = (double)IXMAX_VAL / ipow20(Q, g.global_gain);
     if (g.xrpow_max > w) return LARGE_BITS;
-    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, pn != nullptr, pn ? pn->gain : 0, pn ? pn->sfb_count1 : 0, lane, L); PH_END(L, PH_QUANTIZE); }
+    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, pn != nullptr, pn ? pn->gain : 0, pn ? pn->sfb_count1 : 0, lane, L, Q); PH_END(L, PH_QUANTIZE); }
     int dummy = 0;
     PH_BEGIN();
-    const int r = q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane, L);
+    const int r = q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane, L, Q);
     PH_END(L, PH_COUNT);
     return r;
 }
@@ -548,32 +562,44 @@ LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16
 // One lane per band sums its lines in the reference's order (f64 sums are order-sensitive); all gathers hit LDS.
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           PrevNoise* pn, int lane, QuantLds& L) {
-    // 1) the (sequential) start-line walk: where each band begins and how many pairs it sums
-    if (lane == 0) {
-        int j = 0;
-        for (int sfb = 0; sfb < g.psymax; sfb++) {
-            const int s = sf_step(L, g, scalefac, L.window, sfb);
-            if (pn != nullptr && L.pn_step[sfb] == s) {
-                L.ncached[sfb] = 1; L.nstart[sfb] = j; L.npairs[sfb] = 0;
-                j += L.width[sfb];
-            } else {
+                           PrevNoise* pn, int lane, QuantLds& L, const QuantTabs& Q) {
+    unsigned long long tm_ = PH_NOW(); (void)tm_;
+    // 1) start-line walk (QuantizePVT.js:806-830): j advances by the band width until the first band that
+    //    reaches past max_nonzero_coeff; up to there everything is regular and computed one lane per band,
+    //    the (few) bands from that point on are walked serially by lane 0.
+    int firstcut = 99;
+    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
+        const int s = sf_step(Q, g, scalefac, L.window, sfb);
+        const int cached = (pn != nullptr && L.pn_step[sfb] == s);
+        L.qmode[sfb] = s;                                   // step of the band (reused by the term pass)
+        L.ncached[sfb] = cached; L.nstart[sfb] = L.start[sfb]; L.npairs[sfb] = cached ? 0 : (L.width[sfb] >> 1);
+        if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff && sfb < firstcut) firstcut = sfb;
+    }
+    firstcut = wave_min(firstcut);
+    wave_sync();
+    if (lane == 0 && firstcut < g.psymax) {
+        int j = L.start[firstcut];
+        for (int sfb = firstcut; sfb < g.psymax; sfb++) {
+            L.nstart[sfb] = j;
+            if (L.ncached[sfb]) { L.npairs[sfb] = 0; j += L.width[sfb]; }
+            else {
                 int l = L.width[sfb] >> 1;
                 if ((j + L.width[sfb]) > g.max_nonzero_coeff) {
                     const int usefullsize = g.max_nonzero_coeff - j + 1;
                     l = usefullsize > 0 ? usefullsize >> 1 : 0;
                 }
-                L.ncached[sfb] = 0; L.nstart[sfb] = j; L.npairs[sfb] = l;
+                L.npairs[sfb] = l;
                 j += 2 * l;
             }
         }
     }
     wave_sync();
+    PH_MARK(L, PH_N_WALK, tm_);
     // 2) squared-error term of every line, in parallel.  A line belongs to the band whose summing range
     //    [nstart, nstart + 2 npairs) contains it; ranges are ordered and disjoint and coincide with the
     //    natural bands except after a max_nonzero_coeff cut (where they slide down).
     {
-        const uint8_t* l2s = line2sfb(L, g.block_type);
+        const uint8_t* l2s = line2sfb(Q, g.block_type);
         for (int j = lane; j < 576; j += LHIP_NL) {
             int sfb = l2s[j];
             if (sfb >= g.psymax) sfb = g.psymax - 1;
@@ -581,17 +607,18 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             double t = 0.0;
             const int js = L.nstart[sfb];
             if (!L.ncached[sfb] && j >= js && j < js + 2 * L.npairs[sfb]) {
-                const double step = pow20(L, sf_step(L, g, scalefac, L.window, sfb));
+                const double step = pow20(Q, L.qmode[sfb]);
                 double x;
                 if (js > g.count1) x = L.xr[j];
                 else if (js > g.big_values) x = d_abs((double)L.xr[j]) - (ix[j] == 0 ? 0.0 : (double)(float)step);
-                else x = d_abs((double)L.xr[j]) - pow43v(T, L, ix[j]) * step;
+                else x = d_abs((double)L.xr[j]) - pow43v(T, Q, ix[j]) * step;
                 t = x * x;
             }
             L.term[j] = t;
         }
     }
     wave_sync();
+    PH_MARK(L, PH_N_TERMS, tm_);
     // 3) per band (one lane each): ordered f64 sum of its terms, distortion ratio, log10
     int over = 0, ssd = 0;
     double max_noise = -20.0;
@@ -605,7 +632,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             const int js = L.nstart[sfb], n = 2 * L.npairs[sfb];
             noise = 0;
             for (int t = 0; t < n; t++) noise += L.term[js + t];
-            if (pn != nullptr) { L.pn_step[sfb] = sf_step(L, g, scalefac, L.window, sfb); L.pn_noise[sfb] = (float)noise; }
+            if (pn != nullptr) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
             L.distort[sfb] = (float)noise;
             noise = v8_log10(noise > 1E-20 ? noise : 1E-20);
@@ -624,12 +651,13 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     res->over_SSD = wave_sum(ssd);
     res->max_noise = wave_maxd(max_noise);
     wave_sync();
+    PH_MARK(L, PH_N_SUMS, tm_);
 }
 
 LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           PrevNoise* pn, int lane, QuantLds& L) {
+                           PrevNoise* pn, int lane, QuantLds& L, const QuantTabs& Q) {
     PH_BEGIN();
-    q_calc_noise_(T, g, scalefac, ix, res, pn, lane, L);
+    q_calc_noise_(T, g, scalefac, ix, res, pn, lane, L, Q);
     PH_END(L, PH_NOISE);
 }
 
@@ -667,7 +695,7 @@ LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lan
 // ---------------------------------------------------------------------------------------------
 // amplification helpers (Quantize.js:453-460, 597-778)
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantLds& L) {
+LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     int z = 0;
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL)
         if (scalefac[sfb] + sbgain(g, L.window[sfb]) == 0) z = 1;
@@ -675,10 +703,10 @@ LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantL
 }
 
 // multiply xrpow of the flagged bands (L.qmode[sfb] = 1) by `amp`, tracking xrpow_max
-LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L) {
+LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L, const QuantTabs& Q) {
     float m = 0.f;
     for (int i = lane; i < 576; i += LHIP_NL) {
-        const int sfb = line2sfb(L, g.block_type)[i];
+        const int sfb = line2sfb(Q, g.block_type)[i];
         if (L.qmode[sfb]) {
             const float v = (float)((double)L.xrpow[i] * amp);
             L.xrpow[i] = v;
@@ -690,7 +718,7 @@ LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L) {
     wave_sync();
 }
 
-LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L) {
+LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     const double ifqstep34 = (g.scalefac_scale == 0) ? 1.29683955465100964055 : 1.68179283050742922612;
     float tr = 0.f;
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (tr < L.distort[sfb]) tr = L.distort[sfb];
@@ -719,10 +747,10 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
         wave_sync();
     }
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (L.qmode[sfb]) scalefac[sfb]++;
-    q_amplify_flagged(g, ifqstep34, lane, L);
+    q_amplify_flagged(g, ifqstep34, lane, L, Q);
 }
 
-LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L) {
+LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) {
         int f = 0;
         if (sfb < g.sfbmax) {
@@ -736,11 +764,11 @@ LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, in
     wave_sync();
     g.preflag = 0;
     g.scalefac_scale = 1;
-    q_amplify_flagged(g, 1.29683955465100964055, lane, L);
+    q_amplify_flagged(g, 1.29683955465100964055, lane, L, Q);
 }
 
 // inc_subblock_gain (Quantize.js:705-778); returns 1 on failure.  Short blocks only (sfb_lmax == 0).
-LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L) {
+LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     for (int window = 0; window < 3; window++) {
         int s1 = 0, s2 = 0;
         for (int sfb = window + 3 * lane; sfb < g.sfbmax; sfb += 3 * LHIP_NL) {
@@ -763,10 +791,10 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
                 if (s >= 0) { if (lane == 0) scalefac[sfb] = s; }
                 else {
                     if (lane == 0) scalefac[sfb] = 0;
-                    amp = ipow20(L, 210 + (s << (g.scalefac_scale + 1)));
+                    amp = ipow20(Q, 210 + (s << (g.scalefac_scale + 1)));
                     doamp = 1;
                 }
-            } else { amp = ipow20(L, 202); doamp = 1; }
+            } else { amp = ipow20(Q, 202); doamp = 1; }
             wave_sync();
             if (doamp) {
                 float m = 0.f;
@@ -786,18 +814,18 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
 }
 
 // balance_noise (Quantize.js:793-846); returns 1 to continue the outer loop
-LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L) {
-    q_amp_scalefac_bands(T, g, scalefac, lane, L);
-    int status = q_loop_break(g, scalefac, lane, L);
+LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+    q_amp_scalefac_bands(T, g, scalefac, lane, L, Q);
+    int status = q_loop_break(g, scalefac, lane, L, Q);
     if (status) return 0;
     status = q_scale_bitcount(T, g, scalefac, lane);
     if (!status) return 1;
     if (T.noise_shaping > 1) {
         if (0 == g.scalefac_scale) {
-            q_inc_scalefac_scale(T, g, scalefac, lane, L);
+            q_inc_scalefac_scale(T, g, scalefac, lane, L, Q);
             status = 0;
         } else if (g.block_type == SHORT_TYPE && T.subblock_gain > 0) {
-            status = (q_inc_subblock_gain(T, g, scalefac, lane, L) || q_loop_break(g, scalefac, lane, L));
+            status = (q_inc_subblock_gain(T, g, scalefac, lane, L, Q) || q_loop_break(g, scalefac, lane, L, Q));
         }
     }
     if (!status) status = q_scale_bitcount(T, g, scalefac, lane);
@@ -806,13 +834,13 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
 
 // bin_search_StepSize (Quantize.js:322-381) on the kept copy (ixb / sfb arrays)
 LHIP_DEV int q_bin_search(const Tables& T, GI& g, int desired_rate, int start, int CurrentStep, int* step_out,
-                          int lane, QuantLds& L) {
+                          int lane, QuantLds& L, const QuantTabs& Q) {
     int nBits, flagGoneOver = 0, Direction = 0;
     g.global_gain = start;
     desired_rate -= g.part2_length;
     for (;;) {
         int step;
-        nBits = q_count_bits(T, g, L.sfb, L.ixb, nullptr, lane, L);
+        nBits = q_count_bits(T, g, L.sfb, L.ixb, nullptr, lane, L, Q);
         if (CurrentStep == 1 || nBits == desired_rate) break;
         if (nBits > desired_rate) {
             if (Direction == 2) flagGoneOver = 1;
@@ -831,7 +859,7 @@ LHIP_DEV int q_bin_search(const Tables& T, GI& g, int desired_rate, int start, i
     }
     while (nBits > desired_rate && g.global_gain < 255) {
         g.global_gain++;
-        nBits = q_count_bits(T, g, L.sfb, L.ixb, nullptr, lane, L);
+        nBits = q_count_bits(T, g, L.sfb, L.ixb, nullptr, lane, L, Q);
     }
     *step_out = (start - g.global_gain >= 4) ? 4 : 2;
     g.part2_3_length = nBits;
@@ -852,15 +880,15 @@ LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // 
 
 // outer_loop (Quantize.js:871-1052).  g = kept copy (cod_info); seeds in/out via start/step.
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
-                           int lane, QuantLds& L) {
+                           int lane, QuantLds& L, const QuantTabs& Q) {
     int step_unused;
-    q_bin_search(T, g, targ_bits, bs_start, bs_step, &step_unused, lane, L);
+    q_bin_search(T, g, targ_bits, bs_start, bs_step, &step_unused, lane, L, Q);
     *bs_gain_out = g.global_gain;                        // OldValue[ch] after this granule
     if (0 == T.noise_shaping) return;
     NoiseRes best; PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
     for (int i = lane; i <= SFBMAX; i += LHIP_NL) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_noise_log[i] = 0.f; L.distort[i] = 0.f; }
     wave_sync();
-    q_calc_noise(T, g, L.sfb, L.ixb, &best, &pn, lane, L);
+    q_calc_noise(T, g, L.sfb, L.ixb, &best, &pn, lane, L, Q);
     best.bits = g.part2_3_length;
     GI w = g;                                            // cod_info_w.assign(cod_info)
     for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = L.ixb[i];
@@ -872,20 +900,20 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         const int search_limit = 3;
         int maxggain = 255;
         int bal_;
-        { PH_BEGIN(); bal_ = q_balance_noise(T, w, L.sfw, lane, L); PH_END(L, PH_BALANCE); }
+        { PH_BEGIN(); bal_ = q_balance_noise(T, w, L.sfw, lane, L, Q); PH_END(L, PH_BALANCE); }
         if (!bal_) break;
         if (w.scalefac_scale != 0) maxggain = 254;
         const int huff_bits = targ_bits - w.part2_length;
         if (huff_bits <= 0) break;
-        while ((w.part2_3_length = q_count_bits(T, w, L.sfw, L.ixw, &pn, lane, L)) > huff_bits && w.global_gain <= maxggain)
+        while ((w.part2_3_length = q_count_bits(T, w, L.sfw, L.ixw, &pn, lane, L, Q)) > huff_bits && w.global_gain <= maxggain)
             w.global_gain++;
         if (w.global_gain > maxggain) break;
         if (best.over_count == 0) {
-            while ((w.part2_3_length = q_count_bits(T, w, L.sfw, L.ixw, &pn, lane, L)) > best_part2_3_length && w.global_gain <= maxggain)
+            while ((w.part2_3_length = q_count_bits(T, w, L.sfw, L.ixw, &pn, lane, L, Q)) > best_part2_3_length && w.global_gain <= maxggain)
                 w.global_gain++;
             if (w.global_gain > maxggain) break;
         }
-        q_calc_noise(T, w, L.sfw, L.ixw, &ni, &pn, lane, L);
+        q_calc_noise(T, w, L.sfw, L.ixw, &ni, &pn, lane, L, Q);
         ni.bits = w.part2_3_length;
         if (q_quant_compare(best, ni)) {
             best_part2_3_length = g.part2_3_length;       // value BEFORE the copy (reference quirk)
@@ -906,7 +934,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
 // best_huffman_divide (727-800)
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int gr0_block_type, int* scfsi /*[4]*/,
-                                    int lane, QuantLds& L) {
+                                    int lane, QuantLds& L, const QuantTabs& Q) {
     int32_t* sf = L.sfb;
     int recalc = 0;
     {
@@ -975,23 +1003,23 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
 // row 0 max (kept per band), 1 t1, 2 table23 (packed), 3 table56 (packed), 4..6 t7-9, 7..9 t10-12, 10..12 t13-15,
 // 13 largetbl hi, 14 largetbl lo, 15 number of escaped values.  A row is only meaningful for regions whose
 // maximum admits the table group, which is exactly when the reference would look at it.
-LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int lane, QuantLds& L) {
+LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int lane, QuantLds& L, const QuantTabs& Q) {
     for (int band = lane; band < SBMAX_l; band += LHIP_NL) {
-        const int a = L.tabs->sfb_l[band];
-        int b = L.tabs->sfb_l[band + 1];
+        const int a = Q.sfb_l[band];
+        int b = Q.sfb_l[band + 1];
         if (b > limit) b = limit;
         int mx = 0;
         for (int p = a; p < b; p++) if (mx < ix[p]) mx = ix[p];
         int s[16];
         for (int k = 0; k < 16; k++) s[k] = 0;
         s[0] = mx;
-        const uint8_t *h1 = hlen_of(L, 1), *h7 = hlen_of(L, 7), *h8 = hlen_of(L, 8), *h9 = hlen_of(L, 9), *h10 = hlen_of(L, 10),
-                      *h11 = hlen_of(L, 11), *h12 = hlen_of(L, 12), *h13 = hlen_of(L, 13), *h14 = hlen_of(L, 14), *h15 = hlen_of(L, 15);
+        const uint8_t *h1 = hlen_of(Q, 1), *h7 = hlen_of(Q, 7), *h8 = hlen_of(Q, 8), *h9 = hlen_of(Q, 9), *h10 = hlen_of(Q, 10),
+                      *h11 = hlen_of(Q, 11), *h12 = hlen_of(Q, 12), *h13 = hlen_of(Q, 13), *h14 = hlen_of(Q, 14), *h15 = hlen_of(Q, 15);
         for (int p = a; p < b; p += 2) {
             const int x = ix[p], y = ix[p + 1];
             if (mx <= 1) s[1] += h1[x * 2 + y];
-            if (mx <= 2) s[2] += L.tabs->table23[x * 3 + y];
-            if (mx <= 3) s[3] += L.tabs->table56[x * 4 + y];
+            if (mx <= 2) s[2] += Q.table23[x * 3 + y];
+            if (mx <= 3) s[3] += Q.table56[x * 4 + y];
             if (mx <= 5) { const int q = x * 6 + y; s[4] += h7[q]; s[5] += h8[q]; s[6] += h9[q]; }
             if (mx <= 7) { const int q = x * 8 + y; s[7] += h10[q]; s[8] += h11[q]; s[9] += h12[q]; }
             if (mx <= 15) { const int q = x * 16 + y; s[10] += h13[q]; s[11] += h14[q]; s[12] += h15[q]; }
@@ -999,7 +1027,7 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
                 int xx = x, yy = y, n = 0;
                 if (xx != 0) { if (xx > 14) { xx = 15; n++; } xx *= 16; }
                 if (yy != 0) { if (yy > 14) { yy = 15; n++; } xx += yy; }
-                const int lt = L.tabs->largetbl[xx];
+                const int lt = Q.largetbl[xx];
                 s[13] += lt >> 16; s[14] += lt & 0xffff; s[15] += n;
             }
         }
@@ -1016,10 +1044,10 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
 }
 
 // choose_table for the union of whole bands [b0, b1) from the statistics above (bits are added to *bits)
-LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, const QuantLds& L) {
+LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, const QuantLds& L, const QuantTabs& Q) {
     int mx = 0;
     for (int b = b0; b < b1; b++) if (mx < L.hd.bstat[0][b + 1]) mx = L.hd.bstat[0][b + 1];
-    const RegionPlan r = plan_region_(*L.tabs, mx);
+    const RegionPlan r = plan_region_(Q, mx);
 #define SUMROW(k) (L.hd.bstat[k][b1] - L.hd.bstat[k][b0])
     switch (r.kind) {
         case 0: return 0;
@@ -1033,14 +1061,14 @@ LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, con
 }
 
 // recalc_divide_sub (Takehiro.js:698-725); region 2 = bands r2.. up to big_values, from the band statistics
-LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const QuantLds& L) {
+LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const QuantLds& L, const QuantTabs& Q) {
     const int bigv = c2.big_values;
     for (int r2 = 2; r2 < SBMAX_l + 1; r2++) {
-        const int a2 = L.tabs->sfb_l[r2];
+        const int a2 = Q.sfb_l[r2];
         if (a2 >= bigv) break;
         int bits = L.r01_bits[r2 - 2] + c2.count1bits;
         if (g.part2_3_length <= bits) break;
-        const int r2t = q_choose_from_stats(T, r2, SBMAX_l, &bits, L);
+        const int r2t = q_choose_from_stats(T, r2, SBMAX_l, &bits, L, Q);
         if (g.part2_3_length <= bits) continue;
         g = c2;
         g.part2_3_length = bits;
@@ -1052,12 +1080,12 @@ LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const Qu
     }
 }
 
-LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L) {
+LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     const int16_t* ix = L.ixb;
     GI c2 = g;
     if (g.block_type == NORM_TYPE) {
         // recalc_divide_init: every (region0, region1) split evaluated from the per-band statistics
-        q_band_stats(T, ix, g.big_values, lane, L);
+        q_band_stats(T, ix, g.big_values, lane, L, Q);
         const int bigv = g.big_values;
         for (int s = lane; s < 24; s += LHIP_NL) { L.r01_bits[s] = LARGE_BITS; L.r01_div[s] = 0; L.r0_tbl[s] = 0; L.r1_tbl[s] = 0; }
         // all 16 x 8 splits in parallel; candidate bits go to cand[r0 + r1][r0]
@@ -1065,10 +1093,10 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
             const int r0 = c >> 3, r1 = c & 7, sidx = r0 + r1;
             if (sidx > 20) continue;
             int bits = LARGE_BITS;
-            if (L.tabs->sfb_l[r0 + 1] < bigv && L.tabs->sfb_l[r0 + r1 + 2] < bigv) {
+            if (Q.sfb_l[r0 + 1] < bigv && Q.sfb_l[r0 + r1 + 2] < bigv) {
                 bits = 0;
-                q_choose_from_stats(T, 0, r0 + 1, &bits, L);
-                q_choose_from_stats(T, r0 + 1, r0 + r1 + 2, &bits, L);
+                q_choose_from_stats(T, 0, r0 + 1, &bits, L, Q);
+                q_choose_from_stats(T, r0 + 1, r0 + r1 + 2, &bits, L, Q);
             }
             L.hd.cand[sidx][r0] = bits;
         }
@@ -1081,12 +1109,12 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
             if (bd >= 0) {
                 int dummy = 0;
                 L.r01_bits[sidx] = bb; L.r01_div[sidx] = bd;
-                L.r0_tbl[sidx] = q_choose_from_stats(T, 0, bd + 1, &dummy, L);
-                L.r1_tbl[sidx] = q_choose_from_stats(T, bd + 1, sidx + 2, &dummy, L);
+                L.r0_tbl[sidx] = q_choose_from_stats(T, 0, bd + 1, &dummy, L, Q);
+                L.r1_tbl[sidx] = q_choose_from_stats(T, bd + 1, sidx + 2, &dummy, L, Q);
             }
         }
         wave_sync();
-        q_recalc_divide_sub(T, c2, g, L);
+        q_recalc_divide_sub(T, c2, g, L, Q);
     }
     int i = c2.big_values;
     if (i == 0 || (ix[i - 2] | ix[i - 1]) > 1) return;
@@ -1100,7 +1128,7 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
     for (int k = lane; k < nq; k += LHIP_NL) {
         const int e = i - 4 * k;
         const int p = ((ix[e - 4] * 2 + ix[e - 3]) * 2 + ix[e - 2]) * 2 + ix[e - 1];
-        a12 += L.tabs->t32l[p] + (L.tabs->t33l[p] << 16);
+        a12 += Q.t32l[p] + (Q.t33l[p] << 16);
     }
     a12 = wave_sum(a12);
     int a1 = a12 & 0xffff, a2 = a12 >> 16;
@@ -1110,14 +1138,14 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
     if (a1 > a2) { a1 = a2; c2.count1table_select = 1; }
     c2.count1bits = a1;
     if (c2.block_type == NORM_TYPE) {
-        if (c2.big_values != g.big_values) q_band_stats(T, ix, c2.big_values, lane, L);   // statistics must honour the new limit
-        q_recalc_divide_sub(T, c2, g, L);
+        if (c2.big_values != g.big_values) q_band_stats(T, ix, c2.big_values, lane, L, Q);   // statistics must honour the new limit
+        q_recalc_divide_sub(T, c2, g, L, Q);
     } else {
         c2.part2_3_length = a1;
-        a1 = L.tabs->sfb_l[7 + 1];
+        a1 = Q.sfb_l[7 + 1];
         if (a1 > i) a1 = i;
-        if (a1 > 0) c2.table_select[0] = q_choose_table(T, ix, 0, a1, &c2.part2_3_length, lane, L);
-        if (i > a1) c2.table_select[1] = q_choose_table(T, ix, a1, i, &c2.part2_3_length, lane, L);
+        if (a1 > 0) c2.table_select[0] = q_choose_table(T, ix, 0, a1, &c2.part2_3_length, lane, L, Q);
+        if (i > a1) c2.table_select[1] = q_choose_table(T, ix, a1, i, &c2.part2_3_length, lane, L, Q);
         if (g.part2_3_length > c2.part2_3_length) g = c2;
     }
 }
@@ -1189,7 +1217,7 @@ LHIP_DEV void targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize
 // One wave per frame slot.  chain == 0: speculative reset seed (exact for the first frame of a stream
 // batch, whose seed is the carried one); chain == 1: chain-implied seed (repair pass, flagged frames only).
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
-                       int chain, int lane, QuantLds& L) {
+                       int chain, int lane, QuantLds& L, const QuantTabs& Q) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -1198,7 +1226,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     const int fidx = sd.out_slot0 + k;                    // dense frame index
     if (chain && !W.seed_flag[fidx]) return;
 #ifdef LHIP_PHASE_PROF
-    if (lane == 0) for (int i = 0; i < 32; i++) L.prof[i] = 0;
+    if (lane == 0) for (int i = 0; i < 64; i++) L.prof[i] = 0;
     const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();
 #endif
     const double ath_adjust = W.ath_adjust[fslot];        // after adjust_ATH of this frame
@@ -1220,13 +1248,13 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             const int bt = W.blocktype[(int64_t)gslot * C + ch];
             const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
             const float* ratio = W.E + ((int64_t)(gslot - 1) * C + ch) * E_STRIDE;   // thresholds of the previous psy call
-            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, lane, L); PH_END(L, PH_INIT); }
+            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, lane, L, Q); PH_END(L, PH_INIT); }
             int active = 0, bs_gain = 0;
             const Seed used = seed[ch];
-            if (q_init_xrpow(g, lane, L)) {
+            if (q_init_xrpow(g, lane, L, Q)) {
                 active = 1;
-                { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L); PH_END(L, PH_XMIN); }
-                q_outer_loop(T, g, targ[ch], used.start, used.step, &bs_gain, lane, L);
+                { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
+                q_outer_loop(T, g, targ[ch], used.start, used.step, &bs_gain, lane, L, Q);
                 seed[ch].step = (used.start - bs_gain >= 4) ? 4 : 2;
                 seed[ch].start = bs_gain;
             } else {
@@ -1234,8 +1262,8 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 wave_sync();
             }
             int scfsi[4];
-            { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt[ch], scfsi, lane, L); PH_END(L, PH_SFSTORE); }
-            if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L); PH_END(L, PH_HUFFDIV); }
+            { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt[ch], scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
+            if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
             ResvSize -= g.part2_3_length + g.part2_length;
             if (gr == 0) {
                 gr0_bt[ch] = g.block_type;
@@ -1267,15 +1295,15 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
 #ifdef LHIP_PHASE_PROF
     if (lane == 0) {
-        L.prof[PH_TOTAL] = __builtin_amdgcn_s_memtime() - ph_total0_; L.prof[16 + PH_TOTAL] = 1;
-        for (int i = 0; i < 32; i++) atomicAdd((unsigned long long*)W.prof + i, L.prof[i]);
+        L.prof[PH_TOTAL] = __builtin_amdgcn_s_memtime() - ph_total0_; L.prof[32 + PH_TOTAL] = 1;
+        for (int i = 0; i < 64; i++) atomicAdd((unsigned long long*)W.prof + i, L.prof[i]);
     }
 #endif
 }
 
 // Re-run the bin searches of a frame with the chain-implied seeds; flag the frame if any result differs.
 LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
-                          int lane, QuantLds& L) {
+                          int lane, QuantLds& L, const QuantTabs& Q) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -1293,8 +1321,8 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             if (s.start == rec->bs_start && s.step == rec->bs_step_in) continue;     // already quantized with this seed
             GI g;
             q_init_outer_loop(T, pb10, ath_adjust, g, W.blocktype[(int64_t)gslot * C + ch],
-                              W.xr + ((int64_t)gslot * C + ch) * 576, lane, L);
-            q_init_xrpow(g, lane, L);
+                              W.xr + ((int64_t)gslot * C + ch) * 576, lane, L, Q);
+            q_init_xrpow(g, lane, L, Q);
             // max_nonzero_coeff is set by calc_xmin in the reference before the bin search
             if (g.block_type != SHORT_TYPE) {
                 int t = -1;
@@ -1303,7 +1331,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
                 g.max_nonzero_coeff = (t >= 575) ? 575 : t + 1;
             }
             int step_unused;
-            q_bin_search(T, g, rec->targ_bits, s.start, s.step, &step_unused, lane, L);
+            q_bin_search(T, g, rec->targ_bits, s.start, s.step, &step_unused, lane, L, Q);
             if (g.global_gain != rec->bs_gain) bad = 1;
         }
     }

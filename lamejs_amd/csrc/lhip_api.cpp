@@ -189,9 +189,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowB
     __syncthreads();
     const int wv = threadIdx.x >> 6, fslot = blockIdx.x * QWAVES + wv;
     if (fslot >= nfs) return;
-    if ((threadIdx.x & 63) == 0) L[wv].tabs = &Q;
-    wave_sync();
-    kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv]);
+    kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv], Q);
 }
 __global__ __launch_bounds__(64 * QWAVES) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
     __shared__ QuantTabs Q;
@@ -200,9 +198,7 @@ __global__ __launch_bounds__(64 * QWAVES) void g_validate(Tables T, PowBase pb, 
     __syncthreads();
     const int wv = threadIdx.x >> 6, fslot = blockIdx.x * QWAVES + wv;
     if (fslot >= nfs) return;
-    if ((threadIdx.x & 63) == 0) L[wv].tabs = &Q;
-    wave_sync();
-    kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv]);
+    kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv], Q);
 }
 __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ BitsLds L;
@@ -556,7 +552,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #ifdef LHIP_HOSTSIM
     {
         static PsyALds LA; static PsyBLds LB; static MdctLds LM; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
-        q_load_tabs(T, QT, 0, 1); LQ.tabs = &QT;
+        q_load_tabs(T, QT, 0, 1);
         for (int s = 0; s < S; s++) kb_load(T, W, dSD, dIO, s, 0);
         kb_prep(T, W, dSD, dIO, S, 0, 1);
         for (int b = 0; b < ngs * C; b++) kb_psyA(T, W, dSD, b / C, b % C, 0, LA);
@@ -567,14 +563,14 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_psyB(T, W, dSD, b, 0, LB);
         for (int b = 0; b < ngs * C; b++) kb_polyphase(T, W, dSD, b / C, b % C, 0);
         for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
-        for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ);
+        for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ, QT);
         for (;;) {
             W.nflagged[0] = 0;
-            for (int b = 0; b < nfs; b++) kb_validate(T, ts.pb10, W, dSD, b, 0, LQ);
+            for (int b = 0; b < nfs; b++) kb_validate(T, ts.pb10, W, dSD, b, 0, LQ, QT);
             const int nf = W.nflagged[0];
             if (nf == 0) break;
             repaired += nf; iters++;
-            for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 1, 0, LQ);
+            for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 1, 0, LQ, QT);
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
         for (int b = 0; b < nfs; b++) kb_bits(T, W, dSD, b, 0, LBi);
@@ -827,7 +823,7 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
         case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ctx->lastC * sizeof(GrSide); break;
         case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;
         case 6: src = W.peaks; n = GC * PK_STRIDE * 4; break;
-        case 7: src = W.prof; n = 256; break;
+        case 7: src = W.prof; n = 512; break;
         default: set_err("unknown tap"); return LHIP_ERR_INTERNAL;
     }
     if (n > cap) n = cap;

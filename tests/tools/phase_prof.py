@@ -6,16 +6,17 @@ ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import lamejs_amd, pcm
 lib = lamejs_amd.load_library(ROOT / "lamejs_amd" / "lib" / "liblamejs_hip_prof.so")
-names = ["init", "xrpow", "xmin", "quantize", "count", "noise", "balance", "sfstore", "huffdiv", "publish", "copy", "total"]
-for corpus, ch, kbps in [("sine", 1, 128), ("sine", 2, 128), ("sine", 2, 320)]:
+names = ["init", "xrpow", "xmin", "quantize", "count", "noise", "balance", "sfstore", "huffdiv", "publish", "copy", "total",
+         "c_load", "c_quads", "c_max", "c_sums", "c_fin", "n_walk", "n_terms", "n_sums", "q_mask", "q_lines"]
+for corpus, ch, kbps in [("sine", 1, 128), ("sine", 2, 128)]:
     nfr = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     L, R = pcm.CORPORA[corpus](1152 * nfr, ch)
     enc = lamejs_amd.Mp3Encoder(ch, 44100, kbps, lib=lib)
     enc.encodeBuffer(L, R)
-    buf = (ctypes.c_uint64 * 32)()
-    lib.lhip_debug_read(7, buf, 256)
+    buf = (ctypes.c_uint64 * 64)()
+    lib.lhip_debug_read(7, buf, 512)
     tot = buf[11]
     print(f"== {corpus} ch={ch} {kbps}k frames={nfr}: total cycles/frame = {tot / nfr:.0f}")
     for i, n in enumerate(names):
-        if buf[16 + i]:
-            print(f"   {n:9s} {100.0 * buf[i] / tot:5.1f}%  calls/frame {buf[16 + i] / nfr:7.2f}  cycles/call {buf[i] / buf[16 + i]:9.0f}")
+        if buf[32 + i]:
+            print(f"   {n:9s} {100.0 * buf[i] / tot:5.1f}%  calls/frame {buf[32 + i] / nfr:7.2f}  cycles/call {buf[i] / buf[32 + i]:9.0f}")
