@@ -115,6 +115,7 @@ struct QuantLds {
     float pn_noise[SFBMAX + 1], pn_noise_log[SFBMAX + 1];
     int32_t qmode[SFBMAX + 1], qlen[SFBMAX + 1];
     int32_t nstart[SFBMAX + 1], npairs[SFBMAX + 1], ncached[SFBMAX + 1];
+    struct BandInfo { int32_t nstart, nend, kind; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range + term formula per band
     int32_t sf_gr0[2][SFBMAX + 1];                // final gr0 scalefactors per channel (for scfsi)
     int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24];
     double ath_pseudo[6];
@@ -349,21 +350,25 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     PH_MARK(L, PH_Q_MASK, tm_);
     const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
-    for (int i = lane; i < 576; i += LHIP_NL) {
-        const int sfb = l2s[i];
-        const int proc = (i < last_line) && !((m_cached >> sfb) & 1);
-        if (proc) {
-            const double xv = L.xrpow[i];
-            int v;
-            if ((m_zo >> sfb) & 1) v = (compareval0 > xv) ? 0 : 1;
-            else {
-                double x = xv * istep;                 // 0 <= x <= 8206 (guarded by count_bits): plain truncation == ToInt32
-                const int rx = (int)x;
-                x += adj43v(T, Q, rx);
-                v = (int)x;
-            }
-            ix[i] = (int16_t)v;
-        } else if (i >= fill_from) ix[i] = 0;
+    // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here)
+    enum { NLN = 576 / LHIP_NL };
+    float xv[NLN]; int sf[NLN], rx[NLN]; double xq[NLN]; float aj[NLN];
+#pragma unroll
+    for (int j = 0; j < NLN; j++) { const int i = lane + LHIP_NL * j; sf[j] = l2s[i]; xv[j] = L.xrpow[i]; }
+#pragma unroll
+    for (int j = 0; j < NLN; j++) { xq[j] = (double)xv[j] * istep; rx[j] = (int)xq[j]; }   // 0 <= x <= 8206: truncation == ToInt32
+#pragma unroll
+    for (int j = 0; j < NLN; j++) aj[j] = Q.adj43[rx[j] < QT_N ? rx[j] : QT_N - 1];
+#pragma unroll
+    for (int j = 0; j < NLN; j++) {
+        const int i = lane + LHIP_NL * j;
+        if (rx[j] >= QT_N) aj[j] = T.adj43[rx[j]];                 // rare: large quantized values
+        const int proc = (i < last_line) && !((m_cached >> sf[j]) & 1);
+        const int v1 = (int)(xq[j] + (double)aj[j]);
+        const int v01 = (compareval0 > (double)xv[j]) ? 0 : 1;
+        const int v = ((m_zo >> sf[j]) & 1) ? v01 : v1;
+        if (proc) ix[i] = (int16_t)v;
+        else if (i >= fill_from) ix[i] = 0;
     }
     wave_sync();
     PH_MARK(L, PH_Q_LINES, tm_);
@@ -514,17 +519,26 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
     const RegionPlan r0 = plan_region_(Q, m0), r1 = plan_region_(Q, m1), r2 = plan_region_(Q, m2);
     PH_MARK(L, PH_C_MAX, tm_);
-    // ... and the candidate-table length sums of all three regions
+    // ... and the candidate-table length sums, region by region: the table group of a region is wave-uniform,
+    // so each region is a branch-free, fully unrolled pass over the register-resident pairs
     int s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
-#pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        const int p = 2 * (lane + LHIP_NL * j);
-        if (p < i) {
-            if (p < a1) pair_bits(Q, r0, vx[j], vy[j], s00, s01, s02);
-            else if (p < a2) pair_bits(Q, r1, vx[j], vy[j], s10, s11, s12);
-            else pair_bits(Q, r2, vx[j], vy[j], s20, s21, s22);
-        }
+#define REGION_PASS(R, LO, HI, S0, S1, S2)                                                                   \
+    switch ((R).kind) {                                                                                      \
+        case 1: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
+                if (p >= (LO) && p < (HI)) S0 += Q.hlen[(R).o0 + vx[j] * 2 + vy[j]]; } break;                  \
+        case 2: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
+                if (p >= (LO) && p < (HI)) S0 += ((R).t1 == 2) ? Q.table23[vx[j] * 3 + vy[j]] : Q.table56[vx[j] * 4 + vy[j]]; } break; \
+        case 4: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
+                if (p >= (LO) && p < (HI)) { const int q = vx[j] * (R).xlen + vy[j];                           \
+                    S0 += Q.hlen[(R).o0 + q]; S1 += Q.hlen[(R).o1 + q]; S2 += Q.hlen[(R).o2 + q]; } } break;   \
+        case 5: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
+                if (p >= (LO) && p < (HI)) pair_bits(Q, (R), vx[j], vy[j], S0, S1, S2); } break;               \
+        default: break;                                                                                      \
     }
+    REGION_PASS(r0, 0, a1, s00, s01, s02)
+    REGION_PASS(r1, a1, a2, s10, s11, s12)
+    REGION_PASS(r2, a2, i, s20, s21, s22)
+#undef REGION_PASS
     s00 = wave_sum(s00); s10 = wave_sum(s10); s20 = wave_sum(s20);
     if (r0.kind >= 4) s01 = wave_sum(s01);
     if (r1.kind >= 4) s11 = wave_sum(s11);
@@ -594,27 +608,46 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         }
     }
     wave_sync();
+    // per band: summing range and which of the three error formulas applies (calc_noise_core's branches)
+    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
+        const int js = L.nstart[sfb];
+        QuantLds::BandInfo bi;
+        bi.nstart = js; bi.nend = js + 2 * L.npairs[sfb];
+        bi.kind = L.ncached[sfb] ? 0 : (js > g.count1) ? 1 : (js > g.big_values) ? 2 : 3;
+        bi.step = Q.pow20[L.qmode[sfb] + Q_MAX2];
+        L.binfo[sfb] = bi;
+    }
+    wave_sync();
     PH_MARK(L, PH_N_WALK, tm_);
-    // 2) squared-error term of every line, in parallel.  A line belongs to the band whose summing range
-    //    [nstart, nstart + 2 npairs) contains it; ranges are ordered and disjoint and coincide with the
-    //    natural bands except after a max_nonzero_coeff cut (where they slide down).
+    // 2) squared-error term of every line, in parallel (staged so that the LDS reads of a stage overlap).
+    //    A line belongs to the band whose summing range contains it; ranges coincide with the natural bands
+    //    except after a max_nonzero_coeff cut, where they slide down (slow path).
     {
         const uint8_t* l2s = line2sfb(Q, g.block_type);
-        for (int j = lane; j < 576; j += LHIP_NL) {
-            int sfb = l2s[j];
-            if (sfb >= g.psymax) sfb = g.psymax - 1;
-            while (sfb + 1 < g.psymax && j >= L.nstart[sfb + 1]) sfb++;
-            double t = 0.0;
-            const int js = L.nstart[sfb];
-            if (!L.ncached[sfb] && j >= js && j < js + 2 * L.npairs[sfb]) {
-                const double step = pow20(Q, L.qmode[sfb]);
-                double x;
-                if (js > g.count1) x = L.xr[j];
-                else if (js > g.big_values) x = d_abs((double)L.xr[j]) - (ix[j] == 0 ? 0.0 : (double)(float)step);
-                else x = d_abs((double)L.xr[j]) - pow43v(T, Q, ix[j]) * step;
-                t = x * x;
-            }
-            L.term[j] = t;
+        enum { NLN = 576 / LHIP_NL };
+        int sf[NLN], iv[NLN]; float xa[NLN], pw[NLN]; QuantLds::BandInfo bi[NLN];
+        const int cut = firstcut < g.psymax;
+#pragma unroll
+        for (int j = 0; j < NLN; j++) { const int i = lane + LHIP_NL * j; sf[j] = l2s[i]; xa[j] = L.xr[i]; iv[j] = ix[i]; }
+#pragma unroll
+        for (int j = 0; j < NLN; j++) {
+            const int i = lane + LHIP_NL * j;
+            int sfb = sf[j] < g.psymax ? sf[j] : g.psymax - 1;
+            if (cut) while (sfb + 1 < g.psymax && i >= L.nstart[sfb + 1]) sfb++;
+            sf[j] = sfb;
+        }
+#pragma unroll
+        for (int j = 0; j < NLN; j++) { bi[j] = L.binfo[sf[j]]; pw[j] = Q.pow43[iv[j] < QT_N ? iv[j] : QT_N - 1]; }
+#pragma unroll
+        for (int j = 0; j < NLN; j++) {
+            const int i = lane + LHIP_NL * j;
+            if (iv[j] >= QT_N) pw[j] = T.pow43[iv[j]];
+            const double ax = d_abs((double)xa[j]), step = (double)bi[j].step;
+            double x = (double)xa[j];                                         // kind 1: above count1
+            if (bi[j].kind == 2) x = ax - (iv[j] == 0 ? 0.0 : step);          // count1 region: ix in {0,1}
+            if (bi[j].kind == 3) x = ax - (double)pw[j] * step;               // big values
+            const int in = bi[j].kind != 0 && i >= bi[j].nstart && i < bi[j].nend;
+            L.term[i] = in ? x * x : 0.0;
         }
     }
     wave_sync();
