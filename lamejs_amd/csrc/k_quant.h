@@ -912,44 +912,79 @@ LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // 
 }
 
 // outer_loop (Quantize.js:871-1052).  g = kept copy (cod_info); seeds in/out via start/step.
+// bin_search_StepSize (Quantize.js:322-381) + outer_loop (Quantize.js:871-1052) as ONE state machine, so that the
+// three big building blocks -- count_bits, calc_noise, balance_noise -- are each instantiated exactly once
+// (code size decides instruction-cache behaviour here).  Everything runs on the working copy `w`
+// (ixw / sfw); `g` (ixb / sfb) is the kept quantization, exactly the reference's cod_info / cod_info_w pair
+// with the roles of the first copy swapped (bin search on w, then g = w).
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
                            int lane, QuantLds& L, const QuantTabs& Q) {
-    int step_unused;
-    q_bin_search(T, g, targ_bits, bs_start, bs_step, &step_unused, lane, L, Q);
-    *bs_gain_out = g.global_gain;                        // OldValue[ch] after this granule
-    if (0 == T.noise_shaping) return;
-    NoiseRes best; PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
+    enum { ST_BS, ST_BSUP, ST_A, ST_B };
+    NoiseRes best, ni;
+    PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
+    best.max_noise = 0; best.over_count = 0; best.over_SSD = 0; best.bits = 0;
     for (int i = lane; i <= SFBMAX; i += LHIP_NL) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_noise_log[i] = 0.f; L.distort[i] = 0.f; }
     wave_sync();
-    q_calc_noise(T, g, L.sfb, L.ixb, &best, &pn, lane, L, Q);
-    best.bits = g.part2_3_length;
-    GI w = g;                                            // cod_info_w.assign(cod_info)
-    for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = L.ixb[i];
-    for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sfw[i] = L.sfb[i];
-    wave_sync();
-    int best_part2_3_length = 9999999, age = 0;
-    do {
-        NoiseRes ni;
-        const int search_limit = 3;
-        int maxggain = 255;
-        int bal_;
-        { PH_BEGIN(); bal_ = q_balance_noise(T, w, L.sfw, lane, L, Q); PH_END(L, PH_BALANCE); }
-        if (!bal_) break;
-        if (w.scalefac_scale != 0) maxggain = 254;
-        const int huff_bits = targ_bits - w.part2_length;
-        if (huff_bits <= 0) break;
-        while ((w.part2_3_length = q_count_bits(T, w, L.sfw, L.ixw, &pn, lane, L, Q)) > huff_bits && w.global_gain <= maxggain)
-            w.global_gain++;
-        if (w.global_gain > maxggain) break;
-        if (best.over_count == 0) {
-            while ((w.part2_3_length = q_count_bits(T, w, L.sfw, L.ixw, &pn, lane, L, Q)) > best_part2_3_length && w.global_gain <= maxggain)
-                w.global_gain++;
+    GI w = g;
+    // bin-search state
+    int CurrentStep = bs_step, flagGoneOver = 0, Direction = 0;
+    const int desired_rate = targ_bits - w.part2_length;
+    w.global_gain = bs_start;
+    // outer-loop state
+    int best_part2_3_length = 9999999, age = 0, maxggain = 255, huff_bits = 0, first = 1;
+    const int search_limit = 3;
+    int st = ST_BS;
+    for (;;) {
+        const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A ? &pn : nullptr, lane, L, Q);   // the only call site
+        if (st == ST_BS) {
+            if (CurrentStep == 1 || nBits == desired_rate) st = ST_BSUP;
+            else {
+                int step;
+                if (nBits > desired_rate) {
+                    if (Direction == 2) flagGoneOver = 1;
+                    if (flagGoneOver) CurrentStep /= 2;
+                    Direction = 1;
+                    step = CurrentStep;
+                } else {
+                    if (Direction == 1) flagGoneOver = 1;
+                    if (flagGoneOver) CurrentStep /= 2;
+                    Direction = 2;
+                    step = -CurrentStep;
+                }
+                w.global_gain += step;
+                if (w.global_gain < 0) { w.global_gain = 0; flagGoneOver = 1; }
+                if (w.global_gain > 255) { w.global_gain = 255; flagGoneOver = 1; }
+                continue;
+            }
+        }
+        if (st == ST_BSUP) {
+            if (nBits > desired_rate && w.global_gain < 255) { w.global_gain++; continue; }
+            w.part2_3_length = nBits;
+            *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
+            if (0 == T.noise_shaping) {
+                g = w;
+                for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = L.ixw[i];
+                for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sfb[i] = L.sfw[i];
+                wave_sync();
+                return;
+            }
+        } else if (st == ST_A) {
+            w.part2_3_length = nBits;
+            if (nBits > huff_bits && w.global_gain <= maxggain) { w.global_gain++; continue; }
+            if (w.global_gain > maxggain) break;
+            if (best.over_count == 0) { st = ST_B; continue; }   // the reference re-counts at the same gain first
+        } else {   // ST_B
+            w.part2_3_length = nBits;
+            if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
         }
-        q_calc_noise(T, w, L.sfw, L.ixw, &ni, &pn, lane, L, Q);
+        q_calc_noise(T, w, L.sfw, L.ixw, &ni, &pn, lane, L, Q);                                       // the only call site
         ni.bits = w.part2_3_length;
-        if (q_quant_compare(best, ni)) {
-            best_part2_3_length = g.part2_3_length;       // value BEFORE the copy (reference quirk)
+        int keep;
+        if (first) keep = 1;
+        else keep = q_quant_compare(best, ni);
+        if (keep) {
+            if (!first) best_part2_3_length = g.part2_3_length;   // value BEFORE the copy (reference quirk)
             best = ni;
             g = w;
             for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = L.ixw[i];
@@ -959,7 +994,16 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         } else if (T.full_outer_loop == 0) {
             if (++age > search_limit && best.over_count == 0) break;
         }
-    } while ((w.global_gain + w.scalefac_scale) < 255);
+        if (!first && !((w.global_gain + w.scalefac_scale) < 255)) break;
+        first = 0;
+        int bal_;
+        { PH_BEGIN(); bal_ = q_balance_noise(T, w, L.sfw, lane, L, Q); PH_END(L, PH_BALANCE); }       // the only call site
+        if (!bal_) break;
+        maxggain = (w.scalefac_scale != 0) ? 254 : 255;
+        huff_bits = targ_bits - w.part2_length;
+        if (huff_bits <= 0) break;
+        st = ST_A;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
