@@ -46,14 +46,13 @@ enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, 
 
 // Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
 // inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
-enum { QT_N = 512 };
+enum { QT_N = 256 };
 struct QuantTabs {
     float pow43[QT_N], adj43[QT_N];
     float ipow20[Q_MAX], pow20[Q_MAX + Q_MAX2 + 1];
     int32_t largetbl[256], table23[9], table56[16];
     int32_t sfb_l[SBMAX_l + 1], sfb_s[SBMAX_s + 1], pretab[SBMAX_l];
     uint16_t hoff[16];
-    uint16_t reorder_s[576];
     uint8_t hlen[1088];          // code lengths of tables 1, 7..15 (offsets in hoff)
     uint8_t t32l[16], t33l[16];
     uint8_t l2s_long[576], l2s_short[576];
@@ -95,16 +94,15 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
         const int st = T.sfb_s[sfb], w = T.sfb_s[sfb + 1] - st;
         const int r = d - 3 * st, win = r / w, l = st + (r - win * w);
         Q.l2s_short[d] = (uint8_t)(3 * sfb + win);
-        Q.reorder_s[d] = (uint16_t)(3 * l + win);
+        (void)l;
     }
 }
 
 struct QuantLds {
     float xr[576];
-    double term[576];            // per-line squared-error terms (calc_noise)
     union {                      // xrpow is dead once the outer loop has finished; the Huffman-split scratch reuses it
         float xrpow[576];
-        struct { int32_t bstat[16][SBMAX_l + 2]; int32_t cand[21][16]; } hd;
+        struct { int32_t bstat[16][SBMAX_l + 2]; int16_t cand[21][16]; } hd;   // cand: bits clipped to 0x7fff (LARGE_BITS marker)
     };
     int16_t ixw[576];            // l3_enc of the working copy (cod_info_w)
     int16_t ixb[576];            // l3_enc of the best/kept copy (cod_info)
@@ -195,7 +193,11 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         }
         if (lane == 0) L.start[nsfb] = 576;
         // re-order: within each short sfb the three windows become consecutive runs
-        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[Q.reorder_s[d]];
+        for (int d = lane; d < 576; d += LHIP_NL) {
+            const int sw = Q.l2s_short[d], sfb = sw / 3, win = sw - 3 * sfb;
+            const int st = Q.sfb_s[sfb], w = Q.sfb_s[sfb + 1] - st;
+            L.xr[d] = xr_g[3 * (st + (d - 3 * st - win * w)) + win];
+        }
     } else {
         nsfb = SBMAX_l;
         for (int i = lane; i < SBMAX_l; i += LHIP_NL) {
@@ -619,52 +621,46 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     }
     wave_sync();
     PH_MARK(L, PH_N_WALK, tm_);
-    // 2) squared-error term of every line, in parallel (staged so that the LDS reads of a stage overlap).
-    //    A line belongs to the band whose summing range contains it; ranges coincide with the natural bands
-    //    except after a max_nonzero_coeff cut, where they slide down (slow path).
-    {
-        const uint8_t* l2s = line2sfb(Q, g.block_type);
-        enum { NLN = 576 / LHIP_NL };
-        int sf[NLN], iv[NLN]; float xa[NLN], pw[NLN]; QuantLds::BandInfo bi[NLN];
-        const int cut = firstcut < g.psymax;
-#pragma unroll
-        for (int j = 0; j < NLN; j++) { const int i = lane + LHIP_NL * j; sf[j] = l2s[i]; xa[j] = L.xr[i]; iv[j] = ix[i]; }
-#pragma unroll
-        for (int j = 0; j < NLN; j++) {
-            const int i = lane + LHIP_NL * j;
-            int sfb = sf[j] < g.psymax ? sf[j] : g.psymax - 1;
-            if (cut) while (sfb + 1 < g.psymax && i >= L.nstart[sfb + 1]) sfb++;
-            sf[j] = sfb;
-        }
-#pragma unroll
-        for (int j = 0; j < NLN; j++) { bi[j] = L.binfo[sf[j]]; pw[j] = Q.pow43[iv[j] < QT_N ? iv[j] : QT_N - 1]; }
-#pragma unroll
-        for (int j = 0; j < NLN; j++) {
-            const int i = lane + LHIP_NL * j;
-            if (iv[j] >= QT_N) pw[j] = T.pow43[iv[j]];
-            const double ax = d_abs((double)xa[j]), step = (double)bi[j].step;
-            double x = (double)xa[j];                                         // kind 1: above count1
-            if (bi[j].kind == 2) x = ax - (iv[j] == 0 ? 0.0 : step);          // count1 region: ix in {0,1}
-            if (bi[j].kind == 3) x = ax - (double)pw[j] * step;               // big values
-            const int in = bi[j].kind != 0 && i >= bi[j].nstart && i < bi[j].nend;
-            L.term[i] = in ? x * x : 0.0;
-        }
-    }
-    wave_sync();
-    PH_MARK(L, PH_N_TERMS, tm_);
-    // 3) per band (one lane each): ordered f64 sum of its terms, distortion ratio, log10
+    // 2) per band (one lane each): squared errors summed in the reference's line order (f64 sums are
+    //    order-sensitive).  Loads are issued four lines ahead of the dependent add chain.
     int over = 0, ssd = 0;
     double max_noise = -20.0;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
         double noise;
-        if (L.ncached[sfb]) {
+        const QuantLds::BandInfo bi = L.binfo[sfb];
+        if (bi.kind == 0) {
             noise = L.pn_noise[sfb];
             L.distort[sfb] = (float)(noise / (double)L.xmin[sfb]);
             noise = L.pn_noise_log[sfb];
         } else {
-            const int js = L.nstart[sfb], n = 2 * L.npairs[sfb];
+            const double step = (double)bi.step;
             noise = 0;
-            for (int t = 0; t < n; t++) noise += L.term[js + t];
+            int j = bi.nstart;
+            for (; j + 4 <= bi.nend; j += 4) {
+                float xa[4]; int iv[4]; float pw[4]; double t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { xa[u] = L.xr[j + u]; iv[u] = ix[j + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) pw[u] = Q.pow43[iv[u] < QT_N ? iv[u] : QT_N - 1];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (iv[u] >= QT_N) pw[u] = T.pow43[iv[u]];
+                    const double ax = d_abs((double)xa[u]);
+                    double x = (double)xa[u];
+                    if (bi.kind == 2) x = ax - (iv[u] == 0 ? 0.0 : step);
+                    if (bi.kind == 3) x = ax - (double)pw[u] * step;
+                    t[u] = x * x;
+                }
+                noise += t[0]; noise += t[1]; noise += t[2]; noise += t[3];
+            }
+            for (; j < bi.nend; j++) {
+                const float xa = L.xr[j]; const int iv = ix[j];
+                const double ax = d_abs((double)xa);
+                double x = (double)xa;
+                if (bi.kind == 2) x = ax - (iv == 0 ? 0.0 : step);
+                if (bi.kind == 3) x = ax - pow43v(T, Q, iv) * step;
+                noise += x * x;
+            }
             if (pn != nullptr) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
             L.distort[sfb] = (float)noise;
@@ -672,13 +668,14 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             if (pn != nullptr) L.pn_noise_log[sfb] = (float)noise;
         }
         if (noise > 0.0) {
-            int tmp = (int)(noise * 10 + .5);          // 0 < noise < ~300: truncation == ToInt32
+            int tmp = (int)(noise * 10 + .5);          // 0 < noise < ~400: truncation == ToInt32
             if (tmp < 1) tmp = 1;
             ssd += tmp * tmp;
             over++;
         }
         if (noise > max_noise) max_noise = noise;
     }
+    PH_MARK(L, PH_N_TERMS, tm_);
     if (pn != nullptr) pn->gain = g.global_gain;
     res->over_count = wave_sum(over);
     res->over_SSD = wave_sum(ssd);
@@ -1175,12 +1172,12 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
                 q_choose_from_stats(T, 0, r0 + 1, &bits, L, Q);
                 q_choose_from_stats(T, r0 + 1, r0 + r1 + 2, &bits, L, Q);
             }
-            L.hd.cand[sidx][r0] = bits;
+            L.hd.cand[sidx][r0] = (int16_t)(bits > 0x7fff ? 0x7fff : bits);
         }
         wave_sync();
         // lane s: the first r0 (ascending) with the strictly smallest bits wins, as in the reference's loop order
         for (int sidx = lane; sidx <= 20; sidx += LHIP_NL) {
-            int bb = LARGE_BITS, bd = -1;
+            int bb = 0x7fff, bd = -1;               // 0x7fff == no valid split (the reference keeps LARGE_BITS there)
             for (int r0 = (sidx > 7 ? sidx - 7 : 0); r0 < 16 && r0 <= sidx; r0++)
                 if (bb > L.hd.cand[sidx][r0]) { bb = L.hd.cand[sidx][r0]; bd = r0; }
             if (bd >= 0) {
