@@ -25,8 +25,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-CH, SR, KBPS = 1, 44100, 128
-ALG_BYTES_PER_FRAME = 1152 * CH * 2 + 417.96   # Int16 PCM in + MP3 bytes out: 2722 B
+SR = 44100
 
 
 def main():
@@ -36,9 +35,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=100000, help="frames per step per GPU (BASELINE: 1e5)")
     ap.add_argument("--cpu-frames", type=int, default=40000, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--channels", type=int, default=1, help="1 = BASELINE configs[1] (the metric's configuration); 2 = configs[2]/[3]")
+    ap.add_argument("--kbps", type=int, default=128)
     ap.add_argument("--check-frames", type=int, default=2000, help="prefix checked against the CPU oracle")
     args = ap.parse_args()
 
+    CH, KBPS = args.channels, args.kbps
+    ALG_BYTES_PER_FRAME = 1152 * CH * 2 + 144000.0 * KBPS / SR   # Int16 PCM in + MP3 bytes out: 2722 B mono 128k
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -61,22 +64,15 @@ def main():
 
     # table blob: rank 0 builds it with the host JavaScript, everyone receives it over RCCL (setup, untimed)
     if world > 1:
-        if rank == 0:
-            blob = lamejs_amd.tables_blob(CH, SR, KBPS)
-            n = torch.tensor([len(blob)], device=dev, dtype=torch.int64)
-        else:
-            n = torch.zeros(1, device=dev, dtype=torch.int64)
-        dist.broadcast(n, 0)
-        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev) if rank == 0 else torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(t, 0)
-        blob = bytes(t.cpu().numpy().tobytes())
+        from lamejs_amd.shard import broadcast_blob
+        blob = broadcast_blob(dist, lamejs_amd.tables_blob(CH, SR, KBPS) if rank == 0 else None, dev, rank)
     else:
         blob = lamejs_amd.tables_blob(CH, SR, KBPS)
 
-    L, _ = pcm.sine(nsamp, CH, seed=12345 + rank)
+    L, R = pcm.sine(nsamp, CH, seed=12345 + rank)            # rank r owns stream r (lamejs_amd.shard.shard_streams(world, world, r))
     d_pcm = torch.from_numpy(L).to(dev)                      # Int16 PCM resident in HBM
-    cap = lib.lhip_max_output_bytes.__call__  # noqa
-    out_cap = (nfr + 4) * 419
+    d_pcm_r = torch.from_numpy(R).to(dev) if CH == 2 else d_pcm
+    out_cap = (nfr + 4) * (144000 * KBPS // SR + 1)
     d_out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
 
     cfg = lamejs_amd._Config(CH, SR, KBPS, local_rank)
@@ -94,7 +90,7 @@ def main():
     wr = (ctypes.c_int64 * 1)()
 
     def step(h):
-        rc = lib.lhip_encode_batch_device(H1(h), 1, H1(d_pcm.data_ptr()), H1(d_pcm.data_ptr()), S1(nsamp), H1(d_out.data_ptr()), S1(out_cap), wr, 0)
+        rc = lib.lhip_encode_batch_device(H1(h), 1, H1(d_pcm.data_ptr()), H1(d_pcm_r.data_ptr()), S1(nsamp), H1(d_out.data_ptr()), S1(out_cap), wr, 0)
         assert rc == 0, lib.lhip_last_error()
         return wr[0]
 
@@ -131,7 +127,7 @@ def main():
     if args.check_frames > 0:
         from oracle_py import oracle_encode
         k = min(args.check_frames, nfr - 2)
-        ref = oracle_encode(CH, SR, KBPS, L[: 1152 * k], flush=False)
+        ref = oracle_encode(CH, SR, KBPS, L[: 1152 * k], R[: 1152 * k] if CH == 2 else None, flush=False)
         parity = bool(mp3[: len(ref)] == ref)
 
     # per-kernel timing pass (untimed extra step with HIP events on the launch stream)
@@ -159,11 +155,12 @@ def main():
         total_frames = frames_per_step * args.steps * world
         value = total_frames / dt
         line = {
-            "metric": "1152-sample frames/s encoded (44.1kHz 128kbps CBR); bit-exact",
+            "metric": f"1152-sample frames/s encoded (44.1kHz {KBPS}kbps CBR); bit-exact",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: mono 44.1kHz 128kbps CBR, 1e5 synthetic sine+noise frames, one stream per GPU",
+            "config": {"workload": (f"BASELINE configs[1]: mono 44.1kHz 128kbps CBR, {nfr} synthetic sine+noise frames, one stream per GPU" if (CH, KBPS) == (1, 128)
+                                    else f"{'stereo' if CH == 2 else 'mono'} 44.1kHz {KBPS}kbps CBR, {nfr} synthetic sine+noise frames, one stream per GPU"),
                        "frames_per_step_per_gpu": frames_per_step, "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
                        "bit_exact_prefix_vs_oracle": parity, "seed_repaired_frames": b.value, "output_md5_per_rank": digests},
             "kernels_ms": kern,
@@ -179,7 +176,7 @@ def main():
             from oracle_py import oracle_encode
             k = min(args.cpu_frames, nfr)
             t1 = time.perf_counter()
-            oracle_encode(CH, SR, KBPS, L[: 1152 * k])
+            oracle_encode(CH, SR, KBPS, L[: 1152 * k], R[: 1152 * k] if CH == 2 else None)
             cdt = time.perf_counter() - t1
             line["cpu_baseline"] = {"value": round(k / cdt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": f"first {k} frames of the same stream, plain-C oracle (oracle/), 1 thread"}

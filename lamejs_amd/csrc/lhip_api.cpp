@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const Stream
 // quantization kernels: 4 waves (= 4 frames) per workgroup share one copy of the lookup tables in LDS
 enum { QWAVES = 4 };
 #ifndef LHIP_QOCC
-#define LHIP_QOCC 2     /* waves per SIMD the quantization kernel is register-budgeted for */
+#define LHIP_QOCC 3     /* waves per SIMD the quantization kernel is register-budgeted for */
 #endif
 __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain, int nfs) {
     __shared__ QuantTabs Q;

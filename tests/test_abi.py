@@ -2,6 +2,8 @@
 import ctypes
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -34,3 +36,13 @@ def test_product_does_not_reference_oracle():
     for p in list((ROOT / "lamejs_amd").rglob("*.h")) + list((ROOT / "lamejs_amd").rglob("*.cpp")) + list((ROOT / "lamejs_amd").rglob("*.py")) + list((ROOT / "lamejs_amd").rglob("*.js")):
         txt = p.read_text(errors="ignore")
         assert "oracle/" not in txt and "lame_oracle" not in txt and "oracle_py" not in txt, p
+
+
+def test_configs_outside_the_envelope_fail_loudly(golden):
+    """Configurations the reference would resample to an MPEG-2 rate are refused (no silent fallback)."""
+    import lamejs_amd
+    outside = [c for c in golden if c.get("outside_envelope")]
+    assert len(outside) >= 3
+    for c in outside:
+        with pytest.raises(lamejs_amd.LhipError, match="resampl"):
+            lamejs_amd.tables_blob(c["channels"], c.get("samplerate", 44100), c["kbps"])

@@ -20,9 +20,9 @@ def sim():
     return lib
 
 
-def _encode(lib, ch, kbps, L, R, chunk):
+def _encode(lib, ch, kbps, L, R, chunk, sr=44100):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, 44100, kbps, lib=lib)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -37,11 +37,13 @@ def test_hostsim_matches_goldens(sim, golden):
     for case in golden:
         if case["corpus"] == "wavfull" or case["nsamples"] > 1152 * 300:
             continue
+        if case.get("outside_envelope"):
+            continue
         L, R = load_case_pcm(case)
-        mp3 = _encode(sim, case["channels"], case["kbps"], L, R, case["chunk"])
+        mp3 = _encode(sim, case["channels"], case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100))
         assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
         n += 1
-    assert n >= 8
+    assert n >= 22
 
 
 def test_hostsim_batch_streams_match_single(sim):

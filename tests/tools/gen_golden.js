@@ -16,8 +16,8 @@ fs.mkdirSync(OUT, { recursive: true });
 const md5 = (b) => crypto.createHash('md5').update(b).digest('hex');
 const lamejs = refPublic();
 
-function encode(L, R, ch, kbps, chunk) {
-    const enc = new lamejs.Mp3Encoder(ch, 44100, kbps);
+function encode(L, R, ch, kbps, chunk, sr) {
+    const enc = new lamejs.Mp3Encoder(ch, sr || 44100, kbps);
     const parts = [];
     for (let i = 0; i < L.length; i += chunk) {
         const l = L.subarray(i, i + chunk), r = R ? R.subarray(i, i + chunk) : undefined;
@@ -53,13 +53,20 @@ const synth = [
     ['bursts', 1, 128, 400, 1152], ['bursts', 2, 128, 400, 1152], ['bursts', 2, 320, 400, 1152],
     ['bursts', 2, 128, 250, 777], ['sine', 1, 128, 250, 4096], ['bursts', 1, 64, 200, 1152], ['sine', 2, 192, 200, 1152],
     ['sine', 1, 128, 2000, 1152 * 2000], ['bursts', 2, 128, 2000, 1152 * 2000], ['sine', 2, 320, 1000, 1152 * 1000],
-    ['sine', 1, 128, 1, 1152], ['sine', 2, 128, 2, 100], ['bursts', 1, 128, 3, 1]
+    ['sine', 1, 128, 1, 1152], ['sine', 2, 128, 2, 100], ['bursts', 1, 128, 3, 1],
+    /* the other MPEG-1 sample rates and bitrates of the envelope */
+    ['sine', 2, 128, 150, 1152, 48000], ['bursts', 1, 128, 150, 1152, 48000], ['bursts', 2, 192, 150, 1152, 48000], ['bursts', 2, 224, 120, 999, 48000],
+    ['sine', 1, 64, 150, 1152, 32000], ['bursts', 2, 128, 150, 1152, 32000], ['sine', 1, 320, 100, 1152, 32000],
+    ['sine', 2, 256, 100, 1152], ['bursts', 2, 160, 100, 1152], ['sine', 1, 96, 100, 1152], ['bursts', 1, 320, 100, 1152],
+    ['sine', 1, 32, 100, 1152], ['bursts', 2, 64, 100, 1152], ['bursts', 2, 96, 100, 1152], ['sine', 1, 48, 60, 1152], ['bursts', 1, 160, 60, 500]
 ];
-for (const [corpus, ch, kbps, nframes, chunk] of synth) {
+for (const [corpus, ch, kbps, nframes, chunk, sr] of synth) {
     const n = nframes * 1152;
     const [L, R] = gen[corpus](n, ch);
-    const mp3 = encode(L, R, ch, kbps, chunk);
+    const mp3 = encode(L, R, ch, kbps, chunk, sr);
     const c = { corpus, channels: ch, kbps, nsamples: n, chunk, pcm_md5: pcmMd5(L, R), mp3_md5: md5(mp3), mp3_len: mp3.length };
+    if (sr) c.samplerate = sr;
+    try { require('../../lamejs_amd/js/tables.js').buildBlob(ch, sr || 44100, kbps); } catch (e) { c.outside_envelope = String(e.message); }   /* reference resamples to an MPEG-2 rate: SURVEY 8f row 2 */
     if (mp3.length < 30000) { c.mp3_file = `${corpus}_${ch}_${kbps}_${nframes}_${chunk}.mp3`; fs.writeFileSync(path.join(OUT, c.mp3_file), mp3); }
     cases.push(c);
     console.log(corpus, ch, kbps, nframes, chunk, mp3.length, c.mp3_md5);
