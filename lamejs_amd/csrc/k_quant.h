@@ -29,6 +29,21 @@ struct GI {   // wave-uniform scalar part of the reference's GrInfo
 
 struct NoiseRes { double max_noise; int over_count, over_SSD, bits; };
 
+// Re-asserts that the granule state is wave-uniform (it is by construction: every lane executes the same
+// decisions).  The compiler's divergence analysis loses that fact at joins of lane-guarded code, and once one
+// loop-carried scalar counts as divergent every decision of the loop turns into exec-masked vector code.
+LHIP_DEV void uni_gi(GI& g) {
+    g.xrpow_max = unid(g.xrpow_max);
+    g.part2_3_length = uni(g.part2_3_length); g.big_values = uni(g.big_values); g.count1 = uni(g.count1); g.global_gain = uni(g.global_gain);
+    g.scalefac_compress = uni(g.scalefac_compress); g.block_type = uni(g.block_type);
+    for (int i = 0; i < 3; i++) g.table_select[i] = uni(g.table_select[i]);
+    for (int i = 0; i < 4; i++) g.subblock_gain[i] = uni(g.subblock_gain[i]);
+    g.region0_count = uni(g.region0_count); g.region1_count = uni(g.region1_count); g.preflag = uni(g.preflag); g.scalefac_scale = uni(g.scalefac_scale);
+    g.count1table_select = uni(g.count1table_select); g.part2_length = uni(g.part2_length); g.sfb_lmax = uni(g.sfb_lmax); g.sfb_smin = uni(g.sfb_smin);
+    g.psy_lmax = uni(g.psy_lmax); g.sfbmax = uni(g.sfbmax); g.psymax = uni(g.psymax); g.sfbdivide = uni(g.sfbdivide);
+    g.count1bits = uni(g.count1bits); g.max_nonzero_coeff = uni(g.max_nonzero_coeff);
+}
+
 // optional phase profiling (build with -DLHIP_PHASE_PROF; never in the product library)
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
 #define PH_BEGIN() const unsigned long long ph_t0_ = __builtin_amdgcn_s_memtime()
@@ -562,13 +577,16 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 struct PrevNoise { int gain, sfb_count1; };   // scalar part of CalcNoiseData (arrays are L.pn_*)
 
 // count_bits (Takehiro.js:630-660)
-LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, PrevNoise* pn, int lane, QuantLds& L, const QuantTabs& Q) {
+// `use_pn` selects the prev_noise cache; pn is passed by reference with a flag (never as a nullable pointer to a
+// local: a select between private addresses is a per-lane value for the compiler and makes the control flow divergent)
+LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
     const double w = (double)IXMAX_VAL / ipow20(Q, g.global_gain);
     if (g.xrpow_max > w) return LARGE_BITS;
-    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, pn != nullptr, pn ? pn->gain : 0, pn ? pn->sfb_count1 : 0, lane, L, Q); PH_END(L, PH_QUANTIZE); }
-    int dummy = 0;
+    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, use_pn, use_pn ? pn.gain : 0, use_pn ? pn.sfb_count1 : 0, lane, L, Q); PH_END(L, PH_QUANTIZE); }
+    int cnt1 = pn.sfb_count1;
     PH_BEGIN();
-    const int r = q_noquant_count_bits(T, g, ix, pn != nullptr, pn ? &pn->sfb_count1 : &dummy, lane, L, Q);
+    const int r = q_noquant_count_bits(T, g, ix, use_pn, &cnt1, lane, L, Q);
+    if (use_pn) pn.sfb_count1 = cnt1;
     PH_END(L, PH_COUNT);
     return r;
 }
@@ -578,7 +596,7 @@ LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16
 // One lane per band sums its lines in the reference's order (f64 sums are order-sensitive); all gathers hit LDS.
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           PrevNoise* pn, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     // 1) start-line walk (QuantizePVT.js:806-830): j advances by the band width until the first band that
     //    reaches past max_nonzero_coeff; up to there everything is regular and computed one lane per band,
@@ -586,7 +604,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     int firstcut = 99;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
         const int s = sf_step(Q, g, scalefac, L.window, sfb);
-        const int cached = (pn != nullptr && L.pn_step[sfb] == s);
+        const int cached = (use_pn && L.pn_step[sfb] == s);
         L.qmode[sfb] = s;                                   // step of the band (reused by the term pass)
         L.ncached[sfb] = cached; L.nstart[sfb] = L.start[sfb]; L.npairs[sfb] = cached ? 0 : (L.width[sfb] >> 1);
         if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff && sfb < firstcut) firstcut = sfb;
@@ -661,11 +679,11 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
                 if (bi.kind == 3) x = ax - pow43v(T, Q, iv) * step;
                 noise += x * x;
             }
-            if (pn != nullptr) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
+            if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
             L.distort[sfb] = (float)noise;
             noise = v8_log10(noise > 1E-20 ? noise : 1E-20);
-            if (pn != nullptr) L.pn_noise_log[sfb] = (float)noise;
+            if (use_pn) L.pn_noise_log[sfb] = (float)noise;
         }
         if (noise > 0.0) {
             int tmp = (int)(noise * 10 + .5);          // 0 < noise < ~400: truncation == ToInt32
@@ -676,7 +694,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         if (noise > max_noise) max_noise = noise;
     }
     PH_MARK(L, PH_N_TERMS, tm_);
-    if (pn != nullptr) pn->gain = g.global_gain;
+    if (use_pn) pn.gain = g.global_gain;
     res->over_count = wave_sum(over);
     res->over_SSD = wave_sum(ssd);
     res->max_noise = wave_maxd(max_noise);
@@ -685,9 +703,9 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
 }
 
 LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           PrevNoise* pn, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
     PH_BEGIN();
-    q_calc_noise_(T, g, scalefac, ix, res, pn, lane, L, Q);
+    q_calc_noise_(T, g, scalefac, ix, res, use_pn, pn, lane, L, Q);
     PH_END(L, PH_NOISE);
 }
 
@@ -866,11 +884,12 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
 LHIP_DEV int q_bin_search(const Tables& T, GI& g, int desired_rate, int start, int CurrentStep, int* step_out,
                           int lane, QuantLds& L, const QuantTabs& Q) {
     int nBits, flagGoneOver = 0, Direction = 0;
+    PrevNoise pn_none; pn_none.gain = 0; pn_none.sfb_count1 = 0;
     g.global_gain = start;
     desired_rate -= g.part2_length;
     for (;;) {
         int step;
-        nBits = q_count_bits(T, g, L.sfb, L.ixb, nullptr, lane, L, Q);
+        nBits = q_count_bits(T, g, L.sfb, L.ixb, 0, pn_none, lane, L, Q);
         if (CurrentStep == 1 || nBits == desired_rate) break;
         if (nBits > desired_rate) {
             if (Direction == 2) flagGoneOver = 1;
@@ -889,7 +908,7 @@ LHIP_DEV int q_bin_search(const Tables& T, GI& g, int desired_rate, int start, i
     }
     while (nBits > desired_rate && g.global_gain < 255) {
         g.global_gain++;
-        nBits = q_count_bits(T, g, L.sfb, L.ixb, nullptr, lane, L, Q);
+        nBits = q_count_bits(T, g, L.sfb, L.ixb, 0, pn_none, lane, L, Q);
     }
     *step_out = (start - g.global_gain >= 4) ? 4 : 2;
     g.part2_3_length = nBits;
@@ -932,7 +951,13 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     const int search_limit = 3;
     int st = ST_BS;
     for (;;) {
-        const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A ? &pn : nullptr, lane, L, Q);   // the only call site
+#ifndef LHIP_NO_FORCE_UNI
+        uni_gi(w); uni_gi(g); st = uni(st); CurrentStep = uni(CurrentStep); flagGoneOver = uni(flagGoneOver); Direction = uni(Direction);
+        best_part2_3_length = uni(best_part2_3_length); age = uni(age); maxggain = uni(maxggain); huff_bits = uni(huff_bits); first = uni(first);
+        pn.gain = uni(pn.gain); pn.sfb_count1 = uni(pn.sfb_count1);
+        best.max_noise = unid(best.max_noise); best.over_count = uni(best.over_count); best.over_SSD = uni(best.over_SSD); best.bits = uni(best.bits);
+#endif
+        const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, lane, L, Q);   // the only call site
         if (st == ST_BS) {
             if (CurrentStep == 1 || nBits == desired_rate) st = ST_BSUP;
             else {
@@ -975,7 +1000,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
         }
-        q_calc_noise(T, w, L.sfw, L.ixw, &ni, &pn, lane, L, Q);                                       // the only call site
+        q_calc_noise(T, w, L.sfw, L.ixw, &ni, 1, pn, lane, L, Q);                                       // the only call site
         ni.bits = w.part2_3_length;
         int keep;
         if (first) keep = 1;
@@ -1306,17 +1331,21 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     const double ath_adjust = W.ath_adjust[fslot];        // after adjust_ATH of this frame
     const int padding = frame_padding(T, sd, k);
     const int mean_bits = (frame_bits_of(T, padding) - T.sideinfo_len * 8) / T.mode_gr;
-    Seed seed[2];
-    for (int ch = 0; ch < C; ch++) {
-        if (chain || k == 0) seed[ch] = seed_before(W, sd, C, k, 0, ch);
-        else { seed[ch].start = 180; seed[ch].step = 4; }
+    // per-channel state as named scalars: a dynamically indexed local array would live in scratch memory,
+    // and everything read back from scratch counts as divergent for the compiler
+    Seed seed0, seed1;
+    seed0.start = seed1.start = 180; seed0.step = seed1.step = 4;
+    if (chain || k == 0) {
+        seed0 = seed_before(W, sd, C, k, 0, 0);
+        if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
     }
     int ResvSize = 0;
-    int gr0_bt[2] = {0, 0};
+    int gr0_bt0 = 0, gr0_bt1 = 0;
     for (int gr = 0; gr < 2; gr++) {
         const int gslot = sd.gslot0 + 1 + 2 * k + gr;
-        int targ[2];
+        int targ[2] = {0, 0};
         targ_bits_for(T, mean_bits, gr, ResvSize, targ);
+        const int targ0 = targ[0], targ1 = targ[1];
         for (int ch = 0; ch < C; ch++) {
             GI g;
             const int bt = W.blocktype[(int64_t)gslot * C + ch];
@@ -1324,23 +1353,24 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             const float* ratio = W.E + ((int64_t)(gslot - 1) * C + ch) * E_STRIDE;   // thresholds of the previous psy call
             { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, lane, L, Q); PH_END(L, PH_INIT); }
             int active = 0, bs_gain = 0;
-            const Seed used = seed[ch];
+            const Seed used = ch == 0 ? seed0 : seed1;
+            const int targ_ch = ch == 0 ? targ0 : targ1;
             if (q_init_xrpow(g, lane, L, Q)) {
                 active = 1;
                 { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
-                q_outer_loop(T, g, targ[ch], used.start, used.step, &bs_gain, lane, L, Q);
-                seed[ch].step = (used.start - bs_gain >= 4) ? 4 : 2;
-                seed[ch].start = bs_gain;
+                q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, lane, L, Q);
+                Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
+                if (ch == 0) seed0 = nx; else seed1 = nx;
             } else {
                 for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = 0;
                 wave_sync();
             }
             int scfsi[4];
-            { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt[ch], scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
+            { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, ch == 0 ? gr0_bt0 : gr0_bt1, scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
             if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
             ResvSize -= g.part2_3_length + g.part2_length;
             if (gr == 0) {
-                gr0_bt[ch] = g.block_type;
+                if (ch == 0) gr0_bt0 = g.block_type; else gr0_bt1 = g.block_type;
                 for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sf_gr0[ch][i] = L.sfb[i];
             }
             // ---- publish the record and the signed quantized spectrum ----
@@ -1354,7 +1384,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 out->scalefac_scale = g.scalefac_scale; out->count1table_select = g.count1table_select;
                 out->sfbmax = g.sfbmax; out->sfbdivide = g.sfbdivide;
                 out->active = active; out->bs_start = used.start; out->bs_step_in = used.step; out->bs_gain = bs_gain;
-                out->targ_bits = targ[ch];
+                out->targ_bits = targ_ch;
                 out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
             }
             for (int i = lane; i < SFBMAX; i += LHIP_NL) out->scalefac[i] = L.sfb[i];

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowB
     __shared__ QuantLds L[QWAVES];
     q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
-    const int wv = threadIdx.x >> 6, fslot = blockIdx.x * QWAVES + wv;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fslot = blockIdx.x * QWAVES + wv;   // wave index as an SGPR: everything derived from it stays scalar
     if (fslot >= nfs) return;
     kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv], Q);
 }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * QWAVES) void g_validate(Tables T, PowBase pb, 
     __shared__ QuantLds L[QWAVES];
     q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
-    const int wv = threadIdx.x >> 6, fslot = blockIdx.x * QWAVES + wv;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fslot = blockIdx.x * QWAVES + wv;   // wave index as an SGPR: everything derived from it stays scalar
     if (fslot >= nfs) return;
     kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv], Q);
 }

@@ -20,7 +20,12 @@ LHIP_DEV int wave_bcast(int v, int) { return v; }
 LHIP_DEV int wave_any(int p) { return p != 0; }
 LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { (void)lane; *total = v; return 0; }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+LHIP_DEV int uni(int v) { return v; }
+LHIP_DEV double unid(double v) { return v; }
 #else
+extern "C" __device__ float __ockl_wfred_max_f32(float);
+extern "C" __device__ double __ockl_wfred_max_f64(double);
+extern "C" __device__ double __ockl_wfred_add_f64(double);
 struct Wave { int lane; };
 // Orders this wave's LDS/global traffic around a role change between lanes.  One wavefront
 // executes in lock-step, so no s_barrier is needed; the fences stop the compiler from
@@ -38,30 +43,28 @@ LHIP_DEV uint64_t wave_or64(uint64_t v) {
     const unsigned lo = __reduce_or_sync(~0ull, (unsigned)v), hi = __reduce_or_sync(~0ull, (unsigned)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
-LHIP_DEV float wave_maxf(float v) {
-    // max is exact and associative for non-NaN operands: any reduction order gives the same bits
-    for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o); v = (t > v) ? t : v; }
-    return v;
-}
-LHIP_DEV double wave_maxd(double v) {
-    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = (t > v) ? t : v; }
-    return v;
-}
+// Float reductions go through the device library's DPP wavefront reductions: the result lands in an SGPR,
+// so everything computed from it (branch conditions, loop bounds) is known to be wave-uniform by the
+// compiler and runs on the scalar unit.  (A __shfl butterfly leaves a per-lane copy that the compiler must
+// treat as divergent -- it turns the whole control flow downstream into exec-masked code.)
+// max is exact and associative for non-NaN operands: any reduction order gives the same bits.
+LHIP_DEV float wave_maxf(float v) { return __ockl_wfred_max_f32(v); }
+LHIP_DEV double wave_maxd(double v) { return __ockl_wfred_max_f64(v); }
 // tree sum: NOT order-exact; only for order-insensitive decisions
-LHIP_DEV double wave_sumd(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-LHIP_DEV int wave_bcast(int v, int src) { return __shfl(v, src); }
+LHIP_DEV double wave_sumd(double v) { return __ockl_wfred_add_f64(v); }
+LHIP_DEV int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }   // src must be wave-uniform
 LHIP_DEV int wave_any(int p) { return __any(p); }
 // exclusive prefix sum over the 64 lanes (integers: exact in any order); *total = sum over all lanes
 LHIP_DEV int wave_excl_scan(int v, int lane, int* total) {
     int x = v;
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(x, o); if (lane >= o) x += t; }
-    *total = __shfl(x, 63);
+    *total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+// asserts to the compiler that v is wave-uniform (moves it to an SGPR)
+LHIP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
 #endif
 
 }  // namespace lhip
