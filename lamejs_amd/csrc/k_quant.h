@@ -844,7 +844,7 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
                 }
             } else { amp = ipow20(Q, 202); doamp = 1; }
             wave_sync();
-            if (doamp) {
+            if (uni(doamp)) {
                 float m = 0.f;
                 const int st = L.start[sfb], w = L.width[sfb];
                 for (int i = st + lane; i < st + w; i += LHIP_NL) {
@@ -941,6 +941,8 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     best.max_noise = 0; best.over_count = 0; best.over_SSD = 0; best.bits = 0;
     for (int i = lane; i <= SFBMAX; i += LHIP_NL) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_noise_log[i] = 0.f; L.distort[i] = 0.f; }
     wave_sync();
+    targ_bits = uni(targ_bits); bs_start = uni(bs_start); bs_step = uni(bs_step);
+    uni_gi(g);
     GI w = g;
     // bin-search state
     int CurrentStep = bs_step, flagGoneOver = 0, Direction = 0;
@@ -1067,7 +1069,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
         }
     }
     for (int i = 0; i < 4; i++) scfsi[i] = 0;
-    if (T.mode_gr == 2 && gr == 1 && gr0_block_type != SHORT_TYPE && g.block_type != SHORT_TYPE) {
+    if (T.mode_gr == 2 && gr == 1 && uni(gr0_block_type) != SHORT_TYPE && g.block_type != SHORT_TYPE) {
         // scfsi_calc: uniform scalar code over 21 bands, reading gr0's final scalefactors
         const int32_t* g0 = L.sf_gr0[ch];
         for (int i = 0; i < 4; i++) {
@@ -1094,7 +1096,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     wave_sync();
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (sf[sfb] == -2) sf[sfb] = 0;
     wave_sync();
-    if (recalc != 0) q_scale_bitcount(T, g, sf, lane);
+    if (uni(recalc) != 0) q_scale_bitcount(T, g, sf, lane);
 }
 
 // Huffman statistics per scalefactor band over the pairs below `limit`, then turned into prefix sums over
@@ -1359,6 +1361,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 active = 1;
                 { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
                 q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, lane, L, Q);
+                uni_gi(g); bs_gain = uni(bs_gain);
                 Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
                 if (ch == 0) seed0 = nx; else seed1 = nx;
             } else {
@@ -1367,8 +1370,10 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             }
             int scfsi[4];
             { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, ch == 0 ? gr0_bt0 : gr0_bt1, scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
+            uni_gi(g);
             if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
-            ResvSize -= g.part2_3_length + g.part2_length;
+            uni_gi(g);
+            ResvSize = uni(ResvSize - (g.part2_3_length + g.part2_length));
             if (gr == 0) {
                 if (ch == 0) gr0_bt0 = g.block_type; else gr0_bt1 = g.block_type;
                 for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sf_gr0[ch][i] = L.sfb[i];
