@@ -62,13 +62,24 @@ enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, 
 // Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
 // inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
 enum { QT_N = 256 };
+// Layout of the Huffman code-length pool (bytes): the table sizes are fixed by ISO 11172-3, so the offsets are
+// compile-time constants (tables 4 and 14 do not exist in the standard; the reference keeps a 256-entry row 14).
+enum { HL_T1 = 0, HL_T2 = 4, HL_T3 = 13, HL_T5 = 22, HL_T6 = 38, HL_T7 = 54, HL_T8 = 90, HL_T9 = 126, HL_T10 = 162, HL_T11 = 226,
+       HL_T12 = 290, HL_T13 = 354, HL_T14 = 610, HL_T15 = 866, HL_EHI = 1122, HL_ELO = 1378, HL_END = 1634 };
+LHIP_DEV int hl_off(int t) {
+    switch (t) {
+        case 1: return HL_T1; case 2: return HL_T2; case 3: return HL_T3; case 5: return HL_T5; case 6: return HL_T6;
+        case 7: return HL_T7; case 8: return HL_T8; case 9: return HL_T9; case 10: return HL_T10; case 11: return HL_T11;
+        case 12: return HL_T12; case 13: return HL_T13; case 14: return HL_T14; case 15: return HL_T15; default: return 0;
+    }
+}
 struct QuantTabs {
     float pow43[QT_N], adj43[QT_N];
     float ipow20[Q_MAX], pow20[Q_MAX + Q_MAX2 + 1];
     int32_t largetbl[256], table23[9], table56[16];
     int32_t sfb_l[SBMAX_l + 1], sfb_s[SBMAX_s + 1], pretab[SBMAX_l];
     uint16_t hoff[16];
-    uint8_t hlen[1088];          // code lengths of tables 1, 7..15 (offsets in hoff)
+    uint8_t hlen[HL_END];        // code-length pool: tables 1-3, 5-15, then the two ESC length tables (layout: hl_off)
     uint8_t t32l[16], t33l[16];
     uint8_t l2s_long[576], l2s_short[576];
     uint8_t bv_scf[576];
@@ -89,17 +100,15 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int i = tid; i < 576; i += nthr) Q.bv_scf[i] = (uint8_t)T.bv_scf[i];
     for (int i = tid; i < 15; i += nthr) Q.huf_tbl_noESC[i] = (uint8_t)T.huf_tbl_noESC[i];
     for (int i = tid; i < 34; i += nthr) { Q.ht_xlen[i] = (uint8_t)T.ht_xlen[i]; Q.ht_linmax[i] = (uint16_t)T.ht_linmax[i]; }
-    // Huffman length pool: table 1 (4 entries), 7-9 (36), 10-12 (64), 13-15 (256)
-    {
-        int off = 0;
-        for (int t = 1; t < 16; t++) {
-            const int xl = T.ht_xlen[t];
-            const int n = (t == 1 || t >= 7) ? (t == 14 ? 256 : xl * xl) : 0;
-            if (tid == 0) Q.hoff[t] = (uint16_t)off;
-            for (int i = tid; i < n; i += nthr) Q.hlen[off + i] = (uint8_t)T.ht_hlen[T.ht_off[t] + i];
-            off += n;
-        }
+    // Huffman code-length pool
+    for (int t = 1; t < 16; t++) {
+        if (t == 4) continue;
+        const int xl = T.ht_xlen[t];
+        const int n = (t == 14) ? 256 : xl * xl, off = hl_off(t);
+        if (tid == 0) Q.hoff[t] = (uint16_t)off;
+        for (int i = tid; i < n; i += nthr) Q.hlen[off + i] = (uint8_t)T.ht_hlen[T.ht_off[t] + i];
     }
+    for (int i = tid; i < 256; i += nthr) { Q.hlen[HL_EHI + i] = (uint8_t)(T.largetbl[i] >> 16); Q.hlen[HL_ELO + i] = (uint8_t)(T.largetbl[i] & 0xffff); }
     for (int d = tid; d < 576; d += nthr) {
         int sfb = 0;
         while (T.sfb_l[sfb + 1] <= d) sfb++;
@@ -131,6 +140,7 @@ struct QuantLds {
     struct BandInfo { int32_t nstart, nend, kind; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range + term formula per band
     int32_t sf_gr0[2][SFBMAX + 1];                // final gr0 scalefactors per channel (for scfsi)
     int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24];
+    uint32_t rdesc[4][2];        // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
     unsigned long long prof[64];
@@ -396,22 +406,37 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
 // ---------------------------------------------------------------------------------------------
 struct RegionPlan { int kind, t1, xlen, lb1, lb2, choice, choice2, o0, o1, o2; };   // kind 0 empty/zero, 1 t1, 2 table23/56, 4 triple, 5 ESC, 6 overflow
 
+// ESC table pair for a maximum > 15 (Takehiro.js:479-497): linmax of table t is 2^linbits - 1, so "linmax >= mx"
+// is "linbits >= bit length of mx"; linbits of tables 16..23 = 1,2,3,4,6,8,10,13 and of 24..31 = 4,5,6,7,8,9,11,13.
+LHIP_DEV void esc_choice(int mx15, int* choice, int* choice2, int* lb1, int* lb2) {
+    const int bl = 32 - __builtin_clz((unsigned)mx15);            // 1..13
+    const int c24 = bl <= 4 ? 0 : bl <= 9 ? bl - 4 : bl <= 11 ? 6 : 7;
+    int f16 = bl <= 4 ? bl - 1 : 4 + ((bl - 5) >> 1);
+    if (f16 > 7) f16 = 7;
+    int c16 = c24 - 8 + 8;                                         // choice2 - 8 - 16 == c24
+    if (c16 < f16) c16 = f16;
+    // c16 can reach 8 only if c24 == 8, which cannot happen (c24 <= 7)
+    *choice2 = 24 + c24; *choice = 16 + c16;
+    *lb1 = (int)((0xDA864321u >> (4 * c16)) & 15u);
+    *lb2 = (int)((0xDB987654u >> (4 * c24)) & 15u);
+}
+
 LHIP_DEV RegionPlan plan_region_(const QuantTabs& Q, int mx) {
+    (void)Q;
     RegionPlan r; r.kind = 0; r.t1 = 0; r.xlen = 0; r.lb1 = r.lb2 = 0; r.choice = r.choice2 = 0; r.o0 = r.o1 = r.o2 = 0;
     if (mx == 0) return r;
-    if (mx == 1) { r.kind = 1; r.t1 = 1; r.xlen = 2; r.o0 = Q.hoff[1]; return r; }
-    if (mx <= 3) { r.kind = 2; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 2) ? 3 : 4; return r; }
+    if (mx == 1) { r.kind = 1; r.t1 = 1; r.xlen = 2; r.o0 = HL_T1; return r; }
+    if (mx <= 3) { r.kind = 2; r.t1 = (mx == 2) ? 2 : 5; r.xlen = (mx == 2) ? 3 : 4; return r; }
     if (mx <= 15) {
-        r.kind = 4; r.t1 = Q.huf_tbl_noESC[mx - 1]; r.xlen = (r.t1 == 7) ? 6 : (r.t1 == 10) ? 8 : 16;
-        r.o0 = Q.hoff[r.t1]; r.o1 = Q.hoff[r.t1 + 1]; r.o2 = Q.hoff[r.t1 + 2];
+        r.kind = 4;
+        if (mx <= 5) { r.t1 = 7; r.xlen = 6; r.o0 = HL_T7; r.o1 = HL_T8; r.o2 = HL_T9; }
+        else if (mx <= 7) { r.t1 = 10; r.xlen = 8; r.o0 = HL_T10; r.o1 = HL_T11; r.o2 = HL_T12; }
+        else { r.t1 = 13; r.xlen = 16; r.o0 = HL_T13; r.o1 = HL_T14; r.o2 = HL_T15; }
         return r;
     }
     if (mx > IXMAX_VAL) { r.kind = 6; return r; }
-    mx -= 15;
-    int choice2, choice;
-    for (choice2 = 24; choice2 < 32; choice2++) if (Q.ht_linmax[choice2] >= mx) break;
-    for (choice = choice2 - 8; choice < 24; choice++) if (Q.ht_linmax[choice] >= mx) break;
-    r.kind = 5; r.choice = choice; r.choice2 = choice2; r.lb1 = Q.ht_xlen[choice]; r.lb2 = Q.ht_xlen[choice2];
+    r.kind = 5;
+    esc_choice(mx - 15, &r.choice, &r.choice2, &r.lb1, &r.lb2);
     return r;
 }
 
@@ -472,7 +497,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     for (int j = 0; j < NPL; j++) {
         const int p = 2 * (lane + LHIP_NL * j);
         vx[j] = 0; vy[j] = 0;
-        if (p < i) { vx[j] = ix[p]; vy[j] = ix[p + 1]; }
+        if (p < i) { const uint32_t w2 = *(const uint32_t*)(ix + p); vx[j] = (int)(w2 & 0xffffu); vy[j] = (int)(w2 >> 16); }   // magnitudes, two per word
     }
     // count1 boundary: highest pair with a non-zero value
     int top = 0;
@@ -525,45 +550,73 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     }
     if (a1 > i) a1 = i;
     if (a2 > i) a2 = i;
-    // region maxima ...
+    // region maxima: region of a pair = number of boundaries at or below it
     int m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const int p = 2 * (lane + LHIP_NL * j);
         const int m = (p < i) ? (vx[j] > vy[j] ? vx[j] : vy[j]) : 0;
-        if (p < a1) { if (m0 < m) m0 = m; } else if (p < a2) { if (m1 < m) m1 = m; } else { if (m2 < m) m2 = m; }
+        const int mr0 = (p < a1) ? m : 0, mr1 = (p >= a1 && p < a2) ? m : 0, mr2 = (p >= a2) ? m : 0;
+        m0 = m0 > mr0 ? m0 : mr0; m1 = m1 > mr1 ? m1 : mr1; m2 = m2 > mr2 ? m2 : mr2;
     }
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
     const RegionPlan r0 = plan_region_(Q, m0), r1 = plan_region_(Q, m1), r2 = plan_region_(Q, m2);
-    PH_MARK(L, PH_C_MAX, tm_);
-    // ... and the candidate-table length sums, region by region: the table group of a region is wave-uniform,
-    // so each region is a branch-free, fully unrolled pass over the register-resident pairs
-    int s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
-#define REGION_PASS(R, LO, HI, S0, S1, S2)                                                                   \
-    switch ((R).kind) {                                                                                      \
-        case 1: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
-                if (p >= (LO) && p < (HI)) S0 += Q.hlen[(R).o0 + vx[j] * 2 + vy[j]]; } break;                  \
-        case 2: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
-                if (p >= (LO) && p < (HI)) S0 += ((R).t1 == 2) ? Q.table23[vx[j] * 3 + vy[j]] : Q.table56[vx[j] * 4 + vy[j]]; } break; \
-        case 4: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
-                if (p >= (LO) && p < (HI)) { const int q = vx[j] * (R).xlen + vy[j];                           \
-                    S0 += Q.hlen[(R).o0 + q]; S1 += Q.hlen[(R).o1 + q]; S2 += Q.hlen[(R).o2 + q]; } } break;   \
-        case 5: _Pragma("unroll") for (int j = 0; j < NPL; j++) { const int p = 2 * (lane + LHIP_NL * j);      \
-                if (p >= (LO) && p < (HI)) pair_bits(Q, (R), vx[j], vy[j], S0, S1, S2); } break;               \
-        default: break;                                                                                      \
+    // Data-driven length sums: every region publishes the pool offsets of its (up to three) candidate tables and
+    // its row stride; a pair then costs three byte gathers whatever its region's table group is, and all regions
+    // are handled in ONE pass.  Per-lane partial sums of the three regions share a register (10 bits each).
+    for (int r = lane; r < 3; r += LHIP_NL) {
+        const RegionPlan& rp = (r == 0) ? r0 : (r == 1) ? r1 : r2;
+        int oA = rp.o0, oB = rp.o1, oC = rp.o2, xl = rp.xlen;
+        if (rp.kind == 2) { oA = (rp.t1 == 2) ? HL_T2 : HL_T5; oB = (rp.t1 == 2) ? HL_T3 : HL_T6; oC = oA; }
+        else if (rp.kind == 5) { oA = HL_EHI; oB = HL_ELO; oC = HL_EHI; xl = 16; }
+        else if (rp.kind == 1) { oB = oC = oA; }
+        else if (rp.kind != 4) { oA = oB = oC = 0; xl = 0; }
+        L.rdesc[r][0] = (uint32_t)oA | ((uint32_t)oB << 16);
+        L.rdesc[r][1] = (uint32_t)oC | ((uint32_t)xl << 16);
     }
-    REGION_PASS(r0, 0, a1, s00, s01, s02)
-    REGION_PASS(r1, a1, a2, s10, s11, s12)
-    REGION_PASS(r2, a2, i, s20, s21, s22)
-#undef REGION_PASS
-    s00 = wave_sum(s00); s10 = wave_sum(s10); s20 = wave_sum(s20);
-    if (r0.kind >= 4) s01 = wave_sum(s01);
-    if (r1.kind >= 4) s11 = wave_sum(s11);
-    if (r2.kind >= 4) s21 = wave_sum(s21);
-    if (r0.kind == 4) s02 = wave_sum(s02);
-    if (r1.kind == 4) s12 = wave_sum(s12);
-    if (r2.kind == 4) s22 = wave_sum(s22);
+    wave_sync();
+    PH_MARK(L, PH_C_MAX, tm_);
+    // field width: a lane owns at most NPL pairs (5 x 21 bits < 2^10); the one-lane host simulation owns all 288
+#ifdef LHIP_HOSTSIM
+    typedef uint64_t acc_t; enum { FB = 21 };
+#else
+    typedef uint32_t acc_t; enum { FB = 10 };
+#endif
+    const acc_t FM = ((acc_t)1 << FB) - 1;
+    acc_t accA = 0, accB = 0, accC = 0, accN = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        if (p < i) {
+            const int r = (p >= a1) + (p >= a2), sh = FB * r;
+            const uint32_t d0 = L.rdesc[r][0], d1 = L.rdesc[r][1];
+            const int x = vx[j], y = vy[j];
+            const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
+            accA += (acc_t)Q.hlen[(d0 & 0xffffu) + idx] << sh;
+            accB += (acc_t)Q.hlen[(d0 >> 16) + idx] << sh;
+            accC += (acc_t)Q.hlen[(d1 & 0xffffu) + idx] << sh;
+            accN += (acc_t)((x > 14) + (y > 14)) << sh;
+        }
+    }
+    // unpack to (A|B<<16), (C|N<<16) per region: wave totals stay below 2^16 (<= 288 pairs x 21 bits = 6048)
+#define FLD(A, R) ((uint32_t)(((A) >> (FB * (R))) & FM))
+    const int q0 = wave_sum((int)(FLD(accA, 0) | (FLD(accB, 0) << 16)));
+    const int q1 = wave_sum((int)(FLD(accC, 0) | (FLD(accN, 0) << 16)));
+    const int q2 = wave_sum((int)(FLD(accA, 1) | (FLD(accB, 1) << 16)));
+    const int q3 = wave_sum((int)(FLD(accC, 1) | (FLD(accN, 1) << 16)));
+    const int q4 = wave_sum((int)(FLD(accA, 2) | (FLD(accB, 2) << 16)));
+    const int q5 = wave_sum((int)(FLD(accC, 2) | (FLD(accN, 2) << 16)));
+#undef FLD
     PH_MARK(L, PH_C_SUMS, tm_);
+    // per region: (s0, s1, s2) as finish_region expects them
+#define REGION_SUMS(R, QA, QC, S0, S1, S2)                                                            \
+    int S0 = (QA) & 0xffff, S1 = (int)((unsigned)(QA) >> 16), S2 = (QC) & 0xffff;                     \
+    if ((R).kind == 2) S0 = (S0 << 16) | S1;                                                          \
+    else if ((R).kind == 5) { const int n_ = (int)((unsigned)(QC) >> 16); S0 += n_ * (R).lb1; S1 += n_ * (R).lb2; }
+    REGION_SUMS(r0, q0, q1, s00, s01, s02)
+    REGION_SUMS(r1, q2, q3, s10, s11, s12)
+    REGION_SUMS(r2, q4, q5, s20, s21, s22)
+#undef REGION_SUMS
     // the reference evaluates region 2 first (NORM only), then 0, then 1; an overflowing region *sets* bits
     if (use2) g.table_select[2] = finish_region(r2, s20, s21, s22, &bits);
     if (0 < a1) g.table_select[0] = finish_region(r0, s00, s01, s02, &bits);
@@ -734,9 +787,13 @@ LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lan
         if (sfb < g.sfbdivide) { if (m1 < v) m1 = v; } else { if (m2 < v) m2 = v; }
     }
     m1 = wave_max(m1); m2 = wave_max(m2);
+    // first k with the smallest tab[k] among the admissible ones == minimum of (tab[k], k) pairs; one lane per k
+    int best = 0x7fffffff;
+    for (int k = lane; k < 16; k += LHIP_NL)
+        if (m1 < T.slen1_n[k] && m2 < T.slen2_n[k]) { const int v = tab[k] * 16 + k; if (v < best) best = v; }
+    best = wave_min(best);
     g.part2_length = LARGE_BITS;
-    for (int k = 0; k < 16; k++)
-        if (m1 < T.slen1_n[k] && m2 < T.slen2_n[k] && g.part2_length > tab[k]) { g.part2_length = tab[k]; g.scalefac_compress = k; }
+    if (best != 0x7fffffff) { g.part2_length = best >> 4; g.scalefac_compress = best & 15; }
     return g.part2_length == LARGE_BITS;
 }
 
