@@ -101,6 +101,7 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int i = tid; i < 15; i += nthr) Q.huf_tbl_noESC[i] = (uint8_t)T.huf_tbl_noESC[i];
     for (int i = tid; i < 34; i += nthr) { Q.ht_xlen[i] = (uint8_t)T.ht_xlen[i]; Q.ht_linmax[i] = (uint16_t)T.ht_linmax[i]; }
     // Huffman code-length pool
+    if (tid == 0) { Q.hoff[0] = 0; Q.hoff[4] = 0; }
     for (int t = 1; t < 16; t++) {
         if (t == 4) continue;
         const int xl = T.ht_xlen[t];
@@ -560,19 +561,31 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         m0 = m0 > mr0 ? m0 : mr0; m1 = m1 > mr1 ? m1 : mr1; m2 = m2 > mr2 ? m2 : mr2;
     }
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
-    const RegionPlan r0 = plan_region_(Q, m0), r1 = plan_region_(Q, m1), r2 = plan_region_(Q, m2);
     // Data-driven length sums: every region publishes the pool offsets of its (up to three) candidate tables and
     // its row stride; a pair then costs three byte gathers whatever its region's table group is, and all regions
-    // are handled in ONE pass.  Per-lane partial sums of the three regions share a register (10 bits each).
+    // are handled in ONE pass.  Region r is planned (and later finished) by lane r, branch-free: there is no
+    // scalar per-region control flow left.
+    struct LanePlan { int kind, t0, t1, t2, lbA, lbB; };
+    enum { NSLOT = (LHIP_NL == 1) ? 3 : 1 };
+    LanePlan lp[NSLOT];
     for (int r = lane; r < 3; r += LHIP_NL) {
-        const RegionPlan& rp = (r == 0) ? r0 : (r == 1) ? r1 : r2;
-        int oA = rp.o0, oB = rp.o1, oC = rp.o2, xl = rp.xlen;
-        if (rp.kind == 2) { oA = (rp.t1 == 2) ? HL_T2 : HL_T5; oB = (rp.t1 == 2) ? HL_T3 : HL_T6; oC = oA; }
-        else if (rp.kind == 5) { oA = HL_EHI; oB = HL_ELO; oC = HL_EHI; xl = 16; }
-        else if (rp.kind == 1) { oB = oC = oA; }
-        else if (rp.kind != 4) { oA = oB = oC = 0; xl = 0; }
+        const int m = (r == 0) ? m0 : (r == 1) ? m1 : m2;
+        // first candidate table for maxima 0..15 (huf_tbl_noESC, Takehiro.js:336-346), one nibble per value
+        const int mc = m < 15 ? m : 15;
+        const int tn = (int)((mc < 8 ? (0xAA775210u >> (4 * mc)) : (0xDDDDDDDDu >> (4 * (mc - 8)))) & 15u);
+        const int kind = (m == 0) ? 0 : (m == 1) ? 1 : (m <= 3) ? 2 : (m <= 15) ? 4 : (m <= IXMAX_VAL) ? 5 : 6;
+        int choice, choice2, lb1, lb2;
+        esc_choice(m > 15 ? m - 15 : 1, &choice, &choice2, &lb1, &lb2);
+        const int esc = (kind == 5);
+        int xl = (tn == 1) ? 2 : (tn == 2) ? 3 : (tn == 5) ? 4 : (tn == 7) ? 6 : (tn == 10) ? 8 : 16;
+        int oA = Q.hoff[tn], oB = Q.hoff[tn + 1], oC = Q.hoff[tn + 2 > 15 ? 15 : tn + 2];
+        if (esc) { oA = HL_EHI; oB = HL_ELO; oC = HL_EHI; xl = 16; }
+        if (kind == 0 || kind == 6) { oA = oB = oC = 0; xl = 0; }
         L.rdesc[r][0] = (uint32_t)oA | ((uint32_t)oB << 16);
         L.rdesc[r][1] = (uint32_t)oC | ((uint32_t)xl << 16);
+        LanePlan& q = lp[r / LHIP_NL];
+        q.kind = kind; q.t0 = esc ? choice : tn; q.t1 = esc ? choice2 : tn + 1; q.t2 = tn + 2;
+        q.lbA = esc ? lb1 : 0; q.lbB = esc ? lb2 : 0;
     }
     wave_sync();
     PH_MARK(L, PH_C_MAX, tm_);
@@ -608,19 +621,32 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     const int q5 = wave_sum((int)(FLD(accC, 2) | (FLD(accN, 2) << 16)));
 #undef FLD
     PH_MARK(L, PH_C_SUMS, tm_);
-    // per region: (s0, s1, s2) as finish_region expects them
-#define REGION_SUMS(R, QA, QC, S0, S1, S2)                                                            \
-    int S0 = (QA) & 0xffff, S1 = (int)((unsigned)(QA) >> 16), S2 = (QC) & 0xffff;                     \
-    if ((R).kind == 2) S0 = (S0 << 16) | S1;                                                          \
-    else if ((R).kind == 5) { const int n_ = (int)((unsigned)(QC) >> 16); S0 += n_ * (R).lb1; S1 += n_ * (R).lb2; }
-    REGION_SUMS(r0, q0, q1, s00, s01, s02)
-    REGION_SUMS(r1, q2, q3, s10, s11, s12)
-    REGION_SUMS(r2, q4, q5, s20, s21, s22)
-#undef REGION_SUMS
+    // finish (Takehiro.js count_bit_noESC / _from2 / _from3 / count_bit_ESC tie-breaking): lane r picks the cheapest
+    // admissible candidate of region r; result packed as table | overflow << 6 | bits << 8
+    int pv[NSLOT];
+    for (int r = lane; r < 3; r += LHIP_NL) {
+        const LanePlan& q = lp[r / LHIP_NL];
+        const int qa = (r == 0) ? q0 : (r == 1) ? q2 : q4, qc = (r == 0) ? q1 : (r == 1) ? q3 : q5;
+        const int n = (int)((unsigned)qc >> 16);
+        const int c0 = (qa & 0xffff) + n * q.lbA, c1 = (int)((unsigned)qa >> 16) + n * q.lbB, c2 = qc & 0xffff;
+        int b = c0, t = q.t0;
+        if ((q.kind == 2 || q.kind == 4 || q.kind == 5) && b > c1) { b = c1; t = q.t1; }
+        if (q.kind == 4 && b > c2) { b = c2; t = q.t2; }
+        if (q.kind == 0) { b = 0; t = 0; }
+        if (q.kind == 6) { b = 0; t = 63; }              // table_select := -1 (never emitted: overflow cannot pass count_bits)
+        pv[r / LHIP_NL] = t | ((q.kind == 6) << 6) | (b << 8);
+    }
+#ifdef LHIP_HOSTSIM
+    const int pv0 = pv[0], pv1 = pv[1], pv2 = pv[2];
+#else
+    const int pv0 = __builtin_amdgcn_readlane(pv[0], 0), pv1 = __builtin_amdgcn_readlane(pv[0], 1), pv2 = __builtin_amdgcn_readlane(pv[0], 2);
+#endif
     // the reference evaluates region 2 first (NORM only), then 0, then 1; an overflowing region *sets* bits
-    if (use2) g.table_select[2] = finish_region(r2, s20, s21, s22, &bits);
-    if (0 < a1) g.table_select[0] = finish_region(r0, s00, s01, s02, &bits);
-    if (a1 < a2) g.table_select[1] = finish_region(r1, s10, s11, s12, &bits);
+#define APPLY(PV, SLOT) do { const int t_ = (PV) & 63; if ((PV) & 64) bits = LARGE_BITS; else bits += (PV) >> 8; g.table_select[SLOT] = (t_ == 63) ? -1 : t_; } while (0)
+    if (use2) APPLY(pv2, 2);
+    if (0 < a1) APPLY(pv0, 0);
+    if (a1 < a2) APPLY(pv1, 1);
+#undef APPLY
     // first band whose start is >= big_values (PrevNoise.sfb_count1): one table look-up instead of a walk
     if (use_prev && g.block_type == NORM_TYPE) *pn_sfb_count1 = g.big_values > 0 ? Q.l2s_long[g.big_values - 1] + 1 : 0;
     PH_MARK(L, PH_C_FIN, tm_);
