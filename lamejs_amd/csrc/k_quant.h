@@ -140,7 +140,7 @@ struct QuantLds {
     int32_t nstart[SFBMAX + 1], npairs[SFBMAX + 1], ncached[SFBMAX + 1];
     struct BandInfo { int32_t nstart, nend, kind; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range + term formula per band
     int32_t sf_gr0[2][SFBMAX + 1];                // final gr0 scalefactors per channel (for scfsi)
-    int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24];
+    int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24];
     uint32_t rdesc[4][2];        // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
@@ -1188,42 +1188,63 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
 // 13 largetbl hi, 14 largetbl lo, 15 number of escaped values.  A row is only meaningful for regions whose
 // maximum admits the table group, which is exactly when the reference would look at it.
 LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int lane, QuantLds& L, const QuantTabs& Q) {
-    for (int band = lane; band < SBMAX_l; band += LHIP_NL) {
-        const int a = Q.sfb_l[band];
-        int b = Q.sfb_l[band + 1];
-        if (b > limit) b = limit;
-        int mx = 0;
-        for (int p = a; p < b; p++) if (mx < ix[p]) mx = ix[p];
-        int s[16];
-        for (int k = 0; k < 16; k++) s[k] = 0;
-        s[0] = mx;
-        const uint8_t *h1 = hlen_of(Q, 1), *h7 = hlen_of(Q, 7), *h8 = hlen_of(Q, 8), *h9 = hlen_of(Q, 9), *h10 = hlen_of(Q, 10),
-                      *h11 = hlen_of(Q, 11), *h12 = hlen_of(Q, 12), *h13 = hlen_of(Q, 13), *h14 = hlen_of(Q, 14), *h15 = hlen_of(Q, 15);
-        for (int p = a; p < b; p += 2) {
-            const int x = ix[p], y = ix[p + 1];
-            if (mx <= 1) s[1] += h1[x * 2 + y];
-            if (mx <= 2) s[2] += Q.table23[x * 3 + y];
-            if (mx <= 3) s[3] += Q.table56[x * 4 + y];
-            if (mx <= 5) { const int q = x * 6 + y; s[4] += h7[q]; s[5] += h8[q]; s[6] += h9[q]; }
-            if (mx <= 7) { const int q = x * 8 + y; s[7] += h10[q]; s[8] += h11[q]; s[9] += h12[q]; }
-            if (mx <= 15) { const int q = x * 16 + y; s[10] += h13[q]; s[11] += h14[q]; s[12] += h15[q]; }
-            {
-                int xx = x, yy = y, n = 0;
-                if (xx != 0) { if (xx > 14) { xx = 15; n++; } xx *= 16; }
-                if (yy != 0) { if (yy > 14) { yy = 15; n++; } xx += yy; }
-                const int lt = Q.largetbl[xx];
-                s[13] += lt >> 16; s[14] += lt & 0xffff; s[15] += n;
-            }
-        }
-        for (int k = 0; k < 16; k++) L.hd.bstat[k][band + 1] = s[k];
-    }
+    // One lane per run of consecutive pairs (5 on the device): every pair contributes its 17 code lengths, the
+    // lane keeps running sums, an exclusive wave scan of the lane totals turns them into prefix sums over ALL
+    // pairs, and the lanes owning the last pair of a band publish the prefix there.  Sums are packed two per
+    // word (a total is at most 288 x 21 < 2^16).  A length is only added when the PAIR admits the table; a row
+    // is only read for regions whose maximum admits it, where that is the same thing.
+    enum { PPL = (288 + LHIP_NL - 1) / LHIP_NL, NW = 9 };
+    for (int bnd = lane; bnd <= SBMAX_l + 1; bnd += LHIP_NL) L.hd.bstat[0][bnd] = 0;
     wave_sync();
-    // prefix over bands: bstat[k][b] becomes the sum over bands < b (row 0: running maximum is NOT a prefix -- kept per band)
-    for (int k = 1 + lane; k < 16; k += LHIP_NL) {
-        int acc = 0;
-        L.hd.bstat[k][0] = 0;
-        for (int b = 1; b <= SBMAX_l; b++) { acc += L.hd.bstat[k][b]; L.hd.bstat[k][b] = acc; }
+    uint32_t pre[PPL][NW];
+    uint32_t run[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) run[w] = 0;
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        const int q = PPL * lane + j, p = 2 * q;
+        if (q < 288 && p < limit) {
+            const uint32_t w2 = *(const uint32_t*)(ix + p);
+            const int x = (int)(w2 & 0xffffu), y = (int)(w2 >> 16), m = x > y ? x : y;
+            if (m > 0) lds_max(&L.hd.bstat[0][Q.l2s_long[p] + 1], m);
+            const int xc = x < 15 ? x : 15, yc = y < 15 ? y : 15, e = xc * 16 + yc;
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+            if (m <= 1) c0 = Q.hlen[HL_T1 + x * 2 + y];
+            if (m <= 2) { const int k = x * 3 + y; c0 |= (uint32_t)Q.hlen[HL_T2 + k] << 16; c1 = Q.hlen[HL_T3 + k]; }
+            if (m <= 3) { const int k = x * 4 + y; c1 |= (uint32_t)Q.hlen[HL_T5 + k] << 16; c2 = Q.hlen[HL_T6 + k]; }
+            if (m <= 5) { const int k = x * 6 + y; c2 |= (uint32_t)Q.hlen[HL_T7 + k] << 16; c3 = Q.hlen[HL_T8 + k] | ((uint32_t)Q.hlen[HL_T9 + k] << 16); }
+            if (m <= 7) { const int k = x * 8 + y; c4 = Q.hlen[HL_T10 + k] | ((uint32_t)Q.hlen[HL_T11 + k] << 16); c5 = Q.hlen[HL_T12 + k]; }
+            if (m <= 15) { c5 |= (uint32_t)Q.hlen[HL_T13 + e] << 16; c6 = Q.hlen[HL_T14 + e] | ((uint32_t)Q.hlen[HL_T15 + e] << 16); }
+            const uint32_t c7 = Q.hlen[HL_EHI + e] | ((uint32_t)Q.hlen[HL_ELO + e] << 16);
+            const uint32_t c8 = (uint32_t)((x > 14) + (y > 14));
+            run[0] += c0; run[1] += c1; run[2] += c2; run[3] += c3; run[4] += c4; run[5] += c5; run[6] += c6; run[7] += c7; run[8] += c8;
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) pre[j][w] = run[w];
     }
+    uint32_t base[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) { int tot; base[w] = (uint32_t)wave_excl_scan((int)run[w], lane, &tot); }
+    // word layout: 0: t1 | t2<<16   1: t3 | t5<<16   2: t6 | t7<<16   3: t8 | t9<<16   4: t10 | t11<<16
+    //              5: t12 | t13<<16  6: t14 | t15<<16  7: esc_hi | esc_lo<<16   8: escaped values
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        const int q = PPL * lane + j, p = 2 * q;
+        if (q < 288 && (p + 2 == 576 || Q.l2s_long[p] != Q.l2s_long[p + 2])) {
+            const int col = Q.l2s_long[p] + 1;
+            uint32_t v[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) v[w] = base[w] + pre[j][w];
+            L.hd.bstat[1][col] = (int)(v[0] & 0xffffu);
+            L.hd.bstat[2][col] = (int)((v[0] & 0xffff0000u) | (v[1] & 0xffffu));          // t2 << 16 | t3 (count_bit_noESC_from2 packing)
+            L.hd.bstat[3][col] = (int)((v[1] & 0xffff0000u) | (v[2] & 0xffffu));          // t5 << 16 | t6
+            L.hd.bstat[4][col] = (int)(v[2] >> 16); L.hd.bstat[5][col] = (int)(v[3] & 0xffffu); L.hd.bstat[6][col] = (int)(v[3] >> 16);
+            L.hd.bstat[7][col] = (int)(v[4] & 0xffffu); L.hd.bstat[8][col] = (int)(v[4] >> 16); L.hd.bstat[9][col] = (int)(v[5] & 0xffffu);
+            L.hd.bstat[10][col] = (int)(v[5] >> 16); L.hd.bstat[11][col] = (int)(v[6] & 0xffffu); L.hd.bstat[12][col] = (int)(v[6] >> 16);
+            L.hd.bstat[13][col] = (int)(v[7] & 0xffffu); L.hd.bstat[14][col] = (int)(v[7] >> 16); L.hd.bstat[15][col] = (int)v[8];
+        }
+    }
+    for (int k = 1 + lane; k < 16; k += LHIP_NL) L.hd.bstat[k][0] = 0;
     wave_sync();
 }
 
@@ -1244,24 +1265,37 @@ LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, con
 #undef SUMROW
 }
 
-// recalc_divide_sub (Takehiro.js:698-725); region 2 = bands r2.. up to big_values, from the band statistics
-LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, const QuantLds& L, const QuantTabs& Q) {
+// recalc_divide_sub (Takehiro.js:698-725); region 2 = bands r2.. up to big_values, from the band statistics.
+// The cost of region 2 for every split point r2 is independent of the loop state, so lane r2 evaluates it; the
+// reference's running comparison (its `break`s depend on the best length so far) is then replayed over those.
+LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     const int bigv = c2.big_values;
-    for (int r2 = 2; r2 < SBMAX_l + 1; r2++) {
-        const int a2 = Q.sfb_l[r2];
-        if (a2 >= bigv) break;
-        int bits = L.r01_bits[r2 - 2] + c2.count1bits;
-        if (g.part2_3_length <= bits) break;
-        const int r2t = q_choose_from_stats(T, r2, SBMAX_l, &bits, L, Q);
-        if (g.part2_3_length <= bits) continue;
-        g = c2;
-        g.part2_3_length = bits;
-        g.region0_count = L.r01_div[r2 - 2];
-        g.region1_count = r2 - 2 - L.r01_div[r2 - 2];
-        g.table_select[0] = L.r0_tbl[r2 - 2];
-        g.table_select[1] = L.r1_tbl[r2 - 2];
-        g.table_select[2] = r2t;
+    for (int r2 = 2 + lane; r2 < SBMAX_l + 1; r2 += LHIP_NL) {
+        int bits2 = 0;
+        const int tbl = q_choose_from_stats(T, r2, SBMAX_l, &bits2, L, Q);
+        L.r2_bits[r2] = bits2; L.r2_tbl[r2] = tbl;
     }
+    wave_sync();
+    int best = -1, cur = g.part2_3_length;
+    for (int r2 = 2; r2 < SBMAX_l + 1; r2++) {
+        if (Q.sfb_l[r2] >= bigv) break;
+        int bits = L.r01_bits[r2 - 2] + c2.count1bits;
+        if (cur <= bits) break;
+        bits += L.r2_bits[r2];
+        if (cur <= bits) continue;
+        cur = bits; best = r2;
+    }
+    best = uni(best);
+    if (best >= 0) {
+        g = c2;
+        g.part2_3_length = uni(cur);
+        g.region0_count = L.r01_div[best - 2];
+        g.region1_count = best - 2 - L.r01_div[best - 2];
+        g.table_select[0] = L.r0_tbl[best - 2];
+        g.table_select[1] = L.r1_tbl[best - 2];
+        g.table_select[2] = L.r2_tbl[best];
+    }
+    wave_sync();
 }
 
 LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
@@ -1298,7 +1332,7 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
             }
         }
         wave_sync();
-        q_recalc_divide_sub(T, c2, g, L, Q);
+        q_recalc_divide_sub(T, c2, g, lane, L, Q);
     }
     int i = c2.big_values;
     if (i == 0 || (ix[i - 2] | ix[i - 1]) > 1) return;
@@ -1323,7 +1357,7 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
     c2.count1bits = a1;
     if (c2.block_type == NORM_TYPE) {
         if (c2.big_values != g.big_values) q_band_stats(T, ix, c2.big_values, lane, L, Q);   // statistics must honour the new limit
-        q_recalc_divide_sub(T, c2, g, L, Q);
+        q_recalc_divide_sub(T, c2, g, lane, L, Q);
     } else {
         c2.part2_3_length = a1;
         a1 = Q.sfb_l[7 + 1];

@@ -20,6 +20,7 @@ LHIP_DEV int wave_bcast(int v, int) { return v; }
 LHIP_DEV int wave_any(int p) { return p != 0; }
 LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { (void)lane; *total = v; return 0; }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 LHIP_DEV int uni(int v) { return v; }
 LHIP_DEV double unid(double v) { return v; }
 #else
@@ -62,6 +63,7 @@ LHIP_DEV int wave_excl_scan(int v, int lane, int* total) {
     return x - v;
 }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+LHIP_DEV void lds_max(int32_t* p, int32_t v) { atomicMax(p, v); }
 // asserts to the compiler that v is wave-uniform (moves it to an SGPR)
 LHIP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
