@@ -140,7 +140,10 @@ struct QuantLds {
     int32_t nstart[SFBMAX + 1], npairs[SFBMAX + 1], ncached[SFBMAX + 1];
     struct BandInfo { int32_t nstart, nend, kind; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range + term formula per band
     int32_t sf_gr0[2][SFBMAX + 1];                // final gr0 scalefactors per channel (for scfsi)
-    int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24];
+    union {                      // calc_noise band sums live only inside the outer loop, the split tables only after it
+        struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
+        double nsum[SFBMAX + 1];
+    };
     uint32_t rdesc[4][2];        // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
@@ -718,8 +721,78 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     }
     wave_sync();
     PH_MARK(L, PH_N_WALK, tm_);
-    // 2) per band (one lane each): squared errors summed in the reference's line order (f64 sums are
-    //    order-sensitive).  Loads are issued four lines ahead of the dependent add chain.
+    // 2) squared errors summed per band in the reference's line order (f64 sums are order-sensitive) as a
+    //    systolic fold: lane l owns NLN consecutive lines and folds their terms, in order, onto the running sum
+    //    handed over by lane l-1 (reset at band starts).  One hand-over step extends every band's chain by one
+    //    lane, so ceil(longest band / NLN) + 1 steps reproduce the strictly sequential sums exactly, while the
+    //    terms themselves are computed once, all lanes busy.  All non-empty summing ranges start at their band's
+    //    first line (after the first band cut by max_nonzero_coeff every range is empty).
+    enum { NLN = 576 / LHIP_NL };
+    {
+        double tq[NLN];
+        unsigned resetm = 0, lastm = 0;          // bit k: line k of this lane starts a band / ends a summing range
+        int lastb[NLN];
+        int prevb = (lane == 0) ? -1 : (int)line2sfb(Q, g.block_type)[NLN * lane - 1];
+        const uint8_t* l2s = line2sfb(Q, g.block_type);
+#pragma unroll
+        for (int k = 0; k < NLN; k++) {
+            const int j = NLN * lane + k;
+            const int bnd = l2s[j];
+            const QuantLds::BandInfo bi = L.binfo[bnd < g.psymax ? bnd : g.psymax - 1];
+            const int in = (bnd < g.psymax) && bi.kind != 0 && j < bi.nend;
+            const float xa = L.xr[j]; const int iv = ix[j];
+            float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
+            if (iv >= QT_N) pw = T.pow43[iv];
+            const double step = (double)bi.step, ax = d_abs((double)xa);
+            double x = (double)xa;
+            if (bi.kind == 2) x = ax - (iv == 0 ? 0.0 : step);
+            if (bi.kind == 3) x = ax - (double)pw * step;
+            tq[k] = in ? x * x : 0.0;            // sums are >= +0, so adding +0.0 leaves them unchanged
+            if (bnd != prevb) resetm |= 1u << (k & 31);
+            if (in && j == bi.nend - 1) lastm |= 1u << (k & 31);
+            lastb[k] = bnd; prevb = bnd;
+        }
+        // NLN <= 32 on the device; the one-lane host build folds everything in a single pass below
+        int maxw = 0;
+        for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) if (maxw < L.width[sfb]) maxw = L.width[sfb];
+        maxw = wave_max(maxw);
+        const int nsteps = (LHIP_NL == 1) ? 1 : (maxw + NLN - 1) / NLN + 1;
+        // keep[k] = 0 at a band start, 1 elsewhere: fma(sum, keep, t) is `sum + t` or `t` with ONE rounding, i.e.
+        // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit
+        double keep[NLN];
+#pragma unroll
+        for (int k = 0; k < NLN; k++) keep[k] = ((resetm >> (k & 31)) & 1u) ? 0.0 : 1.0;
+#if LHIP_NL == 1
+        {
+            double sacc = 0.0;
+            for (int k = 0; k < NLN; k++) {
+                const int bnd = lastb[k];
+                if ((k == 0) || (lastb[k - 1] != bnd)) sacc = 0.0;
+                sacc += tq[k];
+                const QuantLds::BandInfo bi = L.binfo[bnd < g.psymax ? bnd : g.psymax - 1];
+                if (bnd < g.psymax && bi.kind != 0 && k == bi.nend - 1) L.nsum[bnd] = sacc;
+            }
+            (void)keep; (void)nsteps; (void)lastm;
+        }
+#else
+        double carry = 0.0;
+        for (int st = 0; st + 1 < nsteps; st++) {
+            double sacc = carry;
+#pragma unroll
+            for (int k = 0; k < NLN; k++) sacc = __builtin_fma(sacc, keep[k], tq[k]);
+            carry = wave_shr1d(sacc, 0.0);
+        }
+        double fin[NLN];
+        {
+            double sacc = carry;
+#pragma unroll
+            for (int k = 0; k < NLN; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); fin[k] = sacc; }
+        }
+#pragma unroll
+        for (int k = 0; k < NLN; k++) if ((lastm >> k) & 1u) L.nsum[lastb[k]] = fin[k];
+#endif
+        wave_sync();
+    }
     int over = 0, ssd = 0;
     double max_noise = -20.0;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
@@ -730,34 +803,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             L.distort[sfb] = (float)(noise / (double)L.xmin[sfb]);
             noise = L.pn_noise_log[sfb];
         } else {
-            const double step = (double)bi.step;
-            noise = 0;
-            int j = bi.nstart;
-            for (; j + 4 <= bi.nend; j += 4) {
-                float xa[4]; int iv[4]; float pw[4]; double t[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { xa[u] = L.xr[j + u]; iv[u] = ix[j + u]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) pw[u] = Q.pow43[iv[u] < QT_N ? iv[u] : QT_N - 1];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (iv[u] >= QT_N) pw[u] = T.pow43[iv[u]];
-                    const double ax = d_abs((double)xa[u]);
-                    double x = (double)xa[u];
-                    if (bi.kind == 2) x = ax - (iv[u] == 0 ? 0.0 : step);
-                    if (bi.kind == 3) x = ax - (double)pw[u] * step;
-                    t[u] = x * x;
-                }
-                noise += t[0]; noise += t[1]; noise += t[2]; noise += t[3];
-            }
-            for (; j < bi.nend; j++) {
-                const float xa = L.xr[j]; const int iv = ix[j];
-                const double ax = d_abs((double)xa);
-                double x = (double)xa;
-                if (bi.kind == 2) x = ax - (iv == 0 ? 0.0 : step);
-                if (bi.kind == 3) x = ax - pow43v(T, Q, iv) * step;
-                noise += x * x;
-            }
+            noise = (bi.nend > bi.nstart) ? L.nsum[sfb] : 0.0;
             if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
             L.distort[sfb] = (float)noise;

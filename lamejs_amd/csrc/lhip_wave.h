@@ -23,6 +23,7 @@ LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 LHIP_DEV int uni(int v) { return v; }
 LHIP_DEV double unid(double v) { return v; }
+LHIP_DEV double wave_shr1d(double v, double first) { (void)v; return first; }
 #else
 extern "C" __device__ float __ockl_wfred_max_f32(float);
 extern "C" __device__ double __ockl_wfred_max_f64(double);
@@ -66,6 +67,13 @@ LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { atomicMax(p, v); }
 // asserts to the compiler that v is wave-uniform (moves it to an SGPR)
 LHIP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// value of lane - 1 (lane 0 receives `first`): two DPP moves (wave_shr:1), no LDS round trip
+LHIP_DEV double wave_shr1d(double v, double first) {
+    union { double d; int i[2]; } a, f, r; a.d = v; f.d = first;
+    r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x138, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x138, 0xf, 0xf, false);
+    return r.d;
+}
 LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
 #endif
 
