@@ -47,8 +47,8 @@ LHIP_DEV void uni_gi(GI& g) {
 // optional phase profiling (build with -DLHIP_PHASE_PROF; never in the product library)
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
 #define PH_BEGIN() const unsigned long long ph_t0_ = __builtin_amdgcn_s_memtime()
-#define PH_END(L, id) do { if (lane == 0) { (L).prof[id] += __builtin_amdgcn_s_memtime() - ph_t0_; (L).prof[32 + id] += 1; } } while (0)
-#define PH_MARK(L, id, t) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) { (L).prof[id] += n_ - (t); (L).prof[32 + id] += 1; } (t) = n_; } while (0)
+#define PH_END(L, id) do { if (lane == 0) { (L).prof[id] += (unsigned int)(__builtin_amdgcn_s_memtime() - ph_t0_); (L).prof[32 + id] += 1; } } while (0)
+#define PH_MARK(L, id, t) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) { (L).prof[id] += (unsigned int)(n_ - (t)); (L).prof[32 + id] += 1; } (t) = n_; } while (0)
 #define PH_NOW() __builtin_amdgcn_s_memtime()
 #else
 #define PH_BEGIN() do {} while (0)
@@ -147,7 +147,7 @@ struct QuantLds {
     uint32_t rdesc[4][2];        // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
-    unsigned long long prof[64];
+    unsigned int prof[64];           // per-frame cycle sums fit 32 bits
 #endif
 };
 
@@ -198,6 +198,7 @@ LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, c
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath_adjust, GI& g, int block_type,
                                 const float* xr_g, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     g.part2_3_length = 0; g.big_values = 0; g.count1 = 0; g.global_gain = 210; g.scalefac_compress = 0;
     g.block_type = block_type;
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
@@ -281,6 +282,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
 
 // init_xrpow (Quantize.js:92-138); returns 1 if the granule has energy
 LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     float m = 0.f;
     double sum = 0;
     for (int i = lane; i < 576; i += LHIP_NL) {
@@ -302,6 +304,7 @@ LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
 // calc_xmin (QuantizePVT.js:569-719), CBR flavour
 LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_lower, const float* ratio /*E layout*/,
                           GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     if (g.block_type != SHORT_TYPE) {
         for (int gsfb = lane; gsfb < g.psy_lmax; gsfb += LHIP_NL) {
             double xmin = ath_adjust * (double)T.ATH_l[gsfb];
@@ -350,6 +353,7 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, int16_t* ix, int use_prev,
                          int pn_gain, int pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     const double istep = ipow20(Q, g.global_gain);
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
@@ -382,24 +386,28 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
     // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here)
-    enum { NLN = 576 / LHIP_NL };
-    float xv[NLN]; int sf[NLN], rx[NLN]; double xq[NLN]; float aj[NLN];
+    // two half-batches (5 + 4 lines per lane on the device) keep the staged registers under ~35
+    enum { NLN = 576 / LHIP_NL, HB = (NLN + 1) / 2 };
 #pragma unroll
-    for (int j = 0; j < NLN; j++) { const int i = lane + LHIP_NL * j; sf[j] = l2s[i]; xv[j] = L.xrpow[i]; }
+    for (int h0 = 0; h0 < NLN; h0 += HB) {
+        float xv[HB]; int sf[HB], rx[HB]; double xq[HB]; float aj[HB];
 #pragma unroll
-    for (int j = 0; j < NLN; j++) { xq[j] = (double)xv[j] * istep; rx[j] = (int)xq[j]; }   // 0 <= x <= 8206: truncation == ToInt32
+        for (int j = 0; j < HB; j++) if (h0 + j < NLN) { const int i = lane + LHIP_NL * (h0 + j); sf[j] = l2s[i]; xv[j] = L.xrpow[i]; }
 #pragma unroll
-    for (int j = 0; j < NLN; j++) aj[j] = Q.adj43[rx[j] < QT_N ? rx[j] : QT_N - 1];
+        for (int j = 0; j < HB; j++) if (h0 + j < NLN) { xq[j] = (double)xv[j] * istep; rx[j] = (int)xq[j]; }   // 0 <= x <= 8206: truncation == ToInt32
 #pragma unroll
-    for (int j = 0; j < NLN; j++) {
-        const int i = lane + LHIP_NL * j;
-        if (rx[j] >= QT_N) aj[j] = T.adj43[rx[j]];                 // rare: large quantized values
-        const int proc = (i < last_line) && !((m_cached >> sf[j]) & 1);
-        const int v1 = (int)(xq[j] + (double)aj[j]);
-        const int v01 = (compareval0 > (double)xv[j]) ? 0 : 1;
-        const int v = ((m_zo >> sf[j]) & 1) ? v01 : v1;
-        if (proc) ix[i] = (int16_t)v;
-        else if (i >= fill_from) ix[i] = 0;
+        for (int j = 0; j < HB; j++) if (h0 + j < NLN) aj[j] = Q.adj43[rx[j] < QT_N ? rx[j] : QT_N - 1];
+#pragma unroll
+        for (int j = 0; j < HB; j++) if (h0 + j < NLN) {
+            const int i = lane + LHIP_NL * (h0 + j);
+            if (rx[j] >= QT_N) aj[j] = T.adj43[rx[j]];                 // rare: large quantized values
+            const int proc = (i < last_line) && !((m_cached >> sf[j]) & 1);
+            const int v1 = (int)(xq[j] + (double)aj[j]);
+            const int v01 = (compareval0 > (double)xv[j]) ? 0 : 1;
+            const int v = ((m_zo >> sf[j]) & 1) ? v01 : v1;
+            if (proc) ix[i] = (int16_t)v;
+            else if (i >= fill_from) ix[i] = 0;
+        }
     }
     wave_sync();
     PH_MARK(L, PH_Q_LINES, tm_);
@@ -490,6 +498,7 @@ LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, in
 
 // noquant_count_bits (Takehiro.js:521-628); updates g, returns bits.  pn_sfb_count1 as in/out.
 LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int use_prev, int* pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
     if (i > 576) i = 576;
@@ -679,6 +688,7 @@ LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
                            int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     // 1) start-line walk (QuantizePVT.js:806-830): j advances by the band width until the first band that
     //    reaches past max_nonzero_coeff; up to there everything is regular and computed one lane per band,
@@ -782,14 +792,13 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             for (int k = 0; k < NLN; k++) sacc = __builtin_fma(sacc, keep[k], tq[k]);
             carry = wave_shr1d(sacc, 0.0);
         }
-        double fin[NLN];
         {
             double sacc = carry;
 #pragma unroll
-            for (int k = 0; k < NLN; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); fin[k] = sacc; }
+            for (int k = 0; k < NLN; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); tq[k] = sacc; }   // tq := running sums of the last step
         }
 #pragma unroll
-        for (int k = 0; k < NLN; k++) if ((lastm >> k) & 1u) L.nsum[lastb[k]] = fin[k];
+        for (int k = 0; k < NLN; k++) if ((lastm >> k) & 1u) L.nsum[lastb[k]] = tq[k];
 #endif
         wave_sync();
     }
@@ -838,6 +847,7 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
 // scale_bitcount (Takehiro.js:980-1030), MPEG-1, no mixed blocks.  returns 1 on failure
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lane) {
+    lane = fresh_lane(lane);
     const int32_t* tab;
     if (g.block_type == SHORT_TYPE) tab = T.scale_short;
     else {
@@ -881,6 +891,7 @@ LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantL
 
 // multiply xrpow of the flagged bands (L.qmode[sfb] = 1) by `amp`, tracking xrpow_max
 LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     float m = 0.f;
     for (int i = lane; i < 576; i += LHIP_NL) {
         const int sfb = line2sfb(Q, g.block_type)[i];
@@ -896,6 +907,7 @@ LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L, const 
 }
 
 LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     const double ifqstep34 = (g.scalefac_scale == 0) ? 1.29683955465100964055 : 1.68179283050742922612;
     float tr = 0.f;
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (tr < L.distort[sfb]) tr = L.distort[sfb];
@@ -1165,6 +1177,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int gr0_block_type, int* scfsi /*[4]*/,
                                     int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     int32_t* sf = L.sfb;
     int recalc = 0;
     {
@@ -1234,6 +1247,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
 // 13 largetbl hi, 14 largetbl lo, 15 number of escaped values.  A row is only meaningful for regions whose
 // maximum admits the table group, which is exactly when the reference would look at it.
 LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     // One lane per run of consecutive pairs (5 on the device): every pair contributes its 17 code lengths, the
     // lane keeps running sums, an exclusive wave scan of the lane totals turns them into prefix sums over ALL
     // pairs, and the lanes owning the last pair of a band publish the prefix there.  Sums are packed two per
@@ -1345,6 +1359,7 @@ LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, int lane
 }
 
 LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     const int16_t* ix = L.ixb;
     GI c2 = g;
     if (g.block_type == NORM_TYPE) {
@@ -1567,8 +1582,8 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
 #ifdef LHIP_PHASE_PROF
     if (lane == 0) {
-        L.prof[PH_TOTAL] = __builtin_amdgcn_s_memtime() - ph_total0_; L.prof[32 + PH_TOTAL] = 1;
-        for (int i = 0; i < 64; i++) atomicAdd((unsigned long long*)W.prof + i, L.prof[i]);
+        L.prof[PH_TOTAL] = (unsigned int)(__builtin_amdgcn_s_memtime() - ph_total0_); L.prof[32 + PH_TOTAL] = 1;
+        for (int i = 0; i < 64; i++) atomicAdd((unsigned long long*)W.prof + i, (unsigned long long)L.prof[i]);
     }
 #endif
 }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowB
     if (fslot >= nfs) return;
     kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv], Q);
 }
-__global__ __launch_bounds__(64 * QWAVES) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
+__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);

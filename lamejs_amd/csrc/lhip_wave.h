@@ -22,6 +22,7 @@ LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { (void)lane; *total = 
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 LHIP_DEV int uni(int v) { return v; }
+LHIP_DEV int fresh_lane(int lane) { return lane; }
 LHIP_DEV double unid(double v) { return v; }
 LHIP_DEV double wave_shr1d(double v, double first) { (void)v; return first; }
 #else
@@ -65,6 +66,9 @@ LHIP_DEV int wave_excl_scan(int v, int lane, int* total) {
 }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { atomicMax(p, v); }
+// An opaque copy of the lane index: addresses derived from it cannot be merged with (and hoisted like) the ones
+// derived from other copies, which keeps loop-invariant address registers from piling up and spilling.
+LHIP_DEV int fresh_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
 // asserts to the compiler that v is wave-uniform (moves it to an SGPR)
 LHIP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // value of lane - 1 (lane 0 receives `first`): two DPP moves (wave_shr:1), no LDS round trip
