@@ -129,16 +129,21 @@ LHIP_DEV void window_subband(const double* W, const float* x, float* a) {
 #undef R
 }
 
-// one wave per (granule slot >= 1, channel); lane j < 18 owns polyphase slot j
-LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int ch, int lane) {
+// One wave serves POLY_PER_WAVE (granule slot, channel) work items: lane = item * 18 + polyphase slot
+// (54 of 64 lanes busy instead of 18).
+enum { POLY_PER_WAVE = 3 };
+LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int wave_idx, int nitems, int lane) {
     const int C = T.channels_out;
-    const int st = W.gslot_stream[gslot];
-    const StreamDesc sd = SD[st];
-    const int q = gslot - sd.gslot0 - 1;
-    if (q < 0) return;
-    const float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
-    float* out = W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE;
-    for (int j = lane; j < 18; j += LHIP_NL) {
+    for (int u = lane; u < 18 * POLY_PER_WAVE; u += LHIP_NL) {
+        const int item = wave_idx * POLY_PER_WAVE + u / 18, j = u % 18;
+        if (item >= nitems) continue;
+        const int gslot = item / C, ch = item - gslot * C;
+        const int st = W.gslot_stream[gslot];
+        const StreamDesc sd = SD[st];
+        const int q = gslot - sd.gslot0 - 1;
+        if (q < 0) continue;
+        const float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
+        float* out = W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE;
         float a[32];
         window_subband(T.enwindow, seg + 576 * q + 286 + 32 * j, a);
         if (j & 1)

@@ -200,12 +200,15 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
 
-    // --- loudness: strictly sequential f64 sum (PsyModel.js:241-249); lane 0 only ---
-    if (lane == 0) {
-        double lp = 0.0;
-        for (int i = 0; i < BLKSIZE / 2; ++i) lp += (double)L.fe[i] * (double)T.eql_w[i];
+    // --- loudness: strictly sequential f64 sum (PsyModel.js:241-249), products in parallel, ordered fold ---
+    {
+        enum { K = (BLKSIZE / 2) / LHIP_NL };
+        double pr[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (double)L.fe[i] * (double)T.eql_w[i]; }
+        double lp = wave_seq_sum<K>(pr);
         lp *= T.VO_SCALE;
-        W.loud[o] = (float)lp;
+        if (lane == 0) W.loud[o] = (float)lp;
     }
 
     // --- long partitions: energy, max, average (calc_energy, PsyModel.js:906-928) ---

@@ -196,8 +196,10 @@ LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, c
 // init_outer_loop (Quantize.js:204-306) incl. psfb21_analogsilence (147-202)
 // xr_g: this granule-channel's MDCT output in HBM (natural order)
 // ---------------------------------------------------------------------------------------------
+// xr_wb != nullptr: lines zeroed by the analog-silence rule are also zeroed in HBM, so that a later pass over the
+// same granule (kb_validate) can skip the rule (`skip_silence`); the rule is idempotent.
 LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath_adjust, GI& g, int block_type,
-                                const float* xr_g, int lane, QuantLds& L, const QuantTabs& Q) {
+                                const float* xr_g, float* xr_wb, int skip_silence, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     g.part2_3_length = 0; g.big_values = 0; g.count1 = 0; g.global_gain = 210; g.scalefac_compress = 0;
     g.block_type = block_type;
@@ -240,6 +242,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
     wave_sync();
 
     // analog silence in the pseudo bands above sfb21 / sfb12: zero trailing lines below the adjusted ATH
+    if (skip_silence) return;
     if (block_type != SHORT_TYPE) {
         for (int gsfb = lane; gsfb < PSFB21; gsfb += LHIP_NL) {
             double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb21[gsfb], T.ATH_floor);
@@ -255,7 +258,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
             if (!(d_abs((double)L.xr[j]) < L.ath_pseudo[gsfb])) top = j;   // ascending j per lane
         }
         top = wave_max(top);
-        for (int j = lo + lane; j < 576; j += LHIP_NL) if (j > top) L.xr[j] = 0;
+        for (int j = lo + lane; j < 576; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[j] = 0; }
     } else {
         for (int gsfb = lane; gsfb < PSFB12; gsfb += LHIP_NL) {
             double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb12[gsfb], T.ATH_floor);
@@ -274,7 +277,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
                 if (!(d_abs((double)L.xr[j]) < L.ath_pseudo[gsfb])) top = j;
             }
             top = wave_max(top);
-            for (int j = lo + lane; j < lo + w12; j += LHIP_NL) if (j > top) L.xr[j] = 0;
+            for (int j = lo + lane; j < lo + w12; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[3 * (T.sfb_s[12] + (j - lo)) + block] = 0; }
         }
     }
     wave_sync();
@@ -1531,7 +1534,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             const int bt = W.blocktype[(int64_t)gslot * C + ch];
             const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
             const float* ratio = W.E + ((int64_t)(gslot - 1) * C + ch) * E_STRIDE;   // thresholds of the previous psy call
-            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, lane, L, Q); PH_END(L, PH_INIT); }
+            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
             int active = 0, bs_gain = 0;
             const Seed used = ch == 0 ? seed0 : seed1;
             const int targ_ch = ch == 0 ? targ0 : targ1;
@@ -1608,7 +1611,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             if (s.start == rec->bs_start && s.step == rec->bs_step_in) continue;     // already quantized with this seed
             GI g;
             q_init_outer_loop(T, pb10, ath_adjust, g, W.blocktype[(int64_t)gslot * C + ch],
-                              W.xr + ((int64_t)gslot * C + ch) * 576, lane, L, Q);
+                              W.xr + ((int64_t)gslot * C + ch) * 576, nullptr, 1, lane, L, Q);
             q_init_xrpow(g, lane, L, Q);
             // max_nonzero_coeff is set by calc_xmin in the reference before the bin search
             if (g.block_type != SHORT_TYPE) {

@@ -169,9 +169,8 @@ __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const Stream
     __shared__ PsyBLds L;
     kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-__global__ __launch_bounds__(64) void g_poly(Tables T, Workspace W, const StreamDesc* SD) {
-    const int C = T.channels_out;
-    kb_polyphase(T, W, SD, blockIdx.x / C, blockIdx.x % C, threadIdx.x);
+__global__ __launch_bounds__(64) void g_poly(Tables T, Workspace W, const StreamDesc* SD, int nitems) {
+    kb_polyphase(T, W, SD, blockIdx.x, nitems, threadIdx.x);
 }
 __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ MdctLds L;
@@ -561,7 +560,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
         for (int b = 0; b < ngs; b++) kb_psyB(T, W, dSD, b, 0, LB);
-        for (int b = 0; b < ngs * C; b++) kb_polyphase(T, W, dSD, b / C, b % C, 0);
+        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) kb_polyphase(T, W, dSD, b, ngs * C, 0);
         for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
         for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ, QT);
         for (;;) {
@@ -590,7 +589,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_ath, S, st, T, W, dSD);
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
-    LAUNCH(KT_POLY, g_poly, ngs * C, st, T, W, dSD);
+    LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
     LAUNCHB(KT_QUANT, g_quant, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, 0, nfs);
     if (nfr > 0) {

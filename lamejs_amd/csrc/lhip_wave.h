@@ -25,6 +25,8 @@ LHIP_DEV int uni(int v) { return v; }
 LHIP_DEV int fresh_lane(int lane) { return lane; }
 LHIP_DEV double unid(double v) { return v; }
 LHIP_DEV double wave_shr1d(double v, double first) { (void)v; return first; }
+// strictly sequential (index order) f64 sum of LHIP_NL * K values, lane l holding elements [l*K, (l+1)*K)
+template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) { double s = 0.0; for (int k = 0; k < K; k++) s += p[k]; return s; }
 #else
 extern "C" __device__ float __ockl_wfred_max_f32(float);
 extern "C" __device__ double __ockl_wfred_max_f64(double);
@@ -77,6 +79,22 @@ LHIP_DEV double wave_shr1d(double v, double first) {
     r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x138, 0xf, 0xf, false);
     r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x138, 0xf, 0xf, false);
     return r.d;
+}
+// Strictly sequential (index order) f64 sum of 64 * K values, lane l holding elements [l*K, (l+1)*K): a systolic
+// fold -- every step each lane adds its K values, in order, onto the sum handed over by lane l-1; after step t
+// lanes 0..t hold exact prefixes, so 64 steps give the exact left-to-right total in lane 63.  Same additions in
+// the same order as a scalar loop, but without funnelling the operands through one lane.
+template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) {
+    double carry = 0.0, s = 0.0;
+    for (int st = 0; st < 64; st++) {
+        s = carry;
+#pragma unroll
+        for (int k = 0; k < K; k++) s += p[k];
+        carry = wave_shr1d(s, 0.0);
+    }
+    union { double d; int i[2]; } u; u.d = s;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], 63); u.i[1] = __builtin_amdgcn_readlane(u.i[1], 63);
+    return u.d;
 }
 LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
 #endif
