@@ -13,51 +13,61 @@
 
 namespace lhip {
 
-// One 32-band slot.  x points at the slot anchor (reference x1[x1Pos]); a[] lives in registers.
-LHIP_DEV void window_subband(const double* W, const float* x, float* a) {
-    const float* p = x;
-    const float* q = x - 62;
-    int wp = 10;
-    for (int i = -15; i < 0; i++) {
+// PCM window of one (granule, channel) work item staged in LDS, transposed: sample n (relative to the first slot
+// anchor minus POLY_BIAS) lives at [(n & 31) * POLY_ROW + (n >> 5)].  Lane j (slot j, anchor 32 j) then reads
+// anchor-relative offset `off` at [((off + BIAS) & 31) * ROW + ((off + BIAS) >> 5) + j]: consecutive lanes hit
+// consecutive banks, and the whole index except `+ j` is a compile-time constant.
+enum { POLY_BIAS = 320, POLY_ROW = 37, POLY_N = 32 * 17 + 256 + POLY_BIAS + 1, POLY_ITEM = 32 * POLY_ROW };
+#define XT(off) ((double)xt[(((off) + POLY_BIAS) & 31) * POLY_ROW + (((off) + POLY_BIAS) >> 5)])
+
+// One 32-band slot.  xt = transposed window base of this lane's slot; a[] lives in registers.
+LHIP_DEV void window_subband(const double* W, const float* xt, float* a) {
+    // reference pointers: p = x - d, q = x - 62 + d with d = i + 15 (NewMDCT.js:540-583)
+#pragma unroll
+    for (int d = 0; d < 15; d++) {
+        const int wp = 10 + 18 * d;
         double w = W[wp - 10];
-        double s = (double)q[-224] * w;
-        double t = (double)p[224] * w;
+        double s = XT(-62 + d - 224) * w;
+        double t = XT(-d + 224) * w;
+#pragma unroll
         for (int k = 1; k < 8; k++) {
             w = W[wp - 10 + k];
-            s += (double)q[-224 + 64 * k] * w;
-            t += (double)p[224 - 64 * k] * w;
+            s += XT(-62 + d - 224 + 64 * k) * w;
+            t += XT(-d + 224 - 64 * k) * w;
         }
+#pragma unroll
         for (int k = 0; k < 8; k++) {
             w = W[wp - 2 + k];
-            s += (double)p[-256 + 64 * k] * w;
-            t -= (double)q[256 - 64 * k] * w;
+            s += XT(-d - 256 + 64 * k) * w;
+            t -= XT(-62 + d + 256 - 64 * k) * w;
         }
         s *= W[wp + 6];
         w = t - s;
-        a[30 + i * 2] = (float)(t + s);
-        a[31 + i * 2] = (float)(W[wp + 7] * w);
-        wp += 18;
-        p--;
-        q++;
+        a[2 * d] = (float)(t + s);
+        a[2 * d + 1] = (float)(W[wp + 7] * w);
     }
+    const int wp = 10 + 18 * 15;
     {
+        // p = x - 15 here (NewMDCT.js:585-622)
+#define P(o) XT(-15 + (o))
         double s, t, u, v;
-        t = (double)p[-16] * W[wp - 10];
-        s = (double)p[-32] * W[wp - 2];
-        t += ((double)p[-48] - (double)p[16]) * W[wp - 9];
-        s += (double)p[-96] * W[wp - 1];
-        t += ((double)p[-80] + (double)p[48]) * W[wp - 8];
-        s += (double)p[-160] * W[wp + 0];
-        t += ((double)p[-112] - (double)p[80]) * W[wp - 7];
-        s += (double)p[-224] * W[wp + 1];
-        t += ((double)p[-144] + (double)p[112]) * W[wp - 6];
-        s -= (double)p[32] * W[wp + 2];
-        t += ((double)p[-176] - (double)p[144]) * W[wp - 5];
-        s -= (double)p[96] * W[wp + 3];
-        t += ((double)p[-208] + (double)p[176]) * W[wp - 4];
-        s -= (double)p[160] * W[wp + 4];
-        t += ((double)p[-240] - (double)p[208]) * W[wp - 3];
-        s -= (double)p[224];
+        t = P(-16) * W[wp - 10];
+        s = P(-32) * W[wp - 2];
+        t += (P(-48) - P(16)) * W[wp - 9];
+        s += P(-96) * W[wp - 1];
+        t += (P(-80) + P(48)) * W[wp - 8];
+        s += P(-160) * W[wp + 0];
+        t += (P(-112) - P(80)) * W[wp - 7];
+        s += P(-224) * W[wp + 1];
+        t += (P(-144) + P(112)) * W[wp - 6];
+        s -= P(32) * W[wp + 2];
+        t += (P(-176) - P(144)) * W[wp - 5];
+        s -= P(96) * W[wp + 3];
+        t += (P(-208) + P(176)) * W[wp - 4];
+        s -= P(160) * W[wp + 4];
+        t += (P(-240) - P(208)) * W[wp - 3];
+        s -= P(224);
+#undef P
         u = s - t;
         v = s + t;
         t = a[14];
@@ -130,22 +140,32 @@ LHIP_DEV void window_subband(const double* W, const float* x, float* a) {
 }
 
 // One wave serves POLY_PER_WAVE (granule slot, channel) work items: lane = item * 18 + polyphase slot
-// (54 of 64 lanes busy instead of 18).
+// (54 of 64 lanes busy), reading PCM from the transposed LDS staging of the item.
 enum { POLY_PER_WAVE = 3 };
-LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int wave_idx, int nitems, int lane) {
+struct PolyLds { float xs[POLY_PER_WAVE][POLY_ITEM]; };
+LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int wave_idx, int nitems, int lane, PolyLds& L) {
     const int C = T.channels_out;
-    for (int u = lane; u < 18 * POLY_PER_WAVE; u += LHIP_NL) {
-        const int item = wave_idx * POLY_PER_WAVE + u / 18, j = u % 18;
-        if (item >= nitems) continue;
+    for (int it = 0; it < POLY_PER_WAVE; it++) {
+        const int item = wave_idx * POLY_PER_WAVE + it;
+        if (item >= nitems) break;
         const int gslot = item / C, ch = item - gslot * C;
-        const int st = W.gslot_stream[gslot];
-        const StreamDesc sd = SD[st];
+        const StreamDesc sd = SD[W.gslot_stream[gslot]];
         const int q = gslot - sd.gslot0 - 1;
         if (q < 0) continue;
-        const float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
+        const float* src = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 286 - POLY_BIAS;
+        const int lo = POLY_BIAS - 286;                       // samples before the stream segment are never used
+        for (int n = lane; n < POLY_N; n += LHIP_NL) L.xs[it][(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? src[n] : 0.f;
+    }
+    wave_sync();
+    for (int u = lane; u < 18 * POLY_PER_WAVE; u += LHIP_NL) {
+        const int it = u / 18, j = u - 18 * it, item = wave_idx * POLY_PER_WAVE + it;
+        if (item >= nitems) continue;
+        const int gslot = item / C, ch = item - gslot * C;
+        const StreamDesc sd = SD[W.gslot_stream[gslot]];
+        if (gslot - sd.gslot0 - 1 < 0) continue;
         float* out = W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE;
         float a[32];
-        window_subband(T.enwindow, seg + 576 * q + 286 + 32 * j, a);
+        window_subband(T.enwindow, L.xs[it] + j, a);
         if (j & 1)
             for (int band = 1; band < 32; band += 2) a[band] = (float)((double)a[band] * -1);
         for (int band = 0; band < 32; band++) {

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const Stream
     kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64) void g_poly(Tables T, Workspace W, const StreamDesc* SD, int nitems) {
-    kb_polyphase(T, W, SD, blockIdx.x, nitems, threadIdx.x);
+    __shared__ PolyLds L;
+    kb_polyphase(T, W, SD, blockIdx.x, nitems, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ MdctLds L;
@@ -550,7 +551,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
 #ifdef LHIP_HOSTSIM
     {
-        static PsyALds LA; static PsyBLds LB; static MdctLds LM; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
+        static PsyALds LA; static PsyBLds LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
         q_load_tabs(T, QT, 0, 1);
         for (int s = 0; s < S; s++) kb_load(T, W, dSD, dIO, s, 0);
         kb_prep(T, W, dSD, dIO, S, 0, 1);
@@ -560,7 +561,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
         for (int b = 0; b < ngs; b++) kb_psyB(T, W, dSD, b, 0, LB);
-        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) kb_polyphase(T, W, dSD, b, ngs * C, 0);
+        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) kb_polyphase(T, W, dSD, b, ngs * C, 0, LP);
         for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
         for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ, QT);
         for (;;) {
