@@ -364,19 +364,18 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // per-band decision as wave-uniform bit masks: cached (keep old values) / 0-1 shortcut; the first
     // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
     unsigned long long tm_ = PH_NOW(); (void)tm_;
-    uint64_t m_cached = 0, m_zo = 0;
-    int cand = 99;
+    uint64_t m_cached = 0, m_zo = 0, m_cut = 0;       // bit sfb, produced by lane sfb (sfbmax < 64)
     for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
         int step = -1;
         if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
         if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
         else {
             if (use_prev && pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) m_zo |= 1ull << sfb;
-            if (L.start[sfb] + L.width[sfb] > mnz && sfb < cand) cand = sfb;
+            if (L.start[sfb] + L.width[sfb] > mnz) m_cut |= 1ull << sfb;
         }
     }
-    m_cached = wave_or64(m_cached); m_zo = wave_or64(m_zo);
-    const int sstar = wave_min(cand);
+    m_cached = wave_lane_bits(m_cached); m_zo = wave_lane_bits(m_zo); m_cut = wave_lane_bits(m_cut);
+    const int sstar = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
     int fill_from = 576, last_line = 576;       // lines >= last_line are not quantized (bands after sstar, tail of sstar)
     if (sstar <= sfbmax) {
         int l = mnz - L.start[sstar] + 1;
@@ -515,21 +514,40 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         vx[j] = 0; vy[j] = 0;
         if (p < i) { const uint32_t w2 = *(const uint32_t*)(ix + p); vx[j] = (int)(w2 & 0xffffu); vy[j] = (int)(w2 >> 16); }   // magnitudes, two per word
     }
-    // count1 boundary: highest pair with a non-zero value
-    int top = 0;
+    // count1 boundary (highest pair with a non-zero value) and the end of the big-values region (the quad scan of
+    // Takehiro.js:540-560 stops at the first quad, counted from the top, that holds a value > 1).
+    int firstbig;
+#ifdef LHIP_HOSTSIM
+    {
+        int top = 0;
+        for (int j = 0; j < NPL; j++) if ((vx[j] | vy[j]) != 0) top = 2 * (lane + LHIP_NL * j) + 2;
+        i = top;
+        const int nq = i >> 2;
+        firstbig = nq;
+        for (int k = 0; k < nq; k++) {
+            const int e = i - 4 * k;
+            if (((ix[e - 1] | ix[e - 2] | ix[e - 3] | ix[e - 4]) & 0x7fff) > 1) { firstbig = k; break; }
+        }
+    }
+#else
+    {
+        // Pair lane + 64 j is bit `lane` of ballot j, so the two boundaries are "highest set bit" questions
+        // answered on the scalar unit: no reduction chain, no second pass over the spectrum.
+        int tp = -1, bp = -1;                    // highest non-zero pair / highest pair with a value > 1
 #pragma unroll
-    for (int j = 0; j < NPL; j++) if ((vx[j] | vy[j]) != 0) top = 2 * (lane + LHIP_NL * j) + 2;
-    i = wave_max(top);
+        for (int j = 0; j < NPL; j++) {
+            const uint64_t nz = __ballot((vx[j] | vy[j]) != 0), bg = __ballot((vx[j] | vy[j]) > 1);
+            if (nz) tp = 64 * j + 63 - (int)__builtin_clzll(nz);
+            if (bg) bp = 64 * j + 63 - (int)__builtin_clzll(bg);
+        }
+        i = 2 * tp + 2;
+        const int P = tp + 1, nq = i >> 2;
+        firstbig = (P - 1 - bp) >> 1;
+        if (firstbig > nq) firstbig = nq;
+    }
+#endif
     g.count1 = i;
     PH_MARK(L, PH_C_LOAD, tm_);
-    // quad k covers lines [i-4(k+1), i-4k); the scan stops at the first quad holding a value > 1, or at i <= 3
-    const int nq = i >> 2;
-    int firstbig = nq;
-    for (int k = lane; k < nq; k += LHIP_NL) {
-        const int e = i - 4 * k;
-        if (((ix[e - 1] | ix[e - 2] | ix[e - 3] | ix[e - 4]) & 0x7fff) > 1) { if (k < firstbig) firstbig = k; }
-    }
-    firstbig = wave_min(firstbig);
     int a12 = 0;
     for (int k = lane; k < firstbig; k += LHIP_NL) {
         const int e = i - 4 * k;
@@ -696,15 +714,16 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     // 1) start-line walk (QuantizePVT.js:806-830): j advances by the band width until the first band that
     //    reaches past max_nonzero_coeff; up to there everything is regular and computed one lane per band,
     //    the (few) bands from that point on are walked serially by lane 0.
-    int firstcut = 99;
+    uint64_t m_cut = 0;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
         const int s = sf_step(Q, g, scalefac, L.window, sfb);
         const int cached = (use_pn && L.pn_step[sfb] == s);
         L.qmode[sfb] = s;                                   // step of the band (reused by the term pass)
         L.ncached[sfb] = cached; L.nstart[sfb] = L.start[sfb]; L.npairs[sfb] = cached ? 0 : (L.width[sfb] >> 1);
-        if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff && sfb < firstcut) firstcut = sfb;
+        if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m_cut |= 1ull << sfb;
     }
-    firstcut = wave_min(firstcut);
+    m_cut = wave_lane_bits(m_cut);
+    const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
     wave_sync();
     if (lane == 0 && firstcut < g.psymax) {
         int j = L.start[firstcut];
@@ -926,13 +945,14 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
             else trigger *= .95;
             break;
     }
-    int first = 99;
+    uint64_t m_amp = 0;
     for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) {
         int f = 0;
-        if (sfb < g.sfbmax && !((double)L.distort[sfb] < trigger)) { f = 1; if (sfb < first) first = sfb; }
+        if (sfb < g.sfbmax && !((double)L.distort[sfb] < trigger)) { f = 1; m_amp |= 1ull << sfb; }
         L.qmode[sfb] = f;
     }
-    first = wave_min(first);
+    m_amp = wave_lane_bits(m_amp);
+    const int first = m_amp ? (int)__builtin_ctzll(m_amp) : 99;
     wave_sync();
     if (T.noise_shaping_amp == 2) {          // amplify exactly one band
         for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) L.qmode[sfb] = (sfb == first) ? 1 : 0;

@@ -21,6 +21,8 @@ LHIP_DEV int wave_any(int p) { return p != 0; }
 LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { (void)lane; *total = v; return 0; }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
+// see the device version
+LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return v; }
 LHIP_DEV int uni(int v) { return v; }
 LHIP_DEV int fresh_lane(int lane) { return lane; }
 LHIP_DEV double unid(double v) { return v; }
@@ -68,6 +70,9 @@ LHIP_DEV int wave_excl_scan(int v, int lane, int* total) {
 }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { atomicMax(p, v); }
+// OR over the lanes of masks in which lane l can only have bit l set (the `for (i = lane; i < n; i += 64)` idiom
+// with n <= 64): that is a ballot -- one compare, result in SGPRs, no reduction chain.
+LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return __ballot(v != 0); }
 // An opaque copy of the lane index: addresses derived from it cannot be merged with (and hoisted like) the ones
 // derived from other copies, which keeps loop-invariant address registers from piling up and spilling.
 LHIP_DEV int fresh_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
