@@ -111,6 +111,11 @@ int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* lau
  * 3 1/x, 4 (double)(float)x, 5 ToInt32, 6 x/3 + x*0.1 (must not fuse). */
 int lhip_debug_math(int op, const double* in, double* out, size_t n);
 
+/* Test hook: the seed the speculative quantization pass assumes for the reference's bin-search chain
+ * (gfc.OldValue / gfc.CurrentStep, Quantize.js:324-326); default 180 / 4.  A poor seed (e.g. 255 / 1) makes the
+ * validation flag frames, which exercises the repair passes; the output must not change. */
+int lhip_debug_set_spec_seed(int start, int step);
+
 const char* lhip_last_error(void);
 const char* lhip_version(void);
 

@@ -144,6 +144,7 @@ struct QuantLds {
         struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
         double nsum[SFBMAX + 1];
     };
+    int32_t bs_ntab, bs_tab[BS_TAB_MAX];   // bin-search memo of this granule (published in GrSide)
     uint32_t rdesc[4][2];        // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
@@ -1115,7 +1116,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     // outer-loop state
     int best_part2_3_length = 9999999, age = 0, maxggain = 255, huff_bits = 0, first = 1;
     const int search_limit = 3;
-    int st = ST_BS;
+    int st = ST_BS, nbs = 0;
     for (;;) {
 #ifndef LHIP_NO_FORCE_UNI
         uni_gi(w); uni_gi(g); st = uni(st); CurrentStep = uni(CurrentStep); flagGoneOver = uni(flagGoneOver); Direction = uni(Direction);
@@ -1124,6 +1125,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         best.max_noise = unid(best.max_noise); best.over_count = uni(best.over_count); best.over_SSD = uni(best.over_SSD); best.bits = uni(best.bits);
 #endif
         const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, lane, L, Q);   // the only call site
+        if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) L.bs_tab[nbs] = (w.global_gain << 24) | nBits; nbs++; }
         if (st == ST_BS) {
             if (CurrentStep == 1 || nBits == desired_rate) st = ST_BSUP;
             else {
@@ -1149,6 +1151,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (nBits > desired_rate && w.global_gain < 255) { w.global_gain++; continue; }
             w.part2_3_length = nBits;
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
+            if (lane == 0) L.bs_ntab = nbs;
             if (0 == T.noise_shaping) {
                 g = w;
                 for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = L.ixw[i];
@@ -1537,7 +1540,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     // per-channel state as named scalars: a dynamically indexed local array would live in scratch memory,
     // and everything read back from scratch counts as divergent for the compiler
     Seed seed0, seed1;
-    seed0.start = seed1.start = 180; seed0.step = seed1.step = 4;
+    seed0.start = seed1.start = W.spec_start; seed0.step = seed1.step = W.spec_step;
     if (chain || k == 0) {
         seed0 = seed_before(W, sd, C, k, 0, 0);
         if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
@@ -1594,6 +1597,11 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
             }
             for (int i = lane; i < SFBMAX; i += LHIP_NL) out->scalefac[i] = L.sfb[i];
+            {
+                const int ntab = active ? L.bs_ntab : 0;
+                if (lane == 0) out->bs_ntab = ntab;
+                for (int i = lane; i < ntab; i += LHIP_NL) out->bs_tab[i] = L.bs_tab[i];
+            }
             int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
             for (int i = lane; i < 576; i += LHIP_NL) {
                 const int v = L.ixb[i];
@@ -1611,7 +1619,10 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
 #endif
 }
 
-// Re-run the bin searches of a frame with the chain-implied seeds; flag the frame if any result differs.
+// Replay the bin searches of a frame with the chain-implied seeds; flag the frame if any result differs.
+// The search only asks for count_bits(gain) with all-zero scalefactors; the speculative pass left a memo of every
+// such evaluation (GrSide::bs_tab), so most replays are pure scalar look-ups and the spectrum is only re-quantized
+// on a miss.
 LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
                           int lane, QuantLds& L, const QuantTabs& Q) {
     const int C = T.channels_out;
@@ -1629,20 +1640,70 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             if (!rec->active) continue;
             const Seed s = seed_before(W, sd, C, k, gr, ch);
             if (s.start == rec->bs_start && s.step == rec->bs_step_in) continue;     // already quantized with this seed
+            const int ntab = uni(rec->bs_ntab);
+            // memo entry per lane (device) / linear search (host simulation)
+            int my_ent = 0;
+            for (int i = lane; i < ntab; i += LHIP_NL) my_ent = rec->bs_tab[i];
             GI g;
-            q_init_outer_loop(T, pb10, ath_adjust, g, W.blocktype[(int64_t)gslot * C + ch],
-                              W.xr + ((int64_t)gslot * C + ch) * 576, nullptr, 1, lane, L, Q);
-            q_init_xrpow(g, lane, L, Q);
-            // max_nonzero_coeff is set by calc_xmin in the reference before the bin search
-            if (g.block_type != SHORT_TYPE) {
-                int t = -1;
-                for (int i = lane; i < 576; i += LHIP_NL) if (!((double)L.xr[i] == 0)) t = i;
-                t = wave_max(t);
-                g.max_nonzero_coeff = (t >= 575) ? 575 : t + 1;
+            PrevNoise pn_none; pn_none.gain = 0; pn_none.sfb_count1 = 0;
+            int inited = 0;
+            // bin_search_StepSize (Quantize.js:322-381), part2_length == 0 at this point
+            const int desired_rate = uni(rec->targ_bits);
+            int gain = uni(s.start), CurrentStep = uni(s.step), flagGoneOver = 0, Direction = 0, up = 0;
+            for (;;) {
+                int nBits = -1;
+#ifdef LHIP_HOSTSIM
+                for (int i = 0; i < ntab; i++) if ((int)((uint32_t)rec->bs_tab[i] >> 24) == gain) { nBits = rec->bs_tab[i] & 0xffffff; break; }
+                (void)my_ent;
+#else
+                {
+                    const uint64_t hit = __ballot(lane < ntab && (int)((uint32_t)my_ent >> 24) == gain);
+                    if (hit) nBits = __builtin_amdgcn_readlane(my_ent, (int)__builtin_ctzll(hit)) & 0xffffff;
+                }
+#endif
+                if (nBits < 0) {
+                    if (!inited) {
+                        q_init_outer_loop(T, pb10, ath_adjust, g, W.blocktype[(int64_t)gslot * C + ch],
+                                          W.xr + ((int64_t)gslot * C + ch) * 576, nullptr, 1, lane, L, Q);
+                        q_init_xrpow(g, lane, L, Q);
+                        // max_nonzero_coeff is set by calc_xmin in the reference before the bin search
+                        if (g.block_type != SHORT_TYPE) {
+                            int t = -1;
+                            for (int i = lane; i < 576; i += LHIP_NL) if (!((double)L.xr[i] == 0)) t = i;
+                            t = wave_max(t);
+                            g.max_nonzero_coeff = (t >= 575) ? 575 : t + 1;
+                        }
+                        inited = 1;
+                    }
+                    g.global_gain = gain;
+                    nBits = q_count_bits(T, g, L.sfb, L.ixb, 0, pn_none, lane, L, Q);
+                }
+                nBits = uni(nBits);
+                if (!up) {
+                    if (CurrentStep == 1 || nBits == desired_rate) up = 1;
+                    else {
+                        int step;
+                        if (nBits > desired_rate) {
+                            if (Direction == 2) flagGoneOver = 1;
+                            if (flagGoneOver) CurrentStep /= 2;
+                            Direction = 1;
+                            step = CurrentStep;
+                        } else {
+                            if (Direction == 1) flagGoneOver = 1;
+                            if (flagGoneOver) CurrentStep /= 2;
+                            Direction = 2;
+                            step = -CurrentStep;
+                        }
+                        gain += step;
+                        if (gain < 0) { gain = 0; flagGoneOver = 1; }
+                        if (gain > 255) { gain = 255; flagGoneOver = 1; }
+                        continue;
+                    }
+                }
+                if (nBits > desired_rate && gain < 255) { gain++; continue; }
+                break;
             }
-            int step_unused;
-            q_bin_search(T, g, rec->targ_bits, s.start, s.step, &step_unused, lane, L, Q);
-            if (g.global_gain != rec->bs_gain) bad = 1;
+            if (gain != rec->bs_gain) bad = 1;
         }
     }
     if (lane == 0 && bad) {

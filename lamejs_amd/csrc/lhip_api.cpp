@@ -256,6 +256,7 @@ __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase 
 // ===========================================================================================
 // tables (shared between streams with identical blobs)
 // ===========================================================================================
+static int g_spec_start = 180, g_spec_step = 4;   // seed assumed by the speculative quantization pass (test hook)
 struct lhtb_entry { char name[32]; uint32_t dtype, count, offset, pad; };
 
 struct TableSet {
@@ -485,6 +486,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // ---- workspace ----
     Workspace W;
     memset(&W, 0, sizeof W);
+    W.spec_start = g_spec_start; W.spec_step = g_spec_step;
     W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
     const size_t GC = (size_t)ngs * C, FR = (size_t)(nfr > 0 ? nfr : 1);
 #define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
@@ -851,6 +853,12 @@ int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* lau
 #else
     (void)idx; (void)name; (void)total_ms; (void)launches; return -1;
 #endif
+}
+
+int lhip_debug_set_spec_seed(int start, int step) {
+    if (start < 0 || start > 255 || step < 1) return LHIP_ERR_INTERNAL;
+    g_spec_start = start; g_spec_step = step;
+    return 0;
 }
 
 int lhip_debug_math(int op, const double* in, double* out, size_t n) {

@@ -67,6 +67,7 @@ struct Tables {
 
 // Per-granule-channel side information produced by the quantization kernel and consumed by the
 // bit-packing kernel (the subset of the reference's GrInfo that reaches the bitstream).
+enum { BS_TAB_MAX = 24 };
 struct GrSide {
     int32_t part2_3_length, part2_length, big_values, count1, global_gain, scalefac_compress, block_type;
     int32_t table_select[3], subblock_gain[3];
@@ -77,6 +78,9 @@ struct GrSide {
     int32_t targ_bits;
     int32_t scfsi;                           // gr1 only: bit i = scfsi[ch][i]
     int32_t scalefac[SFBMAX];
+    // bin-search memo: (gain << 24 | bits) of every count_bits evaluation made with all-zero scalefactors;
+    // the seed-chain validation replays the search from these and only recomputes on a miss
+    int32_t bs_ntab, bs_tab[BS_TAB_MAX];
 };
 
 }  // namespace lhip

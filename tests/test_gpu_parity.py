@@ -142,3 +142,23 @@ def test_gpu_full_size_properties(lib):
     assert k == nfr + 1 and pos == len(one)
     ref = oracle_encode(1, 44100, 128, L[: 1152 * 3000], flush=False)
     assert one[: len(ref)] == ref
+
+
+@pytest.mark.gpu
+def test_gpu_seed_repair_path(lib):
+    """Poor speculative seed -> frames flagged by the validation kernel -> repair passes -> reference bytes."""
+    import lamejs_amd, pcm
+    from oracle_py import oracle_encode
+    L, R = pcm.bursts(1152 * 40, 2, seed=78)
+    want = oracle_encode(2, 44100, 128, L, R)
+    lib.lhip_debug_set_spec_seed.argtypes = [ctypes.c_int, ctypes.c_int]
+    try:
+        assert lib.lhip_debug_set_spec_seed(255, 1) == 0
+        enc = lamejs_amd.Mp3Encoder(2, 44100, 128)
+        got = enc.encodeBuffer(L, R)
+        stats = enc.last_batch_stats()
+        got += enc.flush()
+        assert stats["repaired_frames"] > 0, stats
+        assert got == want
+    finally:
+        lib.lhip_debug_set_spec_seed(180, 4)

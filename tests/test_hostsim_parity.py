@@ -53,3 +53,22 @@ def test_hostsim_batch_streams_match_single(sim):
     got = lamejs_amd.encode_streams(encs, streams)
     for s, g in zip(streams, got):
         assert g == oracle_encode(1, 44100, 128, s)
+
+
+def test_hostsim_seed_repair_path(sim):
+    """A deliberately poor speculative bin-search seed makes the validation flag frames; the repair passes
+    must converge to the reference's bytes (the chain-implied seeds), whatever was speculated."""
+    import lamejs_amd, pcm
+    L, R = pcm.bursts(1152 * 12, 2, seed=77)
+    want = oracle_encode(2, 44100, 128, L, R)
+    sim.lhip_debug_set_spec_seed.argtypes = [ctypes.c_int, ctypes.c_int]
+    try:
+        assert sim.lhip_debug_set_spec_seed(255, 1) == 0
+        enc = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim)
+        got = enc.encodeBuffer(L, R)
+        stats = enc.last_batch_stats()
+        got += enc.flush()
+        assert stats["repaired_frames"] > 0 and stats["repair_iterations"] > 0, stats
+        assert got == want
+    finally:
+        sim.lhip_debug_set_spec_seed(180, 4)
