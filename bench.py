@@ -169,9 +169,20 @@ def main():
             kt = kern[dom]["ms"] / max(kern[dom]["launches"], 1) / 1000.0
             alg = ALG_BYTES_PER_FRAME * frames_per_step
             ach = alg / kt / 1e9
+            # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # runs, gfx950 FETCH_SIZE x2 correction) -- measured offline on this exact workload, committed under profiles/
+            traffic = None
+            pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic_mono128_1e5.json"
+            if (CH, KBPS, nfr) == (1, 128, 100000) and pmc.exists():
+                try:
+                    traffic = json.loads(pmc.read_text())["kernels"]["g_" + dom]["hbm_bytes_per_launch"]
+                except (KeyError, ValueError):
+                    traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                                "note": "path is latency/ALU bound (SURVEY.md 8d): HBM fraction is small by construction"}
+                                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_unit": "bytes/launch",
+                                "algorithmic_bytes_per_launch": int(alg),
+                                "note": "path is latency/issue bound (SURVEY.md 8d): the HBM fraction is small by construction; "
+                                        "traffic from profiles/r01_pmc_hbm_traffic_mono128_1e5.json"}
         if args.cpu_frames > 0:
             from oracle_py import oracle_encode
             k = min(args.cpu_frames, nfr)
