@@ -355,8 +355,12 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
 // ---------------------------------------------------------------------------------------------
 // quantize_xrpow (Takehiro.js:171-314) -> ix ; `use_prev` = the prev_noise cache (pn_* in LDS) is live
 // ---------------------------------------------------------------------------------------------
+// Lane l owns the PAIRS 2(l + 64 j), +1 (bands start and end on even lines, so a pair never straddles a band):
+// xrpow comes in as one 8-byte load and ix goes out as one 32-bit store per pair, and the quantized values stay in
+// registers (vx, vy) for the Huffman bit count that follows -- no LDS round trip between the two.
+enum { NPL = (288 + LHIP_NL - 1) / LHIP_NL };
 LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, int16_t* ix, int use_prev,
-                         int pn_gain, int pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+                         int pn_gain, int pn_sfb_count1, int (&vx)[NPL], int (&vy)[NPL], int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     const double istep = ipow20(Q, g.global_gain);
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
@@ -366,13 +370,18 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     uint64_t m_cached = 0, m_zo = 0, m_cut = 0;       // bit sfb, produced by lane sfb (sfbmax < 64)
-    for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
-        int step = -1;
-        if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
-        if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
-        else {
-            if (use_prev && pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) m_zo |= 1ull << sfb;
+    if (!use_prev) {                                     // bin-search rounds: no cache, only the cut matters
+        for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL)
             if (L.start[sfb] + L.width[sfb] > mnz) m_cut |= 1ull << sfb;
+    } else {
+        for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
+            int step = -1;
+            if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
+            if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
+            else {
+                if (pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) m_zo |= 1ull << sfb;
+                if (L.start[sfb] + L.width[sfb] > mnz) m_cut |= 1ull << sfb;
+            }
         }
     }
     m_cached = wave_lane_bits(m_cached); m_zo = wave_lane_bits(m_zo); m_cut = wave_lane_bits(m_cut);
@@ -388,29 +397,40 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     PH_MARK(L, PH_Q_MASK, tm_);
     const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
-    // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here)
-    // two half-batches (5 + 4 lines per lane on the device) keep the staged registers under ~35
-    enum { NLN = 576 / LHIP_NL, HB = (NLN + 1) / 2 };
+    // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here).
+    // Without cached bands every line is either quantized or at/after fill_from (last_line is mnz or mnz + 1), so
+    // the previous values are only fetched when some band is cached.
+    const int need_old = (m_cached != 0);
+    float xa[NPL], xb[NPL]; int sf[NPL]; uint32_t oldw[NPL];
 #pragma unroll
-    for (int h0 = 0; h0 < NLN; h0 += HB) {
-        float xv[HB]; int sf[HB], rx[HB]; double xq[HB]; float aj[HB];
-#pragma unroll
-        for (int j = 0; j < HB; j++) if (h0 + j < NLN) { const int i = lane + LHIP_NL * (h0 + j); sf[j] = l2s[i]; xv[j] = L.xrpow[i]; }
-#pragma unroll
-        for (int j = 0; j < HB; j++) if (h0 + j < NLN) { xq[j] = (double)xv[j] * istep; rx[j] = (int)xq[j]; }   // 0 <= x <= 8206: truncation == ToInt32
-#pragma unroll
-        for (int j = 0; j < HB; j++) if (h0 + j < NLN) aj[j] = Q.adj43[rx[j] < QT_N ? rx[j] : QT_N - 1];
-#pragma unroll
-        for (int j = 0; j < HB; j++) if (h0 + j < NLN) {
-            const int i = lane + LHIP_NL * (h0 + j);
-            if (rx[j] >= QT_N) aj[j] = T.adj43[rx[j]];                 // rare: large quantized values
-            const int proc = (i < last_line) && !((m_cached >> sf[j]) & 1);
-            const int v1 = (int)(xq[j] + (double)aj[j]);
-            const int v01 = (compareval0 > (double)xv[j]) ? 0 : 1;
-            const int v = ((m_zo >> sf[j]) & 1) ? v01 : v1;
-            if (proc) ix[i] = (int16_t)v;
-            else if (i >= fill_from) ix[i] = 0;
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        xa[j] = 0.f; xb[j] = 0.f; sf[j] = 0; oldw[j] = 0;
+        if (p < 576) {
+            sf[j] = l2s[p];
+            struct F2 { float x, y; };
+            const F2 xx = *(const F2*)(L.xrpow + p);       // 8-byte aligned: p is even and xrpow is
+            xa[j] = xx.x; xb[j] = xx.y;
+            if (need_old) oldw[j] = *(const uint32_t*)(ix + p);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        const double qa = (double)xa[j] * istep, qb = (double)xb[j] * istep;
+        const int ra = (int)qa, rb = (int)qb;                              // 0 <= x <= 8206: truncation == ToInt32
+        float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
+        if (ra >= QT_N) aa = T.adj43[ra];                                  // rare: large quantized values
+        if (rb >= QT_N) ab = T.adj43[rb];
+        const int cached = (int)((m_cached >> sf[j]) & 1), zo = (int)((m_zo >> sf[j]) & 1);
+        int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
+        if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
+        const int oa = (int)(oldw[j] & 0xffffu), ob = (int)(oldw[j] >> 16);
+        const int ia = p, ib = p + 1;
+        va = ((ia < last_line) && !cached) ? va : (ia >= fill_from ? 0 : oa);
+        vb = ((ib < last_line) && !cached) ? vb : (ib >= fill_from ? 0 : ob);
+        vx[j] = va; vy[j] = vb;
+        if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
     }
     wave_sync();
     PH_MARK(L, PH_Q_LINES, tm_);
@@ -500,20 +520,17 @@ LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, in
 }
 
 // noquant_count_bits (Takehiro.js:521-628); updates g, returns bits.  pn_sfb_count1 as in/out.
-LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int use_prev, int* pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int (&vx)[NPL], int (&vy)[NPL], int use_prev, int* pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
     if (i > 576) i = 576;
     if (use_prev) *pn_sfb_count1 = 0;
-    // each lane keeps its pairs (lines 2(lane + NL j), +1) in registers for all passes
-    enum { NPL = (288 + LHIP_NL - 1) / LHIP_NL };
-    int vx[NPL], vy[NPL];
+    // the lane's pairs arrive in registers from q_quantize; pairs at or above the max_nonzero_coeff bound count as zero
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const int p = 2 * (lane + LHIP_NL * j);
-        vx[j] = 0; vy[j] = 0;
-        if (p < i) { const uint32_t w2 = *(const uint32_t*)(ix + p); vx[j] = (int)(w2 & 0xffffu); vy[j] = (int)(w2 >> 16); }   // magnitudes, two per word
+        if (!(p < i)) { vx[j] = 0; vy[j] = 0; }
     }
     // count1 boundary (highest pair with a non-zero value) and the end of the big-values region (the quad scan of
     // Takehiro.js:540-560 stops at the first quad, counted from the top, that holds a value > 1).
@@ -695,10 +712,11 @@ struct PrevNoise { int gain, sfb_count1; };   // scalar part of CalcNoiseData (a
 LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
     const double w = (double)IXMAX_VAL / ipow20(Q, g.global_gain);
     if (g.xrpow_max > w) return LARGE_BITS;
-    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, use_pn, use_pn ? pn.gain : 0, use_pn ? pn.sfb_count1 : 0, lane, L, Q); PH_END(L, PH_QUANTIZE); }
+    int vx[NPL], vy[NPL];
+    { PH_BEGIN(); q_quantize(T, g, scalefac, ix, use_pn, use_pn ? pn.gain : 0, use_pn ? pn.sfb_count1 : 0, vx, vy, lane, L, Q); PH_END(L, PH_QUANTIZE); }
     int cnt1 = pn.sfb_count1;
     PH_BEGIN();
-    const int r = q_noquant_count_bits(T, g, ix, use_pn, &cnt1, lane, L, Q);
+    const int r = q_noquant_count_bits(T, g, ix, vx, vy, use_pn, &cnt1, lane, L, Q);
     if (use_pn) pn.sfb_count1 = cnt1;
     PH_END(L, PH_COUNT);
     return r;
@@ -1043,41 +1061,6 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
     }
     if (!status) status = q_scale_bitcount(T, g, scalefac, lane);
     return !status;
-}
-
-// bin_search_StepSize (Quantize.js:322-381) on the kept copy (ixb / sfb arrays)
-LHIP_DEV int q_bin_search(const Tables& T, GI& g, int desired_rate, int start, int CurrentStep, int* step_out,
-                          int lane, QuantLds& L, const QuantTabs& Q) {
-    int nBits, flagGoneOver = 0, Direction = 0;
-    PrevNoise pn_none; pn_none.gain = 0; pn_none.sfb_count1 = 0;
-    g.global_gain = start;
-    desired_rate -= g.part2_length;
-    for (;;) {
-        int step;
-        nBits = q_count_bits(T, g, L.sfb, L.ixb, 0, pn_none, lane, L, Q);
-        if (CurrentStep == 1 || nBits == desired_rate) break;
-        if (nBits > desired_rate) {
-            if (Direction == 2) flagGoneOver = 1;
-            if (flagGoneOver) CurrentStep /= 2;
-            Direction = 1;
-            step = CurrentStep;
-        } else {
-            if (Direction == 1) flagGoneOver = 1;
-            if (flagGoneOver) CurrentStep /= 2;
-            Direction = 2;
-            step = -CurrentStep;
-        }
-        g.global_gain += step;
-        if (g.global_gain < 0) { g.global_gain = 0; flagGoneOver = 1; }
-        if (g.global_gain > 255) { g.global_gain = 255; flagGoneOver = 1; }
-    }
-    while (nBits > desired_rate && g.global_gain < 255) {
-        g.global_gain++;
-        nBits = q_count_bits(T, g, L.sfb, L.ixb, 0, pn_none, lane, L, Q);
-    }
-    *step_out = (start - g.global_gain >= 4) ? 4 : 2;
-    g.part2_3_length = nBits;
-    return nBits;
 }
 
 LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // Quantize.js:481-568 case 9
