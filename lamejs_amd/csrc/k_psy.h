@@ -82,14 +82,19 @@ LHIP_DEV void fht_item(float* fz, int k1, int kx, int t, const double* tw) {
     }
 }
 
+// LDS of one psy-A wave.  The energies overwrite the lower halves of the FHT buffers they are computed from
+// (fe = fz[0..512], fes[b] = fs[b][0..128]) and the partition arrays live in the then-dead upper half of fz:
+// 7.2 KB instead of 12.3 KB per wave, i.e. LDS no longer caps the kernel at 3 waves per SIMD.
 struct PsyALds {
-    float fz[BLKSIZE];              // long FHT buffer
-    float fs[3][BLKSIZE_s];         // short FHT buffers
-    float fe[HBLKSIZE + 3];         // long energies
-    float fes[3][HBLKSIZE_s + 3];   // short energies
-    float eb[CBANDS], mx[CBANDS], av[CBANDS];
-    float ebs[3][CBANDS];
+    float fz[BLKSIZE];              // long FHT buffer; after the energies: [0..512] fe, [516..] eb/mx/av/ebs
+    float fs[3][BLKSIZE_s];         // short FHT buffers; after the energies: [b][0..128] fes
 };
+#define PSYA_FE(L) ((L).fz)
+#define PSYA_FES(L, b) ((L).fs[b])
+#define PSYA_EB(L) ((L).fz + 516)
+#define PSYA_MX(L) ((L).fz + 516 + CBANDS)
+#define PSYA_AV(L) ((L).fz + 516 + 2 * CBANDS)
+#define PSYA_EBS(L, b) ((L).fz + 516 + (3 + (b)) * CBANDS)
 
 // one wave per (granule slot >= 1 of a stream, channel)
 LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int ch, int lane, PsyALds& L) {
@@ -182,20 +187,34 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
     }
 
-    // --- energies (PsyModel.js:274-296) ---
-    for (int j = lane; j <= BLKSIZE / 2; j += LHIP_NL) {
-        if (j == 0) { float e0 = L.fz[0]; L.fe[0] = (float)((double)e0 * (double)e0); }
-        else {
-            const double re = L.fz[j], im = L.fz[BLKSIZE - j];
-            L.fe[j] = (float)((re * re + im * im) * 0.5);
+    // --- energies (PsyModel.js:274-296), written over the lower halves of the transform buffers ---
+    {
+        enum { KE = (BLKSIZE / 2 + 1 + LHIP_NL - 1) / LHIP_NL, KS = (3 * (BLKSIZE_s / 2 + 1) + LHIP_NL - 1) / LHIP_NL };
+        float el[KE], es[KS];
+#pragma unroll
+        for (int u = 0; u < KE; u++) {
+            const int j = lane + LHIP_NL * u;
+            el[u] = 0.f;
+            if (j == 0) { const float e0 = L.fz[0]; el[u] = (float)((double)e0 * (double)e0); }
+            else if (j <= BLKSIZE / 2) { const double re = L.fz[j], im = L.fz[BLKSIZE - j]; el[u] = (float)((re * re + im * im) * 0.5); }
         }
-    }
-    for (int it = lane; it < 3 * (BLKSIZE_s / 2 + 1); it += LHIP_NL) {
-        const int b = it / (BLKSIZE_s / 2 + 1), j = it - b * (BLKSIZE_s / 2 + 1);
-        if (j == 0) { float e0 = L.fs[b][0]; L.fes[b][0] = (float)((double)e0 * (double)e0); }
-        else {
-            const double re = L.fs[b][j], im = L.fs[b][BLKSIZE_s - j];
-            L.fes[b][j] = (float)((re * re + im * im) * 0.5);
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            const int it = lane + LHIP_NL * u;
+            es[u] = 0.f;
+            if (it < 3 * (BLKSIZE_s / 2 + 1)) {
+                const int b = it / (BLKSIZE_s / 2 + 1), j = it - b * (BLKSIZE_s / 2 + 1);
+                if (j == 0) { const float e0 = L.fs[b][0]; es[u] = (float)((double)e0 * (double)e0); }
+                else { const double re = L.fs[b][j], im = L.fs[b][BLKSIZE_s - j]; es[u] = (float)((re * re + im * im) * 0.5); }
+            }
+        }
+        wave_sync();                                  // every lane has read its operands before anything is overwritten
+#pragma unroll
+        for (int u = 0; u < KE; u++) { const int j = lane + LHIP_NL * u; if (j <= BLKSIZE / 2) PSYA_FE(L)[j] = el[u]; }
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            const int it = lane + LHIP_NL * u;
+            if (it < 3 * (BLKSIZE_s / 2 + 1)) { const int b = it / (BLKSIZE_s / 2 + 1), j = it - b * (BLKSIZE_s / 2 + 1); PSYA_FES(L, b)[j] = es[u]; }
         }
     }
     wave_sync();
@@ -205,7 +224,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         enum { K = (BLKSIZE / 2) / LHIP_NL };
         double pr[K];
 #pragma unroll
-        for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (double)L.fe[i] * (double)T.eql_w[i]; }
+        for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (double)PSYA_FE(L)[i] * (double)T.eql_w[i]; }
         double lp = wave_seq_sum<K>(pr);
         lp *= T.VO_SCALE;
         if (lane == 0) W.loud[o] = (float)lp;
@@ -216,21 +235,21 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         double ebb = 0, m = 0;
         int j = T.lineoff_l[b];
         for (int i = 0; i < T.numlines_l[b]; ++i, ++j) {
-            const double el = L.fe[j];
+            const double el = PSYA_FE(L)[j];
             ebb += el;
             if (m < el) m = el;
         }
-        L.eb[b] = (float)ebb;
-        L.mx[b] = (float)m;
-        L.av[b] = (float)(ebb * (double)T.rnumlines_l[b]);
+        PSYA_EB(L)[b] = (float)ebb;
+        PSYA_MX(L)[b] = (float)m;
+        PSYA_AV(L)[b] = (float)(ebb * (double)T.rnumlines_l[b]);
     }
     // --- short partitions: energy per sub-block (compute_masking_s first loop, 740-750) ---
     for (int it = lane; it < 3 * T.npart_s; it += LHIP_NL) {
         const int sblock = it / T.npart_s, b = it - sblock * T.npart_s;
         double ebb = 0;
         int j = T.lineoff_s[b];
-        for (int i = 0; i < T.numlines_s[b]; ++i, ++j) ebb += (double)L.fes[sblock][j];
-        L.ebs[sblock][b] = (float)ebb;
+        for (int i = 0; i < T.numlines_s[b]; ++i, ++j) ebb += (double)PSYA_FES(L, sblock)[j];
+        PSYA_EBS(L, sblock)[b] = (float)ebb;
     }
     wave_sync();
 
@@ -243,17 +262,17 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             const int lo = b > 0 ? b - 1 : b, hi = b < last ? b + 1 : b;
             double a, m;
             int nl;
-            if (b == 0) { a = (double)L.av[0] + (double)L.av[1]; nl = T.numlines_l[0] + T.numlines_l[1] - 1; }
-            else if (b == last) { a = (double)L.av[b - 1] + (double)L.av[b]; nl = T.numlines_l[b - 1] + T.numlines_l[b] - 1; }
-            else { a = (double)L.av[b - 1] + (double)L.av[b] + (double)L.av[b + 1]; nl = T.numlines_l[b - 1] + T.numlines_l[b] + T.numlines_l[b + 1] - 1; }
+            if (b == 0) { a = (double)PSYA_AV(L)[0] + (double)PSYA_AV(L)[1]; nl = T.numlines_l[0] + T.numlines_l[1] - 1; }
+            else if (b == last) { a = (double)PSYA_AV(L)[b - 1] + (double)PSYA_AV(L)[b]; nl = T.numlines_l[b - 1] + T.numlines_l[b] - 1; }
+            else { a = (double)PSYA_AV(L)[b - 1] + (double)PSYA_AV(L)[b] + (double)PSYA_AV(L)[b + 1]; nl = T.numlines_l[b - 1] + T.numlines_l[b] + T.numlines_l[b + 1] - 1; }
             if (a > 0.0) {
-                m = L.mx[lo];
-                for (int t = lo + 1; t <= hi; t++) if (m < (double)L.mx[t]) m = L.mx[t];
+                m = PSYA_MX(L)[lo];
+                for (int t = lo + 1; t <= hi; t++) if (m < (double)PSYA_MX(L)[t]) m = PSYA_MX(L)[t];
                 a = 20.0 * (m * (double)(hi - lo + 1) - a) / (a * nl);
                 k = js_toint32(a);
                 if (k > 8) k = 8;
             }
-            ebv = L.eb[b];
+            ebv = PSYA_EB(L)[b];
         }
         W.eb_l[o * EBL_STRIDE + b] = ebv;
         W.mask_idx[o * EBL_STRIDE + b] = k;
@@ -264,11 +283,11 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         float ecbv = 0.f, ebv = 0.f;
         if (b < T.npart_s) {
             int kk = T.s3ind_s[2 * b], j = T.s3off_s[b];
-            double ecb = (double)T.s3_ss[j++] * (double)L.ebs[sblock][kk];
+            double ecb = (double)T.s3_ss[j++] * (double)PSYA_EBS(L, sblock)[kk];
             ++kk;
-            while (kk <= T.s3ind_s[2 * b + 1]) { ecb += (double)T.s3_ss[j] * (double)L.ebs[sblock][kk]; ++j; ++kk; }
+            while (kk <= T.s3ind_s[2 * b + 1]) { ecb += (double)T.s3_ss[j] * (double)PSYA_EBS(L, sblock)[kk]; ++j; ++kk; }
             ecbv = (float)ecb;
-            ebv = L.ebs[sblock][b];
+            ebv = PSYA_EBS(L, sblock)[b];
         }
         W.ecb_s[o * EBS_STRIDE + it] = ecbv;
         W.eb_s[o * EBS_STRIDE + it] = ebv;
