@@ -411,15 +411,24 @@ LHIP_DEV void kb_scan_blocktype(const Tables& T, const Workspace& W, const Strea
     }
 }
 
-// ATH auto-adjust recurrence (Encoder.js:166-243), one wave per stream.
+// ATH auto-adjust recurrence (Encoder.js:166-243), one 1024-thread workgroup per stream.
 // The recurrence (adjust, adjustLimit) <- F_k(adjust, adjustLimit) is serial in general (repeated f64
 // multiplications during a loudness descent cannot be re-associated), but two consecutive "loud" frames
 // (max_pow > 0.03125) force the state to (1, 1) whatever came before.  Frames are processed in chunks of
-// ATH_CHUNK; inside a chunk every lane owns a contiguous segment: pass A evaluates each segment from its
-// first such reset point onwards (no dependence on other lanes), then the segment prefixes are filled in
-// as soon as the state at the end of the previous segment is known (at most NL rounds, 1 in the common case).
-enum { ATH_CHUNK = 2048 };
-struct AthLds { double mp[ATH_CHUNK], adj[ATH_CHUNK], lim[ATH_CHUNK]; double e_adj[LHIP_NL + 1], e_lim[LHIP_NL + 1]; int known[LHIP_NL + 1], first_reset[LHIP_NL + 1]; };
+// ATH_NT x ATH_SEG; inside a chunk every thread owns a contiguous segment: pass A evaluates each segment from its
+// first such reset point onwards (no dependence on other threads), then the segment prefixes are filled in
+// as soon as the state at the end of the previous segment is known (at most ATH_NT rounds, 1 in the common case).
+// Nothing but the segment end states is staged: max_pow is recomputed from the per-granule loudness (L2-resident).
+#ifdef LHIP_HOSTSIM
+enum { ATH_NT = 1, ATH_SEG = 1 << 20 };
+LHIP_DEV void block_sync() {}
+LHIP_DEV int block_any(int p) { return p != 0; }
+#else
+enum { ATH_NT = 1024, ATH_SEG = 16 };
+LHIP_DEV void block_sync() { __syncthreads(); }
+LHIP_DEV int block_any(int p) { return __syncthreads_or(p); }
+#endif
+struct AthLds { double e_adj[ATH_NT + 1], e_lim[ATH_NT + 1]; int known[ATH_NT + 1], first_reset[ATH_NT + 1]; double c_adj, c_lim, c_mp; };
 
 LHIP_DEV void ath_step(const Tables& T, double max_pow, double& adj, double& lim) {
     if (T.ATH_useAdjust == 0) { adj = 1.0; return; }
@@ -440,74 +449,80 @@ LHIP_DEV void ath_step(const Tables& T, double max_pow, double& adj, double& lim
     }
 }
 
-LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc* SD, int st, int lane, AthLds& L) {
+// max_pow of frame k of the stream (Encoder.js:420-440): loudness of the two psy calls before the frame's granules
+LHIP_DEV double ath_max_pow(const Tables& T, const Workspace& W, const StreamDesc& sd, int C, int k) {
+    const int64_t g0 = (int64_t)(sd.gslot0 + 2 * k) * C, g1 = g0 + C;
+    double max_pow = W.loud[g0], gr2_max = W.loud[g1];
+    if (C == 2) { max_pow += (double)W.loud[g0 + 1]; gr2_max += (double)W.loud[g1 + 1]; }
+    else { max_pow += max_pow; gr2_max += gr2_max; }
+    max_pow = max_pow > gr2_max ? max_pow : gr2_max;
+    max_pow *= 0.5;
+    max_pow *= T.ATH_aaSensitivityP;
+    return max_pow;
+}
+
+LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc* SD, int st, int tid, AthLds& L) {
     const int C = T.channels_out;
     const StreamDesc sd = SD[st];
-    double cadj = W.ath_adjust[sd.fslot0], clim = W.ath_limit[sd.fslot0];   // state carried into the chunk
-    double prev_mp = 0.0;                                                    // max_pow of the frame before the chunk (0: unknown/not loud)
-    for (int k0 = 0; k0 < sd.nframes; k0 += ATH_CHUNK) {
-        const int n = (sd.nframes - k0) < ATH_CHUNK ? (sd.nframes - k0) : ATH_CHUNK;
-        // max_pow per frame (parallel): loudness of the two psy calls before the frame's granules
-        for (int k = lane; k < n; k += LHIP_NL) {
-            const int64_t g0 = (int64_t)(sd.gslot0 + 2 * (k0 + k)) * C, g1 = g0 + C;
-            double max_pow = W.loud[g0], gr2_max = W.loud[g1];
-            if (C == 2) { max_pow += (double)W.loud[g0 + 1]; gr2_max += (double)W.loud[g1 + 1]; }
-            else { max_pow += max_pow; gr2_max += gr2_max; }
-            max_pow = max_pow > gr2_max ? max_pow : gr2_max;
-            max_pow *= 0.5;
-            max_pow *= T.ATH_aaSensitivityP;
-            L.mp[k] = max_pow;
-        }
-        wave_sync();
-        const int seglen = (n + LHIP_NL - 1) / LHIP_NL;
-        const int s0 = lane * seglen < n ? lane * seglen : n, s1 = (lane + 1) * seglen < n ? (lane + 1) * seglen : n;
+    if (tid == 0) { L.c_adj = W.ath_adjust[sd.fslot0]; L.c_lim = W.ath_limit[sd.fslot0]; L.c_mp = 0.0; }   // state carried into the chunk; 0: previous frame unknown / not loud
+    block_sync();
+    for (int k0 = 0; k0 < sd.nframes; k0 += ATH_NT * ATH_SEG) {
+        const int rem = sd.nframes - k0;
+        const int n = rem < ATH_NT * ATH_SEG ? rem : ATH_NT * ATH_SEG;
+        const int seglen = (n + ATH_NT - 1) / ATH_NT;
+        const int s0 = tid * seglen < n ? tid * seglen : n, s1 = (tid + 1) * seglen < n ? (tid + 1) * seglen : n;
+        const double cadj = L.c_adj, clim = L.c_lim, prev_mp = L.c_mp;
         // pass A: from the first reset point of the segment to its end
         {
             int fr = -1;
-            if (T.ATH_useAdjust != 0)
+            if (T.ATH_useAdjust != 0) {
+                double pm = (s0 < s1) ? (s0 > 0 ? ath_max_pow(T, W, sd, C, k0 + s0 - 1) : prev_mp) : 0.0;
                 for (int k = s0; k < s1; k++) {
-                    const double pm = k > 0 ? L.mp[k - 1] : prev_mp;
-                    if (pm > 0.03125 && L.mp[k] > 0.03125) { fr = k; break; }
+                    const double m = ath_max_pow(T, W, sd, C, k0 + k);
+                    if (pm > 0.03125 && m > 0.03125) { fr = k; break; }
+                    pm = m;
                 }
-            else if (s0 < s1) fr = s0;
+            } else if (s0 < s1) fr = s0;
             double a = 1.0, l = 1.0;
             if (fr >= 0) {
-                L.adj[fr] = 1.0; L.lim[fr] = (T.ATH_useAdjust != 0) ? 1.0 : clim;
-                l = L.lim[fr];
-                for (int k = fr + 1; k < s1; k++) { ath_step(T, L.mp[k], a, l); L.adj[k] = a; L.lim[k] = l; }
+                l = (T.ATH_useAdjust != 0) ? 1.0 : clim;
+                W.ath_adjust[sd.fslot0 + 1 + k0 + fr] = 1.0; W.ath_limit[sd.fslot0 + 1 + k0 + fr] = l;
+                for (int k = fr + 1; k < s1; k++) {
+                    ath_step(T, ath_max_pow(T, W, sd, C, k0 + k), a, l);
+                    W.ath_adjust[sd.fslot0 + 1 + k0 + k] = a; W.ath_limit[sd.fslot0 + 1 + k0 + k] = l;
+                }
             }
-            L.first_reset[lane] = fr;
-            L.known[lane + 1] = (fr >= 0) || (s0 >= s1 && false);
-            L.e_adj[lane + 1] = a; L.e_lim[lane + 1] = l;
-            if (lane == 0) { L.known[0] = 1; L.e_adj[0] = cadj; L.e_lim[0] = clim; }
+            L.first_reset[tid] = fr;
+            L.known[tid + 1] = (fr >= 0);
+            L.e_adj[tid + 1] = a; L.e_lim[tid + 1] = l;
+            if (tid == 0) { L.known[0] = 1; L.e_adj[0] = cadj; L.e_lim[0] = clim; }
         }
-        wave_sync();
+        block_sync();
         // prefix rounds: a segment's frames before its first reset need the state at the end of the previous segment
         int done = (s0 >= s1);
-        for (int round = 0; round < LHIP_NL + 1; round++) {
+        for (int round = 0; round < ATH_NT + 1; round++) {
             int progressed = 0;
-            if (!done && L.known[lane]) {
-                double a = L.e_adj[lane], l = L.e_lim[lane];
-                const int fr = L.first_reset[lane];
+            if (!done && L.known[tid]) {
+                double a = L.e_adj[tid], l = L.e_lim[tid];
+                const int fr = L.first_reset[tid];
                 const int stop = fr >= 0 ? fr : s1;
-                for (int k = s0; k < stop; k++) { ath_step(T, L.mp[k], a, l); L.adj[k] = a; L.lim[k] = l; }
-                if (fr < 0) { L.e_adj[lane + 1] = a; L.e_lim[lane + 1] = l; }
+                for (int k = s0; k < stop; k++) {
+                    ath_step(T, ath_max_pow(T, W, sd, C, k0 + k), a, l);
+                    W.ath_adjust[sd.fslot0 + 1 + k0 + k] = a; W.ath_limit[sd.fslot0 + 1 + k0 + k] = l;
+                }
+                if (fr < 0) { L.e_adj[tid + 1] = a; L.e_lim[tid + 1] = l; }
                 done = 1; progressed = 1;
             }
-            wave_sync();
-            if (progressed && L.first_reset[lane] < 0) L.known[lane + 1] = 1;
+            block_sync();
+            if (progressed && L.first_reset[tid] < 0) L.known[tid + 1] = 1;
             // empty segments simply forward the state
-            if (s0 >= s1 && L.known[lane] && !L.known[lane + 1]) { L.e_adj[lane + 1] = L.e_adj[lane]; L.e_lim[lane + 1] = L.e_lim[lane]; L.known[lane + 1] = 1; }
-            wave_sync();
-            if (!wave_any(!done) && !wave_any(!L.known[lane + 1])) break;
+            if (s0 >= s1 && L.known[tid] && !L.known[tid + 1]) { L.e_adj[tid + 1] = L.e_adj[tid]; L.e_lim[tid + 1] = L.e_lim[tid]; L.known[tid + 1] = 1; }
+            block_sync();
+            if (!block_any(!done || !L.known[tid + 1])) break;
         }
-        for (int k = lane; k < n; k += LHIP_NL) {
-            W.ath_adjust[sd.fslot0 + 1 + k0 + k] = L.adj[k];
-            W.ath_limit[sd.fslot0 + 1 + k0 + k] = L.lim[k];
-        }
-        wave_sync();
-        cadj = L.adj[n - 1]; clim = L.lim[n - 1]; prev_mp = L.mp[n - 1];
-        wave_sync();
+        // carry: state after the last frame of the chunk = end state of the last non-empty segment
+        if (s0 < s1 && s1 == n) { L.c_adj = L.e_adj[tid + 1]; L.c_lim = L.e_lim[tid + 1]; L.c_mp = ath_max_pow(T, W, sd, C, k0 + n - 1); }
+        block_sync();
     }
 }
 

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void g_prep(Tables T, Workspace W, const Strea
 __global__ __launch_bounds__(64) void g_scan_raw(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_raw(T, W, SD, g); }
 __global__ __launch_bounds__(64) void g_scan_attack(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_attack(T, W, SD, g); }
 __global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_blocktype(T, W, SD, g); }
-__global__ __launch_bounds__(64) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
+__global__ __launch_bounds__(ATH_NT) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
 __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ PsyBLds L;
     kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
@@ -590,7 +590,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
-    LAUNCH(KT_SCAN, g_scan_ath, S, st, T, W, dSD);
+    LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
