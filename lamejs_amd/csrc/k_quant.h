@@ -130,16 +130,14 @@ struct QuantLds {
         struct { int32_t bstat[16][SBMAX_l + 2]; int16_t cand[21][16]; } hd;   // cand: bits clipped to 0x7fff (LARGE_BITS marker)
     };
     int16_t ixw[576];            // l3_enc of the working copy (cod_info_w)
-    int16_t ixb[576];            // l3_enc of the best/kept copy (cod_info)
     int32_t sfw[SFBMAX + 1], sfb[SFBMAX + 1];     // scalefac working / kept
     int32_t width[SFBMAX + 1], window[SFBMAX + 1], start[SFBMAX + 2];
     float xmin[SFBMAX + 1], distort[SFBMAX + 1];
     int32_t pn_step[SFBMAX + 1];
     float pn_noise[SFBMAX + 1], pn_noise_log[SFBMAX + 1];
-    int32_t qmode[SFBMAX + 1], qlen[SFBMAX + 1];
-    int32_t nstart[SFBMAX + 1], npairs[SFBMAX + 1], ncached[SFBMAX + 1];
+    int32_t qmode[SFBMAX + 1];
     struct BandInfo { int32_t nstart, nend, kind; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range + term formula per band
-    int32_t sf_gr0[2][SFBMAX + 1];                // final gr0 scalefactors per channel (for scfsi)
+    int8_t sf_gr0[2][SFBMAX + 1];                 // final gr0 scalefactors per channel (for scfsi): -2..15
     union {                      // calc_noise band sums live only inside the outer loop, the split tables only after it
         struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
         double nsum[SFBMAX + 1];
@@ -730,44 +728,27 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
                            int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
-    // 1) start-line walk (QuantizePVT.js:806-830): j advances by the band width until the first band that
-    //    reaches past max_nonzero_coeff; up to there everything is regular and computed one lane per band,
-    //    the (few) bands from that point on are walked serially by lane 0.
+    // 1) summing range and error formula per band (calc_noise_core's branches).  The reference walks a start line j
+    //    from band to band (QuantizePVT.js:806-830); j stays aligned with the band starts up to the first band that
+    //    reaches past max_nonzero_coeff (`firstcut`), that band is summed over its useful part only, and for every
+    //    later band the walk leaves no pairs at all (j + width > max_nonzero_coeff with j >= max_nonzero_coeff).
     uint64_t m_cut = 0;
+    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL)
+        if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m_cut |= 1ull << sfb;
+    m_cut = wave_lane_bits(m_cut);
+    const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
         const int s = sf_step(Q, g, scalefac, L.window, sfb);
         const int cached = (use_pn && L.pn_step[sfb] == s);
-        L.qmode[sfb] = s;                                   // step of the band (reused by the term pass)
-        L.ncached[sfb] = cached; L.nstart[sfb] = L.start[sfb]; L.npairs[sfb] = cached ? 0 : (L.width[sfb] >> 1);
-        if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m_cut |= 1ull << sfb;
-    }
-    m_cut = wave_lane_bits(m_cut);
-    const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
-    wave_sync();
-    if (lane == 0 && firstcut < g.psymax) {
-        int j = L.start[firstcut];
-        for (int sfb = firstcut; sfb < g.psymax; sfb++) {
-            L.nstart[sfb] = j;
-            if (L.ncached[sfb]) { L.npairs[sfb] = 0; j += L.width[sfb]; }
-            else {
-                int l = L.width[sfb] >> 1;
-                if ((j + L.width[sfb]) > g.max_nonzero_coeff) {
-                    const int usefullsize = g.max_nonzero_coeff - j + 1;
-                    l = usefullsize > 0 ? usefullsize >> 1 : 0;
-                }
-                L.npairs[sfb] = l;
-                j += 2 * l;
-            }
-        }
-    }
-    wave_sync();
-    // per band: summing range and which of the three error formulas applies (calc_noise_core's branches)
-    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
-        const int js = L.nstart[sfb];
+        L.qmode[sfb] = s;                                   // step of the band (stored into the cache below)
+        const int js = L.start[sfb], w = L.width[sfb];
+        int l = w >> 1;
+        if (sfb == firstcut) { const int usefullsize = g.max_nonzero_coeff - js + 1; l = usefullsize > 0 ? usefullsize >> 1 : 0; }
+        if (sfb > firstcut || cached) l = 0;
         QuantLds::BandInfo bi;
-        bi.nstart = js; bi.nend = js + 2 * L.npairs[sfb];
-        bi.kind = L.ncached[sfb] ? 0 : (js > g.count1) ? 1 : (js > g.big_values) ? 2 : 3;
-        bi.step = Q.pow20[L.qmode[sfb] + Q_MAX2];
+        bi.nstart = js; bi.nend = js + 2 * l;
+        bi.kind = cached ? 0 : (js > g.count1) ? 1 : (js > g.big_values) ? 2 : 3;
+        bi.step = Q.pow20[s + Q_MAX2];
         L.binfo[sfb] = bi;
     }
     wave_sync();
@@ -1079,10 +1060,12 @@ LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // 
 // bin_search_StepSize (Quantize.js:322-381) + outer_loop (Quantize.js:871-1052) as ONE state machine, so that the
 // three big building blocks -- count_bits, calc_noise, balance_noise -- are each instantiated exactly once
 // (code size decides instruction-cache behaviour here).  Everything runs on the working copy `w`
-// (ixw / sfw); `g` (ixb / sfb) is the kept quantization, exactly the reference's cod_info / cod_info_w pair
+// (ixw / sfw); `g` (kept spectrum in HBM / sfb) is the kept quantization, exactly the reference's cod_info / cod_info_w pair
 // with the roles of the first copy swapped (bin search on w, then g = w).
+// `kept` (HBM, this granule-channel's slot of W.l3) receives the quantized spectrum of the kept copy whenever a better
+// quantization is found; it is read back into L.ixw once the loop has finished (the working copy is dead then).
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
-                           int lane, QuantLds& L, const QuantTabs& Q) {
+                           int16_t* kept, int lane, QuantLds& L, const QuantTabs& Q) {
     enum { ST_BS, ST_BSUP, ST_A, ST_B };
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
@@ -1137,7 +1120,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (lane == 0) L.bs_ntab = nbs;
             if (0 == T.noise_shaping) {
                 g = w;
-                for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = L.ixw[i];
+                for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
                 for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sfb[i] = L.sfw[i];
                 wave_sync();
                 return;
@@ -1161,7 +1144,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (!first) best_part2_3_length = g.part2_3_length;   // value BEFORE the copy (reference quirk)
             best = ni;
             g = w;
-            for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = L.ixw[i];
+            for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
             for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sfb[i] = L.sfw[i];
             wave_sync();
             age = 0;
@@ -1194,7 +1177,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
         for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) {
             const int st = L.start[sfb], w = L.width[sfb];
             int nz = 0;
-            for (int j = st; j < st + w; j++) if (L.ixb[j] != 0) { nz = 1; break; }
+            for (int j = st; j < st + w; j++) if (L.ixw[j] != 0) { nz = 1; break; }
             if (!nz) { sf[sfb] = -2; any = 1; }
         }
         if (wave_any(any)) recalc = -2;
@@ -1222,7 +1205,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     for (int i = 0; i < 4; i++) scfsi[i] = 0;
     if (T.mode_gr == 2 && gr == 1 && uni(gr0_block_type) != SHORT_TYPE && g.block_type != SHORT_TYPE) {
         // scfsi_calc: uniform scalar code over 21 bands, reading gr0's final scalefactors
-        const int32_t* g0 = L.sf_gr0[ch];
+        const int8_t* g0 = L.sf_gr0[ch];
         for (int i = 0; i < 4; i++) {
             int sfb, same = 1;
             for (sfb = T.scfsi_band[i]; sfb < T.scfsi_band[i + 1]; sfb++)
@@ -1369,7 +1352,7 @@ LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, int lane
 
 LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
-    const int16_t* ix = L.ixb;
+    const int16_t* ix = L.ixw;
     GI c2 = g;
     if (g.block_type == NORM_TYPE) {
         // recalc_divide_init: every (region0, region1) split evaluated from the per-band statistics
@@ -1547,12 +1530,16 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             if (q_init_xrpow(g, lane, L, Q)) {
                 active = 1;
                 { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
-                q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, lane, L, Q);
+                int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+                q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, lane, L, Q);
                 uni_gi(g); bs_gain = uni(bs_gain);
+                wave_sync();                                    // the kept spectrum was written by other lanes of this wave
+                for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
+                wave_sync();
                 Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
                 if (ch == 0) seed0 = nx; else seed1 = nx;
             } else {
-                for (int i = lane; i < 576; i += LHIP_NL) L.ixb[i] = 0;
+                for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = 0;
                 wave_sync();
             }
             int scfsi[4];
@@ -1563,7 +1550,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             ResvSize = uni(ResvSize - (g.part2_3_length + g.part2_length));
             if (gr == 0) {
                 if (ch == 0) gr0_bt0 = g.block_type; else gr0_bt1 = g.block_type;
-                for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sf_gr0[ch][i] = L.sfb[i];
+                for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sf_gr0[ch][i] = (int8_t)L.sfb[i];
             }
             // ---- publish the record and the signed quantized spectrum ----
             GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
@@ -1587,7 +1574,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             }
             int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
             for (int i = lane; i < 576; i += LHIP_NL) {
-                const int v = L.ixb[i];
+                const int v = L.ixw[i];
                 l3o[i] = (int16_t)(((double)L.xr[i] < 0) ? -v : v);
             }
             wave_sync();
@@ -1659,7 +1646,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
                         inited = 1;
                     }
                     g.global_gain = gain;
-                    nBits = q_count_bits(T, g, L.sfb, L.ixb, 0, pn_none, lane, L, Q);
+                    nBits = q_count_bits(T, g, L.sfb, L.ixw, 0, pn_none, lane, L, Q);
                 }
                 nBits = uni(nBits);
                 if (!up) {

@@ -177,10 +177,10 @@ __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const Stream
     __shared__ MdctLds L;
     kb_mdct(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-// quantization kernels: 4 waves (= 4 frames) per workgroup share one copy of the lookup tables in LDS
-enum { QWAVES = 4 };
+// quantization kernels: 8 waves (= 8 frames) per workgroup share one copy of the lookup tables in LDS
+enum { QWAVES = 8 };
 #ifndef LHIP_QOCC
-#define LHIP_QOCC 3     /* waves per SIMD the quantization kernel is register-budgeted for */
+#define LHIP_QOCC 4     /* waves per SIMD the quantization kernels are register-budgeted for */
 #endif
 __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain, int nfs) {
     __shared__ QuantTabs Q;
