@@ -885,12 +885,15 @@ LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lan
             }
         }
     }
-    int m1 = 0, m2 = 0;
+    // slen1_n / slen2_n are powers of two, and "every value < 2^b" is "the OR of the values < 2^b": the two maxima
+    // of the reference become one OR reduction of (part 1 | part 2 << 8)
+    int m12 = 0;
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) {
         const int v = scalefac[sfb];
-        if (sfb < g.sfbdivide) { if (m1 < v) m1 = v; } else { if (m2 < v) m2 = v; }
+        m12 |= (sfb < g.sfbdivide) ? v : (v << 8);
     }
-    m1 = wave_max(m1); m2 = wave_max(m2);
+    m12 = wave_or(m12);
+    const int m1 = m12 & 0xff, m2 = m12 >> 8;
     // first k with the smallest tab[k] among the admissible ones == minimum of (tab[k], k) pairs; one lane per k
     int best = 0x7fffffff;
     for (int k = lane; k < 16; k += LHIP_NL)
@@ -911,16 +914,19 @@ LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantL
     return !wave_any(z);
 }
 
-// multiply xrpow of the flagged bands (L.qmode[sfb] = 1) by `amp`, tracking xrpow_max
-LHIP_DEV void q_amplify_flagged(GI& g, double amp, int lane, QuantLds& L, const QuantTabs& Q) {
+// multiply xrpow of the flagged bands (bit sfb of m_amp) by `amp`, tracking xrpow_max
+LHIP_DEV void q_amplify_flagged(GI& g, double amp, uint64_t m_amp, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     float m = 0.f;
-    for (int i = lane; i < 576; i += LHIP_NL) {
-        const int sfb = line2sfb(Q, g.block_type)[i];
-        if (L.qmode[sfb]) {
-            const float v = (float)((double)L.xrpow[i] * amp);
-            L.xrpow[i] = v;
-            if (v > m) m = v;
+    const uint8_t* l2s = line2sfb(Q, g.block_type);
+    for (int p = 2 * lane; p < 576; p += 2 * LHIP_NL) {        // pairs never straddle a band
+        if ((m_amp >> l2s[p]) & 1) {
+            struct F2 { float x, y; };
+            F2 xx = *(const F2*)(L.xrpow + p);
+            xx.x = (float)((double)xx.x * amp); xx.y = (float)((double)xx.y * amp);
+            *(F2*)(L.xrpow + p) = xx;
+            if (xx.x > m) m = xx.x;
+            if (xx.y > m) m = xx.y;
         }
     }
     m = wave_maxf(m);
@@ -945,38 +951,28 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
             else trigger *= .95;
             break;
     }
-    uint64_t m_amp = 0;
-    for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) {
-        int f = 0;
-        if (sfb < g.sfbmax && !((double)L.distort[sfb] < trigger)) { f = 1; m_amp |= 1ull << sfb; }
-        L.qmode[sfb] = f;
-    }
+    uint64_t m_amp = 0;                                  // bit sfb: band is amplified
+    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL)
+        if (!((double)L.distort[sfb] < trigger)) m_amp |= 1ull << sfb;
     m_amp = wave_lane_bits(m_amp);
-    const int first = m_amp ? (int)__builtin_ctzll(m_amp) : 99;
-    wave_sync();
-    if (T.noise_shaping_amp == 2) {          // amplify exactly one band
-        for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) L.qmode[sfb] = (sfb == first) ? 1 : 0;
-        wave_sync();
-    }
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (L.qmode[sfb]) scalefac[sfb]++;
-    q_amplify_flagged(g, ifqstep34, lane, L, Q);
+    if (T.noise_shaping_amp == 2 && m_amp) m_amp = 1ull << __builtin_ctzll(m_amp);     // amplify exactly one band
+    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if ((m_amp >> sfb) & 1) scalefac[sfb]++;
+    q_amplify_flagged(g, ifqstep34, m_amp, lane, L, Q);
 }
 
 LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
-    for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) {
-        int f = 0;
-        if (sfb < g.sfbmax) {
-            int s = scalefac[sfb];
-            if (g.preflag != 0) s += T.pretab[sfb];
-            if ((s & 1) != 0) { s++; f = 1; }
-            scalefac[sfb] = s >> 1;
-        }
-        L.qmode[sfb] = f;
+    uint64_t m_amp = 0;
+    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) {
+        int s = scalefac[sfb];
+        if (g.preflag != 0) s += T.pretab[sfb];
+        if ((s & 1) != 0) { s++; m_amp |= 1ull << sfb; }
+        scalefac[sfb] = s >> 1;
     }
+    m_amp = wave_lane_bits(m_amp);
     wave_sync();
     g.preflag = 0;
     g.scalefac_scale = 1;
-    q_amplify_flagged(g, 1.29683955465100964055, lane, L, Q);
+    q_amplify_flagged(g, 1.29683955465100964055, m_amp, lane, L, Q);
 }
 
 // inc_subblock_gain (Quantize.js:705-778); returns 1 on failure.  Short blocks only (sfb_lmax == 0).

@@ -178,7 +178,11 @@ __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const Stream
     kb_mdct(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
 // quantization kernels: 8 waves (= 8 frames) per workgroup share one copy of the lookup tables in LDS
+#ifdef LHIP_PHASE_PROF
+enum { QWAVES = 7 };      /* the profiling counters take LDS: 7 waves keep two workgroups per CU */
+#else
 enum { QWAVES = 8 };
+#endif
 #ifndef LHIP_QOCC
 #define LHIP_QOCC 4     /* waves per SIMD the quantization kernels are register-budgeted for */
 #endif
