@@ -186,23 +186,34 @@ enum { QWAVES = 8 };
 #ifndef LHIP_QOCC
 #define LHIP_QOCC 4     /* waves per SIMD the quantization kernels are register-budgeted for */
 #endif
-__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain, int nfs) {
+// Persistent workgroups: each wave draws the next frame slot from a global dispenser until none is left, so a
+// workgroup never idles on its slowest frame (frames differ a lot in the number of quantization rounds they need) and
+// the table copy in LDS is made once per workgroup, not once per 8 frames.
+LHIP_DEV int next_frame_slot(int32_t* ctr) {
+    int v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain, int nfs, int ctr) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fslot = blockIdx.x * QWAVES + wv;   // wave index as an SGPR: everything derived from it stays scalar
-    if (fslot >= nfs) return;
-    kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv], Q);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index as an SGPR: everything derived from it stays scalar
+    for (;;) {
+        const int fslot = next_frame_slot(W.work_ctr + ctr);
+        if (fslot >= nfs) break;
+        kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv], Q);
+    }
 }
 __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fslot = blockIdx.x * QWAVES + wv;   // wave index as an SGPR: everything derived from it stays scalar
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fslot = blockIdx.x * QWAVES + wv;
     if (fslot >= nfs) return;
-    kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv], Q);
+    kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv], Q);    // a replay is a handful of scalar look-ups: static mapping
 }
 __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ BitsLds L;
@@ -407,6 +418,7 @@ struct Context {
         ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, frame_bytes, sd, io, in16, out8, prof;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0; bool have_last = false;
+    int num_cus = 256;
 };
 
 static std::mutex g_ctx_mu;
@@ -418,6 +430,9 @@ static Context* get_context(int device) {
     if (it != g_ctx.end()) return it->second.get();
     std::unique_ptr<Context> c(new Context());
     c->device = device;
+#ifndef LHIP_HOSTSIM
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->num_cus = n; }
+#endif
     Context* r = c.get();
     g_ctx[device] = std::move(c);
     return r;
@@ -511,7 +526,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
-    W.nflagged = (int32_t*)ctx->nflagged.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
+    W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 8; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
@@ -598,9 +613,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
-    LAUNCHB(KT_QUANT, g_quant, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, 0, nfs);
+    // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
+    int qgrid = (nfs + QWAVES - 1) / QWAVES;
+    if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
+    LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, T, ts.pb10, W, dSD, 0, nfs, 0);
     if (nfr > 0) {
         for (;;) {
+            if (!rt::dzero((int32_t*)ctx->nflagged.p + 8, 32, st)) return false;
             LAUNCHB(KT_VALIDATE, g_validate, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, nfs);
             int32_t nf = 0;
             if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
@@ -608,7 +627,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             if (nf == 0) break;
             repaired += nf; iters++;
             if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
-            LAUNCHB(KT_REPAIR, g_quant, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, 1, nfs);
+            LAUNCHB(KT_REPAIR, g_quant, qgrid, 64 * QWAVES, st, T, ts.pb10, W, dSD, 1, nfs, 2);
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
     }

@@ -69,6 +69,7 @@ struct Workspace {
     int32_t* seed;              // [nfslots][C][2]  OldValue, CurrentStep after the frame in that slot
     int32_t* seed_flag;         // [nframes_total] 1 = frame must be (re)quantized with the chain-implied seed
     int32_t* nflagged;          // [1]
+    int32_t* work_ctr;          // [8] frame-slot dispensers of the persistent quantization kernels (zeroed per launch)
     uint8_t* out;               // output MP3 bytes
     int32_t* frame_bytes;       // [nframes_total]
     unsigned long long* prof;   // [32] phase-profiling accumulators (profiling builds only)
