@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40000, help="bounded sample for the CPU baseline (0 = skip)")
     ap.add_argument("--channels", type=int, default=1, help="1 = BASELINE configs[1] (the metric's configuration); 2 = configs[2]/[3]")
     ap.add_argument("--kbps", type=int, default=128)
+    ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU in one batch launch (BASELINE configs[4]: 128 x 1000 frames)")
     ap.add_argument("--check-frames", type=int, default=2000, help="prefix checked against the CPU oracle")
     args = ap.parse_args()
 
@@ -69,11 +70,15 @@ def main():
     else:
         blob = lamejs_amd.tables_blob(CH, SR, KBPS)
 
-    L, R = pcm.sine(nsamp, CH, seed=12345 + rank)            # rank r owns stream r (lamejs_amd.shard.shard_streams(world, world, r))
-    d_pcm = torch.from_numpy(L).to(dev)                      # Int16 PCM resident in HBM
-    d_pcm_r = torch.from_numpy(R).to(dev) if CH == 2 else d_pcm
+    NS = args.streams
+    # rank r owns streams r*NS .. r*NS+NS-1 (lamejs_amd.shard); one stream: seed 12345 + rank (configs[1..3]), many: 1000 + s (configs[4])
+    seeds = [12345 + rank] if NS == 1 else [1000 + rank * NS + i for i in range(NS)]
+    pcs = [pcm.sine(nsamp, CH, seed=sd_) for sd_ in seeds]
+    L, R = pcs[0]
+    d_l = [torch.from_numpy(p[0]).to(dev) for p in pcs]      # Int16 PCM resident in HBM
+    d_r = [torch.from_numpy(p[1]).to(dev) for p in pcs] if CH == 2 else d_l
     out_cap = (nfr + 4) * (144000 * KBPS // SR + 1)
-    d_out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
+    d_out = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(NS)]
 
     cfg = lamejs_amd._Config(CH, SR, KBPS, local_rank)
     bbuf = ctypes.create_string_buffer(blob, len(blob))
@@ -85,16 +90,21 @@ def main():
         return h
 
     lib.lhip_set_hip_stream(local_rank, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    H1 = ctypes.c_void_p * 1
-    S1 = ctypes.c_size_t * 1
-    wr = (ctypes.c_int64 * 1)()
+    HN = ctypes.c_void_p * NS
+    SN = ctypes.c_size_t * NS
+    wr = (ctypes.c_int64 * NS)()
+    a_l = HN(*[t.data_ptr() for t in d_l]); a_r = HN(*[t.data_ptr() for t in d_r]); a_o = HN(*[t.data_ptr() for t in d_out])
+    a_n = SN(*([nsamp] * NS)); a_c = SN(*([out_cap] * NS))
 
-    def step(h):
-        rc = lib.lhip_encode_batch_device(H1(h), 1, H1(d_pcm.data_ptr()), H1(d_pcm_r.data_ptr()), S1(nsamp), H1(d_out.data_ptr()), S1(out_cap), wr, 0)
+    def step(hs):
+        rc = lib.lhip_encode_batch_device(HN(*hs), NS, a_l, a_r, a_n, a_o, a_c, wr, 0)
         assert rc == 0, lib.lhip_last_error()
         return wr[0]
 
-    streams = [new_stream() for _ in range(args.warmup + args.steps)]
+    def new_streams():
+        return [new_stream() for _ in range(NS)]
+
+    streams = [new_streams() for _ in range(args.warmup + args.steps)]
     for w in range(args.warmup):
         step(streams[w])
     torch.cuda.synchronize()
@@ -120,7 +130,7 @@ def main():
     a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     lib.lhip_last_batch_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
     frames_per_step = a.value
-    mp3 = d_out[:nbytes].cpu().numpy().tobytes()
+    mp3 = d_out[0][:nbytes].cpu().numpy().tobytes()
 
     # parity spot check against the CPU oracle on a prefix (bit-exact) -- checker only, outside the timed region
     parity = None
@@ -132,7 +142,7 @@ def main():
 
     # per-kernel timing pass (untimed extra step with HIP events on the launch stream)
     kern = {}
-    extra = new_stream()
+    extra = new_streams()
     nk = lib.lhip_kernel_timing(1)
     step(extra)
     torch.cuda.synchronize()
@@ -159,8 +169,8 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: mono 44.1kHz 128kbps CBR, {nfr} synthetic sine+noise frames, one stream per GPU" if (CH, KBPS) == (1, 128)
-                                    else f"{'stereo' if CH == 2 else 'mono'} 44.1kHz {KBPS}kbps CBR, {nfr} synthetic sine+noise frames, one stream per GPU"),
+            "config": {"workload": (f"BASELINE configs[1]: mono 44.1kHz 128kbps CBR, {nfr} synthetic sine+noise frames, one stream per GPU" if (CH, KBPS, NS) == (1, 128, 1)
+                                    else f"{'stereo' if CH == 2 else 'mono'} 44.1kHz {KBPS}kbps CBR, {NS} stream(s) x {nfr} synthetic sine+noise frames per GPU"),
                        "frames_per_step_per_gpu": frames_per_step, "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
                        "bit_exact_prefix_vs_oracle": parity, "seed_repaired_frames": b.value, "output_md5_per_rank": digests},
             "kernels_ms": kern,
@@ -173,7 +183,7 @@ def main():
             # runs, gfx950 FETCH_SIZE x2 correction) -- measured offline on this exact workload, committed under profiles/
             traffic = None
             pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic_mono128_1e5.json"
-            if (CH, KBPS, nfr) == (1, 128, 100000) and pmc.exists():
+            if (CH, KBPS, nfr, NS) == (1, 128, 100000, 1) and pmc.exists():
                 try:
                     traffic = json.loads(pmc.read_text())["kernels"]["g_" + dom]["hbm_bytes_per_launch"]
                 except (KeyError, ValueError):
