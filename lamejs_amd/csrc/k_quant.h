@@ -737,6 +737,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m_cut |= 1ull << sfb;
     m_cut = wave_lane_bits(m_cut);
     const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
+    int maxlen = 0;                                          // longest summing range of this call (cached bands have none)
     for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
         const int s = sf_step(Q, g, scalefac, L.window, sfb);
         const int cached = (use_pn && L.pn_step[sfb] == s);
@@ -745,12 +746,14 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         int l = w >> 1;
         if (sfb == firstcut) { const int usefullsize = g.max_nonzero_coeff - js + 1; l = usefullsize > 0 ? usefullsize >> 1 : 0; }
         if (sfb > firstcut || cached) l = 0;
+        if (maxlen < 2 * l) maxlen = 2 * l;
         QuantLds::BandInfo bi;
         bi.nstart = js; bi.nend = js + 2 * l;
         bi.kind = cached ? 0 : (js > g.count1) ? 1 : (js > g.big_values) ? 2 : 3;
         bi.step = Q.pow20[s + Q_MAX2];
         L.binfo[sfb] = bi;
     }
+    maxlen = wave_max(maxlen);
     wave_sync();
     PH_MARK(L, PH_N_WALK, tm_);
     // 2) squared errors summed per band in the reference's line order (f64 sums are order-sensitive) as a
@@ -785,10 +788,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             lastb[k] = bnd; prevb = bnd;
         }
         // NLN <= 32 on the device; the one-lane host build folds everything in a single pass below
-        int maxw = 0;
-        for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) if (maxw < L.width[sfb]) maxw = L.width[sfb];
-        maxw = wave_max(maxw);
-        const int nsteps = (LHIP_NL == 1) ? 1 : (maxw + NLN - 1) / NLN + 1;
+        const int nsteps = (LHIP_NL == 1) ? 1 : (maxlen + NLN - 1) / NLN + 1;
         // keep[k] = 0 at a band start, 1 elsewhere: fma(sum, keep, t) is `sum + t` or `t` with ONE rounding, i.e.
         // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit
         double keep[NLN];
@@ -851,8 +851,10 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     }
     PH_MARK(L, PH_N_TERMS, tm_);
     if (use_pn) pn.gain = g.global_gain;
-    res->over_count = wave_sum(over);
-    res->over_SSD = wave_sum(ssd);
+    {   // over <= 39 bands and over_SSD <= 39 * 400^2 < 2^25: one packed integer reduction
+        const int os = wave_sum((ssd << 6) | over);
+        res->over_count = os & 63; res->over_SSD = os >> 6;
+    }
     res->max_noise = wave_maxd(max_noise);
     wave_sync();
     PH_MARK(L, PH_N_SUMS, tm_);
