@@ -194,16 +194,18 @@ LHIP_DEV int next_frame_slot(int32_t* ctr) {
     if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1);
     return __builtin_amdgcn_readfirstlane(v);
 }
-__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int chain, int nfs, int ctr) {
+struct QArgs { Tables T; PowBase pb; Workspace W; const StreamDesc* SD; int chain, nfs, ctr; };
+__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
-    q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
+    const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    q_load_tabs(A->T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index as an SGPR: everything derived from it stays scalar
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (;;) {
-        const int fslot = next_frame_slot(W.work_ctr + ctr);
-        if (fslot >= nfs) break;
-        kb_quant(T, pb, W, SD, fslot, chain, threadIdx.x & 63, L[wv], Q);
+        const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
+        if (fslot >= A->nfs) break;
+        kb_quant(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q);
     }
 }
 __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
@@ -616,7 +618,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
-    LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, T, ts.pb10, W, dSD, 0, nfs, 0);
+    { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0; LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
     if (nfr > 0) {
         for (;;) {
             if (!rt::dzero((int32_t*)ctx->nflagged.p + 8, 32, st)) return false;
@@ -627,7 +629,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             if (nf == 0) break;
             repaired += nf; iters++;
             if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
-            LAUNCHB(KT_REPAIR, g_quant, qgrid, 64 * QWAVES, st, T, ts.pb10, W, dSD, 1, nfs, 2);
+            { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 2; LAUNCHB(KT_REPAIR, g_quant, qgrid, 64 * QWAVES, st, qa); }
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
     }
