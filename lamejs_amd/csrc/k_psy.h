@@ -96,6 +96,14 @@ struct PsyALds {
 #define PSYA_AV(L) ((L).fz + 516 + 2 * CBANDS)
 #define PSYA_EBS(L, b) ((L).fz + 516 + (3 + (b)) * CBANDS)
 
+#if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
+#define PSY_STAMP(i) const unsigned long long psy_t##i = __builtin_amdgcn_s_memtime()
+#define PSY_FLUSH() do { if (lane == 0) { const unsigned long long t_[8] = {psy_t0, psy_t1, psy_t2, psy_t3, psy_t4, psy_t5, psy_t6, psy_t7}; \
+    for (int i_ = 0; i_ < 7; i_++) atomicAdd((unsigned long long*)W.prof + 22 + i_, t_[i_ + 1] - t_[i_]); atomicAdd((unsigned long long*)W.prof + 54, 1ull); } } while (0)
+#else
+#define PSY_STAMP(i) do {} while (0)
+#define PSY_FLUSH() do {} while (0)
+#endif
 // one wave per (granule slot >= 1 of a stream, channel)
 LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int ch, int lane, PsyALds& L) {
     const int C = T.channels_out;
@@ -105,6 +113,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     if (q < 0) return;                                // carry slot: nothing to compute
     const float* buf = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 304;
     const int64_t o = (int64_t)gslot * C + ch;
+    PSY_STAMP(0);
 
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
     {
@@ -127,6 +136,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
     }
 
+    PSY_STAMP(1);
     // --- windowing + first radix-4 stage (FFT.js:185-221 long, 140-180 short) ---
     for (int jj = lane; jj < BLKSIZE / 8; jj += LHIP_NL) {
         const int i = T.fft_rv_tbl[jj] & 0xff;
@@ -172,6 +182,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
 
+    PSY_STAMP(2);
     // --- remaining FHT passes; twiddle table offsets 0,1,8,39 (pass t has kx-1 entries) ---
     {
         int off = 0;
@@ -187,6 +198,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
     }
 
+    PSY_STAMP(3);
     // --- energies (PsyModel.js:274-296), written over the lower halves of the transform buffers ---
     {
         enum { KE = (BLKSIZE / 2 + 1 + LHIP_NL - 1) / LHIP_NL, KS = (3 * (BLKSIZE_s / 2 + 1) + LHIP_NL - 1) / LHIP_NL };
@@ -219,6 +231,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
 
+    PSY_STAMP(4);
     // --- loudness: strictly sequential f64 sum (PsyModel.js:241-249), products in parallel, ordered fold ---
     {
         enum { K = (BLKSIZE / 2) / LHIP_NL };
@@ -230,6 +243,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         if (lane == 0) W.loud[o] = (float)lp;
     }
 
+    PSY_STAMP(5);
     // --- long partitions: energy, max, average (calc_energy, PsyModel.js:906-928) ---
     for (int b = lane; b < T.npart_l; b += LHIP_NL) {
         double ebb = 0, m = 0;
@@ -253,6 +267,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
 
+    PSY_STAMP(6);
     // --- tonality index (calc_mask_index_l, PsyModel.js:930-992) ---
     for (int b = lane; b < CBANDS; b += LHIP_NL) {
         int k = 0;
@@ -292,6 +307,8 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         W.ecb_s[o * EBS_STRIDE + it] = ecbv;
         W.eb_s[o * EBS_STRIDE + it] = ebv;
     }
+    PSY_STAMP(7);
+    PSY_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------

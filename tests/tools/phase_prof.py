@@ -20,3 +20,9 @@ for corpus, ch, kbps in [("sine", 1, 128), ("sine", 2, 128)]:
     for i, n in enumerate(names):
         if buf[32 + i]:
             print(f"   {n:9s} {100.0 * buf[i] / tot:5.1f}%  calls/frame {buf[32 + i] / nfr:7.2f}  cycles/call {buf[i] / buf[32 + i]:9.0f}")
+    if buf[54]:
+        pn = ["hpf_peaks", "window+r4", "fht", "energies", "loudness", "partitions", "tonal+spread"]
+        tp = sum(buf[22 + i] for i in range(7))
+        print(f"   psyA: {tp / buf[54]:.0f} cycles per (granule, channel) wave")
+        for i, n in enumerate(pn):
+            print(f"      {n:13s} {100.0 * buf[22 + i] / tp:5.1f}%  {buf[22 + i] / buf[54]:9.0f}")
