@@ -28,58 +28,66 @@ LHIP_DEV void kb_prep_elem(const Tables& T, float* dst, const int16_t* src, int6
 // FHT butterflies, one radix-4 pass over n points held in LDS (FFT.js:45-112).
 // Work item t in [0, n/8): block m = t / kx, index i = t % kx inside the block.
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV void fht_item(float* fz, int k1, int kx, int t, const double* tw) {
+// The i == 0 butterfly of block m (no twiddles) and the i >= 1 butterflies are separate work lists, so that a
+// wave never executes both code paths for one batch of items.
+LHIP_DEV void fht_item0(float* fz, int k1, int kx, int m) {
     const int k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
-    const int m = t / kx, i = t - m * kx;
+    float* fi = fz + m * k4;
+    float* gi = fi + kx;
+    double f0, f1, f2, f3;
+    f1 = (double)fi[0] - (double)fi[k1];
+    f0 = (double)fi[0] + (double)fi[k1];
+    f3 = (double)fi[k2] - (double)fi[k3];
+    f2 = (double)fi[k2] + (double)fi[k3];
+    fi[k2] = (float)(f0 - f2);
+    fi[0] = (float)(f0 + f2);
+    fi[k3] = (float)(f1 - f3);
+    fi[k1] = (float)(f1 + f3);
+    f1 = (double)gi[0] - (double)gi[k1];
+    f0 = (double)gi[0] + (double)gi[k1];
+    f3 = LHIP_SQRT2 * (double)gi[k3];
+    f2 = LHIP_SQRT2 * (double)gi[k2];
+    gi[k2] = (float)(f0 - f2);
+    gi[0] = (float)(f0 + f2);
+    gi[k3] = (float)(f1 - f3);
+    gi[k1] = (float)(f1 + f3);
+}
+LHIP_DEV void fht_item1(float* fz, int k1, int kx, int m, int i, const double* tw) {
+    const int k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
     float* fi = fz + m * k4 + i;
-    if (i == 0) {
-        float* gi = fi + kx;
-        double f0, f1, f2, f3;
-        f1 = (double)fi[0] - (double)fi[k1];
-        f0 = (double)fi[0] + (double)fi[k1];
-        f3 = (double)fi[k2] - (double)fi[k3];
-        f2 = (double)fi[k2] + (double)fi[k3];
-        fi[k2] = (float)(f0 - f2);
-        fi[0] = (float)(f0 + f2);
-        fi[k3] = (float)(f1 - f3);
-        fi[k1] = (float)(f1 + f3);
-        f1 = (double)gi[0] - (double)gi[k1];
-        f0 = (double)gi[0] + (double)gi[k1];
-        f3 = LHIP_SQRT2 * (double)gi[k3];
-        f2 = LHIP_SQRT2 * (double)gi[k2];
-        gi[k2] = (float)(f0 - f2);
-        gi[0] = (float)(f0 + f2);
-        gi[k3] = (float)(f1 - f3);
-        gi[k1] = (float)(f1 + f3);
-    } else {
-        float* gi = fz + m * k4 + k1 - i;
-        const double c1 = tw[4 * (i - 1) + 0], s1 = tw[4 * (i - 1) + 1], c2 = tw[4 * (i - 1) + 2], s2 = tw[4 * (i - 1) + 3];
-        double a, b, g0, f0, f1, g1, f2, g2, f3, g3;
-        b = s2 * (double)fi[k1] - c2 * (double)gi[k1];
-        a = c2 * (double)fi[k1] + s2 * (double)gi[k1];
-        f1 = (double)fi[0] - a;
-        f0 = (double)fi[0] + a;
-        g1 = (double)gi[0] - b;
-        g0 = (double)gi[0] + b;
-        b = s2 * (double)fi[k3] - c2 * (double)gi[k3];
-        a = c2 * (double)fi[k3] + s2 * (double)gi[k3];
-        f3 = (double)fi[k2] - a;
-        f2 = (double)fi[k2] + a;
-        g3 = (double)gi[k2] - b;
-        g2 = (double)gi[k2] + b;
-        b = s1 * f2 - c1 * g3;
-        a = c1 * f2 + s1 * g3;
-        fi[k2] = (float)(f0 - a);
-        fi[0] = (float)(f0 + a);
-        gi[k3] = (float)(g1 - b);
-        gi[k1] = (float)(g1 + b);
-        b = c1 * g2 - s1 * f3;
-        a = s1 * g2 + c1 * f3;
-        gi[k2] = (float)(g0 - a);
-        gi[0] = (float)(g0 + a);
-        fi[k3] = (float)(f1 - b);
-        fi[k1] = (float)(f1 + b);
-    }
+    float* gi = fz + m * k4 + k1 - i;
+    const double c1 = tw[4 * (i - 1) + 0], s1 = tw[4 * (i - 1) + 1], c2 = tw[4 * (i - 1) + 2], s2 = tw[4 * (i - 1) + 3];
+    double a, b, g0, f0, f1, g1, f2, g2, f3, g3;
+    b = s2 * (double)fi[k1] - c2 * (double)gi[k1];
+    a = c2 * (double)fi[k1] + s2 * (double)gi[k1];
+    f1 = (double)fi[0] - a;
+    f0 = (double)fi[0] + a;
+    g1 = (double)gi[0] - b;
+    g0 = (double)gi[0] + b;
+    b = s2 * (double)fi[k3] - c2 * (double)gi[k3];
+    a = c2 * (double)fi[k3] + s2 * (double)gi[k3];
+    f3 = (double)fi[k2] - a;
+    f2 = (double)fi[k2] + a;
+    g3 = (double)gi[k2] - b;
+    g2 = (double)gi[k2] + b;
+    b = s1 * f2 - c1 * g3;
+    a = c1 * f2 + s1 * g3;
+    fi[k2] = (float)(f0 - a);
+    fi[0] = (float)(f0 + a);
+    gi[k3] = (float)(g1 - b);
+    gi[k1] = (float)(g1 + b);
+    b = c1 * g2 - s1 * f3;
+    a = s1 * g2 + c1 * f3;
+    gi[k2] = (float)(g0 - a);
+    gi[0] = (float)(g0 + a);
+    fi[k3] = (float)(f1 - b);
+    fi[k1] = (float)(f1 + b);
+}
+// one radix-4 pass over n points: the n/8 work items are the n/(8 kx) twiddle-free ones and the rest
+LHIP_DEV void fht_pass(float* fz, int n, int k1, int kx, int lane, int nl, int base, const double* tw) {
+    const int items = n / 8, nz = items / kx, kx1 = kx - 1;
+    for (int t = lane - base; t < nz; t += nl) if (t >= 0) fht_item0(fz, k1, kx, t);
+    for (int t = lane - base; t < items - nz; t += nl) if (t >= 0) { const int m = t / kx1; fht_item1(fz, k1, kx, m, 1 + t - m * kx1, tw); }
 }
 
 // LDS of one psy-A wave.  The energies overwrite the lower halves of the FHT buffers they are computed from
@@ -118,11 +126,16 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
     {
         const float* fir = buf + 397;                 // 576 - 350 - 21 + 192
+        // all nine sub-block outputs of a lane first (their loads are independent and overlap), the maxima after
+        enum { KP = (64 + LHIP_NL - 1) / LHIP_NL };
+        float pk[9];
+#pragma unroll
         for (int sbk = 0; sbk < 9; sbk++) {
             float m = 1.0f;
-            for (int l = lane; l < 64; l += LHIP_NL) {
-                const int i = sbk * 64 + l;
+            for (int u = 0; u < KP; u++) {
+                const int i = sbk * 64 + lane + LHIP_NL * u;
                 double sum1 = (double)fir[i + 10], sum2 = 0.0;
+#pragma unroll
                 for (int j = 0; j < 9; j += 2) {
                     sum1 += T.hpf_fircoef[j] * ((double)fir[i + j] + (double)fir[i + 21 - j]);
                     sum2 += T.hpf_fircoef[j + 1] * ((double)fir[i + j + 1] + (double)fir[i + 21 - j - 1]);
@@ -131,8 +144,13 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
                 v = v < 0 ? -v : v;
                 if (m < v) m = v;
             }
-            m = wave_maxf(m);
-            if (lane == 0) W.peaks[o * PK_STRIDE + sbk] = m;
+            pk[sbk] = m;
+        }
+#pragma unroll
+        for (int sbk = 0; sbk < 9; sbk++) pk[sbk] = wave_maxf(pk[sbk]);
+        if (lane == 0) {
+#pragma unroll
+            for (int sbk = 0; sbk < 9; sbk++) W.peaks[o * PK_STRIDE + sbk] = pk[sbk];
         }
     }
 
@@ -186,13 +204,11 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     // --- remaining FHT passes; twiddle table offsets 0,1,8,39 (pass t has kx-1 entries) ---
     {
         int off = 0;
+#pragma unroll
         for (int k1 = 4, kx = 2; k1 < BLKSIZE; k1 <<= 2, kx <<= 2) {
-            for (int t = lane; t < BLKSIZE / 8; t += LHIP_NL) fht_item(L.fz, k1, kx, t, T.fht_twiddle + 4 * off);
+            fht_pass(L.fz, BLKSIZE, k1, kx, lane, LHIP_NL, 0, T.fht_twiddle + 4 * off);
             if (k1 < BLKSIZE_s)
-                for (int t = lane; t < 3 * (BLKSIZE_s / 8); t += LHIP_NL) {
-                    const int b = t / (BLKSIZE_s / 8);
-                    fht_item(L.fs[b], k1, kx, t - b * (BLKSIZE_s / 8), T.fht_twiddle + 4 * off);
-                }
+                for (int b = 0; b < 3; b++) fht_pass(L.fs[b], BLKSIZE_s, k1, kx, lane, LHIP_NL, 0, T.fht_twiddle + 4 * off);
             wave_sync();
             off += kx - 1;
         }
@@ -293,19 +309,29 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         W.mask_idx[o * EBL_STRIDE + b] = k;
     }
     // --- short spreading (compute_masking_s second loop before limiting, 752-760) ---
-    for (int it = lane; it < 3 * CBANDS; it += LHIP_NL) {
-        const int sblock = it / CBANDS, b = it - sblock * CBANDS;
-        float ecbv = 0.f, ebv = 0.f;
+    // lane = partition; its spreading row is fetched once (independent loads) and applied to the three sub-blocks
+    for (int b = lane; b < CBANDS; b += LHIP_NL) {
+        float ecbv[3] = {0.f, 0.f, 0.f}, ebv[3] = {0.f, 0.f, 0.f};
         if (b < T.npart_s) {
-            int kk = T.s3ind_s[2 * b], j = T.s3off_s[b];
-            double ecb = (double)T.s3_ss[j++] * (double)PSYA_EBS(L, sblock)[kk];
-            ++kk;
-            while (kk <= T.s3ind_s[2 * b + 1]) { ecb += (double)T.s3_ss[j] * (double)PSYA_EBS(L, sblock)[kk]; ++j; ++kk; }
-            ecbv = (float)ecb;
-            ebv = PSYA_EBS(L, sblock)[b];
+            enum { MT = 12 };                         // rows are at most 12 long for every MPEG-1 rate; longer rows take the tail loop
+            const int k0 = T.s3ind_s[2 * b], k1 = T.s3ind_s[2 * b + 1], j0 = T.s3off_s[b];
+            float cf[MT];
+#pragma unroll
+            for (int u = 0; u < MT; u++) cf[u] = (k0 + u <= k1) ? T.s3_ss[j0 + u] : 0.f;
+            for (int sblock = 0; sblock < 3; sblock++) {
+                const float* e = PSYA_EBS(L, sblock);
+                double ecb = (double)cf[0] * (double)e[k0];
+#pragma unroll
+                for (int u = 1; u < MT; u++) if (k0 + u <= k1) ecb += (double)cf[u] * (double)e[k0 + u];
+                for (int kk = k0 + MT; kk <= k1; kk++) ecb += (double)T.s3_ss[j0 + (kk - k0)] * (double)e[kk];
+                ecbv[sblock] = (float)ecb;
+                ebv[sblock] = e[b];
+            }
         }
-        W.ecb_s[o * EBS_STRIDE + it] = ecbv;
-        W.eb_s[o * EBS_STRIDE + it] = ebv;
+        for (int sblock = 0; sblock < 3; sblock++) {
+            W.ecb_s[o * EBS_STRIDE + sblock * CBANDS + b] = ecbv[sblock];
+            W.eb_s[o * EBS_STRIDE + sblock * CBANDS + b] = ebv[sblock];
+        }
     }
     PSY_STAMP(7);
     PSY_FLUSH();
