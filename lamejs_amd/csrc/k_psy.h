@@ -572,7 +572,14 @@ LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc*
 // ---------------------------------------------------------------------------------------------
 // kb_psyB: one wave per psy call (all channels).
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV double mask_add_l(const Tables& T, double ath_adjust, double m1, double m2, int kk, int b) {
+struct PsyBLds {
+    double mt1[25], mt2[10], mt3[14], mtab[9];     // mask_add tables: looked up inside a serially dependent chain
+    float thr_l[2][CBANDS + 2];
+    float thr_s[2][3][CBANDS + 2];
+    float E[2][E_STRIDE];
+};
+
+LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, double m1, double m2, int b) {
     // PsyModel.js:403-473 (long blocks)
     double ratio;
     if (m2 > m1) {
@@ -586,28 +593,23 @@ LHIP_DEV double mask_add_l(const Tables& T, double ath_adjust, double m1, double
     if ((b + 3) <= 3 + 3) {
         if (ratio >= T.ma_max_i1) return m1;
         const int i = js_toint32(v8_log10(ratio) * 16.0);
-        return m1 * T.ma_table2[i];
+        return m1 * L.mt2[i];
     }
     const int i = js_toint32(v8_log10(ratio) * 16.0);
-    m2 = (double)T.ATH_cb_l[kk] * ath_adjust;
+    m2 = ath_cb;
     if (m1 < T.ma_max_m * m2) {
         if (m1 > m2) {
             double f = 1.0;
-            if (i <= 13) f = T.ma_table3[i];
+            if (i <= 13) f = L.mt3[i];
             const double r = v8_log10(m1 / m2) * (10.0 / 15.0);
-            return m1 * ((T.ma_table1[i] - f) * r + f);
+            return m1 * ((L.mt1[i] - f) * r + f);
         }
         if (i > 13) return m1;
-        return m1 * T.ma_table3[i];
+        return m1 * L.mt3[i];
     }
-    return m1 * T.ma_table1[i];
+    return m1 * L.mt1[i];
 }
 
-struct PsyBLds {
-    float thr_l[2][CBANDS + 2];
-    float thr_s[2][3][CBANDS + 2];
-    float E[2][E_STRIDE];
-};
 
 LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLds& L) {
     const int C = T.channels_out;
@@ -617,19 +619,30 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
     if (q < 0) return;
     const int fs = sd.fslot0 + (q >> 1);                 // ATH.adjust as left by the previous frame
     const double ath_adjust = W.ath_adjust[fs];
+    for (int i = lane; i < 25; i += LHIP_NL) {
+        L.mt1[i] = T.ma_table1[i];
+        if (i < 10) L.mt2[i] = T.ma_table2[i];
+        if (i < 14) L.mt3[i] = T.ma_table3[i];
+        if (i < 9) L.mtab[i] = T.ma_tab[i];
+    }
+    wave_sync();
 
     for (int ch = 0; ch < C; ch++) {
         const int64_t o = (int64_t)gslot * C + ch;
         const float* eb_l = W.eb_l + o * EBL_STRIDE;
         const int32_t* midx = W.mask_idx + o * EBL_STRIDE;
         // long-block spreading with additive masking (PsyModel.js:1274-1320); thr = ecb (pcfact == 0)
+        // The additive-masking chain is serial in the partition's spreading row; the operands of step u + 1 are
+        // fetched while step u is evaluated (one mask_add instance, software-pipelined loads).
         for (int b = lane; b < T.npart_l; b += LHIP_NL) {
-            int kk = T.s3ind[2 * b], k = T.s3off_l[b];
-            double eb2 = (double)eb_l[kk] * T.ma_tab[midx[kk]];
-            double ecb = (double)T.s3_ll[k++] * eb2;
-            while (++kk <= T.s3ind[2 * b + 1]) {
-                eb2 = (double)eb_l[kk] * T.ma_tab[midx[kk]];
-                ecb = mask_add_l(T, ath_adjust, ecb, (double)T.s3_ll[k++] * eb2, kk, kk - b);
+            const int k0 = T.s3ind[2 * b], k1 = T.s3ind[2 * b + 1], j0 = T.s3off_l[b];
+            double ecb = (double)T.s3_ll[j0] * ((double)eb_l[k0] * L.mtab[midx[k0]]);
+            double tn = 0.0, an = 0.0;
+            if (k0 + 1 <= k1) { tn = (double)T.s3_ll[j0 + 1] * ((double)eb_l[k0 + 1] * L.mtab[midx[k0 + 1]]); an = (double)T.ATH_cb_l[k0 + 1] * ath_adjust; }
+            for (int kk = k0 + 1; kk <= k1; kk++) {
+                const double tc = tn, acur = an;
+                if (kk + 1 <= k1) { tn = (double)T.s3_ll[j0 + (kk + 1 - k0)] * ((double)eb_l[kk + 1] * L.mtab[midx[kk + 1]]); an = (double)T.ATH_cb_l[kk + 1] * ath_adjust; }
+                ecb = mask_add_l(T, L, acur, ecb, tc, kk - b);
             }
             ecb *= 0.158489319246111;
             L.thr_l[ch][b] = (float)ecb;

@@ -61,10 +61,18 @@ LHIP_DEV double wave_maxd(double v) { return __ockl_wfred_max_f64(v); }
 LHIP_DEV double wave_sumd(double v) { return __ockl_wfred_add_f64(v); }
 LHIP_DEV int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }   // src must be wave-uniform
 LHIP_DEV int wave_any(int p) { return __any(p); }
-// exclusive prefix sum over the 64 lanes (integers: exact in any order); *total = sum over all lanes
+// exclusive prefix sum over the 64 lanes (integers: exact in any order); *total = sum over all lanes.
+// Kogge-Stone inside each row of 16 lanes with DPP row shifts, then the row totals are broadcast into the later rows
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): six DPP adds, no LDS round trips.
 LHIP_DEV int wave_excl_scan(int v, int lane, int* total) {
+    (void)lane;
     int x = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(x, o); if (lane >= o) x += t; }
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     *total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
