@@ -143,7 +143,7 @@ struct QuantLds {
         double nsum[SFBMAX + 1];
     };
     int32_t bs_ntab, bs_tab[BS_TAB_MAX];   // bin-search memo of this granule (published in GrSide)
-    uint32_t rdesc[4][2];        // per Huffman region: offsets of its candidate length tables | row stride
+    alignas(8) uint32_t rdesc[4][2];   // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
     unsigned int prof[64];           // per-frame cycle sums fit 32 bits
@@ -399,36 +399,57 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // Without cached bands every line is either quantized or at/after fill_from (last_line is mnz or mnz + 1), so
     // the previous values are only fetched when some band is cached.
     const int need_old = (m_cached != 0);
-    float xa[NPL], xb[NPL]; int sf[NPL]; uint32_t oldw[NPL];
+    if (!need_old && m_zo == 0) {
+        // the common round (every bin-search round and most others): no cached band, no 0/1 shortcut -- a line is
+        // quantized below last_line and zero from there on (last_line >= fill_from - 1 and the line between is quantized)
 #pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        const int p = 2 * (lane + LHIP_NL * j);
-        xa[j] = 0.f; xb[j] = 0.f; sf[j] = 0; oldw[j] = 0;
-        if (p < 576) {
-            sf[j] = l2s[p];
-            struct F2 { float x, y; };
-            const F2 xx = *(const F2*)(L.xrpow + p);       // 8-byte aligned: p is even and xrpow is
-            xa[j] = xx.x; xb[j] = xx.y;
-            if (need_old) oldw[j] = *(const uint32_t*)(ix + p);
+        for (int j = 0; j < NPL; j++) {
+            const int p = 2 * (lane + LHIP_NL * j);
+            float xa = 0.f, xb = 0.f;
+            if (p < 576) { struct F2 { float x, y; }; const F2 xx = *(const F2*)(L.xrpow + p); xa = xx.x; xb = xx.y; }
+            const double qa = (double)xa * istep, qb = (double)xb * istep;
+            const int ra = (int)qa, rb = (int)qb;                          // 0 <= x <= 8206: truncation == ToInt32
+            float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
+            if (ra >= QT_N) aa = T.adj43[ra];                              // rare: large quantized values
+            if (rb >= QT_N) ab = T.adj43[rb];
+            int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
+            va = (p < last_line) ? va : 0;
+            vb = (p + 1 < last_line) ? vb : 0;
+            vx[j] = va; vy[j] = vb;
+            if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
         }
-    }
+    } else {
+        float xa[NPL], xb[NPL]; int sf[NPL]; uint32_t oldw[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        const int p = 2 * (lane + LHIP_NL * j);
-        const double qa = (double)xa[j] * istep, qb = (double)xb[j] * istep;
-        const int ra = (int)qa, rb = (int)qb;                              // 0 <= x <= 8206: truncation == ToInt32
-        float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
-        if (ra >= QT_N) aa = T.adj43[ra];                                  // rare: large quantized values
-        if (rb >= QT_N) ab = T.adj43[rb];
-        const int cached = (int)((m_cached >> sf[j]) & 1), zo = (int)((m_zo >> sf[j]) & 1);
-        int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
-        if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
-        const int oa = (int)(oldw[j] & 0xffffu), ob = (int)(oldw[j] >> 16);
-        const int ia = p, ib = p + 1;
-        va = ((ia < last_line) && !cached) ? va : (ia >= fill_from ? 0 : oa);
-        vb = ((ib < last_line) && !cached) ? vb : (ib >= fill_from ? 0 : ob);
-        vx[j] = va; vy[j] = vb;
-        if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
+        for (int j = 0; j < NPL; j++) {
+            const int p = 2 * (lane + LHIP_NL * j);
+            xa[j] = 0.f; xb[j] = 0.f; sf[j] = 0; oldw[j] = 0;
+            if (p < 576) {
+                sf[j] = l2s[p];
+                struct F2 { float x, y; };
+                const F2 xx = *(const F2*)(L.xrpow + p);       // 8-byte aligned: p is even and xrpow is
+                xa[j] = xx.x; xb[j] = xx.y;
+                if (need_old) oldw[j] = *(const uint32_t*)(ix + p);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int p = 2 * (lane + LHIP_NL * j);
+            const double qa = (double)xa[j] * istep, qb = (double)xb[j] * istep;
+            const int ra = (int)qa, rb = (int)qb;
+            float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
+            if (ra >= QT_N) aa = T.adj43[ra];
+            if (rb >= QT_N) ab = T.adj43[rb];
+            const int cached = (int)((m_cached >> sf[j]) & 1), zo = (int)((m_zo >> sf[j]) & 1);
+            int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
+            if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
+            const int oa = (int)(oldw[j] & 0xffffu), ob = (int)(oldw[j] >> 16);
+            const int ia = p, ib = p + 1;
+            va = ((ia < last_line) && !cached) ? va : (ia >= fill_from ? 0 : oa);
+            vb = ((ib < last_line) && !cached) ? vb : (ib >= fill_from ? 0 : ob);
+            vx[j] = va; vy[j] = vb;
+            if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
+        }
     }
     wave_sync();
     PH_MARK(L, PH_Q_LINES, tm_);
@@ -646,18 +667,29 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 #endif
     const acc_t FM = ((acc_t)1 << FB) - 1;
     acc_t accA = 0, accB = 0, accC = 0, accN = 0;
+    const int any_esc = (m0 > 15) | (m1 > 15) | (m2 > 15);          // escaped values only cost extra bits in ESC regions
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const int p = 2 * (lane + LHIP_NL * j);
         if (p < i) {
-            const int r = (p >= a1) + (p >= a2), sh = FB * r;
-            const uint32_t d0 = L.rdesc[r][0], d1 = L.rdesc[r][1];
+            const int r = (p >= a1) + (p >= a2);
+            const uint64_t d = *(const uint64_t*)L.rdesc[r];
+            const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
             const int x = vx[j], y = vy[j];
             const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
+#ifdef LHIP_HOSTSIM
+            const int sh = FB * r;
             accA += (acc_t)Q.hlen[(d0 & 0xffffu) + idx] << sh;
             accB += (acc_t)Q.hlen[(d0 >> 16) + idx] << sh;
             accC += (acc_t)Q.hlen[(d1 & 0xffffu) + idx] << sh;
-            accN += (acc_t)((x > 14) + (y > 14)) << sh;
+            if (any_esc) accN += (acc_t)((x > 14) + (y > 14)) << sh;
+#else
+            const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
+            accA = __umad24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult, accA);
+            accB = __umad24((unsigned)Q.hlen[(d0 >> 16) + idx], mult, accB);
+            accC = __umad24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult, accC);
+            if (any_esc) accN = __umad24((unsigned)((x > 14) + (y > 14)), mult, accN);
+#endif
         }
     }
     // unpack to (A|B<<16), (C|N<<16) per region: wave totals stay below 2^16 (<= 288 pairs x 21 bits = 6048)
