@@ -142,7 +142,6 @@ struct QuantLds {
         struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
         double nsum[SFBMAX + 1];
     };
-    int32_t bs_ntab, bs_tab[BS_TAB_MAX];   // bin-search memo of this granule (published in GrSide)
     alignas(8) uint32_t rdesc[4][2];   // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
@@ -538,8 +537,25 @@ LHIP_DEV int q_choose_table(const Tables& T, const int16_t* ix, int a, int b, in
     return finish_region(r, s0, s1, s2, bits);
 }
 
+// Conditionally assigned GrInfo fields (Takehiro.js:566-612: table_select[r] only for a non-empty region, the region
+// counts only for long blocks with big_values > 0).  Their values after a bin search depend on the gains it visited, so
+// they are part of what the seed-chain validation must reproduce.  mask bits: 1/2/4 table_select[0/1/2], 8 region counts.
+LHIP_DEV int pack_cond_fields(const GI& g, int mask) {
+    return mask | ((g.table_select[0] + 1) << 4) | ((g.table_select[1] + 1) << 10) | ((g.table_select[2] + 1) << 16) |
+           (g.region0_count << 22) | (g.region1_count << 26);
+}
+LHIP_DEV int apply_cond_fields(int state, int asg) {
+    if (asg & 1) state = (state & ~(63 << 4)) | (asg & (63 << 4));
+    if (asg & 2) state = (state & ~(63 << 10)) | (asg & (63 << 10));
+    if (asg & 4) state = (state & ~(63 << 16)) | (asg & (63 << 16));
+    if (asg & 8) state = (state & ~(0x3ff << 22)) | (asg & (0x3ff << 22));
+    return state & ~15;
+}   // scalar part of CalcNoiseData (arrays are L.pn_*)
+
 // noquant_count_bits (Takehiro.js:521-628); updates g, returns bits.  pn_sfb_count1 as in/out.
-LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int (&vx)[NPL], int (&vy)[NPL], int use_prev, int* pn_sfb_count1, int lane, QuantLds& L, const QuantTabs& Q) {
+// *asg_mask: which conditionally assigned fields this call wrote (see pack_cond_fields).
+LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int (&vx)[NPL], int (&vy)[NPL], int use_prev, int* pn_sfb_count1, int* asg_mask, int lane, QuantLds& L, const QuantTabs& Q) {
+    *asg_mask = 0;
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
@@ -621,6 +637,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     }
     if (a1 > i) a1 = i;
     if (a2 > i) a2 = i;
+    *asg_mask = (g.block_type != SHORT_TYPE ? 8 : 0) | (use2 ? 4 : 0) | (0 < a1 ? 1 : 0) | (a1 < a2 ? 2 : 0);
     // region maxima: region of a pair = number of boundaries at or below it
     int m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
@@ -685,10 +702,10 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
             if (any_esc) accN += (acc_t)((x > 14) + (y > 14)) << sh;
 #else
             const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
-            accA = __umad24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult, accA);
-            accB = __umad24((unsigned)Q.hlen[(d0 >> 16) + idx], mult, accB);
-            accC = __umad24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult, accC);
-            if (any_esc) accN = __umad24((unsigned)((x > 14) + (y > 14)), mult, accN);
+            accA = __umul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
+            accB = __umul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
+            accC = __umul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
+            if (any_esc) accN = __umul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
 #endif
         }
     }
@@ -734,19 +751,22 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     return bits;
 }
 
-struct PrevNoise { int gain, sfb_count1; };   // scalar part of CalcNoiseData (arrays are L.pn_*)
+struct PrevNoise { int gain, sfb_count1; };
 
 // count_bits (Takehiro.js:630-660)
 // `use_pn` selects the prev_noise cache; pn is passed by reference with a flag (never as a nullable pointer to a
 // local: a select between private addresses is a per-lane value for the compiler and makes the control flow divergent)
-LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
+LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, int use_pn, PrevNoise& pn, int* asg, int lane, QuantLds& L, const QuantTabs& Q) {
     const double w = (double)IXMAX_VAL / ipow20(Q, g.global_gain);
+    *asg = 0;
     if (g.xrpow_max > w) return LARGE_BITS;
     int vx[NPL], vy[NPL];
     { PH_BEGIN(); q_quantize(T, g, scalefac, ix, use_pn, use_pn ? pn.gain : 0, use_pn ? pn.sfb_count1 : 0, vx, vy, lane, L, Q); PH_END(L, PH_QUANTIZE); }
     int cnt1 = pn.sfb_count1;
     PH_BEGIN();
-    const int r = q_noquant_count_bits(T, g, ix, vx, vy, use_pn, &cnt1, lane, L, Q);
+    int amask = 0;
+    const int r = q_noquant_count_bits(T, g, ix, vx, vy, use_pn, &cnt1, &amask, lane, L, Q);
+    *asg = pack_cond_fields(g, amask);
     if (use_pn) pn.sfb_count1 = cnt1;
     PH_END(L, PH_COUNT);
     return r;
@@ -1095,7 +1115,7 @@ LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // 
 // `kept` (HBM, this granule-channel's slot of W.l3) receives the quantized spectrum of the kept copy whenever a better
 // quantization is found; it is read back into L.ixw once the loop has finished (the working copy is dead then).
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
-                           int16_t* kept, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int16_t* kept, GrSide* rec, int lane, QuantLds& L, const QuantTabs& Q) {
     enum { ST_BS, ST_BSUP, ST_A, ST_B };
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
@@ -1120,8 +1140,9 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         pn.gain = uni(pn.gain); pn.sfb_count1 = uni(pn.sfb_count1);
         best.max_noise = unid(best.max_noise); best.over_count = uni(best.over_count); best.over_SSD = uni(best.over_SSD); best.bits = uni(best.bits);
 #endif
-        const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, lane, L, Q);   // the only call site
-        if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) L.bs_tab[nbs] = (w.global_gain << 24) | nBits; nbs++; }
+        int asg = 0;
+        const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site
+        if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) { rec->bs_tab[nbs] = (w.global_gain << 24) | nBits; rec->bs_asg[nbs] = asg; } nbs++; }   // memo straight into the side record (HBM)
         if (st == ST_BS) {
             if (CurrentStep == 1 || nBits == desired_rate) st = ST_BSUP;
             else {
@@ -1147,7 +1168,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (nBits > desired_rate && w.global_gain < 255) { w.global_gain++; continue; }
             w.part2_3_length = nBits;
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
-            if (lane == 0) L.bs_ntab = nbs;
+            if (lane == 0) { rec->bs_ntab = nbs; rec->bs_state = pack_cond_fields(w, 0); }
             if (0 == T.noise_shaping) {
                 g = w;
                 for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
@@ -1561,7 +1582,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 active = 1;
                 { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
                 int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-                q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, lane, L, Q);
+                q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, lane, L, Q);
                 uni_gi(g); bs_gain = uni(bs_gain);
                 wave_sync();                                    // the kept spectrum was written by other lanes of this wave
                 for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
@@ -1597,11 +1618,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
             }
             for (int i = lane; i < SFBMAX; i += LHIP_NL) out->scalefac[i] = L.sfb[i];
-            {
-                const int ntab = active ? L.bs_ntab : 0;
-                if (lane == 0) out->bs_ntab = ntab;
-                for (int i = lane; i < ntab; i += LHIP_NL) out->bs_tab[i] = L.bs_tab[i];
-            }
+            if (!active && lane == 0) { out->bs_ntab = 0; out->bs_state = 0; }
             int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
             for (int i = lane; i < 576; i += LHIP_NL) {
                 const int v = L.ixw[i];
@@ -1642,23 +1659,30 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             if (s.start == rec->bs_start && s.step == rec->bs_step_in) continue;     // already quantized with this seed
             const int ntab = uni(rec->bs_ntab);
             // memo entry per lane (device) / linear search (host simulation)
-            int my_ent = 0;
-            for (int i = lane; i < ntab; i += LHIP_NL) my_ent = rec->bs_tab[i];
+            int my_ent = 0, my_asg = 0;
+            for (int i = lane; i < ntab; i += LHIP_NL) { my_ent = rec->bs_tab[i]; my_asg = rec->bs_asg[i]; }
             GI g;
             PrevNoise pn_none; pn_none.gain = 0; pn_none.sfb_count1 = 0;
             int inited = 0;
             // bin_search_StepSize (Quantize.js:322-381), part2_length == 0 at this point
             const int desired_rate = uni(rec->targ_bits);
             int gain = uni(s.start), CurrentStep = uni(s.step), flagGoneOver = 0, Direction = 0, up = 0;
+            GI g0;                                          // conditionally assigned fields as init_outer_loop leaves them
+            g0.table_select[0] = g0.table_select[1] = g0.table_select[2] = 0; g0.region0_count = 0; g0.region1_count = 0;
+            int cstate = pack_cond_fields(g0, 0);
             for (;;) {
-                int nBits = -1;
+                int nBits = -1, asg = 0;
 #ifdef LHIP_HOSTSIM
-                for (int i = 0; i < ntab; i++) if ((int)((uint32_t)rec->bs_tab[i] >> 24) == gain) { nBits = rec->bs_tab[i] & 0xffffff; break; }
-                (void)my_ent;
+                for (int i = 0; i < ntab; i++) if ((int)((uint32_t)rec->bs_tab[i] >> 24) == gain) { nBits = rec->bs_tab[i] & 0xffffff; asg = rec->bs_asg[i]; break; }
+                (void)my_ent; (void)my_asg;
 #else
                 {
                     const uint64_t hit = __ballot(lane < ntab && (int)((uint32_t)my_ent >> 24) == gain);
-                    if (hit) nBits = __builtin_amdgcn_readlane(my_ent, (int)__builtin_ctzll(hit)) & 0xffffff;
+                    if (hit) {
+                        const int src = (int)__builtin_ctzll(hit);
+                        nBits = __builtin_amdgcn_readlane(my_ent, src) & 0xffffff;
+                        asg = __builtin_amdgcn_readlane(my_asg, src);
+                    }
                 }
 #endif
                 if (nBits < 0) {
@@ -1676,9 +1700,10 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
                         inited = 1;
                     }
                     g.global_gain = gain;
-                    nBits = q_count_bits(T, g, L.sfb, L.ixw, 0, pn_none, lane, L, Q);
+                    nBits = q_count_bits(T, g, L.sfb, L.ixw, 0, pn_none, &asg, lane, L, Q);
                 }
                 nBits = uni(nBits);
+                cstate = apply_cond_fields(cstate, uni(asg));
                 if (!up) {
                     if (CurrentStep == 1 || nBits == desired_rate) up = 1;
                     else {
@@ -1703,7 +1728,9 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
                 if (nBits > desired_rate && gain < 255) { gain++; continue; }
                 break;
             }
-            if (gain != rec->bs_gain) bad = 1;
+            // the gain AND the path-dependent leftovers (table_select of empty regions, region counts) must be what the
+            // speculative pass produced
+            if (gain != rec->bs_gain || cstate != (rec->bs_state & ~15)) bad = 1;
         }
     }
     if (lane == 0 && bad) {

@@ -183,6 +183,10 @@ enum { QWAVES = 7 };      /* the profiling counters take LDS: 7 waves keep two w
 #else
 enum { QWAVES = 8 };
 #endif
+#ifndef LHIP_PHASE_PROF
+// two workgroups must fit in the 160 KB of LDS of a CU, or occupancy silently halves
+static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
+#endif
 #ifndef LHIP_QOCC
 #define LHIP_QOCC 4     /* waves per SIMD the quantization kernels are register-budgeted for */
 #endif

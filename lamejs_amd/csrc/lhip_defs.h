@@ -81,6 +81,9 @@ struct GrSide {
     // bin-search memo: (gain << 24 | bits) of every count_bits evaluation made with all-zero scalefactors;
     // the seed-chain validation replays the search from these and only recomputes on a miss
     int32_t bs_ntab, bs_tab[BS_TAB_MAX];
+    // what each memoised evaluation assigned (table_select / region counts are only written for non-empty regions, so
+    // their final values depend on the search path) and the resulting state at the end of the bin search
+    int32_t bs_asg[BS_TAB_MAX], bs_state;
 };
 
 }  // namespace lhip

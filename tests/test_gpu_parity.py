@@ -162,3 +162,13 @@ def test_gpu_seed_repair_path(lib):
         assert got == want
     finally:
         lib.lhip_debug_set_spec_seed(180, 4)
+
+
+@pytest.mark.gpu
+def test_gpu_random_material(lib):
+    """Seeded random material vs the oracle (see tests/tools/fuzz_gpu.py): sparse / quiet frames, clicks, level steps."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    assert fuzz_gpu.run(84, 2024, verbose=False) == []
+    assert fuzz_gpu.run(56, 7, verbose=False) == []

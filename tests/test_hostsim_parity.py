@@ -72,3 +72,12 @@ def test_hostsim_seed_repair_path(sim):
         assert got == want
     finally:
         sim.lhip_debug_set_spec_seed(180, 4)
+
+
+def test_hostsim_random_material(sim):
+    """Seeded random material (tones, coloured noise, clicks, silence gaps, level steps) at every supported rate:
+    this is the sweep that exposed the path-dependent table_select leftovers of the bin search (sparse frames)."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    assert fuzz_gpu.run(42, 2024, lib=sim, verbose=False) == []

@@ -1,0 +1,79 @@
+"""DEV/TEST TOOL (GPU): randomised parity sweep -- GPU path vs the CPU oracle on seeded random material.
+
+Corpora mix tones, coloured noise, silence gaps, clicks and level ramps so that short blocks, ESC Huffman tables,
+scalefac_scale / subblock_gain escalation, analog silence and the ATH recurrence all get exercised at every
+supported sample rate and a spread of bitrates.  usage: python tests/tools/fuzz_gpu.py [ncases] [seed]"""
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import lamejs_amd
+from oracle_py import oracle_encode
+
+
+def material(rng, n, ch):
+    t = np.arange(n)
+    out = []
+    for c in range(ch):
+        x = np.zeros(n)
+        kind = rng.integers(0, 6)
+        amp = 10 ** rng.uniform(0.5, 4.45)
+        if kind in (0, 1, 5):
+            for _ in range(rng.integers(1, 5)):
+                x += amp / 3 * np.sin(2 * np.pi * rng.uniform(30, 18000) * t / 44100 + rng.uniform(0, 6.28))
+        if kind in (1, 2, 5):
+            w = rng.standard_normal(n)
+            if rng.random() < 0.5:
+                w = np.convolve(w, np.ones(rng.integers(2, 40)) / 4, mode="same")
+            x += w * 10 ** rng.uniform(0, 4.2)
+        if kind == 3:
+            x += (rng.random(n) < 0.001) * amp * np.sign(rng.standard_normal(n))        # clicks
+        if kind == 4:
+            x += rng.standard_normal(n) * np.abs(np.sin(2 * np.pi * t / rng.uniform(3000, 60000))) ** 8 * amp   # bursts
+        env = np.ones(n)
+        for _ in range(rng.integers(0, 4)):                                               # silence gaps / level steps
+            a = rng.integers(0, n); b = min(n, a + rng.integers(100, 30000))
+            env[a:b] = rng.choice([0.0, 0.001, 0.05, 3.0])
+        x *= env
+        out.append(np.clip(np.round(x), -32768, 32767).astype(np.int16))
+    return out[0], (out[1] if ch == 2 else None)
+
+
+def run(ncases, seed, lib=None, verbose=True):
+    """Returns the list of mismatching case descriptions (empty = parity)."""
+    rng = np.random.default_rng(seed)
+    cfgs = [(1, 44100, 128), (2, 44100, 128), (2, 44100, 320), (1, 44100, 64), (2, 44100, 192), (1, 44100, 320), (2, 48000, 128),
+            (1, 48000, 96), (2, 32000, 160), (1, 32000, 64), (2, 44100, 160), (2, 48000, 256), (1, 44100, 256), (2, 44100, 224)]
+    bad = []
+    t0 = time.time()
+    for c in range(ncases):
+        ch, sr, kbps = cfgs[c % len(cfgs)]
+        nfr = int(rng.integers(20, 260))
+        L, R = material(rng, 1152 * nfr + int(rng.integers(0, 1152)), ch)
+        try:
+            enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib)
+        except lamejs_amd.LhipError as e:
+            print("skip", ch, sr, kbps, str(e)[:60]); continue
+        chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
+        got = b"".join(enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk]) for p in range(0, len(L), chunk)) + enc.flush()
+        enc.close()
+        want = oracle_encode(ch, sr, kbps, L, R)
+        ok = got == want
+        if not ok:
+            d = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
+            bad.append(f"case {c}: ch={ch} sr={sr} kbps={kbps} frames={nfr} chunk={chunk} first diff byte {d} lens {len(got)} {len(want)}")
+            if verbose:
+                print("MISMATCH", bad[-1])
+    if verbose:
+        print(f"fuzz: {ncases} cases, {len(bad)} mismatches, {time.time() - t0:.1f} s")
+    return bad
+
+
+def main():
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
