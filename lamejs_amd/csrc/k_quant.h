@@ -76,7 +76,6 @@ LHIP_DEV int hl_off(int t) {
 struct QuantTabs {
     float pow43[QT_N], adj43[QT_N];
     float ipow20[Q_MAX], pow20[Q_MAX + Q_MAX2 + 1];
-    int32_t largetbl[256], table23[9], table56[16];
     int32_t sfb_l[SBMAX_l + 1], sfb_s[SBMAX_s + 1], pretab[SBMAX_l];
     uint16_t hoff[16];
     uint8_t hlen[HL_END];        // code-length pool: tables 1-3, 5-15, then the two ESC length tables (layout: hl_off)
@@ -91,9 +90,7 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int i = tid; i < QT_N; i += nthr) { Q.pow43[i] = T.pow43[i]; Q.adj43[i] = T.adj43[i]; }
     for (int i = tid; i < Q_MAX; i += nthr) Q.ipow20[i] = T.ipow20[i];
     for (int i = tid; i < Q_MAX + Q_MAX2 + 1; i += nthr) Q.pow20[i] = T.pow20[i];
-    for (int i = tid; i < 256; i += nthr) Q.largetbl[i] = T.largetbl[i];
-    for (int i = tid; i < 9; i += nthr) Q.table23[i] = T.table23[i];
-    for (int i = tid; i < 16; i += nthr) { Q.table56[i] = T.table56[i]; Q.t32l[i] = (uint8_t)T.t32l[i]; Q.t33l[i] = (uint8_t)T.t33l[i]; }
+    for (int i = tid; i < 16; i += nthr) { Q.t32l[i] = (uint8_t)T.t32l[i]; Q.t33l[i] = (uint8_t)T.t33l[i]; }
     for (int i = tid; i < SBMAX_l + 1; i += nthr) Q.sfb_l[i] = T.sfb_l[i];
     for (int i = tid; i < SBMAX_s + 1; i += nthr) Q.sfb_s[i] = T.sfb_s[i];
     for (int i = tid; i < SBMAX_l; i += nthr) Q.pretab[i] = T.pretab[i];
@@ -302,16 +299,72 @@ LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     return has;
 }
 
+// Ordered (line order) f64 sums of per-line terms over scalefactor bands, all bands at once, as a systolic fold:
+// lane l owns NLN consecutive lines and folds their terms, in order, onto the running sum handed over by lane l-1
+// (reset at band starts); ceil(longest band / NLN) + 1 hand-overs reproduce the strictly sequential sums exactly.
+// Result: L.nsum[band] for every band whose length is <= maxlen.
+enum { NLN_FOLD = 576 / LHIP_NL };
+LHIP_DEV void fold_band_sums(double (&tq)[NLN_FOLD], const uint8_t* l2s, int maxlen, int lane, QuantLds& L) {
+#if LHIP_NL == 1
+    (void)maxlen; (void)lane;
+    double sacc = 0.0;
+    for (int j = 0; j < 576; j++) {
+        if (j == 0 || l2s[j - 1] != l2s[j]) sacc = 0.0;
+        sacc += tq[j];
+        if (j == 575 || l2s[j + 1] != l2s[j]) L.nsum[l2s[j]] = sacc;
+    }
+#else
+    unsigned endm = 0;
+    double keep[NLN_FOLD]; int bnd[NLN_FOLD];
+    int prevb = (lane == 0) ? -1 : (int)l2s[NLN_FOLD * lane - 1];
+#pragma unroll
+    for (int k = 0; k < NLN_FOLD; k++) {
+        const int j = NLN_FOLD * lane + k;
+        bnd[k] = l2s[j];
+        keep[k] = (bnd[k] != prevb) ? 0.0 : 1.0;       // fma(sum, keep, t): `sum + t` or a fresh `t`, one rounding either way
+        prevb = bnd[k];
+    }
+    const int nextb = (lane == LHIP_NL - 1) ? -1 : (int)l2s[NLN_FOLD * (lane + 1)];
+#pragma unroll
+    for (int k = 0; k < NLN_FOLD; k++) if (bnd[k] != (k + 1 < NLN_FOLD ? bnd[k + 1 < NLN_FOLD ? k + 1 : k] : nextb)) endm |= 1u << k;
+    const int nsteps = (maxlen + NLN_FOLD - 1) / NLN_FOLD + 1;
+    double carry = 0.0;
+    for (int st = 0; st + 1 < nsteps; st++) {
+        double sacc = carry;
+#pragma unroll
+        for (int k = 0; k < NLN_FOLD; k++) sacc = __builtin_fma(sacc, keep[k], tq[k]);
+        carry = wave_shr1d(sacc, 0.0);
+    }
+    {
+        double sacc = carry;
+#pragma unroll
+        for (int k = 0; k < NLN_FOLD; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); tq[k] = sacc; }
+    }
+#pragma unroll
+    for (int k = 0; k < NLN_FOLD; k++) if ((endm >> k) & 1u) L.nsum[bnd[k]] = tq[k];
+#endif
+    wave_sync();
+}
+
 // calc_xmin (QuantizePVT.js:569-719), CBR flavour
 LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_lower, const float* ratio /*E layout*/,
                           GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
+    // band energies en0 = sum of xr^2 in line order: terms with all lanes busy, then the ordered fold
+    {
+        double tq[NLN_FOLD];
+#pragma unroll
+        for (int k = 0; k < NLN_FOLD; k++) { const double x = L.xr[NLN_FOLD * lane + k]; tq[k] = x * x; }
+        int maxw = 0;
+        const int nb = (g.block_type != SHORT_TYPE) ? g.psy_lmax : 3 * SBPSY_s;
+        for (int b = lane; b < nb; b += LHIP_NL) if (maxw < L.width[b]) maxw = L.width[b];
+        maxw = wave_max(maxw);
+        fold_band_sums(tq, line2sfb(Q, g.block_type), maxw, lane, L);
+    }
     if (g.block_type != SHORT_TYPE) {
         for (int gsfb = lane; gsfb < g.psy_lmax; gsfb += LHIP_NL) {
             double xmin = ath_adjust * (double)T.ATH_l[gsfb];
-            double en0 = 0.0;
-            const int st = L.start[gsfb], w = L.width[gsfb];
-            for (int j = st; j < st + w; j++) { const double x = L.xr[j]; en0 += x * x; }
+            const double en0 = L.nsum[gsfb];
             const double en = ratio[E_EN_L + gsfb];
             if (en > 0.0) {
                 const double x = en0 * (double)ratio[E_THM_L + gsfb] * masking_lower / en;
@@ -328,9 +381,9 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
             const double tmpATH = ath_adjust * (double)T.ATH_s[sfb];
             float px[3];
             for (int b = 0; b < 3; b++) {
-                const int gs = 3 * sfb + b, st = L.start[gs], w = L.width[gs];
-                double en0 = 0.0, xmin = tmpATH;
-                for (int j = st; j < st + w; j++) { const double x = L.xr[j]; en0 += x * x; }
+                const int gs = 3 * sfb + b;
+                double xmin = tmpATH;
+                const double en0 = L.nsum[gs];
                 const double en = ratio[E_EN_S + sfb * 3 + b];
                 if (en > 0.0) {
                     const double x = en0 * (double)ratio[E_THM_S + sfb * 3 + b] * masking_lower / en;
@@ -497,14 +550,14 @@ LHIP_DEV RegionPlan plan_region_(const QuantTabs& Q, int mx) {
 LHIP_DEV void pair_bits(const QuantTabs& Q, const RegionPlan& r, int x, int y, int& s0, int& s1, int& s2) {
     switch (r.kind) {
         case 1: s0 += Q.hlen[r.o0 + x * 2 + y]; break;
-        case 2: s0 += (r.t1 == 2) ? Q.table23[x * 3 + y] : Q.table56[x * 4 + y]; break;   // packed hi|lo
+        case 2: { const int q = (r.t1 == 2) ? x * 3 + y : x * 4 + y, oa = (r.t1 == 2) ? HL_T2 : HL_T5, ob = (r.t1 == 2) ? HL_T3 : HL_T6;
+                  s0 += ((int)Q.hlen[oa + q] << 16) | (int)Q.hlen[ob + q]; } break;      // packed t1 | t1 + 1 as count_bit_noESC_from2 does
         case 4: { const int q = x * r.xlen + y; s0 += Q.hlen[r.o0 + q]; s1 += Q.hlen[r.o1 + q]; s2 += Q.hlen[r.o2 + q]; } break;
         case 5: {
             int n = 0;
             if (x != 0) { if (x > 14) { x = 15; n++; } x *= 16; }
             if (y != 0) { if (y > 14) { y = 15; n++; } x += y; }
-            const int lt = Q.largetbl[x];
-            s0 += (lt >> 16) + n * r.lb1; s1 += (lt & 0xffff) + n * r.lb2;
+            s0 += (int)Q.hlen[HL_EHI + x] + n * r.lb1; s1 += (int)Q.hlen[HL_ELO + x] + n * r.lb2;
         } break;
         default: break;
     }
@@ -1224,13 +1277,16 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     int32_t* sf = L.sfb;
     int recalc = 0;
     {
+        // bands whose quantized lines are all zero get scalefactor -2 (Takehiro.js:870-882): every lane flags the
+        // bands of its non-zero pairs (a pair never straddles a band), then one lane per band reads its flag
+        for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) L.qmode[sfb] = 0;
+        wave_sync();
+        const uint8_t* l2s = line2sfb(Q, g.block_type);
+        for (int p = 2 * lane; p < 576; p += 2 * LHIP_NL)
+            if (*(const uint32_t*)(L.ixw + p) != 0) L.qmode[l2s[p]] = 1;
+        wave_sync();
         int any = 0;
-        for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) {
-            const int st = L.start[sfb], w = L.width[sfb];
-            int nz = 0;
-            for (int j = st; j < st + w; j++) if (L.ixw[j] != 0) { nz = 1; break; }
-            if (!nz) { sf[sfb] = -2; any = 1; }
-        }
+        for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (!L.qmode[sfb]) { sf[sfb] = -2; any = 1; }
         if (wave_any(any)) recalc = -2;
         wave_sync();
     }
@@ -1255,27 +1311,39 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     }
     for (int i = 0; i < 4; i++) scfsi[i] = 0;
     if (T.mode_gr == 2 && gr == 1 && uni(gr0_block_type) != SHORT_TYPE && g.block_type != SHORT_TYPE) {
-        // scfsi_calc: uniform scalar code over 21 bands, reading gr0's final scalefactors
+        // scfsi_calc (Takehiro.js:809-855), one lane per scalefactor band: a group is shared with granule 0 when no
+        // band of it differs (bands already marked negative do not count as different)
         const int8_t* g0 = L.sf_gr0[ch];
+        uint64_t m_diff = 0;
+        for (int sfb = lane; sfb < SBPSY_l; sfb += LHIP_NL) if ((int)g0[sfb] != sf[sfb] && sf[sfb] >= 0) m_diff |= 1ull << sfb;
+        m_diff = wave_lane_bits(m_diff);
+        uint64_t m_same = 0;
         for (int i = 0; i < 4; i++) {
-            int sfb, same = 1;
-            for (sfb = T.scfsi_band[i]; sfb < T.scfsi_band[i + 1]; sfb++)
-                if (g0[sfb] != sf[sfb] && sf[sfb] >= 0) { same = 0; break; }
-            if (same) {
-                wave_sync();
-                if (lane == 0) for (sfb = T.scfsi_band[i]; sfb < T.scfsi_band[i + 1]; sfb++) sf[sfb] = -1;
-                wave_sync();
-                scfsi[i] = 1;
-            }
+            const int b0 = T.scfsi_band[i], b1 = T.scfsi_band[i + 1];
+            const uint64_t rng = ((1ull << b1) - 1) & ~((1ull << b0) - 1);
+            if ((m_diff & rng) == 0) { scfsi[i] = 1; m_same |= rng; }
         }
-        int s1 = 0, c1 = 0, s2 = 0, c2 = 0, sfb;
-        for (sfb = 0; sfb < 11; sfb++) { if (sf[sfb] == -1) continue; c1++; if (s1 < sf[sfb]) s1 = sf[sfb]; }
-        for (; sfb < SBPSY_l; sfb++) { if (sf[sfb] == -1) continue; c2++; if (s2 < sf[sfb]) s2 = sf[sfb]; }
-        for (int i = 0; i < 16; i++)
-            if (s1 < T.slen1_n[i] && s2 < T.slen2_n[i]) {
-                const int c = T.slen1_tab[i] * c1 + T.slen2_tab[i] * c2;
-                if (g.part2_length > c) { g.part2_length = c; g.scalefac_compress = i; }
-            }
+        wave_sync();
+        for (int sfb = lane; sfb < SBPSY_l; sfb += LHIP_NL) if ((m_same >> sfb) & 1) sf[sfb] = -1;
+        wave_sync();
+        // slen1_n / slen2_n are powers of two: the two maxima of the reference reduce to ORs (negative markers count as 0)
+        uint64_t m_cnt = 0;
+        int or12 = 0;
+        for (int sfb = lane; sfb < SBPSY_l; sfb += LHIP_NL) {
+            const int v = sf[sfb];
+            if (v != -1) m_cnt |= 1ull << sfb;
+            const int vp = v > 0 ? v : 0;
+            or12 |= (sfb < 11) ? vp : (vp << 8);
+        }
+        m_cnt = wave_lane_bits(m_cnt);
+        or12 = wave_or(or12);
+        const int c1 = __builtin_popcountll(m_cnt & 0x7ffull), c2 = __builtin_popcountll(m_cnt >> 11);
+        const int s1 = or12 & 0xff, s2 = or12 >> 8;
+        int best = 0x7fffffff;                         // first i with the smallest cost == minimum of (cost, i)
+        for (int i = lane; i < 16; i += LHIP_NL)
+            if (s1 < T.slen1_n[i] && s2 < T.slen2_n[i]) { const int c = (T.slen1_tab[i] * c1 + T.slen2_tab[i] * c2) * 16 + i; if (c < best) best = c; }
+        best = wave_min(best);
+        if (best != 0x7fffffff && g.part2_length > (best >> 4)) { g.part2_length = best >> 4; g.scalefac_compress = best & 15; }
         recalc = 0;
     }
     wave_sync();
