@@ -1419,21 +1419,30 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
     wave_sync();
 }
 
-// choose_table for the union of whole bands [b0, b1) from the statistics above (bits are added to *bits)
+// choose_table for the union of whole bands [b0, b1) from the statistics above (bits are added to *bits).
+// Called with lane-varying ranges, so it is written branch-free (selects), like the region planning of count_bits.
 LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, const QuantLds& L, const QuantTabs& Q) {
+    (void)T; (void)Q;
     int mx = 0;
-    for (int b = b0; b < b1; b++) if (mx < L.hd.bstat[0][b + 1]) mx = L.hd.bstat[0][b + 1];
-    const RegionPlan r = plan_region_(Q, mx);
-#define SUMROW(k) (L.hd.bstat[k][b1] - L.hd.bstat[k][b0])
-    switch (r.kind) {
-        case 0: return 0;
-        case 1: return finish_region(r, SUMROW(1), 0, 0, bits);
-        case 2: return finish_region(r, (r.t1 == 2) ? SUMROW(2) : SUMROW(3), 0, 0, bits);
-        case 4: { const int o = (r.t1 == 7) ? 4 : (r.t1 == 10) ? 7 : 10; return finish_region(r, SUMROW(o), SUMROW(o + 1), SUMROW(o + 2), bits); }
-        case 5: { const int n = SUMROW(15); return finish_region(r, SUMROW(13) + n * r.lb1, SUMROW(14) + n * r.lb2, 0, bits); }
-        default: return finish_region(r, 0, 0, 0, bits);
-    }
-#undef SUMROW
+    for (int b = b0; b < b1; b++) { const int v = L.hd.bstat[0][b + 1]; mx = mx < v ? v : mx; }
+    const int kind = (mx == 0) ? 0 : (mx == 1) ? 1 : (mx <= 3) ? 2 : (mx <= 15) ? 4 : (mx <= IXMAX_VAL) ? 5 : 6;
+    const int t1 = (mx <= 1) ? mx : (mx == 2) ? 2 : (mx == 3) ? 5 : (mx <= 5) ? 7 : (mx <= 7) ? 10 : 13;
+    const int rowA = (kind == 1) ? 1 : (kind == 2) ? (mx == 2 ? 2 : 3) : (kind == 4) ? (mx <= 5 ? 4 : mx <= 7 ? 7 : 10) : 13;
+    int choice, choice2, lb1, lb2;
+    esc_choice(mx > 15 ? mx - 15 : 1, &choice, &choice2, &lb1, &lb2);
+    const int sA = L.hd.bstat[rowA][b1] - L.hd.bstat[rowA][b0];
+    const int sB = L.hd.bstat[rowA + 1][b1] - L.hd.bstat[rowA + 1][b0];
+    const int sC = L.hd.bstat[rowA + 2][b1] - L.hd.bstat[rowA + 2][b0];
+    int c0 = sA, c1 = sB, c2 = sC, ta = t1, tb = t1 + 1;
+    if (kind == 2) { c0 = (int)((unsigned)sA >> 16); c1 = sA & 0xffff; }
+    if (kind == 5) { c0 = sA + sC * lb1; c1 = sB + sC * lb2; ta = choice; tb = choice2; }
+    int bsum = c0, t = ta;
+    if ((kind == 2 || kind == 4 || kind == 5) && bsum > c1) { bsum = c1; t = tb; }
+    if (kind == 4 && bsum > c2) { bsum = c2; t = t1 + 2; }
+    if (kind == 0) { bsum = 0; t = 0; }
+    if (kind == 6) { *bits = LARGE_BITS; return -1; }
+    *bits += bsum;
+    return t;
 }
 
 // recalc_divide_sub (Takehiro.js:698-725); region 2 = bands r2.. up to big_values, from the band statistics.
