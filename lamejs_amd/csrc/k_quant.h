@@ -1725,6 +1725,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
     const int k = fslot - sd.fslot0 - 1;
     if (k < 0) return;
     const int fidx = sd.out_slot0 + k;
+    if (uni(W.seed_flag[fidx]) != 2) return;                  // only frames the memo-only pass could not decide
     const double ath_adjust = W.ath_adjust[fslot];
     int bad = 0;
     for (int gr = 0; gr < 2 && !bad; gr++) {
@@ -1810,13 +1811,78 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             if (gain != rec->bs_gain || cstate != (rec->bs_state & ~15)) bad = 1;
         }
     }
-    if (lane == 0 && bad) {
-        W.seed_flag[fidx] = 1;
+    if (lane == 0) {
+        W.seed_flag[fidx] = bad ? 1 : 0;
+        if (bad) {
 #ifdef LHIP_HOSTSIM
-        W.nflagged[0] += 1;
+            W.nflagged[0] += 1;
 #else
-        atomicAdd(W.nflagged, 1);
+            atomicAdd(W.nflagged, 1);
 #endif
+        }
+    }
+}
+
+// Memo-only replay, one THREAD per frame: the whole check is a few scalar look-ups in the side records, so it runs
+// as a plain grid over the frames without LDS tables.  Outcome per frame in W.seed_flag: 0 consistent, 1 re-quantize
+// with the chain-implied seed, 2 undecided (a gain the speculative pass never evaluated) -> kb_validate decides.
+LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[W.fslot_stream[fslot]];
+    const int k = fslot - sd.fslot0 - 1;
+    if (k < 0) return;
+    const int fidx = sd.out_slot0 + k;
+    int verdict = 0;
+    for (int gr = 0; gr < 2 && verdict == 0; gr++)
+        for (int ch = 0; ch < C && verdict == 0; ch++) {
+            const GrSide* rec = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
+            if (!rec->active) continue;
+            const Seed s = seed_before(W, sd, C, k, gr, ch);
+            if (s.start == rec->bs_start && s.step == rec->bs_step_in) continue;
+            const int ntab = rec->bs_ntab, desired_rate = rec->targ_bits;
+            int gain = s.start, CurrentStep = s.step, flagGoneOver = 0, Direction = 0, up = 0;
+            GI g0;
+            g0.table_select[0] = g0.table_select[1] = g0.table_select[2] = 0; g0.region0_count = 0; g0.region1_count = 0;
+            int cstate = pack_cond_fields(g0, 0);
+            for (;;) {
+                int nBits = -1, asg = 0;
+                for (int i = 0; i < ntab; i++) { const int e = rec->bs_tab[i]; if ((int)((uint32_t)e >> 24) == gain) { nBits = e & 0xffffff; asg = rec->bs_asg[i]; break; } }
+                if (nBits < 0) { verdict = 2; break; }
+                cstate = apply_cond_fields(cstate, asg);
+                if (!up) {
+                    if (CurrentStep == 1 || nBits == desired_rate) up = 1;
+                    else {
+                        int step;
+                        if (nBits > desired_rate) {
+                            if (Direction == 2) flagGoneOver = 1;
+                            if (flagGoneOver) CurrentStep /= 2;
+                            Direction = 1;
+                            step = CurrentStep;
+                        } else {
+                            if (Direction == 1) flagGoneOver = 1;
+                            if (flagGoneOver) CurrentStep /= 2;
+                            Direction = 2;
+                            step = -CurrentStep;
+                        }
+                        gain += step;
+                        if (gain < 0) { gain = 0; flagGoneOver = 1; }
+                        if (gain > 255) { gain = 255; flagGoneOver = 1; }
+                        continue;
+                    }
+                }
+                if (nBits > desired_rate && gain < 255) { gain++; continue; }
+                break;
+            }
+            if (verdict == 0 && (gain != rec->bs_gain || cstate != (rec->bs_state & ~15))) verdict = 1;
+        }
+    W.seed_flag[fidx] = verdict;
+    if (verdict) {
+#ifdef LHIP_HOSTSIM
+        const int pos = W.nflagged[verdict - 1]; W.nflagged[verdict - 1] += 1;
+#else
+        const int pos = atomicAdd(W.nflagged + (verdict - 1), 1);
+#endif
+        if (verdict == 2) W.slow_list[pos] = fslot;
     }
 }
 

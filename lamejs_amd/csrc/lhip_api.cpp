@@ -212,14 +212,18 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused
         kb_quant(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q);
     }
 }
-__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nfs) {
+__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nslow) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fslot = blockIdx.x * QWAVES + wv;
-    if (fslot >= nfs) return;
-    kb_validate(T, pb, W, SD, fslot, threadIdx.x & 63, L[wv], Q);    // a replay is a handful of scalar look-ups: static mapping
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), idx = blockIdx.x * QWAVES + wv;
+    if (idx >= nslow) return;
+    kb_validate(T, pb, W, SD, W.slow_list[idx], threadIdx.x & 63, L[wv], Q);    // only the frames the memo-only pass left undecided
+}
+__global__ __launch_bounds__(256) void g_validate_fast(Tables T, Workspace W, const StreamDesc* SD, int nfs) {
+    const int fslot = blockIdx.x * 256 + threadIdx.x;
+    if (fslot < nfs) kb_validate_fast(T, W, SD, fslot);
 }
 __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ BitsLds L;
@@ -421,7 +425,7 @@ struct Context {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     DevBuf pcm, fmap, gmap, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, frame_bytes, sd, io, in16, out8, prof;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, sd, io, in16, out8, prof;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0; bool have_last = false;
     int num_cus = 256;
@@ -521,7 +525,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
-    ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(frame_bytes, FR * 4); ENS(sd, (size_t)S * sizeof(StreamDesc));
+    ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4); ENS(sd, (size_t)S * sizeof(StreamDesc));
     ENS(io, (size_t)S * sizeof(StreamIO)); ENS(prof, 512);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
@@ -532,7 +536,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
-    W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 8; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
+    W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 8; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
@@ -592,8 +596,9 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
         for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ, QT);
         for (;;) {
-            W.nflagged[0] = 0;
-            for (int b = 0; b < nfs; b++) kb_validate(T, ts.pb10, W, dSD, b, 0, LQ, QT);
+            W.nflagged[0] = 0; W.nflagged[1] = 0;
+            for (int b = 0; b < nfs; b++) kb_validate_fast(T, W, dSD, b);
+            for (int i = 0; i < W.nflagged[1]; i++) kb_validate(T, ts.pb10, W, dSD, W.slow_list[i], 0, LQ, QT);
             const int nf = W.nflagged[0];
             if (nf == 0) break;
             repaired += nf; iters++;
@@ -625,11 +630,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0; LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
     if (nfr > 0) {
         for (;;) {
-            if (!rt::dzero((int32_t*)ctx->nflagged.p + 8, 32, st)) return false;
-            LAUNCHB(KT_VALIDATE, g_validate, (nfs + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, nfs);
-            int32_t nf = 0;
-            if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
+            if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
+            LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
+            int32_t nf2[2] = {0, 0};
+            if (!rt::d2h(nf2, W.nflagged, 8, st)) return false;
             if (!rt::sync(st)) return false;
+            int32_t nf = nf2[0];
+            if (nf2[1] > 0) {       // frames whose replay asked for a gain the speculative pass never evaluated
+                LAUNCHB(KT_VALIDATE, g_validate, (nf2[1] + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, nf2[1]);
+                if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
+                if (!rt::sync(st)) return false;
+            }
             if (nf == 0) break;
             repaired += nf; iters++;
             if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
