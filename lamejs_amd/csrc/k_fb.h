@@ -17,7 +17,8 @@ namespace lhip {
 // anchor minus POLY_BIAS) lives at [(n & 31) * POLY_ROW + (n >> 5)].  Lane j (slot j, anchor 32 j) then reads
 // anchor-relative offset `off` at [((off + BIAS) & 31) * ROW + ((off + BIAS) >> 5) + j]: consecutive lanes hit
 // consecutive banks, and the whole index except `+ j` is a compile-time constant.
-enum { POLY_BIAS = 320, POLY_ROW = 37, POLY_N = 32 * 17 + 256 + POLY_BIAS + 1, POLY_ITEM = 32 * POLY_ROW };
+enum { POLY_PER_WAVE = 3, POLY_BIAS = 320, POLY_N1 = 32 * 17 + 256 + POLY_BIAS + 1, POLY_N = POLY_N1 + 576 * (POLY_PER_WAVE - 1),
+       POLY_ROW = 73 /* odd, >= POLY_N / 32 + 1 */, POLY_ITEM = 32 * POLY_ROW };
 #define XT(off) ((double)xt[(((off) + POLY_BIAS) & 31) * POLY_ROW + (((off) + POLY_BIAS) >> 5)])
 
 // One 32-band slot.  xt = transposed window base of this lane's slot; a[] lives in registers.
@@ -139,43 +140,57 @@ LHIP_DEV void window_subband(const double* W, const float* xt, float* a) {
 #undef R
 }
 
-// One wave serves POLY_PER_WAVE (granule slot, channel) work items: lane = item * 18 + polyphase slot
-// (54 of 64 lanes busy), reading PCM from the transposed LDS staging of the item.
-enum { POLY_PER_WAVE = 3 };
-struct PolyLds { float xs[POLY_PER_WAVE][POLY_ITEM]; };
-LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int wave_idx, int nitems, int lane, PolyLds& L) {
-    const int C = T.channels_out;
-    for (int it = 0; it < POLY_PER_WAVE; it++) {
-        const int item = wave_idx * POLY_PER_WAVE + it;
-        if (item >= nitems) break;
-        const int gslot = item / C, ch = item - gslot * C;
-        const StreamDesc sd = SD[W.gslot_stream[gslot]];
-        const int q = gslot - sd.gslot0 - 1;
-        if (q < 0) continue;
-        const float* src = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 286 - POLY_BIAS;
-        const int lo = POLY_BIAS - 286;                       // samples before the stream segment are never used
-        for (int n = lane; n < POLY_N; n += LHIP_NL) L.xs[it][(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? src[n] : 0.f;
-    }
-    wave_sync();
-    for (int u = lane; u < 18 * POLY_PER_WAVE; u += LHIP_NL) {
-        const int it = u / 18, j = u - 18 * it, item = wave_idx * POLY_PER_WAVE + it;
-        if (item >= nitems) continue;
-        const int gslot = item / C, ch = item - gslot * C;
-        const StreamDesc sd = SD[W.gslot_stream[gslot]];
-        if (gslot - sd.gslot0 - 1 < 0) continue;
-        float* out = W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE;
-        float a[32];
-        window_subband(T.enwindow, L.xs[it] + j, a);
-        if (j & 1)
-            for (int band = 1; band < 32; band += 2) a[band] = (float)((double)a[band] * -1);
-        for (int band = 0; band < 32; band++) {
-            const double af = T.amp_filter[band];
-            if (!(af < 1e-12) && af < 1.0) {
-                const int ob = T.mdct_order[band];
-                a[ob] = (float)((double)a[ob] * af);
-            }
+// One wave serves POLY_PER_WAVE work items (granule slot, channel), numbered channel-major so that the items of a
+// wave are normally consecutive granules of one channel of one stream: their PCM windows overlap (576-sample hop,
+// 1121-sample window), so ONE transposed staging of 2273 samples serves all three and lane u = item * 18 + slot simply
+// reads at column offset u (576 = 18 rows of 32).  Waves that straddle a stream boundary take the items one by one.
+struct PolyLds { float xs[POLY_ITEM]; };
+LHIP_DEV void poly_slot(const Tables& T, const float* xt, float* out, int j) {
+    float a[32];
+    window_subband(T.enwindow, xt, a);
+    if (j & 1)
+        for (int band = 1; band < 32; band += 2) a[band] = (float)((double)a[band] * -1);
+    for (int band = 0; band < 32; band++) {
+        const double af = T.amp_filter[band];
+        if (!(af < 1e-12) && af < 1.0) {
+            const int ob = T.mdct_order[band];
+            a[ob] = (float)((double)a[ob] * af);
         }
-        for (int i = 0; i < 32; i++) out[j * 32 + i] = a[i];
+    }
+    for (int i = 0; i < 32; i++) out[j * 32 + i] = a[i];
+}
+LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int wave_idx, int nitems, int lane, PolyLds& L) {
+    const int C = T.channels_out, ngs = W.ngslots;
+    const int item0 = wave_idx * POLY_PER_WAVE;
+    const int nit = (nitems - item0) < POLY_PER_WAVE ? (nitems - item0) : POLY_PER_WAVE;
+    // item -> (channel, granule slot), channel-major
+    const int ch0 = item0 / ngs, g0 = item0 - ch0 * ngs;
+    const int st0 = W.gslot_stream[g0];
+    const StreamDesc sd0 = SD[st0];
+    const int q0 = g0 - sd0.gslot0 - 1;
+    int together = (q0 >= 0);
+    for (int it = 1; it < nit; it++) {
+        const int item = item0 + it, ch = item / ngs, gs = item - ch * ngs;
+        if (ch != ch0 || gs != g0 + it || W.gslot_stream[gs] != st0) together = 0;
+    }
+    const int lo = POLY_BIAS - 286;                           // samples before the stream segment are never used
+    // one pass over all items when they share a staging, else one pass per item (single instance of the slot code)
+    const int npass = together ? 1 : nit;
+    for (int ps = 0; ps < npass; ps++) {
+        const int itA = together ? 0 : ps, cnt = together ? nit : 1;
+        const int item = item0 + itA, ch = item / ngs, gs = item - ch * ngs;
+        const StreamDesc sd = SD[W.gslot_stream[gs]];
+        const int q = gs - sd.gslot0 - 1;
+        if (q < 0) continue;                                   // carry slot: nothing to compute
+        const float* src = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 286 - POLY_BIAS;
+        const int n_need = POLY_N1 + 576 * (cnt - 1);
+        wave_sync();
+        for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? src[n] : 0.f;
+        wave_sync();
+        for (int u = lane; u < 18 * cnt; u += LHIP_NL) {
+            const int it = u / 18, j = u - 18 * it;
+            poly_slot(T, L.xs + u, W.sb + ((int64_t)(gs + it) * C + ch) * SB_STRIDE, j);
+        }
     }
 }
 

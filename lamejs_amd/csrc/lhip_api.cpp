@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const Stream
     __shared__ PsyBLds L;
     kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-__global__ __launch_bounds__(64) void g_poly(Tables T, Workspace W, const StreamDesc* SD, int nitems) {
+__global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, int nitems) {
     __shared__ PolyLds L;
     kb_polyphase(T, W, SD, blockIdx.x, nitems, threadIdx.x, L);
 }
