@@ -18,8 +18,8 @@
  *   PsyModel.js:2249-2822   partitions, spreading functions, ATH per partition, eql_w
  *   FFT.js:226-242          analysis windows; FFT.js:31-115 twiddle recurrence
  *
- * Supported envelope (everything else throws): CBR, MPEG-1 sample rates
- * (32000/44100/48000) with out_samplerate == in_samplerate, 1 or 2 channels.
+ * Supported envelope (everything else throws): CBR, every MPEG-1 / MPEG-2 / MPEG-2.5 sample rate
+ * with out_samplerate == in_samplerate (no resampling), 1 or 2 channels.
  */
 'use strict';
 
@@ -90,17 +90,20 @@ function resolveParams(channels, samplerate, kbps) {
     if (out_samplerate != samplerate)
         throw new Error('lamejs_amd: (' + channels + ',' + samplerate + ',' + kbps +
             ') would resample to ' + out_samplerate + ' Hz; resampling path not supported');
-    const sr_idx = C.samplerate_table[1].indexOf(out_samplerate);
-    if (sr_idx < 0)
-        throw new Error('lamejs_amd: only MPEG-1 sample rates (32000/44100/48000) are supported');
-    p.version = 1;
+    /* SmpFrqIndex (Lame.js:369-403): MPEG-1 for 32/44.1/48 kHz, "version 0" (LSF) for MPEG-2 and MPEG-2.5 rates */
+    const SFI = { 44100: [1, 0], 48000: [1, 1], 32000: [1, 2], 22050: [0, 0], 24000: [0, 1], 16000: [0, 2],
+        11025: [0, 0], 12000: [0, 1], 8000: [0, 2] };
+    if (!SFI[out_samplerate])
+        throw new Error('lamejs_amd: unsupported sample rate ' + out_samplerate);
+    p.version = SFI[out_samplerate][0];
+    const sr_idx = SFI[out_samplerate][1];
     p.samplerate_index = sr_idx;
-    p.mode_gr = 2;
-    p.framesize = 1152;
+    p.mode_gr = out_samplerate <= 24000 ? 1 : 2;            /* Lame.js:936 */
+    p.framesize = 576 * p.mode_gr;
 
-    /* nearest legal bitrate + index (Lame.js:408-444) */
+    /* nearest legal bitrate + index (Lame.js:408-444); MPEG-2.5 rates use their own bitrate row */
     {
-        const bt = C.bitrate_table[1];
+        const bt = C.bitrate_table[out_samplerate < 16000 ? 2 : p.version];
         let best = bt[1];
         for (let i = 2; i <= 14; i++)
             if (bt[i] > 0 && Math.abs(bt[i] - brate) < Math.abs(best - brate)) best = bt[i];
@@ -138,7 +141,7 @@ function resolveParams(channels, samplerate, kbps) {
     /* scalefactor band edges (Lame.js:1079-1101); note the fractional pseudo-band
      * starts truncated by the Int32 store -- that truncation is the reference's behaviour */
     {
-        const j = sr_idx + 3 * p.version;
+        const j = sr_idx + 3 * p.version + 6 * (out_samplerate < 16000 ? 1 : 0);
         p.sfb_l = i32(SBMAX_l + 1); p.sfb_s = i32(SBMAX_s + 1);
         p.psfb21 = i32(PSFB21 + 1); p.psfb12 = i32(PSFB12 + 1);
         for (let i = 0; i < SBMAX_l + 1; i++) p.sfb_l[i] = C.sfBandIndex[j].l[i];
@@ -154,7 +157,9 @@ function resolveParams(channels, samplerate, kbps) {
         }
         p.psfb12[PSFB12] = 192;
     }
-    p.sideinfo_len = (p.channels_out == 1) ? 4 + 17 : 4 + 32;
+    /* Lame.js:1103-1110 */
+    if (p.version == 1) p.sideinfo_len = (p.channels_out == 1) ? 4 + 17 : 4 + 32;
+    else p.sideinfo_len = (p.channels_out == 1) ? 4 + 9 : 4 + 17;
 
     /* CBR: ABR preset row for this bitrate (Lame.js:1202-1230, Presets.js:270-357) */
     const row = C.abr_switch_map[nearestBitrateFullIndex(brate)];

@@ -95,7 +95,7 @@ static int lo_load_cfg(lo_cfg* c, const void* blob_in, size_t nbytes) {
     c->version_bytes = (const int32_t*)lo_arr(b, "version_bytes", 1, &c->n_version_bytes);
     AD(fht_twiddle); AD(fht_costab); AD(enwindow); AD(mdct_win); AD(ma_tab); AD(ma_table1); AD(ma_table2);
     AD(ma_table3); AD(hpf_fircoef);
-    if (c->quant_comp != 9 || c->quant_comp_short != 9 || c->version != 1 || c->mode_gr != 2 || c->error_protection) {
+    if (c->quant_comp != 9 || c->quant_comp_short != 9 || (c->version != 1 && c->version != 0) || c->mode_gr != (c->version == 1 ? 2 : 1) || c->error_protection) {
         fprintf(stderr, "lame_oracle: configuration outside the supported envelope\n");
         return -1;
     }
@@ -180,8 +180,8 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
     int gr, ch, sfb, band;
     memset(out, 0, (size_t)frame_bits / 8);
     w.p = out; w.bitpos = 0;
-    /* header */
-    lo_put(&w, 0xfff, 12);
+    /* header (BitStream.js:267-270: MPEG-2.5 rates carry the 0xffe sync) */
+    lo_put(&w, c->out_samplerate < 16000 ? 0xffe : 0xfff, 12);
     lo_put(&w, (uint32_t)c->version, 1);
     lo_put(&w, 4 - 3, 2);
     lo_put(&w, (!c->error_protection ? 1 : 0), 1);
@@ -194,18 +194,88 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
     lo_put(&w, (uint32_t)c->copyright, 1);
     lo_put(&w, (uint32_t)c->original, 1);
     lo_put(&w, (uint32_t)c->emphasis, 2);
+    if (c->version == 1) {
     /* side info (MPEG-1) */
-    lo_put(&w, 0, 9);                                   /* main_data_begin */
-    lo_put(&w, 0, c->channels_out == 2 ? 3 : 5);        /* private bits */
-    for (ch = 0; ch < c->channels_out; ch++)
-        for (band = 0; band < 4; band++) lo_put(&w, (uint32_t)e->scfsi[ch][band], 1);
-    for (gr = 0; gr < 2; gr++)
+        lo_put(&w, 0, 9);                                   /* main_data_begin */
+        lo_put(&w, 0, c->channels_out == 2 ? 3 : 5);        /* private bits */
+        for (ch = 0; ch < c->channels_out; ch++)
+            for (band = 0; band < 4; band++) lo_put(&w, (uint32_t)e->scfsi[ch][band], 1);
+        for (gr = 0; gr < 2; gr++)
+            for (ch = 0; ch < c->channels_out; ch++) {
+                lo_gr* gi = &e->tt[gr][ch];
+                lo_put(&w, (uint32_t)(gi->part2_3_length + gi->part2_length), 12);
+                lo_put(&w, (uint32_t)(gi->big_values / 2), 9);
+                lo_put(&w, (uint32_t)gi->global_gain, 8);
+                lo_put(&w, (uint32_t)gi->scalefac_compress, 4);
+                if (gi->block_type != NORM_TYPE) {
+                    lo_put(&w, 1, 1);
+                    lo_put(&w, (uint32_t)gi->block_type, 2);
+                    lo_put(&w, (uint32_t)gi->mixed_block_flag, 1);
+                    if (gi->table_select[0] == 14) gi->table_select[0] = 16;
+                    lo_put(&w, (uint32_t)gi->table_select[0], 5);
+                    if (gi->table_select[1] == 14) gi->table_select[1] = 16;
+                    lo_put(&w, (uint32_t)gi->table_select[1], 5);
+                    lo_put(&w, (uint32_t)gi->subblock_gain[0], 3);
+                    lo_put(&w, (uint32_t)gi->subblock_gain[1], 3);
+                    lo_put(&w, (uint32_t)gi->subblock_gain[2], 3);
+                } else {
+                    lo_put(&w, 0, 1);
+                    if (gi->table_select[0] == 14) gi->table_select[0] = 16;
+                    lo_put(&w, (uint32_t)gi->table_select[0], 5);
+                    if (gi->table_select[1] == 14) gi->table_select[1] = 16;
+                    lo_put(&w, (uint32_t)gi->table_select[1], 5);
+                    if (gi->table_select[2] == 14) gi->table_select[2] = 16;
+                    lo_put(&w, (uint32_t)gi->table_select[2], 5);
+                    lo_put(&w, (uint32_t)gi->region0_count, 4);
+                    lo_put(&w, (uint32_t)gi->region1_count, 3);
+                }
+                lo_put(&w, (uint32_t)gi->preflag, 1);
+                lo_put(&w, (uint32_t)gi->scalefac_scale, 1);
+                lo_put(&w, (uint32_t)gi->count1table_select, 1);
+            }
+        /* main data */
+        for (gr = 0; gr < 2; gr++)
+            for (ch = 0; ch < c->channels_out; ch++) {
+                const lo_gr* gi = &e->tt[gr][ch];
+                const int slen1 = c->slen1_tab[gi->scalefac_compress], slen2 = c->slen2_tab[gi->scalefac_compress];
+                for (sfb = 0; sfb < gi->sfbdivide; sfb++) {
+                    if (gi->scalefac[sfb] == -1) continue;
+                    lo_put(&w, (uint32_t)gi->scalefac[sfb], slen1);
+                }
+                for (; sfb < gi->sfbmax; sfb++) {
+                    if (gi->scalefac[sfb] == -1) continue;
+                    lo_put(&w, (uint32_t)gi->scalefac[sfb], slen2);
+                }
+                if (gi->block_type == SHORT_TYPE) {
+                    int r1 = 3 * c->sfb_s[3];
+                    if (r1 > gi->big_values) r1 = gi->big_values;
+                    lo_huffmancode(c, &w, gi->table_select[0], 0, r1, gi);
+                    lo_huffmancode(c, &w, gi->table_select[1], r1, gi->big_values, gi);
+                } else {
+                    int bigv = gi->big_values, i = gi->region0_count + 1, r1, r2;
+                    r1 = c->sfb_l[i];
+                    i += gi->region1_count + 1;
+                    r2 = c->sfb_l[i];
+                    if (r1 > bigv) r1 = bigv;
+                    if (r2 > bigv) r2 = bigv;
+                    lo_huffmancode(c, &w, gi->table_select[0], 0, r1, gi);
+                    lo_huffmancode(c, &w, gi->table_select[1], r1, r2, gi);
+                    lo_huffmancode(c, &w, gi->table_select[2], r2, bigv, gi);
+                }
+                lo_count1_code(c, &w, gi);
+            }
+    } else {
+        /* MPEG-2 / 2.5 LSF: one granule, 8-bit main_data_begin, 9-bit scalefac_compress, no scfsi/preflag
+         * (BitStream.js:352-405), scalefactors by partition with slen[] (BitStream.js:645-686) */
+        extern const int lo_nr_of_sfb_block[6][3][4];
+        lo_put(&w, 0, 8);                                   /* main_data_begin */
+        lo_put(&w, 0, c->channels_out);                     /* private bits */
         for (ch = 0; ch < c->channels_out; ch++) {
-            lo_gr* gi = &e->tt[gr][ch];
+            lo_gr* gi = &e->tt[0][ch];
             lo_put(&w, (uint32_t)(gi->part2_3_length + gi->part2_length), 12);
             lo_put(&w, (uint32_t)(gi->big_values / 2), 9);
             lo_put(&w, (uint32_t)gi->global_gain, 8);
-            lo_put(&w, (uint32_t)gi->scalefac_compress, 4);
+            lo_put(&w, (uint32_t)gi->scalefac_compress, 9);
             if (gi->block_type != NORM_TYPE) {
                 lo_put(&w, 1, 1);
                 lo_put(&w, (uint32_t)gi->block_type, 2);
@@ -228,41 +298,52 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
                 lo_put(&w, (uint32_t)gi->region0_count, 4);
                 lo_put(&w, (uint32_t)gi->region1_count, 3);
             }
-            lo_put(&w, (uint32_t)gi->preflag, 1);
             lo_put(&w, (uint32_t)gi->scalefac_scale, 1);
             lo_put(&w, (uint32_t)gi->count1table_select, 1);
         }
-    /* main data */
-    for (gr = 0; gr < 2; gr++)
         for (ch = 0; ch < c->channels_out; ch++) {
-            const lo_gr* gi = &e->tt[gr][ch];
-            const int slen1 = c->slen1_tab[gi->scalefac_compress], slen2 = c->slen2_tab[gi->scalefac_compress];
-            for (sfb = 0; sfb < gi->sfbdivide; sfb++) {
-                if (gi->scalefac[sfb] == -1) continue;
-                lo_put(&w, (uint32_t)gi->scalefac[sfb], slen1);
-            }
-            for (; sfb < gi->sfbmax; sfb++) {
-                if (gi->scalefac[sfb] == -1) continue;
-                lo_put(&w, (uint32_t)gi->scalefac[sfb], slen2);
-            }
+            const lo_gr* gi = &e->tt[0][ch];
+            const int* pt = lo_nr_of_sfb_block[gi->sfb_part_tab][gi->sfb_part_row];
+            int part, i;
+            const int dbg_p0 = w.bitpos;
+            sfb = 0;
             if (gi->block_type == SHORT_TYPE) {
-                int r1 = 3 * c->sfb_s[3];
-                if (r1 > gi->big_values) r1 = gi->big_values;
-                lo_huffmancode(c, &w, gi->table_select[0], 0, r1, gi);
-                lo_huffmancode(c, &w, gi->table_select[1], r1, gi->big_values, gi);
+                for (part = 0; part < 4; part++) {
+                    const int sfbs = pt[part] / 3, slen = gi->slen[part];
+                    for (i = 0; i < sfbs; i++, sfb++) {
+                        lo_put(&w, (uint32_t)(gi->scalefac[sfb * 3 + 0] > 0 ? gi->scalefac[sfb * 3 + 0] : 0), slen);
+                        lo_put(&w, (uint32_t)(gi->scalefac[sfb * 3 + 1] > 0 ? gi->scalefac[sfb * 3 + 1] : 0), slen);
+                        lo_put(&w, (uint32_t)(gi->scalefac[sfb * 3 + 2] > 0 ? gi->scalefac[sfb * 3 + 2] : 0), slen);
+                    }
+                }
+                {
+                    int r1 = 3 * c->sfb_s[3];
+                    if (r1 > gi->big_values) r1 = gi->big_values;
+                    lo_huffmancode(c, &w, gi->table_select[0], 0, r1, gi);
+                    lo_huffmancode(c, &w, gi->table_select[1], r1, gi->big_values, gi);
+                }
             } else {
-                int bigv = gi->big_values, i = gi->region0_count + 1, r1, r2;
-                r1 = c->sfb_l[i];
-                i += gi->region1_count + 1;
-                r2 = c->sfb_l[i];
-                if (r1 > bigv) r1 = bigv;
-                if (r2 > bigv) r2 = bigv;
-                lo_huffmancode(c, &w, gi->table_select[0], 0, r1, gi);
-                lo_huffmancode(c, &w, gi->table_select[1], r1, r2, gi);
-                lo_huffmancode(c, &w, gi->table_select[2], r2, bigv, gi);
+                for (part = 0; part < 4; part++) {
+                    const int sfbs = pt[part], slen = gi->slen[part];
+                    for (i = 0; i < sfbs; i++, sfb++) lo_put(&w, (uint32_t)(gi->scalefac[sfb] > 0 ? gi->scalefac[sfb] : 0), slen);
+                }
+                {
+                    int bigv = gi->big_values, i2 = gi->region0_count + 1, r1, r2;
+                    r1 = c->sfb_l[i2];
+                    i2 += gi->region1_count + 1;
+                    r2 = c->sfb_l[i2];
+                    if (r1 > bigv) r1 = bigv;
+                    if (r2 > bigv) r2 = bigv;
+                    lo_huffmancode(c, &w, gi->table_select[0], 0, r1, gi);
+                    lo_huffmancode(c, &w, gi->table_select[1], r1, r2, gi);
+                    lo_huffmancode(c, &w, gi->table_select[2], r2, bigv, gi);
+                }
             }
             lo_count1_code(c, &w, gi);
+            if (getenv("LO_DEBUG") && w.bitpos - dbg_p0 != gi->part2_3_length + gi->part2_length)
+                fprintf(stderr, "frame %ld ch %d: wrote %d, part2 %d part2_3 %d bt %d slen %d %d %d %d tab %d row %d sfc %d\n", e->frame_num, ch, w.bitpos - dbg_p0, gi->part2_length, gi->part2_3_length, gi->block_type, gi->slen[0], gi->slen[1], gi->slen[2], gi->slen[3], gi->sfb_part_tab, gi->sfb_part_row, gi->scalefac_compress);
         }
+    }
     lo_drain(c, &w, e->resvDrain_post);
     if (w.bitpos != frame_bits) {
         fprintf(stderr, "lame_oracle: frame %ld wrote %d bits, expected %d\n", e->frame_num, w.bitpos, frame_bits);
@@ -313,7 +394,7 @@ static int lo_encode_frame(lo_enc* e, uint8_t* out) {
     lo_mdct_sub48(e, inbuf[0], inbuf[1]);
     if (e->tap) {
         e->tap->ath_adjust = e->ATH_adjust;
-        for (gr = 0; gr < 2; gr++)
+        for (gr = 0; gr < c->mode_gr; gr++)
             for (ch = 0; ch < c->channels_out; ch++) {
                 memcpy(e->tap->xr[gr][ch], e->tt[gr][ch].xr, sizeof e->tt[gr][ch].xr);
                 e->tap->block_type[gr][ch] = e->tt[gr][ch].block_type;
@@ -364,12 +445,13 @@ int lo_frame_bytes_max(const lo_enc* e) {
 
 static long lo_feed(lo_enc* e, const float* l, const float* r, size_t nsamples, uint8_t* out, size_t cap) {
     const lo_cfg* c = &e->c;
-    const int mf_needed = 1024 + 1152 - 272;   /* max(BLKSIZE + framesize - FFTOFFSET, 512 + framesize - 32) = 1904 */
+    const int framesize = 576 * c->mode_gr;
+    const int mf_needed = 1024 + framesize - 272;   /* calcNeeded: max(BLKSIZE + framesize - FFTOFFSET, 512 + framesize - 32) */
     long written = 0;
     size_t pos = 0;
     int ch, i;
     while (nsamples > 0) {
-        int n = nsamples < 1152 ? (int)nsamples : 1152;
+        int n = nsamples < (size_t)framesize ? (int)nsamples : framesize;      /* fill_buffer: at most one frame per pass */
         for (i = 0; i < n; i++) {
             e->mfbuf[0][e->mf_size + i] = l[pos + i];
             if (c->channels_out == 2) e->mfbuf[1][e->mf_size + i] = r[pos + i];
@@ -381,10 +463,10 @@ static long lo_feed(lo_enc* e, const float* l, const float* r, size_t nsamples, 
         if (e->mf_size >= mf_needed) {
             if ((size_t)written + (size_t)lo_frame_bytes_max(e) > cap) return -1;
             written += lo_encode_frame(e, out + written);
-            e->mf_size -= 1152;
-            e->mf_samples_to_encode -= 1152;
+            e->mf_size -= framesize;
+            e->mf_samples_to_encode -= framesize;
             for (ch = 0; ch < c->channels_out; ch++)
-                memmove(e->mfbuf[ch], e->mfbuf[ch] + 1152, (size_t)e->mf_size * sizeof(float));
+                memmove(e->mfbuf[ch], e->mfbuf[ch] + framesize, (size_t)e->mf_size * sizeof(float));
         }
     }
     return written;
@@ -417,12 +499,13 @@ long lo_flush(lo_enc* e, uint8_t* out, size_t cap) {
     long written = 0;
     int samples_to_encode, end_padding, frames_left;
     if (e->mf_samples_to_encode < 1) return 0;
+    const int framesize = 576 * e->c.mode_gr, mf_needed = 1024 + framesize - 272;
     samples_to_encode = e->mf_samples_to_encode - 1152;     /* POSTDELAY */
-    end_padding = 1152 - (samples_to_encode % 1152);
-    if (end_padding < 576) end_padding += 1152;
-    frames_left = (samples_to_encode + end_padding) / 1152;
+    end_padding = framesize - (samples_to_encode % framesize);
+    if (end_padding < 576) end_padding += framesize;
+    frames_left = (samples_to_encode + end_padding) / framesize;
     while (frames_left > 0) {
-        int bunch = 1904 - e->mf_size;
+        int bunch = mf_needed - e->mf_size;
         long fn = e->frame_num, n;
         if (bunch > 1152) bunch = 1152;
         if (bunch < 1) bunch = 1;

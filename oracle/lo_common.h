@@ -82,6 +82,7 @@ typedef struct {
     int part2_length, sfb_lmax, sfb_smin, psy_lmax, sfbmax, psymax, sfbdivide;
     int width[SFBMAX], window[SFBMAX];
     int count1bits, max_nonzero_coeff;
+    int slen[4], sfb_part_tab, sfb_part_row;   /* MPEG-2 LSF scalefactor partitions (Takehiro.js:1046-1132) */
 } lo_gr;
 
 typedef struct { float l[SBMAX_l]; float s[SBMAX_s][3]; } lo_xmin;

@@ -313,5 +313,7 @@ static void lo_mdct_sub48(lo_enc* e, const float* w0, const float* w1) {
             }
         }
         wk = w1;
+        if (c->mode_gr == 1)                    /* NewMDCT.js:1154-1159: the single granule becomes "previous" */
+            memcpy(e->sb_sample[ch][0], e->sb_sample[ch][1], sizeof e->sb_sample[ch][0]);
     }
 }

@@ -70,6 +70,7 @@ static void lo_init_outer_loop(lo_enc* e, lo_gr* gi) {
     gi->subblock_gain[0] = gi->subblock_gain[1] = gi->subblock_gain[2] = gi->subblock_gain[3] = 0;
     gi->region0_count = 0; gi->region1_count = 0; gi->preflag = 0; gi->scalefac_scale = 0;
     gi->count1table_select = 0; gi->part2_length = 0;
+    gi->sfb_part_tab = 0; gi->sfb_part_row = 0; gi->slen[0] = gi->slen[1] = gi->slen[2] = gi->slen[3] = 0;   /* Quantize.js:292-296 */
     gi->sfb_lmax = SBPSY_l; gi->sfb_smin = SBPSY_s;
     gi->psy_lmax = c->sfb21_extra ? SBMAX_l : SBPSY_l;
     gi->psymax = gi->psy_lmax;
@@ -675,13 +676,70 @@ static int lo_inc_subblock_gain(const lo_cfg* c, lo_gr* gi, float* xrpow) {
     return 0;
 }
 
+/* MPEG-2 LSF: scalefactor partition tables of ISO 13818-3 2.4.3.2 as the reference holds them
+ * (QuantizePVT.js:116-122 nr_of_sfb_block, Takehiro.js:1035-1037 max_range_sfac_tab, 1138-1139 log2tab) */
+const int lo_nr_of_sfb_block[6][3][4] = {
+    {{6, 5, 5, 5}, {9, 9, 9, 9}, {6, 9, 9, 9}}, {{6, 5, 7, 3}, {9, 9, 12, 6}, {6, 9, 12, 6}},
+    {{11, 10, 0, 0}, {18, 18, 0, 0}, {15, 18, 0, 0}}, {{7, 7, 7, 0}, {12, 12, 12, 0}, {6, 15, 12, 0}},
+    {{6, 6, 6, 3}, {12, 9, 9, 6}, {6, 12, 9, 6}}, {{8, 8, 5, 0}, {15, 12, 9, 0}, {6, 18, 9, 0}}};
+static const int lo_max_range_sfac_tab[6][4] = {{15, 15, 7, 7}, {15, 15, 7, 0}, {7, 3, 0, 0}, {15, 31, 31, 0}, {7, 7, 7, 0}, {3, 3, 0, 0}};
+static const int lo_log2tab[16] = {0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
+
+/* Takehiro.js:1046-1132 scale_bitcount_lsf ; returns 1 when a scalefactor exceeds its partition's range */
+static int lo_scale_bitcount_lsf(const lo_cfg* c, lo_gr* gi) {
+    int table_number, row_in_table, partition, nr_sfb, window, over, i, sfb, max_sfac[4] = {0, 0, 0, 0};
+    const int32_t* scalefac = gi->scalefac;
+    const int* partition_table;
+    (void)c;
+    table_number = (gi->preflag != 0) ? 2 : 0;
+    if (gi->block_type == SHORT_TYPE) {
+        row_in_table = 1;
+        partition_table = lo_nr_of_sfb_block[table_number][row_in_table];
+        for (sfb = 0, partition = 0; partition < 4; partition++) {
+            nr_sfb = partition_table[partition] / 3;
+            for (i = 0; i < nr_sfb; i++, sfb++)
+                for (window = 0; window < 3; window++)
+                    if (scalefac[sfb * 3 + window] > max_sfac[partition]) max_sfac[partition] = scalefac[sfb * 3 + window];
+        }
+    } else {
+        row_in_table = 0;
+        partition_table = lo_nr_of_sfb_block[table_number][row_in_table];
+        for (sfb = 0, partition = 0; partition < 4; partition++) {
+            nr_sfb = partition_table[partition];
+            for (i = 0; i < nr_sfb; i++, sfb++)
+                if (scalefac[sfb] > max_sfac[partition]) max_sfac[partition] = scalefac[sfb];
+        }
+    }
+    for (over = 0, partition = 0; partition < 4; partition++)
+        if (max_sfac[partition] > lo_max_range_sfac_tab[table_number][partition]) over = 1;
+    if (!over) {
+        int slen1, slen2, slen3, slen4;
+        gi->sfb_part_tab = table_number; gi->sfb_part_row = row_in_table;
+        for (partition = 0; partition < 4; partition++) gi->slen[partition] = lo_log2tab[max_sfac[partition]];
+        slen1 = gi->slen[0]; slen2 = gi->slen[1]; slen3 = gi->slen[2]; slen4 = gi->slen[3];
+        switch (table_number) {
+            case 0: gi->scalefac_compress = (((slen1 * 5) + slen2) << 4) + (slen3 << 2) + slen4; break;
+            case 1: gi->scalefac_compress = 400 + (((slen1 * 5) + slen2) << 2) + slen3; break;
+            case 2: gi->scalefac_compress = 500 + (slen1 * 3) + slen2; break;
+            default: break;
+        }
+        gi->part2_length = 0;
+        for (partition = 0; partition < 4; partition++) gi->part2_length += gi->slen[partition] * partition_table[partition];
+    }
+    return over;
+}
+
+static int lo_scale_bitcount_any(const lo_cfg* c, lo_gr* gi) {       /* Quantize.js:814-817, 840-843; Takehiro.js:936-940 */
+    return (c->mode_gr == 2) ? lo_scale_bitcount(c, gi) : lo_scale_bitcount_lsf(c, gi);
+}
+
 /* Quantize.js:793-846 ; returns 1 to continue, 0 to stop */
 static int lo_balance_noise(const lo_cfg* c, lo_gr* gi, const float* distort, float* xrpow) {
     int status;
     lo_amp_scalefac_bands(c, gi, distort, xrpow);
     status = lo_loop_break(gi);
     if (status) return 0;
-    status = lo_scale_bitcount(c, gi);
+    status = lo_scale_bitcount_any(c, gi);
     if (!status) return 1;
     if (c->noise_shaping > 1) {
         if (0 == gi->scalefac_scale) {
@@ -691,7 +749,7 @@ static int lo_balance_noise(const lo_cfg* c, lo_gr* gi, const float* distort, fl
             status = (lo_inc_subblock_gain(c, gi, xrpow) || lo_loop_break(gi));
         }
     }
-    if (!status) status = lo_scale_bitcount(c, gi);
+    if (!status) status = lo_scale_bitcount_any(c, gi);
     return !status;
 }
 
@@ -823,7 +881,7 @@ static void lo_best_scalefac_store(lo_enc* e, int gr, int ch) {
         recalc = 0;
     }
     for (sfb = 0; sfb < gi->sfbmax; sfb++) if (gi->scalefac[sfb] == -2) gi->scalefac[sfb] = 0;
-    if (recalc != 0) lo_scale_bitcount(c, gi);
+    if (recalc != 0) lo_scale_bitcount_any(c, gi);
 }
 
 static void lo_recalc_divide_init(const lo_cfg* c, const lo_gr* gi, const int32_t* ix, int* r01_bits, int* r01_div,
@@ -875,6 +933,7 @@ static void lo_best_huffman_divide(const lo_cfg* c, lo_gr* gi) {
     int32_t ix[576];
     int r01_bits[7 + 15 + 1], r01_div[7 + 15 + 1], r0_tbl[7 + 15 + 1], r1_tbl[7 + 15 + 1];
     int i, a1, a2;
+    if (gi->block_type == SHORT_TYPE && c->mode_gr == 1) return;      /* Takehiro.js:735-737: fails for MPEG-2 short blocks */
     memset(r01_div, 0, sizeof r01_div); memset(r0_tbl, 0, sizeof r0_tbl); memset(r1_tbl, 0, sizeof r1_tbl);
     memcpy(ix, gi->l3_enc, sizeof ix);     /* the reference keeps reading the pre-assign array; contents equal */
     cod_info2 = *gi;

@@ -22,7 +22,9 @@ function cmp(name, mine, ref, n) {
 function cmpS(name, mine, ref) { cmp(name, [mine], [ref]); }
 
 const configs = [[1, 44100, 128], [2, 44100, 128], [2, 44100, 320], [1, 44100, 64], [2, 48000, 192],
-    [1, 32000, 96], [2, 44100, 160], [2, 44100, 256], [1, 48000, 320], [2, 32000, 224]];
+    [1, 32000, 96], [2, 44100, 160], [2, 44100, 256], [1, 48000, 320], [2, 32000, 224],
+    /* MPEG-2 / MPEG-2.5 (LSF) rates */
+    [1, 22050, 64], [2, 24000, 96], [1, 16000, 32], [2, 16000, 48], [1, 11025, 24], [1, 8000, 16], [2, 12000, 32], [1, 22050, 160], [2, 22050, 128]];
 for (const [ch, sr, kb] of configs) {
     let r;
     try { r = tables.buildBlob(ch, sr, kb); } catch (e) { console.log('skip', ch, sr, kb, e.message); continue; }
@@ -34,6 +36,9 @@ for (const [ch, sr, kb] of configs) {
     cmpS(tag + 'bitrate_index', p.bitrate_index, gfc.bitrate_index);
     cmpS(tag + 'samplerate_index', p.samplerate_index, gfc.samplerate_index);
     cmpS(tag + 'sideinfo_len', p.sideinfo_len, gfc.sideinfo_len);
+    cmpS(tag + 'mode_gr', p.mode_gr, gfc.mode_gr);
+    cmpS(tag + 'version', p.version, gfp.version);
+    cmpS(tag + 'brate', p.brate, gfp.brate);
     cmpS(tag + 'frac_SpF', p.frac_SpF, gfc.frac_SpF);
     cmpS(tag + 'scale', p.scale, gfp.scale);
     cmpS(tag + 'attackthre', p.attackthre, gfc.nsPsy.attackthre);

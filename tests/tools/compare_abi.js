@@ -14,6 +14,7 @@ const tables = require('../../lamejs_amd/js/tables.js');
 
 const [corpus, chS, kbS, nfS, chunkS] = process.argv.slice(2);
 const ch = +chS, kbps = +kbS, nframes = +(nfS || 300), chunk = +(chunkS || 1152);
+const SR = +(process.env.LHIP_SR || 44100);       /* sample rate the encoders are told (the corpus itself is rate-agnostic) */
 let L, R;
 if (corpus == 'wav') {
     L = gen.readWav(fs.readFileSync(path.join(REF, 'testdata/Left44100.wav'))).samples;
@@ -27,7 +28,7 @@ if (corpus == 'wav') {
 
 function encodeRef() {
     const lamejs = refPublic();
-    const enc = new lamejs.Mp3Encoder(ch, 44100, kbps);
+    const enc = new lamejs.Mp3Encoder(ch, SR, kbps);
     const parts = [];
     for (let i = 0; i < L.length; i += chunk) {
         const l = L.subarray(i, i + chunk), r = R ? R.subarray(i, i + chunk) : undefined;
@@ -40,7 +41,7 @@ function encodeRef() {
 }
 
 const tmp = fs.mkdtempSync('/tmp/lo_cmp_');
-const blob = tables.buildBlob(ch, 44100, kbps).blob;
+const blob = tables.buildBlob(ch, SR, kbps).blob;
 fs.writeFileSync(path.join(tmp, 't.bin'), blob);
 const inter = new Int16Array(L.length * ch);
 for (let i = 0; i < L.length; i++) { inter[i * ch] = L[i]; if (ch == 2) inter[i * ch + 1] = R[i]; }
@@ -49,7 +50,7 @@ const t0 = Date.now();
 const ref = encodeRef();
 const tRef = Date.now() - t0;
 const cli = path.join(__dirname, '../../tests/hostsim/_build/abi_cli_hostsim');
-const r = cp.spawnSync(process.env.LHIP_CLI || cli, [path.join(tmp, 't.bin'), path.join(tmp, 'in.pcm'), path.join(tmp, 'out.mp3'), '' + ch, '44100', '' + kbps].concat(process.env.LHIP_CHUNK ? [process.env.LHIP_CHUNK] : []), { encoding: 'utf8' });
+const r = cp.spawnSync(process.env.LHIP_CLI || cli, [path.join(tmp, 't.bin'), path.join(tmp, 'in.pcm'), path.join(tmp, 'out.mp3'), '' + ch, '' + SR, '' + kbps].concat(process.env.LHIP_CHUNK ? [process.env.LHIP_CHUNK] : []), { encoding: 'utf8' });
 if (r.status !== 0) { console.log('oracle failed:', r.stderr); process.exit(2); }
 const mine = fs.readFileSync(path.join(tmp, 'out.mp3'));
 const md5 = (b) => require('crypto').createHash('md5').update(b).digest('hex');
@@ -61,7 +62,7 @@ let d = 0; while (d < Math.min(ref.length, mine.length) && ref[d] == mine[d]) d+
 let pos = 0, fr = 0;
 while (pos < ref.length) {
     const pad = (ref[pos + 2] >> 1) & 1;
-    const len = Math.floor(144000 * kbps / 44100) + pad;
+    const len = Math.floor((SR <= 24000 ? 72000 : 144000) * kbps / SR) + pad;
     if (d < pos + len) break;
     pos += len; fr++;
 }
