@@ -3,7 +3,8 @@
 // Follows reference BitStream.js: encodeSideInfo2 (259-426), writeMainData (600-689),
 // Huffmancode (487-552), huffman_coder_count1 (428-482), drain_into_ancillary (175-213).
 // With the reservoir disabled every frame is self-contained (main_data_begin == 0), so the frame
-// is: sideinfo_len bytes | main data of gr0ch0, gr0ch1, gr1ch0, gr1ch1 | stuffing to the frame size.
+// is: sideinfo_len bytes | main data of gr0ch0, gr0ch1, gr1ch0, gr1ch1 | stuffing to the frame size
+// (MPEG-2/2.5 frames carry one granule).
 // Variable-length codes are placed with an integer prefix sum over code lengths (order-free).
 #pragma once
 #include "lhip_defs.h"
@@ -110,26 +111,33 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     for (int i = lane; i < nwords + 1; i += LHIP_NL) L.w[i] = 0;
     wave_sync();
     const GrSide* side = W.side + (int64_t)fidx * 2 * C;
+    const int GR = T.mode_gr;
     int pos = 0;
     if (lane == 0) {
         uint32_t* w = L.w;
 #define PUT(v, n) { put_bits(w, pos, (uint32_t)(v), (n)); pos += (n); }
-        PUT(0xfff, 12) PUT(T.version, 1) PUT(4 - 3, 2) PUT(!T.error_protection ? 1 : 0, 1)
+        PUT(T.out_samplerate < 16000 ? 0xffe : 0xfff, 12) PUT(T.version, 1)       // BitStream.js:262-267
+        PUT(4 - 3, 2) PUT(!T.error_protection ? 1 : 0, 1)
         PUT(T.bitrate_index, 4) PUT(T.samplerate_index, 2) PUT(padding, 1) PUT(T.extension, 1)
         PUT(T.mode, 2) PUT(0, 2) PUT(T.copyright, 1) PUT(T.original, 1) PUT(T.emphasis, 2)
-        PUT(0, 9)
-        PUT(0, C == 2 ? 3 : 5)
-        for (int ch = 0; ch < C; ch++) {
-            const int sc = side[(1 * C) + ch].scfsi;
-            for (int band = 0; band < 4; band++) PUT((sc >> band) & 1, 1)
+        if (GR == 2) {
+            PUT(0, 9)
+            PUT(0, C == 2 ? 3 : 5)
+            for (int ch = 0; ch < C; ch++) {
+                const int sc = side[(1 * C) + ch].scfsi;
+                for (int band = 0; band < 4; band++) PUT((sc >> band) & 1, 1)
+            }
+        } else {                                             // MPEG-2/2.5 (BitStream.js:352-405)
+            PUT(0, 8)
+            PUT(0, C)
         }
-        for (int gr = 0; gr < 2; gr++)
+        for (int gr = 0; gr < GR; gr++)
             for (int ch = 0; ch < C; ch++) {
                 const GrSide& gi = side[gr * C + ch];
                 PUT(gi.part2_3_length + gi.part2_length, 12)
                 PUT(gi.big_values / 2, 9)
                 PUT(gi.global_gain, 8)
-                PUT(gi.scalefac_compress, 4)
+                PUT(gi.scalefac_compress, GR == 2 ? 4 : 9)
                 int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
                 if (ts0 == 14) ts0 = 16;
                 if (ts1 == 14) ts1 = 16;
@@ -142,25 +150,46 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
                     PUT(0, 1) PUT(ts0, 5) PUT(ts1, 5) PUT(ts2, 5)
                     PUT(gi.region0_count, 4) PUT(gi.region1_count, 3)
                 }
-                PUT(gi.preflag, 1) PUT(gi.scalefac_scale, 1) PUT(gi.count1table_select, 1)
+                if (GR == 2) PUT(gi.preflag, 1)
+                PUT(gi.scalefac_scale, 1) PUT(gi.count1table_select, 1)
             }
 #undef PUT
     }
     pos = 8 * T.sideinfo_len;
     wave_sync();
-    for (int gr = 0; gr < 2; gr++)
+    for (int gr = 0; gr < GR; gr++)
         for (int ch = 0; ch < C; ch++) {
             const GrSide& gi = side[gr * C + ch];
             const int16_t* q = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-            const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];
-            // scalefactors: at most 36 short fields
-            {
+            if (GR == 2) {
+                // scalefactors: at most 36 short fields
+                const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];
                 int p2 = pos;
                 for (int sfb = 0; sfb < gi.sfbmax; sfb++) {
                     const int v = gi.scalefac[sfb];
                     if (v == -1) continue;
                     const int n = sfb < gi.sfbdivide ? slen1 : slen2;
                     if (lane == 0) put_bits(L.w, p2, (uint32_t)v, n);
+                    p2 += n;
+                }
+                pos = p2;
+            } else {
+                // MPEG-2/2.5: four partitions with their own field widths (BitStream.js:645-686).  The widths and the
+                // partition sizes are what a decoder derives from scalefac_compress (scale_bitcount_lsf packed them):
+                // table 0 (no preflag) = slen1*80 + slen2*16 + slen3*4 + slen4 over {6,5,5,5} / {9,9,9,9} entries,
+                // table 2 (preflag)    = 500 + slen1*3 + slen2 over {11,10,0,0} / {18,18,0,0} entries.
+                const bool pre = gi.preflag != 0, sh = gi.block_type == SHORT_TYPE;
+                const int sc = gi.scalefac_compress - (pre ? 500 : 0);
+                const int sl0 = pre ? sc / 3 : (sc >> 4) / 5, sl1 = pre ? sc % 3 : (sc >> 4) % 5;
+                const int sl2 = pre ? 0 : (sc >> 2) & 3, sl3 = pre ? 0 : sc & 3;
+                const int n0 = pre ? (sh ? 18 : 11) : (sh ? 9 : 6), n1 = pre ? (sh ? 18 : 10) : (sh ? 9 : 5);
+                const int n2 = pre ? 0 : (sh ? 9 : 5);
+                const int b1 = n0, b2 = n0 + n1, b3 = b2 + n2, end = b3 + n2;
+                int p2 = pos;
+                for (int i = 0; i < end; i++) {
+                    const int n = i < b1 ? sl0 : i < b2 ? sl1 : i < b3 ? sl2 : sl3;
+                    const int v = gi.scalefac[i];
+                    if (lane == 0) put_bits(L.w, p2, (uint32_t)(v > 0 ? v : 0), n);
                     p2 += n;
                 }
                 pos = p2;

@@ -494,11 +494,12 @@ LHIP_DEV void ath_step(const Tables& T, double max_pow, double& adj, double& lim
 
 // max_pow of frame k of the stream (Encoder.js:420-440): loudness of the two psy calls before the frame's granules
 LHIP_DEV double ath_max_pow(const Tables& T, const Workspace& W, const StreamDesc& sd, int C, int k) {
-    const int64_t g0 = (int64_t)(sd.gslot0 + 2 * k) * C, g1 = g0 + C;
-    double max_pow = W.loud[g0], gr2_max = W.loud[g1];
-    if (C == 2) { max_pow += (double)W.loud[g0 + 1]; gr2_max += (double)W.loud[g1 + 1]; }
+    const int GR = T.mode_gr;
+    const int64_t g0 = (int64_t)(sd.gslot0 + GR * k) * C, g1 = g0 + C;
+    double max_pow = W.loud[g0], gr2_max = (GR == 2) ? (double)W.loud[g1] : 0.0;
+    if (C == 2) { max_pow += (double)W.loud[g0 + 1]; if (GR == 2) gr2_max += (double)W.loud[g1 + 1]; }
     else { max_pow += max_pow; gr2_max += gr2_max; }
-    max_pow = max_pow > gr2_max ? max_pow : gr2_max;
+    if (GR == 2) max_pow = max_pow > gr2_max ? max_pow : gr2_max;      // Encoder.js:187-189: only with two granules
     max_pow *= 0.5;
     max_pow *= T.ATH_aaSensitivityP;
     return max_pow;
@@ -617,7 +618,7 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const StreamDesc sd = SD[st];
     const int q = gslot - sd.gslot0 - 1;
     if (q < 0) return;
-    const int fs = sd.fslot0 + (q >> 1);                 // ATH.adjust as left by the previous frame
+    const int fs = sd.fslot0 + q / T.mode_gr;            // ATH.adjust as left by the previous frame
     const double ath_adjust = W.ath_adjust[fs];
     for (int i = lane; i < 25; i += LHIP_NL) {
         L.mt1[i] = T.ma_table1[i];

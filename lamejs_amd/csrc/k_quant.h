@@ -1011,6 +1011,44 @@ LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lan
     return g.part2_length == LARGE_BITS;
 }
 
+// scale_bitcount_lsf (Takehiro.js:1046-1132), MPEG-2/2.5, no mixed blocks, no intensity stereo.  The four
+// partitions of nr_of_sfb_block[table][row] are runs of the linear scalefactor index (a short band contributes its
+// three windows), every max_range_sfac_tab entry is 2^n-1 and log2tab is the bit length, so the four partition maxima
+// of the reference become one OR reduction with a byte per partition.  On failure nothing is written (the reference
+// leaves scalefac_compress / part2_length as they were); returns 1 on failure.
+LHIP_DEV int q_scale_bitcount_lsf(GI& g, const int32_t* scalefac, int lane) {
+    lane = fresh_lane(lane);
+    const bool pre = g.preflag != 0, sh = g.block_type == SHORT_TYPE;
+    // nr_of_sfb_block[0][0..1] = {6,5,5,5} {9,9,9,9}; nr_of_sfb_block[2][0..1] = {11,10,0,0} {18,18,0,0}
+    const int n0 = pre ? (sh ? 18 : 11) : (sh ? 9 : 6), n1 = pre ? (sh ? 18 : 10) : (sh ? 9 : 5);
+    const int n2 = pre ? 0 : (sh ? 9 : 5), n3 = n2;
+    const uint32_t range = pre ? 0x00000307u : 0x07070f0fu;      // max_range_sfac_tab[0] / [2], partition p in byte p
+    const int b1 = n0, b2 = n0 + n1, b3 = b2 + n2, end = b3 + n3;
+    uint32_t m = 0;
+    for (int i = lane; i < end; i += LHIP_NL) {
+        int v = scalefac[i];
+        if (v < 0) v = 0;
+        const int part = (i >= b1) + (i >= b2) + (i >= b3);
+        m |= (uint32_t)v << (8 * part);
+    }
+    m = (uint32_t)wave_or((int)m);
+    int over = 0, slen[4];
+    for (int p = 0; p < 4; p++) {
+        const uint32_t mp = (m >> (8 * p)) & 0xffu;
+        if (mp > ((range >> (8 * p)) & 0xffu)) over = 1;
+        slen[p] = mp ? 32 - __builtin_clz(mp) : 0;
+    }
+    if (!over) {
+        g.scalefac_compress = pre ? 500 + slen[0] * 3 + slen[1] : ((slen[0] * 5 + slen[1]) << 4) + (slen[2] << 2) + slen[3];
+        g.part2_length = slen[0] * n0 + slen[1] * n1 + slen[2] * n2 + slen[3] * n3;
+    }
+    return over;
+}
+
+LHIP_DEV int q_scale_bitcount_any(const Tables& T, GI& g, int32_t* scalefac, int lane) {   // Quantize.js:814-817, 840-843
+    return T.mode_gr == 2 ? q_scale_bitcount(T, g, scalefac, lane) : q_scale_bitcount_lsf(g, scalefac, lane);
+}
+
 // ---------------------------------------------------------------------------------------------
 // amplification helpers (Quantize.js:453-460, 597-778)
 // ---------------------------------------------------------------------------------------------
@@ -1133,7 +1171,7 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
     q_amp_scalefac_bands(T, g, scalefac, lane, L, Q);
     int status = q_loop_break(g, scalefac, lane, L, Q);
     if (status) return 0;
-    status = q_scale_bitcount(T, g, scalefac, lane);
+    status = q_scale_bitcount_any(T, g, scalefac, lane);
     if (!status) return 1;
     if (T.noise_shaping > 1) {
         if (0 == g.scalefac_scale) {
@@ -1143,7 +1181,7 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
             status = (q_inc_subblock_gain(T, g, scalefac, lane, L, Q) || q_loop_break(g, scalefac, lane, L, Q));
         }
     }
-    if (!status) status = q_scale_bitcount(T, g, scalefac, lane);
+    if (!status) status = q_scale_bitcount_any(T, g, scalefac, lane);
     return !status;
 }
 
@@ -1349,7 +1387,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     wave_sync();
     for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (sf[sfb] == -2) sf[sfb] = 0;
     wave_sync();
-    if (uni(recalc) != 0) q_scale_bitcount(T, g, sf, lane);
+    if (uni(recalc) != 0) q_scale_bitcount_any(T, g, sf, lane);
 }
 
 // Huffman statistics per scalefactor band over the pairs below `limit`, then turned into prefix sums over
@@ -1479,6 +1517,7 @@ LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, int lane
 }
 
 LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
+    if (g.block_type == SHORT_TYPE && T.mode_gr == 1) return;     // Takehiro.js:735-737
     lane = fresh_lane(lane);
     const int16_t* ix = L.ixw;
     GI c2 = g;
@@ -1563,8 +1602,9 @@ struct Seed { int start, step; };
 LHIP_DEV Seed seed_before(const Workspace& W, const StreamDesc& sd, int C, int k, int gr, int ch) {
     const int32_t* carry = W.seed + ((int64_t)sd.fslot0 * C + ch) * 2;
     int g1 = -1, g2 = -1;                                    // gains of the last / second-to-last active granule
-    for (int q = 2 * k + gr - 1; q >= 0; q--) {
-        const GrSide* r = W.side + ((int64_t)sd.out_slot0 * 2 + q) * C + ch;
+    const int GR = W.mode_gr;                                 // side records are laid out [frame][2][C] whatever GR is
+    for (int q = GR * k + gr - 1; q >= 0; q--) {
+        const GrSide* r = W.side + (((int64_t)sd.out_slot0 + q / GR) * 2 + q % GR) * C + ch;
         if (r->active) {
             if (g1 < 0) g1 = r->bs_gain;
             else { g2 = r->bs_gain; break; }
@@ -1641,8 +1681,8 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     }
     int ResvSize = 0;
     int gr0_bt0 = 0, gr0_bt1 = 0;
-    for (int gr = 0; gr < 2; gr++) {
-        const int gslot = sd.gslot0 + 1 + 2 * k + gr;
+    for (int gr = 0; gr < T.mode_gr; gr++) {
+        const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
         int targ[2] = {0, 0};
         targ_bits_for(T, mean_bits, gr, ResvSize, targ);
         const int targ0 = targ[0], targ1 = targ[1];
@@ -1728,8 +1768,8 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
     if (uni(W.seed_flag[fidx]) != 2) return;                  // only frames the memo-only pass could not decide
     const double ath_adjust = W.ath_adjust[fslot];
     int bad = 0;
-    for (int gr = 0; gr < 2 && !bad; gr++) {
-        const int gslot = sd.gslot0 + 1 + 2 * k + gr;
+    for (int gr = 0; gr < T.mode_gr && !bad; gr++) {
+        const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
         for (int ch = 0; ch < C && !bad; ch++) {
             const GrSide* rec = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
             if (!rec->active) continue;
@@ -1833,7 +1873,7 @@ LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const Stream
     if (k < 0) return;
     const int fidx = sd.out_slot0 + k;
     int verdict = 0;
-    for (int gr = 0; gr < 2 && verdict == 0; gr++)
+    for (int gr = 0; gr < T.mode_gr && verdict == 0; gr++)
         for (int ch = 0; ch < C && verdict == 0; ch++) {
             const GrSide* rec = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
             if (!rec->active) continue;

@@ -126,12 +126,13 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const StreamIO io = IO[st];
     StreamState* S = io.state;
     const int F = sd.nframes;
-    const int total = io.mf_size + io.n_new, keep = total - FRAME * F;
+    const int frame = 576 * T.mode_gr;
+    const int total = io.mf_size + io.n_new, keep = total - frame * F;
     for (int ch = 0; ch < C; ch++) {
         const float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
-        for (int i = lane; i < keep; i += LHIP_NL) S->pcm_tail[ch][i] = seg[FRAME * F + i];
+        for (int i = lane; i < keep; i += LHIP_NL) S->pcm_tail[ch][i] = seg[frame * F + i];
         if (F == 0) continue;
-        const int64_t o = (int64_t)(sd.gslot0 + 2 * F) * C + ch;
+        const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * C + ch;
         for (int i = lane; i < SB_STRIDE; i += LHIP_NL) S->sb[ch][i] = W.sb[o * SB_STRIDE + i];
         for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[ch][i] = W.E[o * E_STRIDE + i];
         for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[ch][i] = W.ecb_s[o * EBS_STRIDE + i];
@@ -373,9 +374,9 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     if (!ok) return false;
     // ---- envelope checks: fail loudly rather than produce different bytes than the reference ----
     if (T.channels_out != (cfg.channels == 1 ? 1 : 2) || T.out_samplerate != cfg.samplerate || T.brate <= 0) { set_err("tables blob does not match the requested configuration"); return false; }
-    if (T.version != 1 || T.mode_gr != 2 || T.quant_comp != 9 || T.quant_comp_short != 9 || T.error_protection || T.sfb21_extra ||
+    if ((T.version != 1 && T.version != 0) || T.mode_gr != (T.version == 1 ? 2 : 1) || T.quant_comp != 9 || T.quant_comp_short != 9 || T.error_protection || T.sfb21_extra ||
         T.substep_shaping != 0 || T.noise_shaping_amp > 2 || T.use_best_huffman > 1 || T.athaa_loudapprox != 2 || T.full_outer_loop != 0) {
-        set_err("configuration outside the supported envelope (MPEG-1 CBR, quality-3 switches)"); return false;
+        set_err("configuration outside the supported envelope (MPEG-1/2/2.5 CBR, quality-3 switches)"); return false;
     }
     // ---- derived index tables ----
     const int32_t* h_s3ind = (const int32_t*)host_arr("s3ind");
@@ -391,13 +392,29 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     k = 0; j = 0;
     for (int p = 0; p < T.npart_s; p++) { extra[CBANDS + p] = k; k += h_s3ind_s[2 * p + 1] - h_s3ind_s[2 * p] + 1; extra[3 * CBANDS + p] = j; j += h_ns[p]; }
     if (j != HBLKSIZE_s) { set_err("short partitions do not cover 129 lines"); return false; }
-    for (int sb = 1; sb < SBMAX_l; sb++) if (!(h_bo_l[sb] > h_bo_l[sb - 1] || h_bo_l[sb - 1] + 1 >= T.npart_l)) { set_err("unsupported partition/sfb layout (long)"); return false; }
-    for (int sb = 1; sb < SBMAX_s; sb++) if (!(h_bo_s[sb] > h_bo_s[sb - 1] || h_bo_s[sb - 1] + 1 >= T.npart_s)) { set_err("unsupported partition/sfb layout (short)"); return false; }
+    // convert_partition2scalefac walks partitions and bands together (PsyModel.js:644-734): band sb adds partitions
+    // up to min(bo[sb], npart), then splits the partition it stopped at with band sb+1.  Where bo[] does not grow
+    // (8 kHz short blocks) the walk stops at max(entry, bo[sb]) rather than bo[sb]; the kernel works per band from the
+    // stopping points, so hand it those instead of the raw bo[] (identical wherever bo[] is strictly increasing).
+    auto walk = [&](const int32_t* bo, int nb, int npart, int32_t* stop) {
+        int b = 0, sb = 0;
+        for (; sb < nb; ++b, ++sb) {
+            const int lim = bo[sb] < npart ? bo[sb] : npart;
+            if (b < lim) b = lim;
+            stop[sb] = b;
+            if (b >= npart) { ++sb; break; }
+        }
+        for (; sb < nb; ++sb) stop[sb] = npart;              // bands the walk never reaches (zero-filled by the kernel)
+    };
+    extra.resize(4 * CBANDS + SBMAX_l + SBMAX_s);
+    walk(h_bo_l, SBMAX_l, T.npart_l, extra.data() + 4 * CBANDS);
+    walk(h_bo_s, SBMAX_s, T.npart_s, extra.data() + 4 * CBANDS + SBMAX_l);
     ts.d_extra = rt::dmalloc(extra.size() * 4);
     if (!ts.d_extra) { set_err("hipMalloc failed"); return false; }
     if (!rt::h2d(ts.d_extra, extra.data(), extra.size() * 4, stream)) return false;
     if (!rt::sync(stream)) return false;
     T.s3off_l = (const int32_t*)ts.d_extra; T.s3off_s = T.s3off_l + CBANDS; T.lineoff_l = T.s3off_l + 2 * CBANDS; T.lineoff_s = T.s3off_l + 3 * CBANDS;
+    T.bo_l = T.s3off_l + 4 * CBANDS; T.bo_s = T.bo_l + SBMAX_l;
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
     return true;
@@ -488,6 +505,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     TableSet& ts = *jobs[0].s->ts;
     const Tables& T = ts.T;
     const int C = T.channels_out;
+    const int GR = T.mode_gr, frame = 576 * GR, mf_needed = 1024 + frame - 272;   // calcNeeded (Lame.js:1517-1530)
     const int S = (int)jobs.size();
     // ---- plan ----
     std::vector<StreamDesc> sd(S);
@@ -500,7 +518,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (s->ts.get() != &ts) { set_err("batch: all streams must share one configuration"); return false; }
         const int64_t total = (int64_t)s->mf_size + (int64_t)j.n;
         if (total > 0x7fffffff) { set_err("too many samples in one call"); return false; }
-        j.F = total >= MF_NEEDED ? (int)((total - MF_NEEDED) / FRAME) + 1 : 0;
+        j.F = total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
         j.bytes = batch_bytes(ts, s->slot_lag, j.F);
         if ((size_t)j.bytes > j.cap) { j.written = LHIP_ERR_BUFFER_TOO_SMALL; set_err("output buffer too small"); return false; }
         StreamDesc& d = sd[i];
@@ -508,14 +526,14 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         d.nframes = j.F; d.fslot0 = nfs; d.gslot0 = ngs; d.out_slot0 = nfr;
         d.pcm_off = pcm_plane; d.out_off = out_total; d.seg_len = (int)total; d.first_call = s->frame_num == 0;
         d.slot_lag = s->slot_lag; d.frame_num0 = s->frame_num;
-        nfs += j.F + 1; ngs += 2 * j.F + 1; nfr += j.F;
+        nfs += j.F + 1; ngs += GR * j.F + 1; nfr += j.F;
         pcm_plane += (total + 63) & ~(int64_t)63;
         in_total += (int64_t)j.n; out_total += (j.bytes + 15) & ~(int64_t)15;
     }
     // ---- workspace ----
     Workspace W;
     memset(&W, 0, sizeof W);
-    W.spec_start = g_spec_start; W.spec_step = g_spec_step;
+    W.spec_start = g_spec_start; W.spec_step = g_spec_step; W.mode_gr = T.mode_gr;
     W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
     const size_t GC = (size_t)ngs * C, FR = (size_t)(nfr > 0 ? nfr : 1);
 #define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
@@ -544,7 +562,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     for (int i = 0; i < S; i++) {
         Job& j = jobs[i];
         for (int k = 0; k <= j.F; k++) fmap[sd[i].fslot0 + k] = i;
-        for (int k = 0; k <= 2 * j.F; k++) gmap[sd[i].gslot0 + k] = i;
+        for (int k = 0; k <= GR * j.F; k++) gmap[sd[i].gslot0 + k] = i;
         StreamIO& o = io[i];
         o.state = j.s->d_state; o.n_new = (int)j.n; o.mf_size = j.s->mf_size;
         if (dev_io) {
@@ -671,8 +689,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             if (s->mf_samples_to_encode < 1) s->mf_samples_to_encode = 576 + 1152;
             s->mf_samples_to_encode += (int)j.n;
         }
-        s->mf_samples_to_encode -= FRAME * j.F;
-        s->mf_size = (int)(total - (int64_t)FRAME * j.F);
+        s->mf_samples_to_encode -= frame * j.F;
+        s->mf_size = (int)(total - (int64_t)frame * j.F);
         if (T.frac_SpF != 0 && j.F > 0) {
             int64_t m = ((int64_t)s->slot_lag - (int64_t)j.F * T.frac_SpF) % T.out_samplerate;
             if (m < 0) m += T.out_samplerate;
@@ -754,7 +772,8 @@ void lhip_destroy(lhip_stream* s) {
 
 size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples) {
     if (!s || s->magic != 0x4c484950) return 0;
-    return (nsamples / FRAME + 3) * (size_t)(s->ts->base_frame_bytes + 1);
+    const size_t frame = 576 * (size_t)s->ts->T.mode_gr;
+    return (nsamples / frame + 3 + (FRAME / frame)) * (size_t)(s->ts->base_frame_bytes + 1);
 }
 
 static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,
@@ -782,14 +801,31 @@ int64_t lhip_encode(lhip_stream* s, const int16_t* left, const int16_t* right, s
 }
 
 static size_t flush_zeros(lhip_stream* s) {
-    // Lame.js:1381-1443: how many zero samples make the remaining frames come out
+    // Lame.js:1381-1443: the flush loop feeds bunches of at most 1152 zeros (fill_buffer takes them one frame at a
+    // time) until `frames_left` bunches have each completed at least one frame; the total number of zeros is what
+    // the batch path needs, the frames follow from it
     if (s->mf_samples_to_encode < 1) return 0;
+    const int frame = 576 * s->ts->T.mode_gr, mf_needed = 1024 + frame - 272;
     const int samples_to_encode = s->mf_samples_to_encode - 1152;
-    int end_padding = FRAME - (samples_to_encode % FRAME);
-    if (end_padding < 576) end_padding += FRAME;
-    const int frames_left = (samples_to_encode + end_padding) / FRAME;
-    if (frames_left <= 0) return 0;
-    return (size_t)(MF_NEEDED + FRAME * (frames_left - 1) - s->mf_size);
+    int end_padding = frame - (samples_to_encode % frame);
+    if (end_padding < 576) end_padding += frame;
+    int frames_left = (samples_to_encode + end_padding) / frame;
+    int mf = s->mf_size;
+    size_t zeros = 0;
+    while (frames_left > 0) {
+        int bunch = mf_needed - mf;
+        if (bunch > 1152) bunch = 1152;
+        if (bunch < 1) bunch = 1;
+        int emitted = 0;
+        for (int rem = bunch; rem > 0;) {
+            const int n = rem < frame ? rem : frame;
+            mf += n; rem -= n;
+            if (mf >= mf_needed) { emitted++; mf -= frame; }
+        }
+        zeros += (size_t)bunch;
+        if (emitted) frames_left--;
+    }
+    return zeros;
 }
 
 int64_t lhip_flush(lhip_stream* s, uint8_t* out, size_t out_cap) {

@@ -74,6 +74,7 @@ struct Workspace {
     uint8_t* out;               // output MP3 bytes
     int32_t* frame_bytes;       // [nframes_total]
     unsigned long long* prof;   // [32] phase-profiling accumulators (profiling builds only)
+    int32_t mode_gr;            // granules per frame (2: MPEG-1, 1: MPEG-2/2.5 LSF)
     int32_t spec_start, spec_step;   // seed assumed by the speculative pass (Quantize.js reset values 180 / 4)
 };
 

@@ -40,11 +40,17 @@ def material(rng, n, ch):
     return out[0], (out[1] if ch == 2 else None)
 
 
-def run(ncases, seed, lib=None, verbose=True):
+MPEG1_CFGS = [(1, 44100, 128), (2, 44100, 128), (2, 44100, 320), (1, 44100, 64), (2, 44100, 192), (1, 44100, 320), (2, 48000, 128),
+              (1, 48000, 96), (2, 32000, 160), (1, 32000, 64), (2, 44100, 160), (2, 48000, 256), (1, 44100, 256), (2, 44100, 224)]
+# MPEG-2 / MPEG-2.5 (one granule per frame, scale_bitcount_lsf, partitioned scalefactors)
+LSF_CFGS = [(1, 22050, 64), (2, 22050, 64), (2, 24000, 128), (1, 16000, 32), (2, 16000, 64), (1, 8000, 8), (2, 8000, 24), (1, 11025, 24),
+            (2, 11025, 64), (1, 12000, 40), (2, 12000, 48), (2, 22050, 160), (1, 24000, 80), (1, 8000, 64), (2, 16000, 48), (1, 22050, 32)]
+
+
+def run(ncases, seed, lib=None, verbose=True, cfgs=None):
     """Returns the list of mismatching case descriptions (empty = parity)."""
     rng = np.random.default_rng(seed)
-    cfgs = [(1, 44100, 128), (2, 44100, 128), (2, 44100, 320), (1, 44100, 64), (2, 44100, 192), (1, 44100, 320), (2, 48000, 128),
-            (1, 48000, 96), (2, 32000, 160), (1, 32000, 64), (2, 44100, 160), (2, 48000, 256), (1, 44100, 256), (2, 44100, 224)]
+    cfgs = cfgs or MPEG1_CFGS
     bad = []
     t0 = time.time()
     for c in range(ncases):
@@ -71,7 +77,12 @@ def run(ncases, seed, lib=None, verbose=True):
 
 
 def main():
-    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf] [hostsim]"""
+    cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else MPEG1_CFGS
+    lib = None
+    if "hostsim" in sys.argv[3:]:
+        lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs)
     sys.exit(1 if bad else 0)
 
 

@@ -1,0 +1,41 @@
+"""DEV/TEST TOOL (authoring container only: needs /root/reference + node): pins the CPU oracle against the unmodified
+reference on the same seeded random material tests/tools/fuzz_gpu.py feeds the GPU path, so that "GPU == oracle" on that
+material means "GPU == reference".  usage: python tests/tools/fuzz_ref.py [ncases] [seed] [mpeg1|lsf]"""
+import subprocess, sys, tempfile, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tests" / "tools"))
+import fuzz_gpu
+from oracle_py import oracle_encode
+
+
+def run(ncases, seed, cfgs, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = []
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as tmp:
+        for c in range(ncases):
+            ch, sr, kbps = cfgs[c % len(cfgs)]
+            nfr = int(rng.integers(20, 260))
+            L, R = fuzz_gpu.material(rng, 1152 * nfr + int(rng.integers(0, 1152)), ch)
+            chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
+            inter = L if R is None else np.stack([L, R], axis=1).reshape(-1)
+            (Path(tmp) / "in.pcm").write_bytes(inter.astype("<i2").tobytes())
+            r = subprocess.run(["node", str(ROOT / "tests/tools/ref_encode_file.js"), f"{tmp}/in.pcm", f"{tmp}/out.mp3", str(ch), str(sr), str(kbps), str(chunk)],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            want = (Path(tmp) / "out.mp3").read_bytes()
+            got = oracle_encode(ch, sr, kbps, L, R)
+            if got != want:
+                bad.append(f"case {c}: ch={ch} sr={sr} kbps={kbps} frames={nfr} chunk={chunk} lens {len(got)} {len(want)}")
+                if verbose:
+                    print("MISMATCH", bad[-1])
+    if verbose:
+        print(f"fuzz_ref: {ncases} cases, {len(bad)} mismatches, {time.time() - t0:.1f} s")
+    return bad
+
+
+if __name__ == "__main__":
+    cfgs = fuzz_gpu.LSF_CFGS if "lsf" in sys.argv[3:] else fuzz_gpu.MPEG1_CFGS
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, cfgs) else 0)

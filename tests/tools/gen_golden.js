@@ -58,7 +58,14 @@ const synth = [
     ['sine', 2, 128, 150, 1152, 48000], ['bursts', 1, 128, 150, 1152, 48000], ['bursts', 2, 192, 150, 1152, 48000], ['bursts', 2, 224, 120, 999, 48000],
     ['sine', 1, 64, 150, 1152, 32000], ['bursts', 2, 128, 150, 1152, 32000], ['sine', 1, 320, 100, 1152, 32000],
     ['sine', 2, 256, 100, 1152], ['bursts', 2, 160, 100, 1152], ['sine', 1, 96, 100, 1152], ['bursts', 1, 320, 100, 1152],
-    ['sine', 1, 32, 100, 1152], ['bursts', 2, 64, 100, 1152], ['bursts', 2, 96, 100, 1152], ['sine', 1, 48, 60, 1152], ['bursts', 1, 160, 60, 500]
+    ['sine', 1, 32, 100, 1152], ['bursts', 2, 64, 100, 1152], ['bursts', 2, 96, 100, 1152], ['sine', 1, 48, 60, 1152], ['bursts', 1, 160, 60, 500],
+    /* MPEG-2 (22.05 / 24 / 16 kHz) and MPEG-2.5 (11.025 / 12 / 8 kHz): one 576-sample granule per frame */
+    ['bursts', 1, 64, 120, 1152, 22050], ['bursts', 2, 64, 120, 1152, 22050], ['sine', 2, 96, 100, 777, 22050], ['bursts', 2, 160, 80, 1152, 22050],
+    ['bursts', 2, 128, 100, 1152, 24000], ['sine', 1, 80, 100, 576, 24000], ['bursts', 1, 32, 100, 1152, 16000], ['bursts', 2, 64, 100, 1000, 16000],
+    ['sine', 2, 48, 100, 1152, 16000], ['bursts', 1, 24, 100, 1152, 11025], ['bursts', 2, 64, 100, 1152, 11025], ['sine', 1, 40, 100, 333, 12000],
+    ['bursts', 2, 48, 100, 1152, 12000], ['bursts', 1, 8, 100, 1152, 8000], ['bursts', 2, 24, 100, 1152, 8000], ['sine', 1, 64, 100, 4096, 8000],
+    ['bursts', 1, 64, 1000, 1152 * 1000, 22050], ['bursts', 2, 32, 600, 1152 * 600, 16000],
+    ['sine', 1, 64, 1, 1152, 22050], ['bursts', 2, 32, 2, 1, 16000], ['sine', 1, 16, 1, 575, 8000]
 ];
 for (const [corpus, ch, kbps, nframes, chunk, sr] of synth) {
     const n = nframes * 1152;
@@ -67,7 +74,7 @@ for (const [corpus, ch, kbps, nframes, chunk, sr] of synth) {
     const c = { corpus, channels: ch, kbps, nsamples: n, chunk, pcm_md5: pcmMd5(L, R), mp3_md5: md5(mp3), mp3_len: mp3.length };
     if (sr) c.samplerate = sr;
     try { require('../../lamejs_amd/js/tables.js').buildBlob(ch, sr || 44100, kbps); } catch (e) { c.outside_envelope = String(e.message); }   /* reference resamples to an MPEG-2 rate: SURVEY 8f row 2 */
-    if (mp3.length < 30000) { c.mp3_file = `${corpus}_${ch}_${kbps}_${nframes}_${chunk}.mp3`; fs.writeFileSync(path.join(OUT, c.mp3_file), mp3); }
+    if (mp3.length < 30000) { c.mp3_file = `${corpus}_${ch}_${kbps}_${nframes}_${chunk}${sr ? '_' + sr : ''}.mp3`; fs.writeFileSync(path.join(OUT, c.mp3_file), mp3); }
     cases.push(c);
     console.log(corpus, ch, kbps, nframes, chunk, mp3.length, c.mp3_md5);
 }
