@@ -82,13 +82,16 @@ def tables_blob(channels: int, samplerate: int, kbps: int) -> bytes:
     ``node`` is available.
     """
     f = _TABLE_DIR / f"t_{channels}_{samplerate}_{kbps}.bin"
-    if not f.exists():
+    gen = _PKG / "js" / "tables.js"
+    if not f.exists() or f.stat().st_mtime < gen.stat().st_mtime:      # a cached blob older than its generator is stale
         _TABLE_DIR.mkdir(exist_ok=True)
         try:
             subprocess.run(["node", str(_PKG / "js" / "tables.js"), str(channels), str(samplerate), str(kbps), str(f)],
                            check=True, capture_output=True, text=True)
         except (OSError, subprocess.CalledProcessError) as e:  # pragma: no cover
             msg = getattr(e, "stderr", "") or str(e)
+            if isinstance(e, OSError) and f.exists():      # no node on this machine: use the blob that was shipped
+                return f.read_bytes()
             raise LhipError(f"no table blob for ({channels},{samplerate},{kbps}) and node could not build it: {msg}")
     return f.read_bytes()
 

@@ -63,6 +63,8 @@ static bool sync(void* st) { HIPCK(hipStreamSynchronize((hipStream_t)st)); retur
 // ===========================================================================================
 // device-resident per-stream state (what the reference carries from frame to frame)
 // ===========================================================================================
+enum { RS_TAPS = 33 };                       // BLACKSIZE of the reference for an integer ratio (filter_l = 32)
+
 struct StreamState {
     float pcm_tail[2][MF_NEEDED];
     float sb[2][SB_STRIDE];
@@ -73,13 +75,16 @@ struct StreamState {
     int32_t last_attack[2], tent[2];
     double ath_adjust, ath_limit;
     int32_t seed[2][2];
+    float rs_old[2][RS_TAPS - 1];   // resampling streams: the last 32 (scaled) input samples
 };
 
 struct StreamIO {          // per stream, per launch (device array parallel to StreamDesc)
     StreamState* state;
     const int16_t* src[2]; // new samples (device addresses)
     uint8_t* out;          // where this stream's frames go (device address)
-    int32_t n_new, mf_size;
+    int32_t n_new, mf_size;    // samples appended to the encoder's buffer by this call / already buffered
+    int32_t n_in, rs_p0;       // resampling streams: input samples of this call; input position (relative to this call's
+                               // first sample, >= -32) of tap 0 of the first new output sample
 };
 
 // load carried state into the stream's carry slots and build its sample segment (tail + new samples)
@@ -107,6 +112,27 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
     if (lane == 0) { W.ath_adjust[sd.fslot0] = S->ath_adjust; W.ath_limit[sd.fslot0] = S->ath_limit; }
 }
 
+// fill_buffer_resample (Lame.js:1719-1843) for an integer ratio r.  There filter_l = 32, bpc = 1, every clock value
+// is an integer, the window offset is 0 and the filter index is always 1, so the reference computes a plain decimating
+// FIR that does not depend on how the input was chunked:
+//     out[m] = sum_{i=0..32} x[m*r + i - 16] * blackfilt[1][i]        (x[<0] = 0; f64 accumulation in tap order)
+// and emits out[m] as soon as m*r + 16 < (samples received so far).  `p0` is the position of tap 0 of this call's
+// first output relative to this call's first input sample; positions < 0 are the carried tail of earlier calls.
+LHIP_DEV void kb_resample_elem(const Tables& T, float* dst, const int16_t* src, const float* old, int p0, int64_t t) {
+    const float* coef = T.rs_blackfilt + T.rs_bpc * RS_TAPS;
+    const int64_t p = (int64_t)p0 + t * T.rs_ratio;
+    const bool do_scale = !(T.scale == 0.0) && !(T.scale == 1.0);
+    double xvalue = 0.0;
+    for (int i = 0; i < RS_TAPS; i++) {
+        const int64_t q = p + i;
+        float y;
+        if (q < 0) y = old[(RS_TAPS - 1) + q];
+        else { y = (float)src[q]; if (do_scale) y = (float)((double)y * T.scale); }
+        xvalue += (double)y * (double)coef[i];
+    }
+    dst[t] = (float)xvalue;
+}
+
 // Int16 -> scaled f32 for the new samples of every stream: grid-stride over (stream, channel, sample)
 LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int nstreams, int64_t tid, int64_t nthreads) {
     const int C = T.channels_out;
@@ -115,7 +141,8 @@ LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD,
         const int64_t off = SD[st].pcm_off + io.mf_size;
         for (int ch = 0; ch < C; ch++) {
             float* dst = W.pcm + (int64_t)ch * W.pcm_plane + off;
-            for (int64_t i = tid; i < io.n_new; i += nthreads) kb_prep_elem(T, dst, io.src[ch], i);
+            if (T.rs_ratio == 1) { for (int64_t i = tid; i < io.n_new; i += nthreads) kb_prep_elem(T, dst, io.src[ch], i); }
+            else for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, io.src[ch], io.state->rs_old[ch], io.rs_p0, i);
         }
     }
 }
@@ -146,6 +173,23 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
     }
     if (lane == 0 && F > 0) { S->ath_adjust = W.ath_adjust[sd.fslot0 + F]; S->ath_limit = W.ath_limit[sd.fslot0 + F]; }
+    if (T.rs_ratio != 1) {
+        // the last 32 input samples seen so far (carried tail ++ this call's input), as the scaled floats the filter reads
+        const bool do_scale = !(T.scale == 0.0) && !(T.scale == 1.0);
+        for (int ch = 0; ch < C; ch++)
+            for (int base = 0; base < RS_TAPS - 1; base += LHIP_NL) {
+                const int i = base + lane;
+                float v = 0.f;
+                if (i < RS_TAPS - 1) {
+                    const int64_t q = (int64_t)io.n_in - (RS_TAPS - 1) + i;
+                    if (q < 0) v = S->rs_old[ch][(RS_TAPS - 1) + q];
+                    else { v = (float)io.src[ch][q]; if (do_scale) v = (float)((double)v * T.scale); }
+                }
+                wave_sync();
+                if (i < RS_TAPS - 1) S->rs_old[ch][i] = v;
+                wave_sync();
+            }
+    }
 }
 
 // ===========================================================================================
@@ -349,7 +393,8 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     CI(noise_shaping_stop); CI(subblock_gain); CI(use_best_huffman); CI(full_outer_loop); CI(substep_shaping);
     CI(sfb21_extra); CI(quant_comp); CI(quant_comp_short); CI(short_blocks_coupled); CI(useTemporal);
     CI(ATH_useAdjust); CI(athaa_loudapprox); CI(copyright); CI(original); CI(emphasis); CI(extension);
-    CI(error_protection); CI(npart_l); CI(npart_s);
+    CI(error_protection); CI(npart_l); CI(npart_s); CI(in_samplerate); CI(rs_filter_l); CI(rs_bpc);
+    CD(resample_ratio);
     CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
     CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
 #undef CI
@@ -357,6 +402,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
 #define AF(f) T.f = (const float*)arr(#f, 2, nullptr)
 #define AI(f) T.f = (const int32_t*)arr(#f, 1, nullptr)
 #define AD(f) T.f = (const double*)arr(#f, 3, nullptr)
+    AF(rs_blackfilt);
     AF(amp_filter); AF(ATH_l); AF(ATH_s); AF(ATH_psfb21); AF(ATH_psfb12); AF(ATH_cb_l); AF(ATH_cb_s); AF(eql_w);
     AF(pow43); AF(adj43); AF(ipow20); AF(pow20); AF(longfact); AF(shortfact); AF(rnumlines_l); AF(bo_l_weight);
     AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s);
@@ -373,7 +419,16 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
 #undef AD
     if (!ok) return false;
     // ---- envelope checks: fail loudly rather than produce different bytes than the reference ----
-    if (T.channels_out != (cfg.channels == 1 ? 1 : 2) || T.out_samplerate != cfg.samplerate || T.brate <= 0) { set_err("tables blob does not match the requested configuration"); return false; }
+    if (T.channels_out != (cfg.channels == 1 ? 1 : 2) || T.in_samplerate != cfg.samplerate || T.brate <= 0) { set_err("tables blob does not match the requested configuration"); return false; }
+    // resampling (Lame.js:1849): only integer decimation ratios, where the reference's filter is a fixed 33-tap FIR
+    T.rs_ratio = 1;
+    if (T.resample_ratio < .9999 || T.resample_ratio > 1.0001) {
+        const int r = T.out_samplerate > 0 ? T.in_samplerate / T.out_samplerate : 0;
+        if (r < 2 || r * T.out_samplerate != T.in_samplerate || T.rs_filter_l != RS_TAPS - 1 || T.rs_bpc != 1) {
+            set_err("configuration outside the supported envelope (resampling by a non-integer ratio)"); return false;
+        }
+        T.rs_ratio = r;
+    }
     if ((T.version != 1 && T.version != 0) || T.mode_gr != (T.version == 1 ? 2 : 1) || T.quant_comp != 9 || T.quant_comp_short != 9 || T.error_protection || T.sfb21_extra ||
         T.substep_shaping != 0 || T.noise_shaping_amp > 2 || T.use_best_huffman > 1 || T.athaa_loudapprox != 2 || T.full_outer_loop != 0) {
         set_err("configuration outside the supported envelope (MPEG-1/2/2.5 CBR, quality-3 switches)"); return false;
@@ -474,6 +529,7 @@ struct lhip_stream {
     int mf_samples_to_encode = 576 + 1152;
     int slot_lag = 0;
     int64_t frame_num = 0;
+    int64_t rs_n_in = 0;           // resampling streams: input samples received so far
     ~lhip_stream() { rt::dfree(d_state); magic = 0; }
 };
 
@@ -483,7 +539,11 @@ struct lhip_stream {
 struct Job {
     lhip_stream* s; const int16_t* l; const int16_t* r; size_t n; uint8_t* out; size_t cap; int64_t written;
     int F; int64_t bytes;
+    int64_t n_out;              // samples this call appends to the encoder's buffer (== n unless resampling)
 };
+
+// resampling by the integer ratio r: output sample m exists once m*r + 16 < (input samples received) -- see kb_resample_elem
+static int64_t rs_outputs(int64_t n_in_total, int r) { return n_in_total > 16 ? (n_in_total - 16 + r - 1) / r : 0; }
 
 static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
     int64_t npad = 0;
@@ -516,8 +576,9 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         Job& j = jobs[i];
         lhip_stream* s = j.s;
         if (s->ts.get() != &ts) { set_err("batch: all streams must share one configuration"); return false; }
-        const int64_t total = (int64_t)s->mf_size + (int64_t)j.n;
-        if (total > 0x7fffffff) { set_err("too many samples in one call"); return false; }
+        j.n_out = T.rs_ratio == 1 ? (int64_t)j.n : rs_outputs(s->rs_n_in + (int64_t)j.n, T.rs_ratio) - rs_outputs(s->rs_n_in, T.rs_ratio);
+        const int64_t total = (int64_t)s->mf_size + j.n_out;
+        if (total > 0x7fffffff || (int64_t)j.n > 0x7fffffff) { set_err("too many samples in one call"); return false; }
         j.F = total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
         j.bytes = batch_bytes(ts, s->slot_lag, j.F);
         if ((size_t)j.bytes > j.cap) { j.written = LHIP_ERR_BUFFER_TOO_SMALL; set_err("output buffer too small"); return false; }
@@ -564,7 +625,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int k = 0; k <= j.F; k++) fmap[sd[i].fslot0 + k] = i;
         for (int k = 0; k <= GR * j.F; k++) gmap[sd[i].gslot0 + k] = i;
         StreamIO& o = io[i];
-        o.state = j.s->d_state; o.n_new = (int)j.n; o.mf_size = j.s->mf_size;
+        o.state = j.s->d_state; o.n_new = (int)j.n_out; o.mf_size = j.s->mf_size; o.n_in = (int)j.n;
+        o.rs_p0 = T.rs_ratio == 1 ? 0 : (int)(rs_outputs(j.s->rs_n_in, T.rs_ratio) * T.rs_ratio - 16 - j.s->rs_n_in);
         if (dev_io) {
             o.src[0] = j.l; o.src[1] = (C == 2 && j.r) ? j.r : j.l; o.out = j.out;
         } else {
@@ -684,11 +746,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     for (int i = 0; i < S; i++) {
         Job& j = jobs[i];
         lhip_stream* s = j.s;
-        const int64_t total = (int64_t)s->mf_size + (int64_t)j.n;
+        const int64_t total = (int64_t)s->mf_size + j.n_out;
         if (j.n > 0) {
             if (s->mf_samples_to_encode < 1) s->mf_samples_to_encode = 576 + 1152;
-            s->mf_samples_to_encode += (int)j.n;
+            s->mf_samples_to_encode += (int)j.n_out;
         }
+        s->rs_n_in += (int64_t)j.n;
         s->mf_samples_to_encode -= frame * j.F;
         s->mf_size = (int)(total - (int64_t)frame * j.F);
         if (T.frac_SpF != 0 && j.F > 0) {
@@ -783,7 +846,7 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
     for (size_t i = 0; i < n; i++) {
         if (!streams[i] || streams[i]->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
         if (streams[i]->ctx != streams[0]->ctx) { set_err("batch: streams on different devices"); return LHIP_ERR_INTERNAL; }
-        jobs[i] = Job{streams[i], l[i], r ? r[i] : nullptr, ns[i], out[i], cap[i], 0, 0, 0};
+        jobs[i] = Job{streams[i], l[i], r ? r[i] : nullptr, ns[i], out[i], cap[i], 0, 0, 0, 0};
     }
     const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync);
     for (size_t i = 0; i < n; i++) if (written) written[i] = ok ? jobs[i].written : (jobs[i].written < 0 ? jobs[i].written : LHIP_ERR_INTERNAL);
@@ -805,22 +868,33 @@ static size_t flush_zeros(lhip_stream* s) {
     // time) until `frames_left` bunches have each completed at least one frame; the total number of zeros is what
     // the batch path needs, the frames follow from it
     if (s->mf_samples_to_encode < 1) return 0;
-    const int frame = 576 * s->ts->T.mode_gr, mf_needed = 1024 + frame - 272;
-    const int samples_to_encode = s->mf_samples_to_encode - 1152;
-    int end_padding = frame - (samples_to_encode % frame);
+    const Tables& T = s->ts->T;
+    const int frame = 576 * T.mode_gr, mf_needed = 1024 + frame - 272, r = T.rs_ratio;
+    // doubles where the reference's numbers can be fractional (16/r for r = 3)
+    double samples_to_encode = s->mf_samples_to_encode - 1152;
+    if (T.in_samplerate != T.out_samplerate) samples_to_encode += 16. * T.out_samplerate / T.in_samplerate;
+    double end_padding = frame - fmod(samples_to_encode, (double)frame);
     if (end_padding < 576) end_padding += frame;
-    int frames_left = (samples_to_encode + end_padding) / frame;
+    double frames_left = (samples_to_encode + end_padding) / frame;
     int mf = s->mf_size;
+    int64_t n_in = s->rs_n_in;
     size_t zeros = 0;
     while (frames_left > 0) {
-        int bunch = mf_needed - mf;
+        int64_t bunch = (int64_t)(mf_needed - mf) * r;           // bunch *= in_samplerate; bunch /= out_samplerate (exact: integer ratio)
         if (bunch > 1152) bunch = 1152;
         if (bunch < 1) bunch = 1;
         int emitted = 0;
-        for (int rem = bunch; rem > 0;) {
-            const int n = rem < frame ? rem : frame;
-            mf += n; rem -= n;
-            if (mf >= mf_needed) { emitted++; mf -= frame; }
+        if (r == 1) {
+            for (int rem = (int)bunch; rem > 0;) {
+                const int n = rem < frame ? rem : frame;
+                mf += n; rem -= n;
+                if (mf >= mf_needed) { emitted++; mf -= frame; }
+            }
+        } else {
+            // the fill loop adds at most one frame of resampled samples per pass and encodes whenever mf_needed is reached
+            mf += (int)(rs_outputs(n_in + bunch, r) - rs_outputs(n_in, r));
+            n_in += bunch;
+            while (mf >= mf_needed) { emitted++; mf -= frame; }
         }
         zeros += (size_t)bunch;
         if (emitted) frames_left--;

@@ -46,11 +46,14 @@ struct Tables {
         sideinfo_len, frac_SpF, noise_shaping, noise_shaping_amp, noise_shaping_stop, subblock_gain,
         use_best_huffman, full_outer_loop, substep_shaping, sfb21_extra, quant_comp, quant_comp_short,
         short_blocks_coupled, useTemporal, ATH_useAdjust, athaa_loudapprox, copyright, original, emphasis,
-        extension, error_protection, npart_l, npart_s, n_version_bytes;
+        extension, error_protection, npart_l, npart_s, n_version_bytes,
+        in_samplerate, rs_filter_l, rs_bpc,
+        rs_ratio;                           // integer decimation factor (1 = no resampling), derived at create time
     // scalars (doubles)
     double scale, attackthre, attackthre_s, interChRatio, masking_lower_long, masking_lower_short,
-        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE;
+        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE, resample_ratio;
     // arrays
+    const float *rs_blackfilt;              // [2*bpc+1][filter_l+1]; row bpc (= 1) is the only one an integer ratio uses
     const float *amp_filter, *ATH_l, *ATH_s, *ATH_psfb21, *ATH_psfb12, *ATH_cb_l, *ATH_cb_s, *eql_w,
         *pow43, *adj43, *ipow20, *pow20, *longfact, *shortfact, *rnumlines_l, *bo_l_weight, *bo_s_weight,
         *s3_ll, *s3_ss, *window, *window_s;

@@ -87,9 +87,46 @@ function resolveParams(channels, samplerate, kbps) {
     p.out_samplerate = out_samplerate;
     p.lowpassfreq = lowpassfreq;
 
-    if (out_samplerate != samplerate)
-        throw new Error('lamejs_amd: (' + channels + ',' + samplerate + ',' + kbps +
-            ') would resample to ' + out_samplerate + ' Hz; resampling path not supported');
+    /* resampler set-up (Lame.js:943, 1719-1763).  Only integer ratios are in the envelope: for any other ratio the
+     * reference's filter_l / 2 is 15.5, its buffer positions become fractional, typed-array reads return undefined and
+     * the encoder is fed NaN samples (at the latest in flush()) -- there is no well-defined output to reproduce. */
+    p.resample_ratio = samplerate / out_samplerate;
+    p.rs_filter_l = 0; p.rs_bpc = 0; p.rs_blackfilt = f32(1);
+    if (p.resample_ratio < .9999 || p.resample_ratio > 1.0001) {
+        const ratio = p.resample_ratio;
+        const intratio = (Math.abs(ratio - Math.floor(.5 + ratio)) < .0001) ? 1 : 0;
+        if (!intratio)
+            throw new Error('lamejs_amd: (' + channels + ',' + samplerate + ',' + kbps + ') would resample to ' + out_samplerate +
+                ' Hz by the non-integer ratio ' + ratio + '; the reference feeds itself NaN samples there (fractional buffer positions), not supported');
+        const gcd = (i, j) => (j != 0 ? gcd(j, i % j) : i);
+        let bpc = out_samplerate / gcd(out_samplerate, samplerate);
+        if (bpc > 320) bpc = 320;                                            /* LameInternalFlags.BPC */
+        let fcn = 1.00 / ratio;
+        if (fcn > 1.00) fcn = 1.00;
+        let filter_l = 31;
+        if (0 == filter_l % 2) --filter_l;
+        filter_l += intratio;
+        const BLACKSIZE = filter_l + 1;
+        const blackman = function (x, fcn, l) {                               /* Lame.js:1698-1717 */
+            const wcn = (Math.PI * fcn);
+            x /= l;
+            if (x < 0) x = 0;
+            if (x > 1) x = 1;
+            const x2 = x - .5;
+            const bkwn = 0.42 - 0.5 * Math.cos(2 * x * Math.PI) + 0.08 * Math.cos(4 * x * Math.PI);
+            if (Math.abs(x2) < 1e-9) return (wcn / Math.PI);
+            else return (bkwn * Math.sin(l * wcn * x2) / (Math.PI * l * x2));
+        };
+        const bf = f32((2 * bpc + 1) * BLACKSIZE);
+        for (let j = 0; j <= 2 * bpc; j++) {
+            let sum = 0.;
+            const offset = (j - bpc) / (2. * bpc);
+            const row = bf.subarray(j * BLACKSIZE, (j + 1) * BLACKSIZE);
+            for (let i = 0; i <= filter_l; i++) sum += row[i] = blackman(i - offset, fcn, filter_l);   /* adds the unrounded f64 */
+            for (let i = 0; i <= filter_l; i++) row[i] /= sum;
+        }
+        p.rs_filter_l = filter_l; p.rs_bpc = bpc; p.rs_blackfilt = bf;
+    }
     /* SmpFrqIndex (Lame.js:369-403): MPEG-1 for 32/44.1/48 kHz, "version 0" (LSF) for MPEG-2 and MPEG-2.5 rates */
     const SFI = { 44100: [1, 0], 48000: [1, 1], 32000: [1, 2], 22050: [0, 0], 24000: [0, 1], 16000: [0, 2],
         11025: [0, 0], 12000: [0, 1], 8000: [0, 2] };
@@ -555,14 +592,15 @@ function buildBlob(channels, samplerate, kbps) {
         short_blocks_coupled: p.short_blocks_coupled, useTemporal: p.useTemporal,
         ATH_useAdjust: p.ATH_useAdjust, athaa_loudapprox: p.athaa_loudapprox,
         copyright: p.copyright, original: p.original, emphasis: p.emphasis, extension: p.extension,
-        error_protection: p.error_protection, npart_l: T.npart_l, npart_s: T.npart_s
+        error_protection: p.error_protection, npart_l: T.npart_l, npart_s: T.npart_s,
+        in_samplerate: p.in_samplerate, rs_filter_l: p.rs_filter_l, rs_bpc: p.rs_bpc
     };
     const cfg_d = {
         scale: p.scale, attackthre: p.attackthre, attackthre_s: p.attackthre_s,
         interChRatio: p.interChRatio, masking_lower_long: p.masking_lower_long,
         masking_lower_short: p.masking_lower_short, ATH_aaSensitivityP: p.ATH_aaSensitivityP,
         ATH_floor: T.ATH_floor, decay: T.decay, ma_max_i1: T.ma_max_i1, ma_max_i2: T.ma_max_i2,
-        ma_max_m: T.ma_max_m, VO_SCALE: T.VO_SCALE
+        ma_max_m: T.ma_max_m, VO_SCALE: T.VO_SCALE, resample_ratio: p.resample_ratio
     };
     const entries = [];
     entries.push(['cfg_i_names', Int32Array.from(Buffer.from(Object.keys(cfg_i).join(',') + '\0', 'ascii'))]);
@@ -571,6 +609,7 @@ function buildBlob(channels, samplerate, kbps) {
     entries.push(['cfg_d', D(Object.values(cfg_d))]);
     const push = (n, a) => entries.push([n, a]);
     push('amp_filter', p.amp_filter);
+    push('rs_blackfilt', p.rs_blackfilt);
     push('sfb_l', p.sfb_l); push('sfb_s', p.sfb_s); push('psfb21', p.psfb21); push('psfb12', p.psfb12);
     push('ATH_l', T.ATH_l); push('ATH_s', T.ATH_s); push('ATH_psfb21', T.ATH_psfb21); push('ATH_psfb12', T.ATH_psfb12);
     push('ATH_cb_l', T.ATH_cb_l); push('ATH_cb_s', T.ATH_cb_s); push('eql_w', T.eql_w);

@@ -78,12 +78,14 @@ static int lo_load_cfg(lo_cfg* c, const void* blob_in, size_t nbytes) {
     CI(noise_shaping_stop); CI(subblock_gain); CI(use_best_huffman); CI(full_outer_loop); CI(substep_shaping);
     CI(sfb21_extra); CI(quant_comp); CI(quant_comp_short); CI(short_blocks_coupled); CI(useTemporal);
     CI(ATH_useAdjust); CI(athaa_loudapprox); CI(copyright); CI(original); CI(emphasis); CI(extension);
-    CI(error_protection); CI(npart_l); CI(npart_s);
+    CI(error_protection); CI(npart_l); CI(npart_s); CI(in_samplerate); CI(rs_filter_l); CI(rs_bpc);
+    CD(resample_ratio);
     CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
     CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
 #define AF(f) c->f = (const float*)lo_arr(b, #f, 2, NULL)
 #define AI(f) c->f = (const int32_t*)lo_arr(b, #f, 1, NULL)
 #define AD(f) c->f = (const double*)lo_arr(b, #f, 3, NULL)
+    AF(rs_blackfilt);
     AF(amp_filter); AF(ATH_l); AF(ATH_s); AF(ATH_psfb21); AF(ATH_psfb12); AF(ATH_cb_l); AF(ATH_cb_s); AF(eql_w);
     AF(pow43); AF(adj43); AF(ipow20); AF(pow20); AF(longfact); AF(shortfact); AF(rnumlines_l); AF(bo_l_weight);
     AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s);
@@ -443,23 +445,72 @@ int lo_frame_bytes_max(const lo_enc* e) {
     return js_toint32(D((c->version + 1) * 72000 * c->brate) / c->out_samplerate + 1);
 }
 
-static long lo_feed(lo_enc* e, const float* l, const float* r, size_t nsamples, uint8_t* out, size_t cap) {
+/* fill_buffer_resample (Lame.js:1719-1843) for one channel.  `len` and the buffer position stay doubles as in the
+ * reference; with the integer ratios of the envelope they only ever hold integers (filter_l = 32, filter_l / 2 = 16). */
+static int lo_fill_buffer_resample(lo_enc* e, float* outbuf, int desired_len, const float* inbuf, double len, double* num_used, int ch) {
+    const lo_cfg* c = &e->c;
+    const int bpc = c->rs_bpc, filter_l = c->rs_filter_l, BLACKSIZE = filter_l + 1;
+    const double half = D(filter_l) / 2;
+    float* inbuf_old = e->inbuf_old[ch];
+    int i, j = 0, k;
+    for (k = 0; k < desired_len; k++) {
+        double time0 = k * c->resample_ratio, offset, xvalue = 0.;
+        int joff;
+        j = js_toint32(floor(time0 - e->itime[ch]));
+        if ((filter_l + j - half) >= len) break;
+        offset = (time0 - e->itime[ch] - (j + .5 * (filter_l % 2)));
+        joff = js_toint32(floor((offset * 2 * bpc) + bpc + .5));
+        for (i = 0; i <= filter_l; ++i) {
+            const int j2 = js_toint32(i + j - half);
+            const float y = (j2 < 0) ? inbuf_old[BLACKSIZE + j2] : inbuf[j2];
+            xvalue += D(y) * D(c->rs_blackfilt[joff * BLACKSIZE + i]);
+        }
+        outbuf[k] = (float)xvalue;
+    }
+    *num_used = (len < filter_l + j - half) ? len : filter_l + j - half;
+    e->itime[ch] += *num_used - k * c->resample_ratio;
+    if (*num_used != floor(*num_used)) { fprintf(stderr, "lame_oracle: fractional resampler position (outside the envelope)\n"); abort(); }
+    {
+        const int nu = (int)*num_used;
+        if (nu >= BLACKSIZE) {
+            for (i = 0; i < BLACKSIZE; i++) inbuf_old[i] = inbuf[nu + i - BLACKSIZE];
+        } else {
+            const int n_shift = BLACKSIZE - nu;
+            for (i = 0; i < n_shift; ++i) inbuf_old[i] = inbuf_old[i + nu];
+            for (j = 0; i < BLACKSIZE; ++i, ++j) inbuf_old[i] = inbuf[j];
+        }
+    }
+    return k;
+}
+
+static long lo_feed(lo_enc* e, const float* l, const float* r, size_t nsamples_in, uint8_t* out, size_t cap) {
     const lo_cfg* c = &e->c;
     const int framesize = 576 * c->mode_gr;
     const int mf_needed = 1024 + framesize - 272;   /* calcNeeded: max(BLKSIZE + framesize - FFTOFFSET, 512 + framesize - 32) */
+    const int resample = (c->resample_ratio < .9999) || (c->resample_ratio > 1.0001);      /* Lame.js:1849 */
     long written = 0;
     size_t pos = 0;
+    double nsamples = (double)nsamples_in;
     int ch, i;
     while (nsamples > 0) {
-        int n = nsamples < (size_t)framesize ? (int)nsamples : framesize;      /* fill_buffer: at most one frame per pass */
-        for (i = 0; i < n; i++) {
-            e->mfbuf[0][e->mf_size + i] = l[pos + i];
-            if (c->channels_out == 2) e->mfbuf[1][e->mf_size + i] = r[pos + i];
+        int n_out;
+        double n_in;
+        if (resample) {
+            n_out = 0; n_in = 0;
+            for (ch = 0; ch < c->channels_out; ch++)
+                n_out = lo_fill_buffer_resample(e, e->mfbuf[ch] + e->mf_size, framesize, (ch == 0 ? l : r) + pos, nsamples, &n_in, ch);
+        } else {
+            n_out = nsamples < framesize ? (int)nsamples : framesize;                       /* fill_buffer: at most one frame per pass */
+            n_in = n_out;
+            for (i = 0; i < n_out; i++) {
+                e->mfbuf[0][e->mf_size + i] = l[pos + i];
+                if (c->channels_out == 2) e->mfbuf[1][e->mf_size + i] = r[pos + i];
+            }
         }
-        nsamples -= (size_t)n; pos += (size_t)n;
-        e->mf_size += n;
+        nsamples -= n_in; pos += (size_t)n_in;
+        e->mf_size += n_out;
         if (e->mf_samples_to_encode < 1) e->mf_samples_to_encode = 576 + 1152;
-        e->mf_samples_to_encode += n;
+        e->mf_samples_to_encode += n_out;
         if (e->mf_size >= mf_needed) {
             if ((size_t)written + (size_t)lo_frame_bytes_max(e) > cap) return -1;
             written += lo_encode_frame(e, out + written);
@@ -494,21 +545,25 @@ long lo_encode(lo_enc* e, const int16_t* left, const int16_t* right, size_t nsam
     return n;
 }
 
-long lo_flush(lo_enc* e, uint8_t* out, size_t cap) {
+long lo_flush(lo_enc* e, uint8_t* out, size_t cap) {                 /* Lame.js:1381-1443; doubles where the reference's numbers can be fractional */
     static const float zeros[1152];
     long written = 0;
-    int samples_to_encode, end_padding, frames_left;
+    double samples_to_encode, end_padding, frames_left;
     if (e->mf_samples_to_encode < 1) return 0;
     const int framesize = 576 * e->c.mode_gr, mf_needed = 1024 + framesize - 272;
     samples_to_encode = e->mf_samples_to_encode - 1152;     /* POSTDELAY */
-    end_padding = framesize - (samples_to_encode % framesize);
+    if (e->c.in_samplerate != e->c.out_samplerate) samples_to_encode += 16. * e->c.out_samplerate / e->c.in_samplerate;
+    end_padding = framesize - fmod(samples_to_encode, framesize);
     if (end_padding < 576) end_padding += framesize;
     frames_left = (samples_to_encode + end_padding) / framesize;
     while (frames_left > 0) {
-        int bunch = mf_needed - e->mf_size;
+        double bunch = mf_needed - e->mf_size;
         long fn = e->frame_num, n;
+        bunch *= e->c.in_samplerate;
+        bunch /= e->c.out_samplerate;
         if (bunch > 1152) bunch = 1152;
         if (bunch < 1) bunch = 1;
+        if (bunch != floor(bunch)) { fprintf(stderr, "lame_oracle: fractional flush bunch (outside the envelope)\n"); abort(); }
         n = lo_feed(e, zeros, zeros, (size_t)bunch, out + written, cap - (size_t)written);
         if (n < 0) return n;
         written += n;

@@ -55,6 +55,9 @@ typedef struct {
         short_blocks_coupled, useTemporal, ATH_useAdjust, athaa_loudapprox, copyright, original, emphasis,
         extension, error_protection, npart_l, npart_s;
     /* doubles */
+    int in_samplerate, rs_filter_l, rs_bpc;      /* resampler (Lame.js:1719-1763); rs_filter_l == 0: no resampling */
+    double resample_ratio;
+    const float* rs_blackfilt;                  /* [2*bpc+1][filter_l+1] */
     double scale, attackthre, attackthre_s, interChRatio, masking_lower_long, masking_lower_short,
         ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE;
     /* tables */
@@ -101,6 +104,8 @@ typedef struct lo_enc {
     /* stream buffering (Lame.js) */
     float mfbuf[2][MFSIZE];
     int mf_size, mf_samples_to_encode;
+    double itime[2];                            /* resampler clock (Lame.js:1755-1756, 1813) */
+    float inbuf_old[2][40];                     /* last BLACKSIZE input samples */
     long frame_num;
     /* filterbank state */
     float sb_sample[2][2][18][32];

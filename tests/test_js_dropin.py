@@ -14,25 +14,31 @@ NODE = shutil.which("node")
 ADDON = ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node"
 
 
-def _run(env_lib, corpus, ch, kbps, nfr, chunk):
+def _run(env_lib, corpus, ch, kbps, nfr, chunk, sr=44100):
     env = dict(os.environ)
     if env_lib:
         env["LAMEJS_HIP_LIB"] = str(env_lib)
-    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk)],
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk), str(sr)],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def _cases(golden):
-    return [c for c in golden if c["corpus"] in ("sine", "bursts") and c["nsamples"] <= 1152 * 400 and c["nsamples"] >= 1152 * 200]
+    """Three MPEG-1 cases, one MPEG-2 (22.05 kHz) and one that resamples 48 -> 24 kHz in front of the encoder."""
+    ok = [c for c in golden if c["corpus"] in ("sine", "bursts") and not c.get("outside_envelope")]
+    mpeg1 = [c for c in ok if 1152 * 200 <= c["nsamples"] <= 1152 * 400 and c.get("samplerate", 44100) == 44100 and c["kbps"] >= 128][:3]
+    lsf = [c for c in ok if c.get("samplerate") == 22050 and c["nsamples"] <= 1152 * 150][:1]
+    rs = [c for c in ok if c.get("samplerate") == 48000 and c["kbps"] == 64][:1]
+    assert len(mpeg1) == 3 and lsf and rs
+    return mpeg1 + lsf + rs
 
 
 @pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
 def test_js_dropin_hostsim(golden):
     subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
-    for c in _cases(golden)[:3]:
-        got = _run(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"])
+    for c in _cases(golden):
+        got = _run(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100))
         assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
 
 
@@ -40,5 +46,5 @@ def test_js_dropin_hostsim(golden):
 @pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
 def test_js_dropin_gpu(golden):
     for c in _cases(golden):
-        got = _run(None, c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"])
+        got = _run(None, c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100))
         assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c

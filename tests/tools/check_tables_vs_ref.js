@@ -24,7 +24,9 @@ function cmpS(name, mine, ref) { cmp(name, [mine], [ref]); }
 const configs = [[1, 44100, 128], [2, 44100, 128], [2, 44100, 320], [1, 44100, 64], [2, 48000, 192],
     [1, 32000, 96], [2, 44100, 160], [2, 44100, 256], [1, 48000, 320], [2, 32000, 224],
     /* MPEG-2 / MPEG-2.5 (LSF) rates */
-    [1, 22050, 64], [2, 24000, 96], [1, 16000, 32], [2, 16000, 48], [1, 11025, 24], [1, 8000, 16], [2, 12000, 32], [1, 22050, 160], [2, 22050, 128]];
+    [1, 22050, 64], [2, 24000, 96], [1, 16000, 32], [2, 16000, 48], [1, 11025, 24], [1, 8000, 16], [2, 12000, 32], [1, 22050, 160], [2, 22050, 128],
+    /* integer-ratio resampling (in_samplerate = k * out_samplerate) */
+    [1, 44100, 32], [2, 44100, 48], [1, 48000, 24], [2, 48000, 64], [1, 32000, 16], [2, 32000, 8], [1, 16000, 8], [2, 24000, 16], [1, 48000, 40], [1, 48000, 8]];
 for (const [ch, sr, kb] of configs) {
     let r;
     try { r = tables.buildBlob(ch, sr, kb); } catch (e) { console.log('skip', ch, sr, kb, e.message); continue; }
@@ -96,6 +98,13 @@ for (const [ch, sr, kb] of configs) {
     for (let b = 0; b < T.npart_s; b++) { cmpS(tag + 's3inds0', T.s3ind_s[2 * b], gfc.s3ind_s[b][0]); cmpS(tag + 's3inds1', T.s3ind_s[2 * b + 1], gfc.s3ind_s[b][1]); }
     cmpS(tag + 's3_ll.len', T.s3_ll.length, gfc.s3_ll.length); cmp(tag + 's3_ll', T.s3_ll, gfc.s3_ll);
     cmpS(tag + 's3_ss.len', T.s3_ss.length, gfc.s3_ss.length); cmp(tag + 's3_ss', T.s3_ss, gfc.s3_ss);
+    cmpS(tag + 'resample_ratio', p.resample_ratio, gfc.resample_ratio);
+    if (p.rs_filter_l) {       /* the reference builds its filters on the first fill_buffer_resample call */
+        e.encodeBuffer(new Int16Array(64), new Int16Array(64));
+        const BL = p.rs_filter_l + 1;
+        for (let j = 0; j <= 2 * p.rs_bpc; j++) cmp(tag + 'blackfilt' + j, p.rs_blackfilt.subarray(j * BL, (j + 1) * BL), gfc.blackfilt[j], BL);
+        cmpS(tag + 'inbuf_old.len', BL, gfc.inbuf_old[0].length);
+    }
     cmpS(tag + 'decay', T.decay, gfc.decay);
     cmpS(tag + 'ATH.adjust0', 0.01, gfc.ATH.adjust);
     cmpS(tag + 'OldValue', 180, gfc.OldValue[0]);

@@ -1,6 +1,6 @@
 """DEV/TEST TOOL (authoring container only: needs /root/reference + node): pins the CPU oracle against the unmodified
 reference on the same seeded random material tests/tools/fuzz_gpu.py feeds the GPU path, so that "GPU == oracle" on that
-material means "GPU == reference".  usage: python tests/tools/fuzz_ref.py [ncases] [seed] [mpeg1|lsf]"""
+material means "GPU == reference".  usage: python tests/tools/fuzz_ref.py [ncases] [seed] [mpeg1|lsf|resample]"""
 import subprocess, sys, tempfile, time
 from pathlib import Path
 import numpy as np
@@ -37,5 +37,5 @@ def run(ncases, seed, cfgs, verbose=True):
 
 
 if __name__ == "__main__":
-    cfgs = fuzz_gpu.LSF_CFGS if "lsf" in sys.argv[3:] else fuzz_gpu.MPEG1_CFGS
+    cfgs = fuzz_gpu.LSF_CFGS if "lsf" in sys.argv[3:] else fuzz_gpu.RESAMPLE_CFGS if "resample" in sys.argv[3:] else fuzz_gpu.MPEG1_CFGS
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, cfgs) else 0)

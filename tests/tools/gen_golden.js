@@ -65,7 +65,11 @@ const synth = [
     ['sine', 2, 48, 100, 1152, 16000], ['bursts', 1, 24, 100, 1152, 11025], ['bursts', 2, 64, 100, 1152, 11025], ['sine', 1, 40, 100, 333, 12000],
     ['bursts', 2, 48, 100, 1152, 12000], ['bursts', 1, 8, 100, 1152, 8000], ['bursts', 2, 24, 100, 1152, 8000], ['sine', 1, 64, 100, 4096, 8000],
     ['bursts', 1, 64, 1000, 1152 * 1000, 22050], ['bursts', 2, 32, 600, 1152 * 600, 16000],
-    ['sine', 1, 64, 1, 1152, 22050], ['bursts', 2, 32, 2, 1, 16000], ['sine', 1, 16, 1, 575, 8000]
+    ['sine', 1, 64, 1, 1152, 22050], ['bursts', 2, 32, 2, 1, 16000], ['sine', 1, 16, 1, 575, 8000],
+    /* resampling by an integer ratio (fill_buffer_resample, Lame.js:1719-1843): 44.1->22.05, 48->24/16/8, 32->16/8, 24->8, 16->8 kHz */
+    ['bursts', 2, 48, 150, 1152, 44100], ['bursts', 1, 24, 100, 777, 48000], ['bursts', 2, 64, 100, 4096, 48000], ['sine', 1, 16, 100, 100, 32000],
+    ['bursts', 2, 8, 100, 1152, 32000], ['bursts', 1, 8, 100, 1152, 16000], ['sine', 2, 16, 100, 5000, 24000], ['bursts', 1, 40, 100, 1152, 48000],
+    ['bursts', 1, 8, 60, 33, 48000], ['bursts', 2, 24, 3, 1, 48000], ['sine', 1, 32, 600, 1152 * 600, 44100], ['bursts', 2, 40, 1, 17, 32000]
 ];
 for (const [corpus, ch, kbps, nframes, chunk, sr] of synth) {
     const n = nframes * 1152;
@@ -73,7 +77,7 @@ for (const [corpus, ch, kbps, nframes, chunk, sr] of synth) {
     const mp3 = encode(L, R, ch, kbps, chunk, sr);
     const c = { corpus, channels: ch, kbps, nsamples: n, chunk, pcm_md5: pcmMd5(L, R), mp3_md5: md5(mp3), mp3_len: mp3.length };
     if (sr) c.samplerate = sr;
-    try { require('../../lamejs_amd/js/tables.js').buildBlob(ch, sr || 44100, kbps); } catch (e) { c.outside_envelope = String(e.message); }   /* reference resamples to an MPEG-2 rate: SURVEY 8f row 2 */
+    try { require('../../lamejs_amd/js/tables.js').buildBlob(ch, sr || 44100, kbps); } catch (e) { c.outside_envelope = String(e.message); }   /* the reference would resample by a non-integer ratio (NaN samples there): DESIGN.md 0 */
     if (mp3.length < 30000) { c.mp3_file = `${corpus}_${ch}_${kbps}_${nframes}_${chunk}${sr ? '_' + sr : ''}.mp3`; fs.writeFileSync(path.join(OUT, c.mp3_file), mp3); }
     cases.push(c);
     console.log(corpus, ch, kbps, nframes, chunk, mp3.length, c.mp3_md5);
