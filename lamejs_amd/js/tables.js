@@ -19,7 +19,8 @@
  *   FFT.js:226-242          analysis windows; FFT.js:31-115 twiddle recurrence
  *
  * Supported envelope (everything else throws): CBR, every MPEG-1 / MPEG-2 / MPEG-2.5 sample rate
- * with out_samplerate == in_samplerate (no resampling), 1 or 2 channels.
+ * 1 or 2 channels, with out_samplerate == in_samplerate or an integer multiple below it (resampling by a non-integer
+ * ratio makes the reference feed itself NaN samples; refused).
  */
 'use strict';
 
