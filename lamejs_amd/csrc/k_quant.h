@@ -138,6 +138,7 @@ struct QuantLds {
     union {                      // calc_noise band sums live only inside the outer loop, the split tables only after it
         struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
         double nsum[SFBMAX + 1];
+        struct { int32_t bs_tab[BS_TAB_MAX], bs_asg[BS_TAB_MAX]; } memo;   // bin-search memo, flushed to the side record before the first calc_noise
     };
     alignas(8) uint32_t rdesc[4][2];   // per Huffman region: offsets of its candidate length tables | row stride
     double ath_pseudo[6];
@@ -706,8 +707,18 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     // are handled in ONE pass.  Region r is planned (and later finished) by lane r, branch-free: there is no
     // scalar per-region control flow left.
     struct LanePlan { int kind, t0, t1, t2, lbA, lbB; };
-    enum { NSLOT = (LHIP_NL == 1) ? 3 : 1 };
-    LanePlan lp[NSLOT];
+    // one plan per lane on the device (a scalar struct: an array indexed by r / 64 would live in scratch memory and cost a
+    // memory round trip per access); the one-lane host simulation holds all three
+#ifdef LHIP_HOSTSIM
+    LanePlan lp[3]; int pv[3];
+#define LP_(r) lp[r]
+#define PV_(r) pv[r]
+#else
+    LanePlan lp1; int pv1 = 0;
+    lp1.kind = 0; lp1.t0 = lp1.t1 = lp1.t2 = lp1.lbA = lp1.lbB = 0;
+#define LP_(r) lp1
+#define PV_(r) pv1
+#endif
     for (int r = lane; r < 3; r += LHIP_NL) {
         const int m = (r == 0) ? m0 : (r == 1) ? m1 : m2;
         // first candidate table for maxima 0..15 (huf_tbl_noESC, Takehiro.js:336-346), one nibble per value
@@ -723,7 +734,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         if (kind == 0 || kind == 6) { oA = oB = oC = 0; xl = 0; }
         L.rdesc[r][0] = (uint32_t)oA | ((uint32_t)oB << 16);
         L.rdesc[r][1] = (uint32_t)oC | ((uint32_t)xl << 16);
-        LanePlan& q = lp[r / LHIP_NL];
+        LanePlan& q = LP_(r);
         q.kind = kind; q.t0 = esc ? choice : tn; q.t1 = esc ? choice2 : tn + 1; q.t2 = tn + 2;
         q.lbA = esc ? lb1 : 0; q.lbB = esc ? lb2 : 0;
     }
@@ -774,9 +785,8 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     PH_MARK(L, PH_C_SUMS, tm_);
     // finish (Takehiro.js count_bit_noESC / _from2 / _from3 / count_bit_ESC tie-breaking): lane r picks the cheapest
     // admissible candidate of region r; result packed as table | overflow << 6 | bits << 8
-    int pv[NSLOT];
     for (int r = lane; r < 3; r += LHIP_NL) {
-        const LanePlan& q = lp[r / LHIP_NL];
+        const LanePlan& q = LP_(r);
         const int qa = (r == 0) ? q0 : (r == 1) ? q2 : q4, qc = (r == 0) ? q1 : (r == 1) ? q3 : q5;
         const int n = (int)((unsigned)qc >> 16);
         const int c0 = (qa & 0xffff) + n * q.lbA, c1 = (int)((unsigned)qa >> 16) + n * q.lbB, c2 = qc & 0xffff;
@@ -785,19 +795,21 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         if (q.kind == 4 && b > c2) { b = c2; t = q.t2; }
         if (q.kind == 0) { b = 0; t = 0; }
         if (q.kind == 6) { b = 0; t = 63; }              // table_select := -1 (never emitted: overflow cannot pass count_bits)
-        pv[r / LHIP_NL] = t | ((q.kind == 6) << 6) | (b << 8);
+        PV_(r) = t | ((q.kind == 6) << 6) | (b << 8);
     }
 #ifdef LHIP_HOSTSIM
-    const int pv0 = pv[0], pv1 = pv[1], pv2 = pv[2];
+    const int pv0 = pv[0], pv1_ = pv[1], pv2 = pv[2];
 #else
-    const int pv0 = __builtin_amdgcn_readlane(pv[0], 0), pv1 = __builtin_amdgcn_readlane(pv[0], 1), pv2 = __builtin_amdgcn_readlane(pv[0], 2);
+    const int pv0 = __builtin_amdgcn_readlane(pv1, 0), pv1_ = __builtin_amdgcn_readlane(pv1, 1), pv2 = __builtin_amdgcn_readlane(pv1, 2);
 #endif
     // the reference evaluates region 2 first (NORM only), then 0, then 1; an overflowing region *sets* bits
 #define APPLY(PV, SLOT) do { const int t_ = (PV) & 63; if ((PV) & 64) bits = LARGE_BITS; else bits += (PV) >> 8; g.table_select[SLOT] = (t_ == 63) ? -1 : t_; } while (0)
     if (use2) APPLY(pv2, 2);
     if (0 < a1) APPLY(pv0, 0);
-    if (a1 < a2) APPLY(pv1, 1);
+    if (a1 < a2) APPLY(pv1_, 1);
 #undef APPLY
+#undef LP_
+#undef PV_
     // first band whose start is >= big_values (PrevNoise.sfb_count1): one table look-up instead of a walk
     if (use_prev && g.block_type == NORM_TYPE) *pn_sfb_count1 = g.big_values > 0 ? Q.l2s_long[g.big_values - 1] + 1 : 0;
     PH_MARK(L, PH_C_FIN, tm_);
@@ -1233,7 +1245,9 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
 #endif
         int asg = 0;
         const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site
-        if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) { rec->bs_tab[nbs] = (w.global_gain << 24) | nBits; rec->bs_asg[nbs] = asg; } nbs++; }   // memo straight into the side record (HBM)
+        // memo of the bin search: collected in LDS and written to the side record in one burst when the search ends (a global
+        // store per step would sit in front of every later memory wait of the wave -- the VMEM counter retires in order)
+        if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) { L.memo.bs_tab[nbs] = (w.global_gain << 24) | nBits; L.memo.bs_asg[nbs] = asg; } nbs++; }
         if (st == ST_BS) {
             if (CurrentStep == 1 || nBits == desired_rate) st = ST_BSUP;
             else {
@@ -1259,7 +1273,10 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (nBits > desired_rate && w.global_gain < 255) { w.global_gain++; continue; }
             w.part2_3_length = nBits;
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
+            wave_sync();
+            for (int i = lane; i < nbs; i += LHIP_NL) { rec->bs_tab[i] = L.memo.bs_tab[i]; rec->bs_asg[i] = L.memo.bs_asg[i]; }
             if (lane == 0) { rec->bs_ntab = nbs; rec->bs_state = pack_cond_fields(w, 0); }
+            wave_sync();
             if (0 == T.noise_shaping) {
                 g = w;
                 for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
