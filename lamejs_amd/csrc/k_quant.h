@@ -84,9 +84,16 @@ struct QuantTabs {
     uint8_t bv_scf[576];
     uint8_t huf_tbl_noESC[16], ht_xlen[34];
     uint16_t ht_linmax[34];
+    // Huffman region plans by region maximum (count_bits): entries 0..15 = the maximum itself, 16..28 = bit length 1..13
+    // of (maximum - 15), 29 = beyond IXMAX_VAL.  d0/d1 = pool offsets of the candidate length tables | row stride (what
+    // the pairs gather with), pw = kind | candidate table numbers | linbits of the two ESC candidates (plan_word)
+    struct PlanEnt { uint32_t d0, d1, pw; } plan[30];
 };
 
+LHIP_DEV void q_fill_plans(QuantTabs& Q, int tid, int nthr);
+
 LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
+    q_fill_plans(Q, tid, nthr);
     for (int i = tid; i < QT_N; i += nthr) { Q.pow43[i] = T.pow43[i]; Q.adj43[i] = T.adj43[i]; }
     for (int i = tid; i < Q_MAX; i += nthr) Q.ipow20[i] = T.ipow20[i];
     for (int i = tid; i < Q_MAX + Q_MAX2 + 1; i += nthr) Q.pow20[i] = T.pow20[i];
@@ -528,6 +535,31 @@ LHIP_DEV void esc_choice(int mx15, int* choice, int* choice2, int* lb1, int* lb2
     *lb2 = (int)((0xDB987654u >> (4 * c24)) & 15u);
 }
 
+// plan of a Huffman region whose largest value is m (Takehiro.js:336-346 choose_table / 479-497 ESC pair), as stored in
+// QuantTabs::plan.  plan word: kind | t0 << 3 | t1 << 9 | t2 << 15 | lbA << 21 | lbB << 25
+LHIP_DEV int plan_index(int m) { return m <= 15 ? m : (m <= IXMAX_VAL ? 15 + (32 - __builtin_clz((unsigned)(m - 15) | 1u)) : 29); }
+LHIP_DEV void q_fill_plans(QuantTabs& Q, int tid, int nthr) {
+    for (int e = tid; e < 30; e += nthr) {
+        const int m = e <= 15 ? e : (e < 29 ? 15 + (1 << (e - 16)) : IXMAX_VAL + 1);
+        // first candidate table for maxima 0..15 (huf_tbl_noESC, Takehiro.js:336-346), one nibble per value
+        const int mc = m < 15 ? m : 15;
+        const int tn = (int)((mc < 8 ? (0xAA775210u >> (4 * mc)) : (0xDDDDDDDDu >> (4 * (mc - 8)))) & 15u);
+        const int kind = (m == 0) ? 0 : (m == 1) ? 1 : (m <= 3) ? 2 : (m <= 15) ? 4 : (m <= IXMAX_VAL) ? 5 : 6;
+        int choice, choice2, lb1, lb2;
+        esc_choice(m > 15 ? m - 15 : 1, &choice, &choice2, &lb1, &lb2);
+        const int esc = (kind == 5);
+        int xl = (tn == 1) ? 2 : (tn == 2) ? 3 : (tn == 5) ? 4 : (tn == 7) ? 6 : (tn == 10) ? 8 : 16;
+        int oA = hl_off(tn), oB = hl_off(tn + 1), oC = hl_off(tn + 2 > 15 ? 15 : tn + 2);
+        if (esc) { oA = HL_EHI; oB = HL_ELO; oC = HL_EHI; xl = 16; }
+        if (kind == 0 || kind == 6) { oA = oB = oC = 0; xl = 0; }
+        const int t0 = esc ? choice : tn, t1 = esc ? choice2 : tn + 1, t2 = tn + 2;
+        Q.plan[e].d0 = (uint32_t)oA | ((uint32_t)oB << 16);
+        Q.plan[e].d1 = (uint32_t)oC | ((uint32_t)xl << 16);
+        Q.plan[e].pw = (uint32_t)kind | ((uint32_t)t0 << 3) | ((uint32_t)t1 << 9) | ((uint32_t)t2 << 15) |
+                       ((uint32_t)(esc ? lb1 : 0) << 21) | ((uint32_t)(esc ? lb2 : 0) << 25);
+    }
+}
+
 LHIP_DEV RegionPlan plan_region_(const QuantTabs& Q, int mx) {
     (void)Q;
     RegionPlan r; r.kind = 0; r.t1 = 0; r.xlen = 0; r.lb1 = r.lb2 = 0; r.choice = r.choice2 = 0; r.o0 = r.o1 = r.o2 = 0;
@@ -721,22 +753,12 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 #endif
     for (int r = lane; r < 3; r += LHIP_NL) {
         const int m = (r == 0) ? m0 : (r == 1) ? m1 : m2;
-        // first candidate table for maxima 0..15 (huf_tbl_noESC, Takehiro.js:336-346), one nibble per value
-        const int mc = m < 15 ? m : 15;
-        const int tn = (int)((mc < 8 ? (0xAA775210u >> (4 * mc)) : (0xDDDDDDDDu >> (4 * (mc - 8)))) & 15u);
-        const int kind = (m == 0) ? 0 : (m == 1) ? 1 : (m <= 3) ? 2 : (m <= 15) ? 4 : (m <= IXMAX_VAL) ? 5 : 6;
-        int choice, choice2, lb1, lb2;
-        esc_choice(m > 15 ? m - 15 : 1, &choice, &choice2, &lb1, &lb2);
-        const int esc = (kind == 5);
-        int xl = (tn == 1) ? 2 : (tn == 2) ? 3 : (tn == 5) ? 4 : (tn == 7) ? 6 : (tn == 10) ? 8 : 16;
-        int oA = Q.hoff[tn], oB = Q.hoff[tn + 1], oC = Q.hoff[tn + 2 > 15 ? 15 : tn + 2];
-        if (esc) { oA = HL_EHI; oB = HL_ELO; oC = HL_EHI; xl = 16; }
-        if (kind == 0 || kind == 6) { oA = oB = oC = 0; xl = 0; }
-        L.rdesc[r][0] = (uint32_t)oA | ((uint32_t)oB << 16);
-        L.rdesc[r][1] = (uint32_t)oC | ((uint32_t)xl << 16);
+        const QuantTabs::PlanEnt pe = Q.plan[plan_index(m)];          // the whole plan is a function of the maximum: one look-up
+        L.rdesc[r][0] = pe.d0;
+        L.rdesc[r][1] = pe.d1;
         LanePlan& q = LP_(r);
-        q.kind = kind; q.t0 = esc ? choice : tn; q.t1 = esc ? choice2 : tn + 1; q.t2 = tn + 2;
-        q.lbA = esc ? lb1 : 0; q.lbB = esc ? lb2 : 0;
+        q.kind = (int)(pe.pw & 7u); q.t0 = (int)((pe.pw >> 3) & 63u); q.t1 = (int)((pe.pw >> 9) & 63u); q.t2 = (int)((pe.pw >> 15) & 63u);
+        q.lbA = (int)((pe.pw >> 21) & 15u); q.lbB = (int)((pe.pw >> 25) & 15u);
     }
     wave_sync();
     PH_MARK(L, PH_C_MAX, tm_);
