@@ -221,7 +221,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         g.sfbdivide = g.sfbmax - 18;
         g.psy_lmax = 0;
         nsfb = 3 * SBMAX_s;
-        for (int i = lane; i < nsfb; i += LHIP_NL) {
+        LHIP_LANE_ONCE(i, 0, nsfb) {
             const int sfb = i / 3, win = i - 3 * sfb;
             const int w = T.sfb_s[sfb + 1] - T.sfb_s[sfb];
             L.width[i] = w; L.window[i] = win; L.start[i] = 3 * T.sfb_s[sfb] + win * w;
@@ -365,12 +365,12 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
         for (int k = 0; k < NLN_FOLD; k++) { const double x = L.xr[NLN_FOLD * lane + k]; tq[k] = x * x; }
         int maxw = 0;
         const int nb = (g.block_type != SHORT_TYPE) ? g.psy_lmax : 3 * SBPSY_s;
-        for (int b = lane; b < nb; b += LHIP_NL) if (maxw < L.width[b]) maxw = L.width[b];
+        LHIP_LANE_ONCE(b, 0, nb) if (maxw < L.width[b]) maxw = L.width[b];
         maxw = wave_max(maxw);
         fold_band_sums(tq, line2sfb(Q, g.block_type), maxw, lane, L);
     }
     if (g.block_type != SHORT_TYPE) {
-        for (int gsfb = lane; gsfb < g.psy_lmax; gsfb += LHIP_NL) {
+        LHIP_LANE_ONCE(gsfb, 0, g.psy_lmax) {
             double xmin = ath_adjust * (double)T.ATH_l[gsfb];
             const double en0 = L.nsum[gsfb];
             const double en = ratio[E_EN_L + gsfb];
@@ -429,10 +429,10 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     uint64_t m_cached = 0, m_zo = 0, m_cut = 0;       // bit sfb, produced by lane sfb (sfbmax < 64)
     if (!use_prev) {                                     // bin-search rounds: no cache, only the cut matters
-        for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL)
+        LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1)
             if (L.start[sfb] + L.width[sfb] > mnz) m_cut |= 1ull << sfb;
     } else {
-        for (int sfb = lane; sfb <= sfbmax; sfb += LHIP_NL) {
+        LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1) {
             int step = -1;
             if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
             if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
@@ -872,12 +872,12 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     //    reaches past max_nonzero_coeff (`firstcut`), that band is summed over its useful part only, and for every
     //    later band the walk leaves no pairs at all (j + width > max_nonzero_coeff with j >= max_nonzero_coeff).
     uint64_t m_cut = 0;
-    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL)
+    LHIP_LANE_ONCE(sfb, 0, g.psymax)
         if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m_cut |= 1ull << sfb;
     m_cut = wave_lane_bits(m_cut);
     const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
     int maxlen = 0;                                          // longest summing range of this call (cached bands have none)
-    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
+    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
         const int s = sf_step(Q, g, scalefac, L.window, sfb);
         const int cached = (use_pn && L.pn_step[sfb] == s);
         L.qmode[sfb] = s;                                   // step of the band (stored into the cache below)
@@ -965,7 +965,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     }
     int over = 0, ssd = 0;
     double max_noise = -20.0;
-    for (int sfb = lane; sfb < g.psymax; sfb += LHIP_NL) {
+    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
         double noise;
         const QuantLds::BandInfo bi = L.binfo[sfb];
         if (bi.kind == 0) {
@@ -1029,7 +1029,7 @@ LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lan
     // slen1_n / slen2_n are powers of two, and "every value < 2^b" is "the OR of the values < 2^b": the two maxima
     // of the reference become one OR reduction of (part 1 | part 2 << 8)
     int m12 = 0;
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) {
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
         const int v = scalefac[sfb];
         m12 |= (sfb < g.sfbdivide) ? v : (v << 8);
     }
@@ -1059,7 +1059,7 @@ LHIP_DEV int q_scale_bitcount_lsf(GI& g, const int32_t* scalefac, int lane) {
     const uint32_t range = pre ? 0x00000307u : 0x07070f0fu;      // max_range_sfac_tab[0] / [2], partition p in byte p
     const int b1 = n0, b2 = n0 + n1, b3 = b2 + n2, end = b3 + n3;
     uint32_t m = 0;
-    for (int i = lane; i < end; i += LHIP_NL) {
+    LHIP_LANE_ONCE(i, 0, end) {
         int v = scalefac[i];
         if (v < 0) v = 0;
         const int part = (i >= b1) + (i >= b2) + (i >= b3);
@@ -1088,7 +1088,7 @@ LHIP_DEV int q_scale_bitcount_any(const Tables& T, GI& g, int32_t* scalefac, int
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     int z = 0;
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL)
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax)
         if (scalefac[sfb] + sbgain(g, L.window[sfb]) == 0) z = 1;
     return !wave_any(z);
 }
@@ -1117,7 +1117,7 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
     lane = fresh_lane(lane);
     const double ifqstep34 = (g.scalefac_scale == 0) ? 1.29683955465100964055 : 1.68179283050742922612;
     float tr = 0.f;
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (tr < L.distort[sfb]) tr = L.distort[sfb];
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (tr < L.distort[sfb]) tr = L.distort[sfb];
     double trigger = wave_maxf(tr);
     switch (T.noise_shaping_amp) {
         case 2: break;
@@ -1131,17 +1131,17 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
             break;
     }
     uint64_t m_amp = 0;                                  // bit sfb: band is amplified
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL)
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax)
         if (!((double)L.distort[sfb] < trigger)) m_amp |= 1ull << sfb;
     m_amp = wave_lane_bits(m_amp);
     if (T.noise_shaping_amp == 2 && m_amp) m_amp = 1ull << __builtin_ctzll(m_amp);     // amplify exactly one band
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if ((m_amp >> sfb) & 1) scalefac[sfb]++;
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if ((m_amp >> sfb) & 1) scalefac[sfb]++;
     q_amplify_flagged(g, ifqstep34, m_amp, lane, L, Q);
 }
 
 LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     uint64_t m_amp = 0;
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) {
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
         int s = scalefac[sfb];
         if (g.preflag != 0) s += T.pretab[sfb];
         if ((s & 1) != 0) { s++; m_amp |= 1ull << sfb; }
@@ -1158,7 +1158,7 @@ LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, in
 LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     for (int window = 0; window < 3; window++) {
         int s1 = 0, s2 = 0;
-        for (int sfb = window + 3 * lane; sfb < g.sfbmax; sfb += 3 * LHIP_NL) {
+        LHIP_LANE_ONCE3(sfb, window, g.sfbmax) {
             const int v = scalefac[sfb];
             if (sfb < g.sfbdivide) { if (s1 < v) s1 = v; } else { if (s2 < v) s2 = v; }
         }
@@ -1296,7 +1296,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             w.part2_3_length = nBits;
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
             wave_sync();
-            for (int i = lane; i < nbs; i += LHIP_NL) { rec->bs_tab[i] = L.memo.bs_tab[i]; rec->bs_asg[i] = L.memo.bs_asg[i]; }
+            LHIP_LANE_ONCE(i, 0, nbs) { rec->bs_tab[i] = L.memo.bs_tab[i]; rec->bs_asg[i] = L.memo.bs_asg[i]; }
             if (lane == 0) { rec->bs_ntab = nbs; rec->bs_state = pack_cond_fields(w, 0); }
             wave_sync();
             if (0 == T.noise_shaping) {
@@ -1363,16 +1363,16 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
             if (*(const uint32_t*)(L.ixw + p) != 0) L.qmode[l2s[p]] = 1;
         wave_sync();
         int any = 0;
-        for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (!L.qmode[sfb]) { sf[sfb] = -2; any = 1; }
+        LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (!L.qmode[sfb]) { sf[sfb] = -2; any = 1; }
         if (wave_any(any)) recalc = -2;
         wave_sync();
     }
     if (0 == g.scalefac_scale && 0 == g.preflag) {
         int s = 0;
-        for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (sf[sfb] > 0) s |= sf[sfb];
+        LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (sf[sfb] > 0) s |= sf[sfb];
         s = wave_or(s);
         if (0 == (s & 1) && s != 0) {
-            for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (sf[sfb] > 0) sf[sfb] >>= 1;
+            LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (sf[sfb] > 0) sf[sfb] >>= 1;
             g.scalefac_scale = recalc = 1;
             wave_sync();
         }
@@ -1424,7 +1424,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
         recalc = 0;
     }
     wave_sync();
-    for (int sfb = lane; sfb < g.sfbmax; sfb += LHIP_NL) if (sf[sfb] == -2) sf[sfb] = 0;
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (sf[sfb] == -2) sf[sfb] = 0;
     wave_sync();
     if (uni(recalc) != 0) q_scale_bitcount_any(T, g, sf, lane);
 }
@@ -1817,7 +1817,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             const int ntab = uni(rec->bs_ntab);
             // memo entry per lane (device) / linear search (host simulation)
             int my_ent = 0, my_asg = 0;
-            for (int i = lane; i < ntab; i += LHIP_NL) { my_ent = rec->bs_tab[i]; my_asg = rec->bs_asg[i]; }
+            LHIP_LANE_ONCE(i, 0, ntab) { my_ent = rec->bs_tab[i]; my_asg = rec->bs_asg[i]; }
             GI g;
             PrevNoise pn_none; pn_none.gain = 0; pn_none.sfb_count1 = 0;
             int inited = 0;

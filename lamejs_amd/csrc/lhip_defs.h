@@ -25,6 +25,17 @@
 #define LHIP_NL 64
 #endif
 
+// `for (v = lo + lane; v < n; v += NL)` where the author knows n - lo <= NL (band loops: at most 39 bands) but the
+// compiler does not: at most one iteration per lane.  Left as a loop, the compiler emits a generic loop nest (with a
+// 16-fold unrolled body and the spills that come with it) for every one of them.  `lane` must be in scope.
+#if LHIP_NL == 1
+#define LHIP_LANE_ONCE(v, lo, n) for (int v = (lo); v < (n); v++)
+#define LHIP_LANE_ONCE3(v, lo, n) for (int v = (lo); v < (n); v += 3)
+#else
+#define LHIP_LANE_ONCE(v, lo, n) if (const int v = (lo) + lane; v < (n))
+#define LHIP_LANE_ONCE3(v, lo, n) if (const int v = (lo) + 3 * lane; v < (n))
+#endif
+
 namespace lhip {
 
 enum {
