@@ -88,6 +88,8 @@ struct QuantTabs {
     // of (maximum - 15), 29 = beyond IXMAX_VAL.  d0/d1 = pool offsets of the candidate length tables | row stride (what
     // the pairs gather with), pw = kind | candidate table numbers | linbits of the two ESC candidates (plan_word)
     struct PlanEnt { uint32_t d0, d1, pw; } plan[30];
+    // scale_bitcount candidates (Takehiro.js:980-1030): row k = slen1_n | slen2_n << 8 | scale_long << 16 | scale_short << 24
+    uint32_t sbc[16];
 };
 
 LHIP_DEV void q_fill_plans(QuantTabs& Q, int tid, int nthr);
@@ -101,6 +103,8 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int i = tid; i < SBMAX_l + 1; i += nthr) Q.sfb_l[i] = T.sfb_l[i];
     for (int i = tid; i < SBMAX_s + 1; i += nthr) Q.sfb_s[i] = T.sfb_s[i];
     for (int i = tid; i < SBMAX_l; i += nthr) Q.pretab[i] = T.pretab[i];
+    for (int i = tid; i < 16; i += nthr)
+        Q.sbc[i] = (uint32_t)T.slen1_n[i] | ((uint32_t)T.slen2_n[i] << 8) | ((uint32_t)T.scale_long[i] << 16) | ((uint32_t)T.scale_short[i] << 24);
     for (int i = tid; i < 576; i += nthr) Q.bv_scf[i] = (uint8_t)T.bv_scf[i];
     for (int i = tid; i < 15; i += nthr) Q.huf_tbl_noESC[i] = (uint8_t)T.huf_tbl_noESC[i];
     for (int i = tid; i < 34; i += nthr) { Q.ht_xlen[i] = (uint8_t)T.ht_xlen[i]; Q.ht_linmax[i] = (uint16_t)T.ht_linmax[i]; }
@@ -421,6 +425,8 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
                          int pn_gain, int pn_sfb_count1, int (&vx)[NPL], int (&vy)[NPL], int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     const double istep = ipow20(Q, g.global_gain);
+    // every truncated product is <= xrpow_max * istep: below QT_N no lane can need the part of adj43 that is not staged in LDS
+    const int may_big = !(g.xrpow_max * istep < (double)QT_N);
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
     const int mnz = g.max_nonzero_coeff;
@@ -470,8 +476,10 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
             const double qa = (double)xa * istep, qb = (double)xb * istep;
             const int ra = (int)qa, rb = (int)qb;                          // 0 <= x <= 8206: truncation == ToInt32
             float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
-            if (ra >= QT_N) aa = T.adj43[ra];                              // rare: large quantized values
-            if (rb >= QT_N) ab = T.adj43[rb];
+            if (may_big) {                                                 // rare: large quantized values
+                if (ra >= QT_N) aa = T.adj43[ra];
+                if (rb >= QT_N) ab = T.adj43[rb];
+            }
             int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
             va = (p < last_line) ? va : 0;
             vb = (p + 1 < last_line) ? vb : 0;
@@ -498,8 +506,10 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
             const double qa = (double)xa[j] * istep, qb = (double)xb[j] * istep;
             const int ra = (int)qa, rb = (int)qb;
             float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
-            if (ra >= QT_N) aa = T.adj43[ra];
-            if (rb >= QT_N) ab = T.adj43[rb];
+            if (may_big) {
+                if (ra >= QT_N) aa = T.adj43[ra];
+                if (rb >= QT_N) ab = T.adj43[rb];
+            }
             const int cached = (int)((m_cached >> sf[j]) & 1), zo = (int)((m_zo >> sf[j]) & 1);
             int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
             if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
@@ -844,9 +854,15 @@ struct PrevNoise { int gain, sfb_count1; };
 // `use_pn` selects the prev_noise cache; pn is passed by reference with a flag (never as a nullable pointer to a
 // local: a select between private addresses is a per-lane value for the compiler and makes the control flow divergent)
 LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, int use_pn, PrevNoise& pn, int* asg, int lane, QuantLds& L, const QuantTabs& Q) {
-    const double w = (double)IXMAX_VAL / ipow20(Q, g.global_gain);
     *asg = 0;
-    if (g.xrpow_max > w) return LARGE_BITS;
+    {   // Takehiro.js:635-638: `xrpow_max > IXMAX_VAL / IPOW20(gain)`.  The division is only needed when the product is
+        // within rounding of the bound: fl(x * ip) <= 8206 (1 - 2^-50) implies x < fl(8206 / ip)
+        const double ip = ipow20(Q, g.global_gain);
+        if (g.xrpow_max * ip > (double)IXMAX_VAL * (1.0 - 0x1p-50)) {
+            const double w = (double)IXMAX_VAL / ip;
+            if (g.xrpow_max > w) return LARGE_BITS;
+        }
+    }
     int vx[NPL], vy[NPL];
     { PH_BEGIN(); q_quantize(T, g, scalefac, ix, use_pn, use_pn ? pn.gain : 0, use_pn ? pn.sfb_count1 : 0, vx, vy, lane, L, Q); PH_END(L, PH_QUANTIZE); }
     int cnt1 = pn.sfb_count1;
@@ -902,6 +918,9 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     //    terms themselves are computed once, all lanes busy.  All non-empty summing ranges start at their band's
     //    first line (after the first band cut by max_nonzero_coeff every range is empty).
     enum { NLN = 576 / LHIP_NL };
+    // quantized values are <= xrpow_max * ipow20(gain) + 1 (the working copy was quantized at this gain): below QT_N - 1
+    // no line can need the part of pow43 that is not staged in LDS
+    const int may_big = !(g.xrpow_max * ipow20(Q, g.global_gain) < (double)(QT_N - 1));
     {
         double tq[NLN];
         unsigned resetm = 0, lastm = 0;          // bit k: line k of this lane starts a band / ends a summing range
@@ -916,7 +935,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             const int in = (bnd < g.psymax) && bi.kind != 0 && j < bi.nend;
             const float xa = L.xr[j]; const int iv = ix[j];
             float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
-            if (iv >= QT_N) pw = T.pow43[iv];
+            if (may_big && iv >= QT_N) pw = T.pow43[iv];
             const double step = (double)bi.step, ax = d_abs((double)xa);
             double x = (double)xa;
             if (bi.kind == 2) x = ax - (iv == 0 ? 0.0 : step);
@@ -1009,21 +1028,17 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
 // ---------------------------------------------------------------------------------------------
 // scale_bitcount (Takehiro.js:980-1030), MPEG-1, no mixed blocks.  returns 1 on failure
 // ---------------------------------------------------------------------------------------------
-LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lane) {
+LHIP_DEV int q_scale_bitcount(const QuantTabs& Q, GI& g, int32_t* scalefac, int lane) {
     lane = fresh_lane(lane);
-    const int32_t* tab;
-    if (g.block_type == SHORT_TYPE) tab = T.scale_short;
-    else {
-        tab = T.scale_long;
-        if (0 == g.preflag) {
-            int bad = 0;
-            for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) if (scalefac[sfb] < T.pretab[sfb]) bad = 1;
-            if (!wave_any(bad)) {
-                g.preflag = 1;
-                wave_sync();
-                for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) scalefac[sfb] -= T.pretab[sfb];
-                wave_sync();
-            }
+    const int sh = (g.block_type == SHORT_TYPE) ? 24 : 16;       // scale_short / scale_long byte of Q.sbc
+    if (g.block_type != SHORT_TYPE && 0 == g.preflag) {
+        int bad = 0;
+        for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) if (scalefac[sfb] < Q.pretab[sfb]) bad = 1;
+        if (!wave_any(bad)) {
+            g.preflag = 1;
+            wave_sync();
+            for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) scalefac[sfb] -= Q.pretab[sfb];
+            wave_sync();
         }
     }
     // slen1_n / slen2_n are powers of two, and "every value < 2^b" is "the OR of the values < 2^b": the two maxima
@@ -1037,8 +1052,10 @@ LHIP_DEV int q_scale_bitcount(const Tables& T, GI& g, int32_t* scalefac, int lan
     const int m1 = m12 & 0xff, m2 = m12 >> 8;
     // first k with the smallest tab[k] among the admissible ones == minimum of (tab[k], k) pairs; one lane per k
     int best = 0x7fffffff;
-    for (int k = lane; k < 16; k += LHIP_NL)
-        if (m1 < T.slen1_n[k] && m2 < T.slen2_n[k]) { const int v = tab[k] * 16 + k; if (v < best) best = v; }
+    for (int k = lane; k < 16; k += LHIP_NL) {
+        const uint32_t e = Q.sbc[k];
+        if (m1 < (int)(e & 0xffu) && m2 < (int)((e >> 8) & 0xffu)) { const int v = (int)((e >> sh) & 0xffu) * 16 + k; if (v < best) best = v; }
+    }
     best = wave_min(best);
     g.part2_length = LARGE_BITS;
     if (best != 0x7fffffff) { g.part2_length = best >> 4; g.scalefac_compress = best & 15; }
@@ -1079,8 +1096,8 @@ LHIP_DEV int q_scale_bitcount_lsf(GI& g, const int32_t* scalefac, int lane) {
     return over;
 }
 
-LHIP_DEV int q_scale_bitcount_any(const Tables& T, GI& g, int32_t* scalefac, int lane) {   // Quantize.js:814-817, 840-843
-    return T.mode_gr == 2 ? q_scale_bitcount(T, g, scalefac, lane) : q_scale_bitcount_lsf(g, scalefac, lane);
+LHIP_DEV int q_scale_bitcount_any(const Tables& T, const QuantTabs& Q, GI& g, int32_t* scalefac, int lane) {   // Quantize.js:814-817, 840-843
+    return T.mode_gr == 2 ? q_scale_bitcount(Q, g, scalefac, lane) : q_scale_bitcount_lsf(g, scalefac, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1143,7 +1160,7 @@ LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, in
     uint64_t m_amp = 0;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
         int s = scalefac[sfb];
-        if (g.preflag != 0) s += T.pretab[sfb];
+        if (g.preflag != 0) s += Q.pretab[sfb];
         if ((s & 1) != 0) { s++; m_amp |= 1ull << sfb; }
         scalefac[sfb] = s >> 1;
     }
@@ -1205,7 +1222,7 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
     q_amp_scalefac_bands(T, g, scalefac, lane, L, Q);
     int status = q_loop_break(g, scalefac, lane, L, Q);
     if (status) return 0;
-    status = q_scale_bitcount_any(T, g, scalefac, lane);
+    status = q_scale_bitcount_any(T, Q, g, scalefac, lane);
     if (!status) return 1;
     if (T.noise_shaping > 1) {
         if (0 == g.scalefac_scale) {
@@ -1215,7 +1232,7 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
             status = (q_inc_subblock_gain(T, g, scalefac, lane, L, Q) || q_loop_break(g, scalefac, lane, L, Q));
         }
     }
-    if (!status) status = q_scale_bitcount_any(T, g, scalefac, lane);
+    if (!status) status = q_scale_bitcount_any(T, Q, g, scalefac, lane);
     return !status;
 }
 
@@ -1426,7 +1443,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     wave_sync();
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (sf[sfb] == -2) sf[sfb] = 0;
     wave_sync();
-    if (uni(recalc) != 0) q_scale_bitcount_any(T, g, sf, lane);
+    if (uni(recalc) != 0) q_scale_bitcount_any(T, Q, g, sf, lane);
 }
 
 // Huffman statistics per scalefactor band over the pairs below `limit`, then turned into prefix sums over
