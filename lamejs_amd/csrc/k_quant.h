@@ -144,7 +144,7 @@ struct QuantLds {
     int32_t pn_step[SFBMAX + 1];
     float pn_noise[SFBMAX + 1], pn_noise_log[SFBMAX + 1];
     int32_t qmode[SFBMAX + 1];
-    struct BandInfo { int32_t nstart, nend, kind; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range + term formula per band
+    struct alignas(8) BandInfo { int32_t nstart, kind, nend; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range (empty: nend <= nstart), cached flag (kind 0), step
     int8_t sf_gr0[2][SFBMAX + 1];                 // final gr0 scalefactors per channel (for scfsi): -2..15
     union {                      // calc_noise band sums live only inside the outer loop, the split tables only after it
         struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
@@ -239,19 +239,19 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         }
     } else {
         nsfb = SBMAX_l;
-        for (int i = lane; i < SBMAX_l; i += LHIP_NL) {
+        LHIP_LANE_ONCE(i, 0, SBMAX_l) {
             L.width[i] = T.sfb_l[i + 1] - T.sfb_l[i]; L.window[i] = 3; L.start[i] = T.sfb_l[i];
         }
         if (lane == 0) L.start[SBMAX_l] = 576;
         for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[d];
     }
-    for (int i = lane; i <= SFBMAX; i += LHIP_NL) { L.sfw[i] = 0; L.sfb[i] = 0; }
+    LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.sfw[i] = 0; L.sfb[i] = 0; }
     wave_sync();
 
     // analog silence in the pseudo bands above sfb21 / sfb12: zero trailing lines below the adjusted ATH
     if (skip_silence) return;
     if (block_type != SHORT_TYPE) {
-        for (int gsfb = lane; gsfb < PSFB21; gsfb += LHIP_NL) {
+        LHIP_LANE_ONCE(gsfb, 0, PSFB21) {
             double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb21[gsfb], T.ATH_floor);
             if ((double)T.longfact[21] > 1e-12) a *= (double)T.longfact[21];
             L.ath_pseudo[gsfb] = a;
@@ -267,7 +267,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         top = wave_max(top);
         for (int j = lo + lane; j < 576; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[j] = 0; }
     } else {
-        for (int gsfb = lane; gsfb < PSFB12; gsfb += LHIP_NL) {
+        LHIP_LANE_ONCE(gsfb, 0, PSFB12) {
             double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb12[gsfb], T.ATH_floor);
             if ((double)T.shortfact[12] > 1e-12) a *= (double)T.shortfact[12];
             L.ath_pseudo[gsfb] = a;
@@ -389,7 +389,7 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
         t = wave_max(t);
         g.max_nonzero_coeff = (t >= 575) ? 575 : t + 1;
     } else {
-        for (int sfb = lane; sfb < SBPSY_s; sfb += LHIP_NL) {       // psymax/3 bands, 3 windows each
+        LHIP_LANE_ONCE(sfb, 0, SBPSY_s) {       // psymax/3 bands, 3 windows each
             const double tmpATH = ath_adjust * (double)T.ATH_s[sfb];
             float px[3];
             for (int b = 0; b < 3; b++) {
@@ -761,7 +761,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 #define LP_(r) lp1
 #define PV_(r) pv1
 #endif
-    for (int r = lane; r < 3; r += LHIP_NL) {
+    LHIP_LANE_ONCE(r, 0, 3) {
         const int m = (r == 0) ? m0 : (r == 1) ? m1 : m2;
         const QuantTabs::PlanEnt pe = Q.plan[plan_index(m)];          // the whole plan is a function of the maximum: one look-up
         L.rdesc[r][0] = pe.d0;
@@ -817,7 +817,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     PH_MARK(L, PH_C_SUMS, tm_);
     // finish (Takehiro.js count_bit_noESC / _from2 / _from3 / count_bit_ESC tie-breaking): lane r picks the cheapest
     // admissible candidate of region r; result packed as table | overflow << 6 | bits << 8
-    for (int r = lane; r < 3; r += LHIP_NL) {
+    LHIP_LANE_ONCE(r, 0, 3) {
         const LanePlan& q = LP_(r);
         const int qa = (r == 0) ? q0 : (r == 1) ? q2 : q4, qc = (r == 0) ? q1 : (r == 1) ? q3 : q5;
         const int n = (int)((unsigned)qc >> 16);
@@ -893,19 +893,26 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     m_cut = wave_lane_bits(m_cut);
     const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
     int maxlen = 0;                                          // longest summing range of this call (cached bands have none)
-    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
-        const int s = sf_step(Q, g, scalefac, L.window, sfb);
-        const int cached = (use_pn && L.pn_step[sfb] == s);
-        L.qmode[sfb] = s;                                   // step of the band (stored into the cache below)
-        const int js = L.start[sfb], w = L.width[sfb];
-        int l = w >> 1;
-        if (sfb == firstcut) { const int usefullsize = g.max_nonzero_coeff - js + 1; l = usefullsize > 0 ? usefullsize >> 1 : 0; }
-        if (sfb > firstcut || cached) l = 0;
-        if (maxlen < 2 * l) maxlen = 2 * l;
+    // One error formula serves the three branches of calc_noise_core (QuantizePVT.js:725-767): a band that starts above
+    // count1 holds only zeros and one that starts above big_values only 0/1, and pow43[0] = 0, pow43[1] = 1, so
+    // |xr| - pow43[ix] * step is bit for bit `xr` (squared), `|xr| - ix01[ix]` and `|xr| - pow43[ix] * step` there.
+    // Bands past psymax and cached bands get an empty range (nend = 0 / nstart), which is all the per-line code tests.
+    LHIP_LANE_ONCE(sfb, 0, SFBMAX + 1) {
         QuantLds::BandInfo bi;
-        bi.nstart = js; bi.nend = js + 2 * l;
-        bi.kind = cached ? 0 : (js > g.count1) ? 1 : (js > g.big_values) ? 2 : 3;
-        bi.step = Q.pow20[s + Q_MAX2];
+        bi.nstart = 0; bi.nend = 0; bi.kind = 0; bi.step = 0.f;
+        if (sfb < g.psymax) {
+            const int s = sf_step(Q, g, scalefac, L.window, sfb);
+            const int cached = (use_pn && L.pn_step[sfb] == s);
+            L.qmode[sfb] = s;                               // step of the band (stored into the cache below)
+            const int js = L.start[sfb], w = L.width[sfb];
+            int l = w >> 1;
+            if (sfb == firstcut) { const int usefullsize = g.max_nonzero_coeff - js + 1; l = usefullsize > 0 ? usefullsize >> 1 : 0; }
+            if (sfb > firstcut || cached) l = 0;
+            if (maxlen < 2 * l) maxlen = 2 * l;
+            bi.nstart = js; bi.nend = js + 2 * l;
+            bi.kind = cached ? 0 : 1;
+            bi.step = Q.pow20[s + Q_MAX2];
+        }
         L.binfo[sfb] = bi;
     }
     maxlen = wave_max(maxlen);
@@ -931,18 +938,15 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         for (int k = 0; k < NLN; k++) {
             const int j = NLN * lane + k;
             const int bnd = l2s[j];
-            const QuantLds::BandInfo bi = L.binfo[bnd < g.psymax ? bnd : g.psymax - 1];
-            const int in = (bnd < g.psymax) && bi.kind != 0 && j < bi.nend;
+            const int nend = L.binfo[bnd].nend; const float bstep = L.binfo[bnd].step;   // adjacent: one 8-byte load
+            const int in = j < nend;
             const float xa = L.xr[j]; const int iv = ix[j];
             float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
             if (may_big && iv >= QT_N) pw = T.pow43[iv];
-            const double step = (double)bi.step, ax = d_abs((double)xa);
-            double x = (double)xa;
-            if (bi.kind == 2) x = ax - (iv == 0 ? 0.0 : step);
-            if (bi.kind == 3) x = ax - (double)pw * step;
+            const double x = d_abs((double)xa) - (double)pw * (double)bstep;
             tq[k] = in ? x * x : 0.0;            // sums are >= +0, so adding +0.0 leaves them unchanged
             if (bnd != prevb) resetm |= 1u << (k & 31);
-            if (in && j == bi.nend - 1) lastm |= 1u << (k & 31);
+            if (j == nend - 1) lastm |= 1u << (k & 31);
             lastb[k] = bnd; prevb = bnd;
         }
         // NLN <= 32 on the device; the one-lane host build folds everything in a single pass below
@@ -959,8 +963,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
                 const int bnd = lastb[k];
                 if ((k == 0) || (lastb[k - 1] != bnd)) sacc = 0.0;
                 sacc += tq[k];
-                const QuantLds::BandInfo bi = L.binfo[bnd < g.psymax ? bnd : g.psymax - 1];
-                if (bnd < g.psymax && bi.kind != 0 && k == bi.nend - 1) L.nsum[bnd] = sacc;
+                if (k == L.binfo[bnd].nend - 1) L.nsum[bnd] = sacc;
             }
             (void)keep; (void)nsteps; (void)lastm;
         }
@@ -1033,11 +1036,11 @@ LHIP_DEV int q_scale_bitcount(const QuantTabs& Q, GI& g, int32_t* scalefac, int 
     const int sh = (g.block_type == SHORT_TYPE) ? 24 : 16;       // scale_short / scale_long byte of Q.sbc
     if (g.block_type != SHORT_TYPE && 0 == g.preflag) {
         int bad = 0;
-        for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) if (scalefac[sfb] < Q.pretab[sfb]) bad = 1;
+        LHIP_LANE_ONCE(sfb, 11, SBPSY_l) if (scalefac[sfb] < Q.pretab[sfb]) bad = 1;
         if (!wave_any(bad)) {
             g.preflag = 1;
             wave_sync();
-            for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) scalefac[sfb] -= Q.pretab[sfb];
+            LHIP_LANE_ONCE(sfb, 11, SBPSY_l) scalefac[sfb] -= Q.pretab[sfb];
             wave_sync();
         }
     }
@@ -1052,7 +1055,7 @@ LHIP_DEV int q_scale_bitcount(const QuantTabs& Q, GI& g, int32_t* scalefac, int 
     const int m1 = m12 & 0xff, m2 = m12 >> 8;
     // first k with the smallest tab[k] among the admissible ones == minimum of (tab[k], k) pairs; one lane per k
     int best = 0x7fffffff;
-    for (int k = lane; k < 16; k += LHIP_NL) {
+    LHIP_LANE_ONCE(k, 0, 16) {
         const uint32_t e = Q.sbc[k];
         if (m1 < (int)(e & 0xffu) && m2 < (int)((e >> 8) & 0xffu)) { const int v = (int)((e >> sh) & 0xffu) * 16 + k; if (v < best) best = v; }
     }
@@ -1262,7 +1265,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
     best.max_noise = 0; best.over_count = 0; best.over_SSD = 0; best.bits = 0;
-    for (int i = lane; i <= SFBMAX; i += LHIP_NL) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_noise_log[i] = 0.f; L.distort[i] = 0.f; }
+    LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_noise_log[i] = 0.f; L.distort[i] = 0.f; }
     wave_sync();
     targ_bits = uni(targ_bits); bs_start = uni(bs_start); bs_step = uni(bs_step);
     uni_gi(g);
@@ -1319,7 +1322,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (0 == T.noise_shaping) {
                 g = w;
                 for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
-                for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sfb[i] = L.sfw[i];
+                LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sfb[i] = L.sfw[i];
                 wave_sync();
                 return;
             }
@@ -1343,7 +1346,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             best = ni;
             g = w;
             for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
-            for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sfb[i] = L.sfw[i];
+            LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sfb[i] = L.sfw[i];
             wave_sync();
             age = 0;
         } else if (T.full_outer_loop == 0) {
@@ -1373,7 +1376,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     {
         // bands whose quantized lines are all zero get scalefactor -2 (Takehiro.js:870-882): every lane flags the
         // bands of its non-zero pairs (a pair never straddles a band), then one lane per band reads its flag
-        for (int sfb = lane; sfb <= SFBMAX; sfb += LHIP_NL) L.qmode[sfb] = 0;
+        LHIP_LANE_ONCE(sfb, 0, (SFBMAX) + 1) L.qmode[sfb] = 0;
         wave_sync();
         const uint8_t* l2s = line2sfb(Q, g.block_type);
         for (int p = 2 * lane; p < 576; p += 2 * LHIP_NL)
@@ -1396,9 +1399,9 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
     }
     if (0 == g.preflag && g.block_type != SHORT_TYPE && T.mode_gr == 2) {
         int bad = 0;
-        for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) if (sf[sfb] < T.pretab[sfb] && sf[sfb] != -2) bad = 1;
+        LHIP_LANE_ONCE(sfb, 11, SBPSY_l) if (sf[sfb] < T.pretab[sfb] && sf[sfb] != -2) bad = 1;
         if (!wave_any(bad)) {
-            for (int sfb = 11 + lane; sfb < SBPSY_l; sfb += LHIP_NL) if (sf[sfb] > 0) sf[sfb] -= T.pretab[sfb];
+            LHIP_LANE_ONCE(sfb, 11, SBPSY_l) if (sf[sfb] > 0) sf[sfb] -= T.pretab[sfb];
             g.preflag = recalc = 1;
             wave_sync();
         }
@@ -1409,7 +1412,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
         // band of it differs (bands already marked negative do not count as different)
         const int8_t* g0 = L.sf_gr0[ch];
         uint64_t m_diff = 0;
-        for (int sfb = lane; sfb < SBPSY_l; sfb += LHIP_NL) if ((int)g0[sfb] != sf[sfb] && sf[sfb] >= 0) m_diff |= 1ull << sfb;
+        LHIP_LANE_ONCE(sfb, 0, SBPSY_l) if ((int)g0[sfb] != sf[sfb] && sf[sfb] >= 0) m_diff |= 1ull << sfb;
         m_diff = wave_lane_bits(m_diff);
         uint64_t m_same = 0;
         for (int i = 0; i < 4; i++) {
@@ -1418,12 +1421,12 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
             if ((m_diff & rng) == 0) { scfsi[i] = 1; m_same |= rng; }
         }
         wave_sync();
-        for (int sfb = lane; sfb < SBPSY_l; sfb += LHIP_NL) if ((m_same >> sfb) & 1) sf[sfb] = -1;
+        LHIP_LANE_ONCE(sfb, 0, SBPSY_l) if ((m_same >> sfb) & 1) sf[sfb] = -1;
         wave_sync();
         // slen1_n / slen2_n are powers of two: the two maxima of the reference reduce to ORs (negative markers count as 0)
         uint64_t m_cnt = 0;
         int or12 = 0;
-        for (int sfb = lane; sfb < SBPSY_l; sfb += LHIP_NL) {
+        LHIP_LANE_ONCE(sfb, 0, SBPSY_l) {
             const int v = sf[sfb];
             if (v != -1) m_cnt |= 1ull << sfb;
             const int vp = v > 0 ? v : 0;
@@ -1434,7 +1437,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
         const int c1 = __builtin_popcountll(m_cnt & 0x7ffull), c2 = __builtin_popcountll(m_cnt >> 11);
         const int s1 = or12 & 0xff, s2 = or12 >> 8;
         int best = 0x7fffffff;                         // first i with the smallest cost == minimum of (cost, i)
-        for (int i = lane; i < 16; i += LHIP_NL)
+        LHIP_LANE_ONCE(i, 0, 16)
             if (s1 < T.slen1_n[i] && s2 < T.slen2_n[i]) { const int c = (T.slen1_tab[i] * c1 + T.slen2_tab[i] * c2) * 16 + i; if (c < best) best = c; }
         best = wave_min(best);
         if (best != 0x7fffffff && g.part2_length > (best >> 4)) { g.part2_length = best >> 4; g.scalefac_compress = best & 15; }
@@ -1459,7 +1462,7 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
     // word (a total is at most 288 x 21 < 2^16).  A length is only added when the PAIR admits the table; a row
     // is only read for regions whose maximum admits it, where that is the same thing.
     enum { PPL = (288 + LHIP_NL - 1) / LHIP_NL, NW = 9 };
-    for (int bnd = lane; bnd <= SBMAX_l + 1; bnd += LHIP_NL) L.hd.bstat[0][bnd] = 0;
+    LHIP_LANE_ONCE(bnd, 0, (SBMAX_l + 1) + 1) L.hd.bstat[0][bnd] = 0;
     wave_sync();
     uint32_t pre[PPL][NW];
     uint32_t run[NW];
@@ -1509,7 +1512,7 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
             L.hd.bstat[13][col] = (int)(v[7] & 0xffffu); L.hd.bstat[14][col] = (int)(v[7] >> 16); L.hd.bstat[15][col] = (int)v[8];
         }
     }
-    for (int k = 1 + lane; k < 16; k += LHIP_NL) L.hd.bstat[k][0] = 0;
+    LHIP_LANE_ONCE(k, 1, 16) L.hd.bstat[k][0] = 0;
     wave_sync();
 }
 
@@ -1544,7 +1547,7 @@ LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, con
 // reference's running comparison (its `break`s depend on the best length so far) is then replayed over those.
 LHIP_DEV void q_recalc_divide_sub(const Tables& T, const GI& c2, GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     const int bigv = c2.big_values;
-    for (int r2 = 2 + lane; r2 < SBMAX_l + 1; r2 += LHIP_NL) {
+    LHIP_LANE_ONCE(r2, 2, SBMAX_l + 1) {
         int bits2 = 0;
         const int tbl = q_choose_from_stats(T, r2, SBMAX_l, &bits2, L, Q);
         L.r2_bits[r2] = bits2; L.r2_tbl[r2] = tbl;
@@ -1581,7 +1584,7 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
         // recalc_divide_init: every (region0, region1) split evaluated from the per-band statistics
         q_band_stats(T, ix, g.big_values, lane, L, Q);
         const int bigv = g.big_values;
-        for (int s = lane; s < 24; s += LHIP_NL) { L.r01_bits[s] = LARGE_BITS; L.r01_div[s] = 0; L.r0_tbl[s] = 0; L.r1_tbl[s] = 0; }
+        LHIP_LANE_ONCE(s, 0, 24) { L.r01_bits[s] = LARGE_BITS; L.r01_div[s] = 0; L.r0_tbl[s] = 0; L.r1_tbl[s] = 0; }
         // all 16 x 8 splits in parallel; candidate bits go to cand[r0 + r1][r0]
         for (int c = lane; c < 128; c += LHIP_NL) {
             const int r0 = c >> 3, r1 = c & 7, sidx = r0 + r1;
@@ -1596,7 +1599,7 @@ LHIP_DEV void q_best_huffman_divide(const Tables& T, GI& g, int lane, QuantLds& 
         }
         wave_sync();
         // lane s: the first r0 (ascending) with the strictly smallest bits wins, as in the reference's loop order
-        for (int sidx = lane; sidx <= 20; sidx += LHIP_NL) {
+        LHIP_LANE_ONCE(sidx, 0, (20) + 1) {
             int bb = 0x7fff, bd = -1;               // 0x7fff == no valid split (the reference keeps LARGE_BITS there)
             for (int r0 = (sidx > 7 ? sidx - 7 : 0); r0 < 16 && r0 <= sidx; r0++)
                 if (bb > L.hd.cand[sidx][r0]) { bb = L.hd.cand[sidx][r0]; bd = r0; }
@@ -1774,7 +1777,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             ResvSize = uni(ResvSize - (g.part2_3_length + g.part2_length));
             if (gr == 0) {
                 if (ch == 0) gr0_bt0 = g.block_type; else gr0_bt1 = g.block_type;
-                for (int i = lane; i <= SFBMAX; i += LHIP_NL) L.sf_gr0[ch][i] = (int8_t)L.sfb[i];
+                LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i];
             }
             // ---- publish the record and the signed quantized spectrum ----
             GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
@@ -1790,7 +1793,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 out->targ_bits = targ_ch;
                 out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
             }
-            for (int i = lane; i < SFBMAX; i += LHIP_NL) out->scalefac[i] = L.sfb[i];
+            LHIP_LANE_ONCE(i, 0, SFBMAX) out->scalefac[i] = L.sfb[i];
             if (!active && lane == 0) { out->bs_ntab = 0; out->bs_state = 0; }
             int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
             for (int i = lane; i < 576; i += LHIP_NL) {
