@@ -302,7 +302,7 @@ LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
         L.xrpow[i] = v;
         if (v > m) m = v;
     }
-    m = wave_maxf(m);
+    m = wave_maxf_pos(m);
     g.xrpow_max = m;
     // `sum > 1e-20` only separates digital silence from signal; the reduction order cannot change the verdict
     // except within 1e-14 (relative) of the threshold itself
@@ -1128,7 +1128,7 @@ LHIP_DEV void q_amplify_flagged(GI& g, double amp, uint64_t m_amp, int lane, Qua
             if (xx.y > m) m = xx.y;
         }
     }
-    m = wave_maxf(m);
+    m = wave_maxf_pos(m);
     if ((double)m > g.xrpow_max) g.xrpow_max = m;
     wave_sync();
 }
@@ -1138,7 +1138,7 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
     const double ifqstep34 = (g.scalefac_scale == 0) ? 1.29683955465100964055 : 1.68179283050742922612;
     float tr = 0.f;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (tr < L.distort[sfb]) tr = L.distort[sfb];
-    double trigger = wave_maxf(tr);
+    double trigger = wave_maxf_pos(tr);
     switch (T.noise_shaping_amp) {
         case 2: break;
         case 1:
@@ -1211,7 +1211,7 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
                     L.xrpow[i] = v;
                     if (v > m) m = v;
                 }
-                m = wave_maxf(m);
+                m = wave_maxf_pos(m);
                 if ((double)m > g.xrpow_max) g.xrpow_max = m;
             }
         }

@@ -14,6 +14,7 @@ LHIP_DEV int wave_min(int v) { return v; }
 LHIP_DEV int wave_or(int v) { return v; }
 LHIP_DEV uint64_t wave_or64(uint64_t v) { return v; }
 LHIP_DEV float wave_maxf(float v) { return v; }
+LHIP_DEV float wave_maxf_pos(float v) { return v; }
 LHIP_DEV double wave_maxd(double v) { return v; }
 LHIP_DEV double wave_sumd(double v) { return v; }
 LHIP_DEV int wave_bcast(int v, int) { return v; }
@@ -56,6 +57,9 @@ LHIP_DEV uint64_t wave_or64(uint64_t v) {
 // treat as divergent -- it turns the whole control flow downstream into exec-masked code.)
 // max is exact and associative for non-NaN operands: any reduction order gives the same bits.
 LHIP_DEV float wave_maxf(float v) { return __ockl_wfred_max_f32(v); }
+// maximum of values that are all >= +0 (no NaN, no -0): IEEE order == integer order of the bit patterns, and the integer
+// reduction is one fused DPP max per step where the f32 one spends three more on canonicalising its operands
+LHIP_DEV float wave_maxf_pos(float v) { return __int_as_float(__reduce_max_sync(~0ull, __float_as_int(v))); }
 LHIP_DEV double wave_maxd(double v) { return __ockl_wfred_max_f64(v); }
 // tree sum: NOT order-exact; only for order-insensitive decisions
 LHIP_DEV double wave_sumd(double v) { return __ockl_wfred_add_f64(v); }
@@ -83,7 +87,7 @@ LHIP_DEV void lds_max(int32_t* p, int32_t v) { atomicMax(p, v); }
 LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return __ballot(v != 0); }
 // An opaque copy of the lane index: addresses derived from it cannot be merged with (and hoisted like) the ones
 // derived from other copies, which keeps loop-invariant address registers from piling up and spilling.
-LHIP_DEV int fresh_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
+LHIP_DEV int fresh_lane(int lane) { asm volatile("" : "+v"(lane)); __builtin_assume(lane >= 0 && lane < LHIP_NL); return lane; }   // the copy keeps its range
 // asserts to the compiler that v is wave-uniform (moves it to an SGPR)
 LHIP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // value of lane - 1 (lane 0 receives `first`): two DPP moves (wave_shr:1), no LDS round trip
