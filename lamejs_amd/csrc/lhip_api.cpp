@@ -501,6 +501,9 @@ struct Context {
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0; bool have_last = false;
     int num_cus = 256;
+    // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
+    // beside the filterbank kernels, which do not depend on it
+    void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
 };
 
 static std::mutex g_ctx_mu;
@@ -700,10 +703,28 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
-    LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
-    LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
+    // g_scan_ath (needs psyA's loudness, feeds psyB and the quantizer) is one workgroup per stream: it runs on a side
+    // stream while polyphase + MDCT (which need neither) keep the chip busy.  With per-kernel timing on, everything stays
+    // on the launch stream so that the HIP events bracket each kernel.
+    bool forked = false;
+    if (!g_kt_on) {
+        if (!ctx->aux_stream) {
+            hipStream_t a; hipEvent_t e1, e2;
+            if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) { ctx->aux_stream = a; ctx->ev_fork = e1; ctx->ev_join = e2; }
+        }
+        if (ctx->aux_stream && hipEventRecord((hipEvent_t)ctx->ev_fork, (hipStream_t)st) == hipSuccess &&
+            hipStreamWaitEvent((hipStream_t)ctx->aux_stream, (hipEvent_t)ctx->ev_fork, 0) == hipSuccess) {
+            LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, ctx->aux_stream, T, W, dSD);
+            HIPCK(hipEventRecord((hipEvent_t)ctx->ev_join, (hipStream_t)ctx->aux_stream));
+            forked = true;
+        }
+    }
+    if (!forked) LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
+    if (forked) HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0));
+    LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
