@@ -281,7 +281,7 @@ LHIP_DEV void kb_mdct(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const StreamDesc sd = SD[st];
     if (gslot - sd.gslot0 - 1 < 0) return;
     const double* win = T.mdct_win;
-    for (int it = lane; it < C * 32; it += LHIP_NL) {
+    LHIP_LANE_ONCE(it, 0, C * 32) {                            // C <= 2: at most one (channel, band) per lane
         const int ch = it >> 5, band = it & 31;
         const float* band0 = W.sb + ((int64_t)(gslot - 1) * C + ch) * SB_STRIDE;   // previous granule (or carry)
         const float* band1 = W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE;
@@ -324,7 +324,7 @@ LHIP_DEV void kb_mdct(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
     // alias-reduction butterflies between band-1 and band (non-short blocks); disjoint element pairs
-    for (int it = lane; it < C * 32; it += LHIP_NL) {
+    LHIP_LANE_ONCE(it, 0, C * 32) {                            // C <= 2: at most one (channel, band) per lane
         const int ch = it >> 5, band = it & 31;
         const int type = W.blocktype[(int64_t)gslot * C + ch];
         if (type != SHORT_TYPE && band != 0) {

@@ -261,7 +261,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
 
     PSY_STAMP(5);
     // --- long partitions: energy, max, average (calc_energy, PsyModel.js:906-928) ---
-    for (int b = lane; b < T.npart_l; b += LHIP_NL) {
+    LHIP_LANE_ONCE(b, 0, T.npart_l) {                        // npart_l < CBANDS = 64
         double ebb = 0, m = 0;
         int j = T.lineoff_l[b];
         for (int i = 0; i < T.numlines_l[b]; ++i, ++j) {
@@ -635,7 +635,7 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
         // long-block spreading with additive masking (PsyModel.js:1274-1320); thr = ecb (pcfact == 0)
         // The additive-masking chain is serial in the partition's spreading row; the operands of step u + 1 are
         // fetched while step u is evaluated (one mask_add instance, software-pipelined loads).
-        for (int b = lane; b < T.npart_l; b += LHIP_NL) {
+        LHIP_LANE_ONCE(b, 0, T.npart_l) {                        // npart_l < CBANDS = 64
             const int k0 = T.s3ind[2 * b], k1 = T.s3ind[2 * b + 1], j0 = T.s3off_l[b];
             double ecb = (double)T.s3_ll[j0] * ((double)eb_l[k0] * L.mtab[midx[k0]]);
             double tn = 0.0, an = 0.0;

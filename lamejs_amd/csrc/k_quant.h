@@ -57,7 +57,7 @@ LHIP_DEV void uni_gi(GI& g) {
 #define PH_NOW() 0ull
 #endif
 enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL,
-       PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N };
+       PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N, PH_DRAIN = 29 /* 22..28 belong to psyA's stamps */ };
 
 // Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
 // inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
@@ -208,6 +208,11 @@ LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, c
 LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath_adjust, GI& g, int block_type,
                                 const float* xr_g, float* xr_wb, int skip_silence, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
+    unsigned long long tmi_ = PH_NOW(); (void)tmi_;
+#if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
+    __builtin_amdgcn_s_waitcnt(0);           // profiling build only: everything this wave still has in flight (stores of the previous granule)
+    PH_MARK(L, PH_DRAIN, tmi_);
+#endif
     g.part2_3_length = 0; g.big_values = 0; g.count1 = 0; g.global_gain = 210; g.scalefac_compress = 0;
     g.block_type = block_type;
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
@@ -247,6 +252,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
     }
     LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.sfw[i] = 0; L.sfb[i] = 0; }
     wave_sync();
+    PH_MARK(L, PH_COPY, tmi_);
 
     // analog silence in the pseudo bands above sfb21 / sfb12: zero trailing lines below the adjusted ATH
     if (skip_silence) return;
@@ -257,6 +263,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
             L.ath_pseudo[gsfb] = a;
         }
         wave_sync();
+        PH_MARK(L, PH_XRPOW, tmi_);
         const int lo = T.psfb21[0];
         int top = lo - 1;                       // highest line that is NOT below its threshold
         for (int j = lo + lane; j < 576; j += LHIP_NL) {
@@ -266,6 +273,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         }
         top = wave_max(top);
         for (int j = lo + lane; j < 576; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[j] = 0; }
+        PH_MARK(L, PH_PUBLISH, tmi_);
     } else {
         LHIP_LANE_ONCE(gsfb, 0, PSFB12) {
             double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb12[gsfb], T.ATH_floor);
@@ -1724,8 +1732,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     const int fidx = sd.out_slot0 + k;                    // dense frame index
     if (chain && !W.seed_flag[fidx]) return;
 #ifdef LHIP_PHASE_PROF
-    if (lane == 0) for (int i = 0; i < 64; i++) L.prof[i] = 0;
-    const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();     // L.prof is zeroed / flushed once per wave by g_quant
 #endif
     const double ath_adjust = W.ath_adjust[fslot];        // after adjust_ATH of this frame
     const int padding = frame_padding(T, sd, k);
@@ -1805,10 +1812,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     }
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
 #ifdef LHIP_PHASE_PROF
-    if (lane == 0) {
-        L.prof[PH_TOTAL] = (unsigned int)(__builtin_amdgcn_s_memtime() - ph_total0_); L.prof[32 + PH_TOTAL] = 1;
-        for (int i = 0; i < 64; i++) atomicAdd((unsigned long long*)W.prof + i, (unsigned long long)L.prof[i]);
-    }
+    if (lane == 0) { L.prof[PH_TOTAL] += (unsigned int)(__builtin_amdgcn_s_memtime() - ph_total0_); L.prof[32 + PH_TOTAL] += 1; }
 #endif
 }
 

@@ -251,11 +251,17 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused
     q_load_tabs(A->T, Q, threadIdx.x, 64 * QWAVES);
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef LHIP_PHASE_PROF
+    L[wv].prof[threadIdx.x & 63] = 0;                 // per-wave cycle sums, flushed once at the end (a flush per frame would
+#endif                                                // itself congest the memory pipeline it is trying to observe)
     for (;;) {
         const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
         if (fslot >= A->nfs) break;
         kb_quant(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q);
     }
+#ifdef LHIP_PHASE_PROF
+    atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
+#endif
 }
 __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nslow) {
     __shared__ QuantTabs Q;
