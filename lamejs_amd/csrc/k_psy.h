@@ -106,7 +106,7 @@ struct PsyALds {
 
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
 #define PSY_STAMP(i) const unsigned long long psy_t##i = __builtin_amdgcn_s_memtime()
-#define PSY_FLUSH() do { if (lane == 0) { const unsigned long long t_[8] = {psy_t0, psy_t1, psy_t2, psy_t3, psy_t4, psy_t5, psy_t6, psy_t7}; \
+#define PSY_FLUSH() do { if (lane == 0 && (gslot & 63) == 0) {   /* a sample of the waves: a flush per wave congests what it measures */ const unsigned long long t_[8] = {psy_t0, psy_t1, psy_t2, psy_t3, psy_t4, psy_t5, psy_t6, psy_t7}; \
     for (int i_ = 0; i_ < 7; i_++) atomicAdd((unsigned long long*)W.prof + 22 + i_, t_[i_ + 1] - t_[i_]); atomicAdd((unsigned long long*)W.prof + 54, 1ull); } } while (0)
 #else
 #define PSY_STAMP(i) do {} while (0)

@@ -5,9 +5,11 @@
  * addon, or $LAMEJS_HIP_LIB), so the addon itself builds with plain gcc + node headers:
  *     gcc -O2 -fPIC -shared -I/usr/include/node -I../../../include lhip_napi.c -o lhip_napi.node -ldl
  *
- * JS surface:  create(tablesBlob: Buffer, channels, samplerate, kbps) -> handle
+ * JS surface:  create(tablesBlob: Buffer, channels, samplerate, kbps[, device]) -> handle
  *              encode(handle, left: Int16Array, right: Int16Array|null) -> Int8Array
- *              flush(handle) -> Int8Array ;  destroy(handle) ;  deviceCount() -> number
+ *              flush(handle) -> Int8Array ;  deviceCount() -> number
+ *              encodeBatch(handles[], lefts: Int16Array[], rights: Int16Array[]|null) -> Int8Array[]   (lhip_encode_batch:
+ *              flushBatch(handles[]) -> Int8Array[]                                 many independent streams, one launch)
  */
 #define _GNU_SOURCE
 #define NAPI_VERSION 6
@@ -25,6 +27,8 @@ static int64_t (*p_encode)(lhip_stream*, const int16_t*, const int16_t*, size_t,
 static int64_t (*p_flush)(lhip_stream*, uint8_t*, size_t);
 static void (*p_destroy)(lhip_stream*);
 static size_t (*p_max_out)(const lhip_stream*, size_t);
+static int (*p_encode_batch)(lhip_stream* const*, size_t, const int16_t* const*, const int16_t* const*, const size_t*, uint8_t* const*, const size_t*, int64_t*);
+static int (*p_flush_batch)(lhip_stream* const*, size_t, uint8_t* const*, const size_t*, int64_t*);
 static const char* (*p_last_error)(void);
 
 static int load_lib(napi_env env) {
@@ -44,6 +48,7 @@ static int load_lib(napi_env env) {
 #define SYM(v, n) *(void**)(&v) = dlsym(g_lib, n); if (!v) { napi_throw_error(env, NULL, "lamejs_amd: missing symbol " n); return 0; }
     SYM(p_device_count, "lhip_device_count") SYM(p_create, "lhip_create") SYM(p_encode, "lhip_encode") SYM(p_flush, "lhip_flush")
     SYM(p_destroy, "lhip_destroy") SYM(p_max_out, "lhip_max_output_bytes") SYM(p_last_error, "lhip_last_error")
+    SYM(p_encode_batch, "lhip_encode_batch") SYM(p_flush_batch, "lhip_flush_batch")
 #undef SYM
     return 1;
 }
@@ -59,7 +64,7 @@ static napi_value js_device_count(napi_env env, napi_callback_info info) {
 }
 
 static napi_value js_create(napi_env env, napi_callback_info info) {
-    size_t argc = 4; napi_value argv[4];
+    size_t argc = 5; napi_value argv[5];
     napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
     if (!load_lib(env)) return NULL;
     void* blob; size_t nblob;
@@ -68,6 +73,7 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
     napi_get_value_int32(env, argv[1], &cfg.channels);
     napi_get_value_int32(env, argv[2], &cfg.samplerate);
     napi_get_value_int32(env, argv[3], &cfg.kbps);
+    if (argc > 4) { napi_valuetype vt; napi_typeof(env, argv[4], &vt); if (vt == napi_number) napi_get_value_int32(env, argv[4], &cfg.device); }
     lhip_stream* s = NULL;
     if (p_create(&cfg, blob, nblob, &s) != 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
     napi_value ext;
@@ -114,11 +120,66 @@ static napi_value js_flush(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* encodeBatch(handles[], lefts[], rights[]|null) / flushBatch(handles[]): the batch extension of the C ABI.  All streams of a
+ * call must share one configuration and device (the library checks); a failed call throws (there is no reference behaviour to
+ * mirror for it), a stream without completed frames gets an empty array. */
+static napi_value batch_common(napi_env env, napi_callback_info info, int is_flush) {
+    size_t argc = 3; napi_value argv[3];
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    uint32_t n = 0;
+    if (argc < 1 || napi_get_array_length(env, argv[0], &n) != napi_ok) { napi_throw_type_error(env, NULL, "handles must be an array"); return NULL; }
+    napi_value result; napi_create_array_with_length(env, n, &result);
+    if (n == 0) return result;
+    int have_right = 0;
+    if (!is_flush) {
+        uint32_t nl = 0;
+        if (argc < 2 || napi_get_array_length(env, argv[1], &nl) != napi_ok || nl != n) { napi_throw_type_error(env, NULL, "lefts must be an array as long as handles"); return NULL; }
+        if (argc > 2) { napi_valuetype vt; napi_typeof(env, argv[2], &vt); have_right = (vt != napi_null && vt != napi_undefined); }
+    }
+    lhip_stream** hs = (lhip_stream**)calloc(n, sizeof *hs);
+    const int16_t** L = (const int16_t**)calloc(n, sizeof *L); const int16_t** R = (const int16_t**)calloc(n, sizeof *R);
+    size_t* ns = (size_t*)calloc(n, sizeof *ns); size_t* caps = (size_t*)calloc(n, sizeof *caps);
+    uint8_t** outs = (uint8_t**)calloc(n, sizeof *outs); int64_t* wr = (int64_t*)calloc(n, sizeof *wr);
+    const char* err = NULL;
+    for (uint32_t i = 0; i < n && !err; i++) {
+        napi_value h; napi_get_element(env, argv[0], i, &h);
+        if (napi_get_value_external(env, h, (void**)&hs[i]) != napi_ok) { err = "handles must come from create()"; break; }
+        if (!is_flush) {
+            napi_value a; napi_typedarray_type tt; void* d = NULL;
+            napi_get_element(env, argv[1], i, &a);
+            if (napi_get_typedarray_info(env, a, &tt, &ns[i], &d, NULL, NULL) != napi_ok || tt != napi_int16_array) { err = "lefts must hold Int16Arrays"; break; }
+            L[i] = (const int16_t*)d;
+            if (have_right) {
+                size_t nr = 0; void* dr = NULL; napi_valuetype vt;
+                napi_get_element(env, argv[2], i, &a); napi_typeof(env, a, &vt);
+                if (vt != napi_null && vt != napi_undefined) {
+                    if (napi_get_typedarray_info(env, a, &tt, &nr, &dr, NULL, NULL) != napi_ok || tt != napi_int16_array || nr != ns[i]) { err = "rights must hold Int16Arrays as long as their lefts"; break; }
+                    R[i] = (const int16_t*)dr;
+                }
+            }
+        }
+        caps[i] = p_max_out(hs[i], is_flush ? 4 * 1152 : ns[i]);
+        outs[i] = (uint8_t*)malloc(caps[i] ? caps[i] : 1);
+    }
+    if (!err) {
+        const int rc = is_flush ? p_flush_batch(hs, n, outs, caps, wr) : p_encode_batch(hs, n, L, R, ns, outs, caps, wr);
+        if (rc != 0) err = p_last_error();
+    }
+    if (!err) for (uint32_t i = 0; i < n; i++) napi_set_element(env, result, i, make_i8(env, outs[i], wr[i] > 0 ? (size_t)wr[i] : 0));
+    for (uint32_t i = 0; i < n; i++) free(outs[i]);
+    free(hs); free(L); free(R); free(ns); free(caps); free(outs); free(wr);
+    if (err) { napi_throw_error(env, NULL, err); return NULL; }
+    return result;
+}
+static napi_value js_encode_batch(napi_env env, napi_callback_info info) { return batch_common(env, info, 0); }
+static napi_value js_flush_batch(napi_env env, napi_callback_info info) { return batch_common(env, info, 1); }
+
 static napi_value init(napi_env env, napi_value exports) {
     napi_property_descriptor d[] = {
         {"deviceCount", 0, js_device_count, 0, 0, 0, napi_default, 0}, {"create", 0, js_create, 0, 0, 0, napi_default, 0},
-        {"encode", 0, js_encode, 0, 0, 0, napi_default, 0}, {"flush", 0, js_flush, 0, 0, 0, napi_default, 0}};
-    napi_define_properties(env, exports, 4, d);
+        {"encode", 0, js_encode, 0, 0, 0, napi_default, 0}, {"flush", 0, js_flush, 0, 0, 0, napi_default, 0},
+        {"encodeBatch", 0, js_encode_batch, 0, 0, 0, napi_default, 0}, {"flushBatch", 0, js_flush_batch, 0, 0, 0, napi_default, 0}};
+    napi_define_properties(env, exports, 6, d);
     return exports;
 }
 NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

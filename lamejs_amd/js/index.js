@@ -17,6 +17,7 @@ const path = require('path');
 const tables = require('./tables.js');
 
 let addon = null;
+let defaultDevice = -1;                         // -1: the HIP runtime's current device
 function loadAddon() {
     if (!addon) addon = require(path.join(__dirname, 'addon', 'lhip_napi.node'));
     return addon;
@@ -29,7 +30,8 @@ function Mp3Encoder(channels, samplerate, kbps) {
     }
     const native = loadAddon();
     const blob = tables.buildBlob(channels, samplerate, kbps).blob;
-    const handle = native.create(blob, channels, samplerate, kbps);
+    const handle = native.create(blob, channels, samplerate, kbps, defaultDevice);
+    Object.defineProperty(this, '_lhip', { value: { handle: handle, channels: channels }, enumerable: false });
 
     this.encodeBuffer = function (left, right) {
         if (channels == 1) right = null;
@@ -65,3 +67,22 @@ WavHeader.readHeader = function (dataView) {
 module.exports.Mp3Encoder = Mp3Encoder;
 module.exports.WavHeader = WavHeader;
 module.exports.deviceCount = function () { return loadAddon().deviceCount(); };
+
+/*
+ * Extensions (not part of the reference API) for callers with many independent streams (BASELINE config 5):
+ *   setDevice(d)                          encoders constructed afterwards live on HIP device d (deal streams round-robin
+ *                                         over deviceCount() GPUs; streams never exchange data)
+ *   encodeBatch(encoders, lefts[, rights]) one launch for all the encoders' new samples -> Int8Array per encoder, the same
+ *                                         bytes each encoder's own encodeBuffer() would have returned
+ *   flushBatch(encoders)                  likewise for flush()
+ * The encoders of one call must share (channels, samplerate, kbps) and the device.
+ */
+module.exports.setDevice = function (d) { defaultDevice = d | 0; };
+module.exports.encodeBatch = function (encoders, lefts, rights) {
+    const hs = encoders.map((e) => e._lhip.handle);
+    const L = lefts.map((a) => (a instanceof Int16Array ? a : Int16Array.from(a)));
+    const stereo = encoders.length > 0 && encoders[0]._lhip.channels == 2;
+    const R = stereo && rights ? rights.map((a) => (a instanceof Int16Array ? a : Int16Array.from(a))) : null;
+    return loadAddon().encodeBatch(hs, L, R);
+};
+module.exports.flushBatch = function (encoders) { return loadAddon().flushBatch(encoders.map((e) => e._lhip.handle)); };

@@ -48,3 +48,31 @@ def test_js_dropin_gpu(golden):
     for c in _cases(golden):
         got = _run(None, c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100))
         assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
+
+
+def _run_batch(env_lib, ch, kbps, nstreams, nfr, chunk):
+    env = dict(os.environ)
+    if env_lib:
+        env["LAMEJS_HIP_LIB"] = str(env_lib)
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_batch_check.js"), str(ch), str(kbps), str(nstreams), str(nfr), str(chunk)],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_batch_extension_hostsim():
+    """encodeBatch / flushBatch (many independent streams per launch, BASELINE config 5 shape) == every stream on its own."""
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    lib = ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"
+    for ch, kbps, ns, nfr, chunk in ((1, 128, 3, 10, 3000), (2, 128, 2, 6, 1152)):
+        got = _run_batch(lib, ch, kbps, ns, nfr, chunk)
+        assert got["single"] == got["batch"] and len(got["batch"]) == ns
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_batch_extension_gpu():
+    for ch, kbps, ns, nfr, chunk in ((1, 128, 16, 60, 5000), (2, 320, 5, 40, 1152 * 7)):
+        got = _run_batch(None, ch, kbps, ns, nfr, chunk)
+        assert got["single"] == got["batch"] and len(got["batch"]) == ns
