@@ -537,7 +537,8 @@ LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc*
                 }
             }
             L.first_reset[tid] = fr;
-            L.known[tid + 1] = (fr >= 0);
+            L.known[tid + 1] = (fr >= 0) || (s0 >= s1);      // empty segments are all at the tail: nobody waits for their state
+                                                             // (forwarding it one thread per round cost a 1-frame call 1023 rounds)
             L.e_adj[tid + 1] = a; L.e_lim[tid + 1] = l;
             if (tid == 0) { L.known[0] = 1; L.e_adj[0] = cadj; L.e_lim[0] = clim; }
         }
