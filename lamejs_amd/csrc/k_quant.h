@@ -1722,8 +1722,12 @@ LHIP_DEV void targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize
 
 // One wave per frame slot.  chain == 0: speculative reset seed (exact for the first frame of a stream
 // batch, whose seed is the carried one); chain == 1: chain-implied seed (repair pass, flagged frames only).
+// PAIR == 1 (latency path for small stereo batches, g_quant_pair): the workgroup is two waves, wave `my_ch` does that
+// channel only -- the channels of a granule are independent given the granule's bit budget -- and the two meet once per
+// granule to exchange the bits they used (ResvSize feeds the next granule's budget) through `mbox` in LDS.
+template <int PAIR = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
-                       int chain, int lane, QuantLds& L, const QuantTabs& Q) {
+                       int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -1753,6 +1757,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         targ_bits_for(T, mean_bits, gr, ResvSize, targ);
         const int targ0 = targ[0], targ1 = targ[1];
         for (int ch = 0; ch < C; ch++) {
+            if (PAIR && ch != my_ch) continue;
             GI g;
             const int bt = W.blocktype[(int64_t)gslot * C + ch];
             const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
@@ -1781,7 +1786,8 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             uni_gi(g);
             if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
             uni_gi(g);
-            ResvSize = uni(ResvSize - (g.part2_3_length + g.part2_length));
+            if (!PAIR) ResvSize = uni(ResvSize - (g.part2_3_length + g.part2_length));
+            else if (lane == 0) mbox[2 * gr + ch] = g.part2_3_length + g.part2_length;
             if (gr == 0) {
                 if (ch == 0) gr0_bt0 = g.block_type; else gr0_bt1 = g.block_type;
                 LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i];
@@ -1809,6 +1815,12 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             }
             wave_sync();
         }
+#ifndef LHIP_HOSTSIM
+        if (PAIR) {                                   // both waves have published this granule: take the other channel's bits
+            __syncthreads();
+            ResvSize = uni(ResvSize - (mbox[2 * gr] + mbox[2 * gr + 1]));
+        }
+#endif
     }
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
 #ifdef LHIP_PHASE_PROF

@@ -263,6 +263,19 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused
     atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
 #endif
 }
+// Latency path for small stereo batches: one workgroup of two waves per frame, one wave per channel (kb_quant<1>).  A single
+// frame is one wave's serially dependent search; with fewer frames than SIMDs the chip is idle anyway, so the two channels
+// of a granule -- independent given the granule's bit budget -- run side by side.
+__global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pair(QArgs a_unused) {
+    __shared__ QuantTabs Q;
+    __shared__ QuantLds L[2];
+    __shared__ int mbox[4];
+    const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    q_load_tabs(A->T, Q, threadIdx.x, 128);
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    kb_quant<1>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
+}
 __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nslow) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
@@ -734,7 +747,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
-    { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0; LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
+#ifdef LHIP_PHASE_PROF
+    const bool pair = false;
+#else
+    const bool pair = (C == 2 && nfs <= 2 * ctx->num_cus);     // fewer frames than half the SIMDs: spend two waves per frame
+#endif
+    { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
+      if (pair) LAUNCHB(KT_QUANT, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
     if (nfr > 0) {
         for (;;) {
             if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
@@ -751,7 +770,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             if (nf == 0) break;
             repaired += nf; iters++;
             if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
-            { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 2; LAUNCHB(KT_REPAIR, g_quant, qgrid, 64 * QWAVES, st, qa); }
+            { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 2;
+              if (pair) LAUNCHB(KT_REPAIR, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_REPAIR, g_quant, qgrid, 64 * QWAVES, st, qa); }
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
     }
