@@ -750,7 +750,11 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #ifdef LHIP_PHASE_PROF
     const bool pair = false;
 #else
-    const bool pair = (C == 2 && nfs <= 2 * ctx->num_cus);     // fewer frames than half the SIMDs: spend two waves per frame
+    // Two waves per frame while that still leaves SIMDs under-subscribed.  Measured on MI355X (stereo 128 kbps, ms per batch,
+    // persistent / pair): 600 frames 3.40 / 2.20, 1000: 3.52 / 2.41, 2000: 3.66 / 3.61, 4000: 4.82 / 5.15 -> cross-over at
+    // about 2000 frames = 8 x CUs; LAMEJS_HIP_PAIR_MAX_FRAMES overrides the threshold for experiments.
+    static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : -1; }();
+    const bool pair = (C == 2 && nfs <= (pair_max >= 0 ? pair_max : 6 * ctx->num_cus));
 #endif
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
       if (pair) LAUNCHB(KT_QUANT, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
