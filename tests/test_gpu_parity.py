@@ -228,3 +228,22 @@ def test_gpu_random_material(lib):
     assert fuzz_gpu.run(56, 7, verbose=False) == []
     assert fuzz_gpu.run(96, 31, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []               # MPEG-2 / 2.5
     assert fuzz_gpu.run(70, 5, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []           # integer-ratio resampling in front
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kbps", [128, 320])
+def test_gpu_stereo_both_quant_paths(lib, kbps):
+    """Stereo batches up to 6 x CUs frames take the two-waves-per-frame latency kernel (g_quant_pair), larger ones the persistent
+    kernel: the same PCM through one 2600-frame call (persistent), through 300-frame calls (pair) and through the oracle."""
+    import lamejs_amd
+    import pcm
+    from oracle_py import oracle_encode
+    n = 1152 * 2600
+    L, R = pcm.bursts(n, 2)
+    L2, R2 = pcm.sine(n, 2, seed=4242)
+    L = (L // 2 + L2 // 2).astype(np.int16); R = (R // 2 + R2 // 2).astype(np.int16)
+    want = oracle_encode(2, 44100, kbps, L, R)
+    big = _encode(2, kbps, L, R, n)
+    small = _encode(2, kbps, L, R, 1152 * 300)
+    assert big == want, "persistent kernel differs from the oracle: " + _first_diff(big, want)
+    assert small == want, "pair kernel differs from the oracle: " + _first_diff(small, want)
