@@ -488,9 +488,9 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
                 if (ra >= QT_N) aa = T.adj43[ra];
                 if (rb >= QT_N) ab = T.adj43[rb];
             }
-            int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
-            va = (p < last_line) ? va : 0;
-            vb = (p + 1 < last_line) ? vb : 0;
+            // No masking by last_line here: max_nonzero_coeff is the first line of the spectrum's trailing zeros (or 575 with
+            // a full last band), so every line at or after last_line has xrpow == 0 and quantizes to (int)(0 + adj43[0]) = 0.
+            const int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
             vx[j] = va; vy[j] = vb;
             if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
         }
@@ -665,12 +665,8 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     int i = ((g.max_nonzero_coeff + 2) >> 1) << 1;
     if (i > 576) i = 576;
     if (use_prev) *pn_sfb_count1 = 0;
-    // the lane's pairs arrive in registers from q_quantize; pairs at or above the max_nonzero_coeff bound count as zero
-#pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        const int p = 2 * (lane + LHIP_NL * j);
-        if (!(p < i)) { vx[j] = 0; vy[j] = 0; }
-    }
+    // the lane's pairs arrive in registers from q_quantize; pairs at or above the max_nonzero_coeff bound are zero already
+    // (xr, hence xrpow, is zero from max_nonzero_coeff on -- see q_quantize)
     // count1 boundary (highest pair with a non-zero value) and the end of the big-values region (the quad scan of
     // Takehiro.js:540-560 stops at the first quad, counted from the top, that holds a value > 1).
     int firstbig;
@@ -707,8 +703,9 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     PH_MARK(L, PH_C_LOAD, tm_);
     int a12 = 0;
     for (int k = lane; k < firstbig; k += LHIP_NL) {
-        const int e = i - 4 * k;
-        const int p = ((ix[e - 4] * 2 + ix[e - 3]) * 2 + ix[e - 2]) * 2 + ix[e - 1];
+        const int e = i - 4 * k;                 // even: the two pairs of the quad as two aligned 32-bit words; values are 0/1 here
+        const uint32_t w0 = *(const uint32_t*)(ix + e - 4), w1 = *(const uint32_t*)(ix + e - 2);
+        const int p = (int)(((w0 & 1u) << 3) | ((w0 >> 16) << 2) | ((w1 & 1u) << 1) | (w1 >> 16));
         a12 += Q.t32l[p] + (Q.t33l[p] << 16);
     }
     a12 = wave_sum(a12);
