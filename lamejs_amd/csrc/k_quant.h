@@ -442,10 +442,7 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     uint64_t m_cached = 0, m_zo = 0, m_cut = 0;       // bit sfb, produced by lane sfb (sfbmax < 64)
-    if (!use_prev) {                                     // bin-search rounds: no cache, only the cut matters
-        LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1)
-            if (L.start[sfb] + L.width[sfb] > mnz) m_cut |= 1ull << sfb;
-    } else {
+    if (use_prev) {                                      // bin-search rounds have no cache and no 0/1 shortcut: nothing to decide
         LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1) {
             int step = -1;
             if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
@@ -884,8 +881,10 @@ LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16
 // calc_noise (QuantizePVT.js:784-878); distort -> L.distort, cache -> L.pn_*
 // One lane per band sums its lines in the reference's order (f64 sums are order-sensitive); all gathers hit LDS.
 // ---------------------------------------------------------------------------------------------
+// need_max: the caller will look at max_noise even if some band is over its threshold (quant_compare only reads max_noise of
+// results with over_count == 0, and of `best` only while best.over_count == 0), so the f64 wave maximum is skipped otherwise
 LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     // 1) summing range and error formula per band (calc_noise_core's branches).  The reference walks a start line j
@@ -1021,15 +1020,15 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         const int os = wave_sum((ssd << 6) | over);
         res->over_count = os & 63; res->over_SSD = os >> 6;
     }
-    res->max_noise = wave_maxd(max_noise);
+    res->max_noise = (need_max || res->over_count == 0) ? wave_maxd(max_noise) : 0.0;
     wave_sync();
     PH_MARK(L, PH_N_SUMS, tm_);
 }
 
 LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           int use_pn, PrevNoise& pn, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q) {
     PH_BEGIN();
-    q_calc_noise_(T, g, scalefac, ix, res, use_pn, pn, lane, L, Q);
+    q_calc_noise_(T, g, scalefac, ix, res, use_pn, pn, need_max, lane, L, Q);
     PH_END(L, PH_NOISE);
 }
 
@@ -1341,7 +1340,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
         }
-        q_calc_noise(T, w, L.sfw, L.ixw, &ni, 1, pn, lane, L, Q);                                       // the only call site
+        q_calc_noise(T, w, L.sfw, L.ixw, &ni, 1, pn, best.over_count == 0, lane, L, Q);                 // the only call site
         ni.bits = w.part2_3_length;
         int keep;
         if (first) keep = 1;
