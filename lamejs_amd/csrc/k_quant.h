@@ -933,33 +933,32 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     // no line can need the part of pow43 that is not staged in LDS
     const int may_big = !(g.xrpow_max * ipow20(Q, g.global_gain) < (double)(QT_N - 1));
     {
-        double tq[NLN];
-        unsigned resetm = 0, lastm = 0;          // bit k: line k of this lane starts a band / ends a summing range
+        double tq[NLN], keep[NLN];
+        unsigned lastm = 0;                      // bit k: line k of this lane ends a summing range
         int lastb[NLN];
         int prevb = (lane == 0) ? -1 : (int)line2sfb(Q, g.block_type)[NLN * lane - 1];
         const uint8_t* l2s = line2sfb(Q, g.block_type);
+        // Terms are computed for EVERY line, inside a summing range or not: a sum is only stored at the last line of a
+        // non-empty range (lastm), every band's chain starts afresh at its first line (keep = 0), and the lines of a band
+        // that follow its range come after the stored prefix -- whatever the other lines contribute is never read.
+        // keep[k] = 0 at a band start, 1 elsewhere: fma(sum, keep, t) is `sum + t` or `t` with ONE rounding, i.e.
+        // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit
 #pragma unroll
         for (int k = 0; k < NLN; k++) {
             const int j = NLN * lane + k;
             const int bnd = l2s[j];
             const int nend = L.binfo[bnd].nend; const float bstep = L.binfo[bnd].step;   // adjacent: one 8-byte load
-            const int in = j < nend;
             const float xa = L.xr[j]; const int iv = ix[j];
             float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
             if (may_big && iv >= QT_N) pw = T.pow43[iv];
             const double x = d_abs((double)xa) - (double)pw * (double)bstep;
-            tq[k] = in ? x * x : 0.0;            // sums are >= +0, so adding +0.0 leaves them unchanged
-            if (bnd != prevb) resetm |= 1u << (k & 31);
+            tq[k] = x * x;
+            keep[k] = (bnd != prevb) ? 0.0 : 1.0;
             if (j == nend - 1) lastm |= 1u << (k & 31);
             lastb[k] = bnd; prevb = bnd;
         }
         // NLN <= 32 on the device; the one-lane host build folds everything in a single pass below
         const int nsteps = (LHIP_NL == 1) ? 1 : (maxlen + NLN - 1) / NLN + 1;
-        // keep[k] = 0 at a band start, 1 elsewhere: fma(sum, keep, t) is `sum + t` or `t` with ONE rounding, i.e.
-        // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit
-        double keep[NLN];
-#pragma unroll
-        for (int k = 0; k < NLN; k++) keep[k] = ((resetm >> (k & 31)) & 1u) ? 0.0 : 1.0;
 #if LHIP_NL == 1
         {
             double sacc = 0.0;
