@@ -455,24 +455,20 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     }
     m_cached = wave_lane_bits(m_cached); m_zo = wave_lane_bits(m_zo); m_cut = wave_lane_bits(m_cut);
     const int sstar = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
-    int fill_from = 576, last_line = 576;       // lines >= last_line are not quantized (bands after sstar, tail of sstar)
-    if (sstar <= sfbmax) {
-        int l = mnz - L.start[sstar] + 1;
-        if (l < 0) l = 0;
-        fill_from = mnz;
-        last_line = L.start[sstar] + (l & ~1);
-        m_zo &= ~(1ull << sstar);                // the partial band is always quantized in full
-    }
+    // The reference stops quantizing inside band sstar (at max_nonzero_coeff, rounded to a pair) and fills the rest with
+    // zeros.  Every line from max_nonzero_coeff on has xrpow == 0 (it is the first of the spectrum's trailing zeros, or
+    // 575 with a full last band) and quantizes to 0 by either formula, and the kept values of cached bands are zero there
+    // by induction, so that walk needs no masks here; what remains of it is that the partial band never takes the 0/1
+    // shortcut.
+    if (sstar <= sfbmax) m_zo &= ~(1ull << sstar);
     PH_MARK(L, PH_Q_MASK, tm_);
     const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
     // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here).
-    // Without cached bands every line is either quantized or at/after fill_from (last_line is mnz or mnz + 1), so
-    // the previous values are only fetched when some band is cached.
+    // The previous values are only fetched when some band is cached.
     const int need_old = (m_cached != 0);
     if (!need_old && m_zo == 0) {
-        // the common round (every bin-search round and most others): no cached band, no 0/1 shortcut -- a line is
-        // quantized below last_line and zero from there on (last_line >= fill_from - 1 and the line between is quantized)
+        // the common round (every bin-search round and most others): no cached band, no 0/1 shortcut
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             const int p = 2 * (lane + LHIP_NL * j);
@@ -485,8 +481,7 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
                 if (ra >= QT_N) aa = T.adj43[ra];
                 if (rb >= QT_N) ab = T.adj43[rb];
             }
-            // No masking by last_line here: max_nonzero_coeff is the first line of the spectrum's trailing zeros (or 575 with
-            // a full last band), so every line at or after last_line has xrpow == 0 and quantizes to (int)(0 + adj43[0]) = 0.
+            // no masking at the end of the spectrum: zero xrpow quantizes to (int)(0 + adj43[0]) = 0 (see above)
             const int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
             vx[j] = va; vy[j] = vb;
             if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
@@ -519,9 +514,8 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
             int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
             if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
             const int oa = (int)(oldw[j] & 0xffffu), ob = (int)(oldw[j] >> 16);
-            const int ia = p, ib = p + 1;
-            va = ((ia < last_line) && !cached) ? va : (ia >= fill_from ? 0 : oa);
-            vb = ((ib < last_line) && !cached) ? vb : (ib >= fill_from ? 0 : ob);
+            va = cached ? oa : va;
+            vb = cached ? ob : vb;
             vx[j] = va; vy[j] = vb;
             if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
         }
