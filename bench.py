@@ -193,7 +193,7 @@ def main():
                                 "algorithmic_bytes_per_launch": int(alg),
                                 "note": "path is latency/issue bound (SURVEY.md 8d): the HBM fraction is small by construction; "
                                         "traffic from profiles/r01_pmc_hbm_traffic_mono128_1e5.json"}
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:       # the CPU baseline is reported at N = 1 only
             from oracle_py import oracle_encode
             k = min(args.cpu_frames, nfr)
             t1 = time.perf_counter()
