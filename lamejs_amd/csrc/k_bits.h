@@ -164,15 +164,16 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
             if (GR == 2) {
                 // scalefactors: at most 36 short fields
                 const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];
-                int p2 = pos;
-                for (int sfb = 0; sfb < gi.sfbmax; sfb++) {
-                    const int v = gi.scalefac[sfb];
-                    if (v == -1) continue;
-                    const int n = sfb < gi.sfbdivide ? slen1 : slen2;
-                    if (lane == 0) put_bits(L.w, p2, (uint32_t)v, n);
-                    p2 += n;
+                // lane = band: field widths turned into positions by an exclusive scan (bands shared through scfsi are -1: no field)
+                for (int base = 0; base < gi.sfbmax; base += LHIP_NL) {
+                    const int sfb = base + lane;
+                    int n = 0, v = 0;
+                    if (sfb < gi.sfbmax) { v = gi.scalefac[sfb]; if (v != -1) n = sfb < gi.sfbdivide ? slen1 : slen2; }
+                    int tot;
+                    const int off = wave_excl_scan(n, lane, &tot);
+                    put_bits(L.w, pos + off, (uint32_t)v, n);
+                    pos += tot;
                 }
-                pos = p2;
             } else {
                 // MPEG-2/2.5: four partitions with their own field widths (BitStream.js:645-686).  The widths and the
                 // partition sizes are what a decoder derives from scalefac_compress (scale_bitcount_lsf packed them):
@@ -185,14 +186,15 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
                 const int n0 = pre ? (sh ? 18 : 11) : (sh ? 9 : 6), n1 = pre ? (sh ? 18 : 10) : (sh ? 9 : 5);
                 const int n2 = pre ? 0 : (sh ? 9 : 5);
                 const int b1 = n0, b2 = n0 + n1, b3 = b2 + n2, end = b3 + n2;
-                int p2 = pos;
-                for (int i = 0; i < end; i++) {
-                    const int n = i < b1 ? sl0 : i < b2 ? sl1 : i < b3 ? sl2 : sl3;
-                    const int v = gi.scalefac[i];
-                    if (lane == 0) put_bits(L.w, p2, (uint32_t)(v > 0 ? v : 0), n);
-                    p2 += n;
+                for (int base = 0; base < end; base += LHIP_NL) {
+                    const int i = base + lane;
+                    int n = 0, v = 0;
+                    if (i < end) { n = i < b1 ? sl0 : i < b2 ? sl1 : i < b3 ? sl2 : sl3; v = gi.scalefac[i]; }
+                    int tot;
+                    const int off = wave_excl_scan(n, lane, &tot);
+                    put_bits(L.w, pos + off, (uint32_t)(v > 0 ? v : 0), n);
+                    pos += tot;
                 }
-                pos = p2;
             }
             int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
             if (ts0 == 14) ts0 = 16;
