@@ -98,6 +98,43 @@ LHIP_DEV int count1_region(const Tables& T, uint32_t* w, int pos, const GrSide& 
     return total_all;
 }
 
+// field f (0..14) of a granule-channel's side info: value and width (width 0: the field does not exist for this block type)
+LHIP_DEV void side_field(const GrSide& gi, int f, int GR, uint32_t* v, int* n) {
+    const bool win = gi.block_type != NORM_TYPE;
+    int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
+    if (ts0 == 14) ts0 = 16;
+    if (ts1 == 14) ts1 = 16;
+    if (ts2 == 14) ts2 = 16;
+    int val = 0, w = 0;
+    switch (f) {
+        case 0: val = gi.part2_3_length + gi.part2_length; w = 12; break;
+        case 1: val = gi.big_values / 2; w = 9; break;
+        case 2: val = gi.global_gain; w = 8; break;
+        case 3: val = gi.scalefac_compress; w = GR == 2 ? 4 : 9; break;
+        case 4: val = win ? 1 : 0; w = 1; break;                                    // window_switching_flag
+        case 5: val = win ? gi.block_type : ts0; w = win ? 2 : 5; break;
+        case 6: val = win ? 0 : ts1; w = win ? 1 : 5; break;                        // mixed_block_flag | table_select[1]
+        case 7: val = win ? ts0 : ts2; w = 5; break;
+        case 8: val = win ? ts1 : gi.region0_count; w = win ? 5 : 4; break;
+        case 9: val = win ? gi.subblock_gain[0] : gi.region1_count; w = 3; break;
+        case 10: val = gi.subblock_gain[1]; w = win ? 3 : 0; break;
+        case 11: val = gi.subblock_gain[2]; w = win ? 3 : 0; break;
+        case 12: val = gi.preflag; w = GR == 2 ? 1 : 0; break;
+        case 13: val = gi.scalefac_scale; w = 1; break;
+        case 14: val = gi.count1table_select; w = 1; break;
+        default: break;
+    }
+    *v = (uint32_t)val; *n = w;
+}
+// the header part is written by lane 0 only; everybody continues from where it stopped
+LHIP_DEV int uni_bits_pos(int pos) {
+#ifdef LHIP_HOSTSIM
+    return pos;
+#else
+    return __builtin_amdgcn_readfirstlane(pos);
+#endif
+}
+
 LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
@@ -131,29 +168,21 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
             PUT(0, 8)
             PUT(0, C)
         }
-        for (int gr = 0; gr < GR; gr++)
-            for (int ch = 0; ch < C; ch++) {
-                const GrSide& gi = side[gr * C + ch];
-                PUT(gi.part2_3_length + gi.part2_length, 12)
-                PUT(gi.big_values / 2, 9)
-                PUT(gi.global_gain, 8)
-                PUT(gi.scalefac_compress, GR == 2 ? 4 : 9)
-                int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
-                if (ts0 == 14) ts0 = 16;
-                if (ts1 == 14) ts1 = 16;
-                if (ts2 == 14) ts2 = 16;
-                if (gi.block_type != NORM_TYPE) {
-                    PUT(1, 1) PUT(gi.block_type, 2) PUT(0, 1)
-                    PUT(ts0, 5) PUT(ts1, 5)
-                    PUT(gi.subblock_gain[0], 3) PUT(gi.subblock_gain[1], 3) PUT(gi.subblock_gain[2], 3)
-                } else {
-                    PUT(0, 1) PUT(ts0, 5) PUT(ts1, 5) PUT(ts2, 5)
-                    PUT(gi.region0_count, 4) PUT(gi.region1_count, 3)
-                }
-                if (GR == 2) PUT(gi.preflag, 1)
-                PUT(gi.scalefac_scale, 1) PUT(gi.count1table_select, 1)
-            }
 #undef PUT
+    }
+    // per-granule-channel side info (BitStream.js:296-350 / 367-405): lane = (granule-channel, field); the widths are
+    // turned into bit positions by an exclusive scan (lane order == the reference's gr, ch, field order)
+    {
+        pos = uni_bits_pos(pos);
+        for (int base = 0; base < 16 * GR * C; base += LHIP_NL) {
+            const int it = base + lane, gc = it >> 4, f = it & 15;
+            int n = 0; uint32_t v = 0;
+            if (gc < GR * C) side_field(side[gc], f, GR, &v, &n);
+            int tot;
+            const int off = wave_excl_scan(n, lane, &tot);
+            put_bits(L.w, pos + off, v, n);
+            pos += tot;
+        }
     }
     pos = 8 * T.sideinfo_len;
     wave_sync();
