@@ -515,8 +515,8 @@ struct Context {
     void* stream = nullptr;
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
-    DevBuf pcm, fmap, gmap, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, sd, io, in16, out8, prof;
+    DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0; bool have_last = false;
     int num_cus = 256;
@@ -620,17 +620,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
     const size_t GC = (size_t)ngs * C, FR = (size_t)(nfr > 0 ? nfr : 1);
 #define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
-    ENS(pcm, (size_t)pcm_plane * C * 4 + 64); ENS(fmap, (size_t)nfs * 4); ENS(gmap, (size_t)ngs * 4);
+    ENS(pcm, (size_t)pcm_plane * C * 4 + 64);
     ENS(peaks, GC * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GC * EBL_STRIDE * 4); ENS(mask_idx, GC * EBL_STRIDE * 4);
     ENS(eb_s, GC * EBS_STRIDE * 4); ENS(ecb_s, GC * EBS_STRIDE * 4); ENS(att_raw, GC * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GC * 4); ENS(last_attack, GC * 4);
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
-    ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4); ENS(sd, (size_t)S * sizeof(StreamDesc));
-    ENS(io, (size_t)S * sizeof(StreamIO)); ENS(prof, 512);
+    ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
+    ENS(prof, 512);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
-    W.pcm = (float*)ctx->pcm.p; W.fslot_stream = (const int32_t*)ctx->fmap.p; W.gslot_stream = (const int32_t*)ctx->gmap.p;
+    W.pcm = (float*)ctx->pcm.p;
     W.peaks = (float*)ctx->peaks.p; W.loud = (float*)ctx->loud.p; W.eb_l = (float*)ctx->eb_l.p; W.mask_idx = (int32_t*)ctx->mask_idx.p;
     W.eb_s = (float*)ctx->eb_s.p; W.ecb_s = (float*)ctx->ecb_s.p; W.att_raw = (int32_t*)ctx->att_raw.p; W.uselong = (int32_t*)ctx->uselong.p; W.ul_tmp = (int32_t*)ctx->ul_tmp.p;
     W.last_attack = (int32_t*)ctx->last_attack.p; W.tent = (int32_t*)ctx->tent.p; W.prev_short = (int32_t*)ctx->prev_short.p;
@@ -664,24 +664,31 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             o.out = (uint8_t*)ctx->out8.p + sd[i].out_off;
         }
     }
-    if (!rt::h2d(ctx->fmap.p, fmap.data(), fmap.size() * 4, st)) return false;
-    if (!rt::h2d(ctx->gmap.p, gmap.data(), gmap.size() * 4, st)) return false;
-    if (!rt::h2d(ctx->sd.p, sd.data(), sd.size() * sizeof(StreamDesc), st)) return false;
-    if (!rt::h2d(ctx->io.p, io.data(), io.size() * sizeof(StreamIO), st)) return false;
+    // All descriptors travel in ONE host-to-device copy (a small pageable copy costs ~10 us of host time each, and a 1-frame
+    // call is only ~0.4 ms long): [StreamDesc x S | StreamIO x S | frame-slot map | granule-slot map], 16-byte aligned parts.
+    // The out pointer per stream is carried in StreamIO; kb_bits reads W.out + sd.out_off, so W.out is a zero base and
+    // out_off holds the absolute address (the device address space is 64-bit).
+    const size_t o_sd = 0, o_io = (o_sd + (size_t)S * sizeof(StreamDesc) + 15) & ~(size_t)15,
+                 o_fm = (o_io + (size_t)S * sizeof(StreamIO) + 15) & ~(size_t)15, o_gm = (o_fm + (size_t)nfs * 4 + 15) & ~(size_t)15,
+                 desc_bytes = o_gm + (size_t)ngs * 4;
+    if (!ctx->desc.ensure(desc_bytes)) return false;
+    {
+        std::vector<uint8_t> stage(desc_bytes, 0);
+        for (int i = 0; i < S; i++) sd[i].out_off = (int64_t)(uintptr_t)io[i].out;
+        memcpy(stage.data() + o_sd, sd.data(), (size_t)S * sizeof(StreamDesc));
+        memcpy(stage.data() + o_io, io.data(), (size_t)S * sizeof(StreamIO));
+        memcpy(stage.data() + o_fm, fmap.data(), (size_t)nfs * 4);
+        memcpy(stage.data() + o_gm, gmap.data(), (size_t)ngs * 4);
+        if (!rt::h2d(ctx->desc.p, stage.data(), desc_bytes, st)) return false;
+    }
+    W.fslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_gm);
     if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
     if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
     if (!rt::dzero(ctx->prof.p, 512, st)) return false;
-    const StreamDesc* dSD = (const StreamDesc*)ctx->sd.p;
-    const StreamIO* dIO = (const StreamIO*)ctx->io.p;
+    const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ctx->desc.p + o_sd);
+    const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ctx->desc.p + o_io);
 
     int64_t repaired = 0, iters = 0;
-    // out pointer per stream is carried in StreamIO; kb_bits reads W.out + sd.out_off, so give it a zero base
-    // and put the absolute address into out_off (device address space is 64-bit)
-    {
-        std::vector<StreamDesc> sd2 = sd;
-        for (int i = 0; i < S; i++) sd2[i].out_off = (int64_t)(uintptr_t)io[i].out;
-        if (!rt::h2d(ctx->sd.p, sd2.data(), sd2.size() * sizeof(StreamDesc), st)) return false;
-    }
 #ifdef LHIP_HOSTSIM
     {
         static PsyALds LA; static PsyBLds LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
