@@ -127,13 +127,7 @@ LHIP_DEV void side_field(const GrSide& gi, int f, int GR, uint32_t* v, int* n) {
     *v = (uint32_t)val; *n = w;
 }
 // the header part is written by lane 0 only; everybody continues from where it stopped
-LHIP_DEV int uni_bits_pos(int pos) {
-#ifdef LHIP_HOSTSIM
-    return pos;
-#else
-    return __builtin_amdgcn_readfirstlane(pos);
-#endif
-}
+LHIP_DEV int uni_bits_pos(int pos) { return wave_bcast(pos, 0); }
 
 LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L) {
     const int C = T.channels_out;

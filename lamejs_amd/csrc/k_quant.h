@@ -661,7 +661,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     // count1 boundary (highest pair with a non-zero value) and the end of the big-values region (the quad scan of
     // Takehiro.js:540-560 stops at the first quad, counted from the top, that holds a value > 1).
     int firstbig;
-#ifdef LHIP_HOSTSIM
+#if LHIP_NL == 1
     {
         int top = 0;
         for (int j = 0; j < NPL; j++) if ((vx[j] | vy[j]) != 0) top = 2 * (lane + LHIP_NL * j) + 2;
@@ -680,7 +680,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         int tp = -1, bp = -1;                    // highest non-zero pair / highest pair with a value > 1
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
-            const uint64_t nz = __ballot((vx[j] | vy[j]) != 0), bg = __ballot((vx[j] | vy[j]) > 1);
+            const uint64_t nz = wave_ballot((vx[j] | vy[j]) != 0), bg = wave_ballot((vx[j] | vy[j]) > 1);
             if (nz) tp = 64 * j + 63 - (int)__builtin_clzll(nz);
             if (bg) bp = 64 * j + 63 - (int)__builtin_clzll(bg);
         }
@@ -747,7 +747,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     struct LanePlan { int kind, t0, t1, t2, lbA, lbB; };
     // one plan per lane on the device (a scalar struct: an array indexed by r / 64 would live in scratch memory and cost a
     // memory round trip per access); the one-lane host simulation holds all three
-#ifdef LHIP_HOSTSIM
+#if LHIP_NL == 1
     LanePlan lp[3]; int pv[3];
 #define LP_(r) lp[r]
 #define PV_(r) pv[r]
@@ -769,7 +769,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     wave_sync();
     PH_MARK(L, PH_C_MAX, tm_);
     // field width: a lane owns at most NPL pairs (5 x 21 bits < 2^10); the one-lane host simulation owns all 288
-#ifdef LHIP_HOSTSIM
+#if LHIP_NL == 1
     typedef uint64_t acc_t; enum { FB = 21 };
 #else
     typedef uint32_t acc_t; enum { FB = 10 };
@@ -786,7 +786,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
             const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
             const int x = vx[j], y = vy[j];
             const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
-#ifdef LHIP_HOSTSIM
+#if LHIP_NL == 1
             const int sh = FB * r;
             accA += (acc_t)Q.hlen[(d0 & 0xffffu) + idx] << sh;
             accB += (acc_t)Q.hlen[(d0 >> 16) + idx] << sh;
@@ -794,10 +794,10 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
             if (any_esc) accN += (acc_t)((x > 14) + (y > 14)) << sh;
 #else
             const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
-            accA = __umul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
-            accB = __umul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
-            accC = __umul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
-            if (any_esc) accN = __umul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
+            accA = mul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
+            accB = mul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
+            accC = mul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
+            if (any_esc) accN = mul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
 #endif
         }
     }
@@ -825,10 +825,10 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         if (q.kind == 6) { b = 0; t = 63; }              // table_select := -1 (never emitted: overflow cannot pass count_bits)
         PV_(r) = t | ((q.kind == 6) << 6) | (b << 8);
     }
-#ifdef LHIP_HOSTSIM
+#if LHIP_NL == 1
     const int pv0 = pv[0], pv1_ = pv[1], pv2 = pv[2];
 #else
-    const int pv0 = __builtin_amdgcn_readlane(pv1, 0), pv1_ = __builtin_amdgcn_readlane(pv1, 1), pv2 = __builtin_amdgcn_readlane(pv1, 2);
+    const int pv0 = wave_bcast(pv1, 0), pv1_ = wave_bcast(pv1, 1), pv2 = wave_bcast(pv1, 2);
 #endif
     // the reference evaluates region 2 first (NORM only), then 0, then 1; an overflowing region *sets* bits
 #define APPLY(PV, SLOT) do { const int t_ = (PV) & 63; if ((PV) & 64) bits = LARGE_BITS; else bits += (PV) >> 8; g.table_select[SLOT] = (t_ == 63) ? -1 : t_; } while (0)
@@ -1189,8 +1189,9 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
         for (int sfb = window; sfb < g.sfbmax + 3; sfb += 3) {   // last iteration: sfb == sfbmax + window, the sfb12 tail
             double amp;
             int doamp = 0;
+            int s = (sfb < g.sfbmax) ? scalefac[sfb] : 0;
+            wave_sync();                              // every lane has read the scalefactor before lane 0 rewrites it
             if (sfb < g.sfbmax) {
-                int s = scalefac[sfb];
                 s = s - (4 >> g.scalefac_scale);
                 if (s >= 0) { if (lane == 0) scalefac[sfb] = s; }
                 else {
@@ -1854,16 +1855,16 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
             int cstate = pack_cond_fields(g0, 0);
             for (;;) {
                 int nBits = -1, asg = 0;
-#ifdef LHIP_HOSTSIM
+#if LHIP_NL == 1
                 for (int i = 0; i < ntab; i++) if ((int)((uint32_t)rec->bs_tab[i] >> 24) == gain) { nBits = rec->bs_tab[i] & 0xffffff; asg = rec->bs_asg[i]; break; }
                 (void)my_ent; (void)my_asg;
 #else
                 {
-                    const uint64_t hit = __ballot(lane < ntab && (int)((uint32_t)my_ent >> 24) == gain);
+                    const uint64_t hit = wave_ballot(lane < ntab && (int)((uint32_t)my_ent >> 24) == gain);
                     if (hit) {
                         const int src = (int)__builtin_ctzll(hit);
-                        nBits = __builtin_amdgcn_readlane(my_ent, src) & 0xffffff;
-                        asg = __builtin_amdgcn_readlane(my_asg, src);
+                        nBits = wave_bcast(my_ent, src) & 0xffffff;
+                        asg = wave_bcast(my_asg, src);
                     }
                 }
 #endif

@@ -691,31 +691,39 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     int64_t repaired = 0, iters = 0;
 #ifdef LHIP_HOSTSIM
     {
+        // WAVE_RUN: one wave of a kernel body.  Scalar simulation: the body runs once with lane 0 (NL = 1); wave simulation
+        // (-DLHIP_WAVESIM): its 64 lanes run as fibers and meet at every wave primitive (lhip_wave.h).
+#ifdef LHIP_WAVESIM
+#define WAVE_RUN(...) wsim::run([&](int lane_) { __VA_ARGS__; })
+#else
+#define WAVE_RUN(...) do { const int lane_ = 0; __VA_ARGS__; } while (0)
+#endif
         static PsyALds LA; static PsyBLds LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
         q_load_tabs(T, QT, 0, 1);
-        for (int s = 0; s < S; s++) kb_load(T, W, dSD, dIO, s, 0);
+        for (int s = 0; s < S; s++) WAVE_RUN(kb_load(T, W, dSD, dIO, s, lane_));
         kb_prep(T, W, dSD, dIO, S, 0, 1);
-        for (int b = 0; b < ngs * C; b++) kb_psyA(T, W, dSD, b / C, b % C, 0, LA);
+        for (int b = 0; b < ngs * C; b++) WAVE_RUN(kb_psyA(T, W, dSD, b / C, b % C, lane_, LA));
         for (int b = 0; b < ngs; b++) kb_scan_raw(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
-        for (int b = 0; b < ngs; b++) kb_psyB(T, W, dSD, b, 0, LB);
-        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) kb_polyphase(T, W, dSD, b, ngs * C, 0, LP);
-        for (int b = 0; b < ngs; b++) kb_mdct(T, W, dSD, b, 0, LM);
-        for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 0, 0, LQ, QT);
+        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB(T, W, dSD, b, lane_, LB));
+        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, b, ngs * C, lane_, LP));
+        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
+        for (int b = 0; b < nfs; b++) WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, 0, lane_, LQ, QT));
         for (;;) {
             W.nflagged[0] = 0; W.nflagged[1] = 0;
             for (int b = 0; b < nfs; b++) kb_validate_fast(T, W, dSD, b);
-            for (int i = 0; i < W.nflagged[1]; i++) kb_validate(T, ts.pb10, W, dSD, W.slow_list[i], 0, LQ, QT);
+            for (int i = 0; i < W.nflagged[1]; i++) WAVE_RUN(kb_validate(T, ts.pb10, W, dSD, W.slow_list[i], lane_, LQ, QT));
             const int nf = W.nflagged[0];
             if (nf == 0) break;
             repaired += nf; iters++;
-            for (int b = 0; b < nfs; b++) kb_quant(T, ts.pb10, W, dSD, b, 1, 0, LQ, QT);
+            for (int b = 0; b < nfs; b++) WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, 1, lane_, LQ, QT));
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
-        for (int b = 0; b < nfs; b++) kb_bits(T, W, dSD, b, 0, LBi);
-        for (int s = 0; s < S; s++) kb_save(T, W, dSD, dIO, s, 0);
+        for (int b = 0; b < nfs; b++) WAVE_RUN(kb_bits(T, W, dSD, b, lane_, LBi));
+        for (int s = 0; s < S; s++) WAVE_RUN(kb_save(T, W, dSD, dIO, s, lane_));
+#undef WAVE_RUN
     }
 #else
     LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);

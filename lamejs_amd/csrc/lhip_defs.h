@@ -8,8 +8,10 @@
 // The kernel bodies in this directory are written as *wave programs*: NL lanes execute the
 // same uniform control flow, `for (i = lane; i < n; i += NL)` loops have independent
 // iterations, and cross-lane traffic goes through LDS or the wave_* helpers.  NL is 64 on
-// gfx950.  A test-only build (tests/hostsim, -DLHIP_HOSTSIM) compiles the same bodies with
-// NL = 1 for logic checks on a CPU; the product library contains the HIP build only.
+// gfx950.  Two test-only builds (tests/hostsim) compile the same bodies for a CPU: -DLHIP_HOSTSIM with NL = 1 (the
+// scalar variants of the few places that differ), and -DLHIP_HOSTSIM -DLHIP_WAVESIM with NL = 64, where the 64 lanes of
+// a wave run as fibers and every wave_* primitive is a rendezvous -- the wave programs exactly as the GPU executes
+// them, minus the hardware.  The product library contains the HIP build only.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -18,7 +20,11 @@
 #include <math.h>
 #include <string.h>
 #define LHIP_DEV static inline
+#ifdef LHIP_WAVESIM
+#define LHIP_NL 64      /* test-only: the 64-lane wave programs themselves, lanes as fibers (lhip_wave.h) */
+#else
 #define LHIP_NL 1
+#endif
 #else
 #include <hip/hip_runtime.h>
 #define LHIP_DEV static __device__ __forceinline__

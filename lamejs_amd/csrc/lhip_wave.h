@@ -5,7 +5,7 @@
 
 namespace lhip {
 
-#ifdef LHIP_HOSTSIM
+#if defined(LHIP_HOSTSIM) && LHIP_NL == 1
 struct Wave { int lane; };
 LHIP_DEV void wave_sync() {}
 LHIP_DEV int wave_sum(int v) { return v; }
@@ -18,6 +18,8 @@ LHIP_DEV float wave_maxf_pos(float v) { return v; }
 LHIP_DEV double wave_maxd(double v) { return v; }
 LHIP_DEV double wave_sumd(double v) { return v; }
 LHIP_DEV int wave_bcast(int v, int) { return v; }
+LHIP_DEV uint64_t wave_ballot(int p) { return p ? 1ull : 0ull; }
+LHIP_DEV unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 LHIP_DEV int wave_any(int p) { return p != 0; }
 LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { (void)lane; *total = v; return 0; }
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
@@ -30,6 +32,112 @@ LHIP_DEV double unid(double v) { return v; }
 LHIP_DEV double wave_shr1d(double v, double first) { (void)v; return first; }
 // strictly sequential (index order) f64 sum of LHIP_NL * K values, lane l holding elements [l*K, (l+1)*K)
 template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) { double s = 0.0; for (int k = 0; k < K; k++) s += p[k]; return s; }
+#elif defined(LHIP_HOSTSIM)
+// ---------------------------------------------------------------------------------------------------------------------
+// TEST-ONLY wave simulator (-DLHIP_HOSTSIM -DLHIP_WAVESIM): the 64 lanes of a wave are fibers (ucontext) of one host
+// thread and every wave primitive is a rendezvous: a lane deposits its operand, yields, and is resumed once all 64 have
+// deposited (the scheduler runs the lanes round-robin, each up to its next primitive).  Between two primitives a lane
+// runs alone, so LDS hand-overs between lanes are only correct where the kernel orders them with wave_sync() -- exactly
+// the discipline the device code needs for the compiler's sake.  Primitives must be reached by all lanes in the same
+// order (checked by a tag), i.e. under wave-uniform control flow, as on the device.
+// ---------------------------------------------------------------------------------------------------------------------
+}  // namespace lhip
+#include <ucontext.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <functional>
+namespace lhip {
+namespace wsim {
+enum { NLANES = 64, STACK = 1 << 20 };
+struct Ctx {
+    ucontext_t main_ctx, lane_ctx[NLANES];
+    char* stacks = nullptr;
+    int cur = 0, done[NLANES];
+    unsigned gen[NLANES];
+    uint64_t slot[2][NLANES];
+    int tag[2][NLANES];
+    std::function<void(int)> body;
+};
+inline Ctx*& current() { static thread_local Ctx* c = nullptr; return c; }
+inline void trampoline(int lane) { Ctx* c = current(); c->body(lane); c->done[lane] = 1; swapcontext(&c->lane_ctx[lane], &c->main_ctx); }
+// run `body(lane)` for the 64 lanes of one wave
+template <class F> inline void run(F&& body) {
+    static thread_local Ctx ctx;
+    Ctx* c = &ctx;
+    if (!c->stacks) c->stacks = (char*)malloc((size_t)NLANES * STACK);
+    current() = c;
+    c->body = body;
+    for (int l = 0; l < NLANES; l++) {
+        c->done[l] = 0; c->gen[l] = 0;
+        getcontext(&c->lane_ctx[l]);
+        c->lane_ctx[l].uc_stack.ss_sp = c->stacks + (size_t)l * STACK;
+        c->lane_ctx[l].uc_stack.ss_size = STACK;
+        c->lane_ctx[l].uc_link = &c->main_ctx;
+        makecontext(&c->lane_ctx[l], (void (*)())trampoline, 1, l);
+    }
+    for (;;) {
+        int alive = 0;
+        for (int l = 0; l < NLANES; l++) if (!c->done[l]) { c->cur = l; swapcontext(&c->main_ctx, &c->lane_ctx[l]); alive += !c->done[l]; }
+        if (!alive) break;
+    }
+    current() = nullptr;
+}
+// deposit v under `tag`, wait for the other lanes, return everybody's deposits
+inline void exchange(int tag, uint64_t v, uint64_t (&all)[NLANES]) {
+    Ctx* c = current();
+    const int me = c->cur, par = (int)(c->gen[me] & 1u);
+    c->slot[par][me] = v; c->tag[par][me] = tag; c->gen[me]++;
+    swapcontext(&c->lane_ctx[me], &c->main_ctx);
+    c->cur = me;
+    for (int l = 0; l < NLANES; l++) {
+        // lanes before me in the round have already run on to their next primitive (one generation ahead, other parity)
+        const bool gen_ok = (c->gen[l] == c->gen[me]) || (l < me && c->gen[l] == c->gen[me] + 1);
+        if (!gen_ok || c->tag[par][l] != tag) {
+            fprintf(stderr, "wavesim: lanes diverged at a wave primitive (lane %d tag %d vs lane %d tag %d, gen %u/%u, done %d)\n",
+                    me, tag, l, c->tag[par][l], c->gen[me], c->gen[l], c->done[l]);
+            abort();
+        }
+        all[l] = c->slot[par][l];
+    }
+}
+inline int my_lane() { return current()->cur; }
+template <class T> inline uint64_t bits_of(T v) { uint64_t u = 0; memcpy(&u, &v, sizeof v); return u; }
+template <class T> inline T from_bits(uint64_t u) { T v; memcpy(&v, &u, sizeof v); return v; }
+}  // namespace wsim
+struct Wave { int lane; };
+LHIP_DEV void wave_sync() { uint64_t a[64]; wsim::exchange(1, 0, a); }
+LHIP_DEV int wave_sum(int v) { uint64_t a[64]; wsim::exchange(2, (uint64_t)(uint32_t)v, a); int s = 0; for (int l = 0; l < 64; l++) s += (int)(uint32_t)a[l]; return s; }
+LHIP_DEV int wave_max(int v) { uint64_t a[64]; wsim::exchange(3, (uint64_t)(uint32_t)v, a); int m = (int)(uint32_t)a[0]; for (int l = 1; l < 64; l++) if ((int)(uint32_t)a[l] > m) m = (int)(uint32_t)a[l]; return m; }
+LHIP_DEV int wave_min(int v) { uint64_t a[64]; wsim::exchange(4, (uint64_t)(uint32_t)v, a); int m = (int)(uint32_t)a[0]; for (int l = 1; l < 64; l++) if ((int)(uint32_t)a[l] < m) m = (int)(uint32_t)a[l]; return m; }
+LHIP_DEV int wave_or(int v) { uint64_t a[64]; wsim::exchange(5, (uint64_t)(uint32_t)v, a); uint32_t m = 0; for (int l = 0; l < 64; l++) m |= (uint32_t)a[l]; return (int)m; }
+LHIP_DEV uint64_t wave_or64(uint64_t v) { uint64_t a[64]; wsim::exchange(6, v, a); uint64_t m = 0; for (int l = 0; l < 64; l++) m |= a[l]; return m; }
+LHIP_DEV float wave_maxf(float v) { uint64_t a[64]; wsim::exchange(7, wsim::bits_of(v), a); float m = wsim::from_bits<float>(a[0]); for (int l = 1; l < 64; l++) { const float x = wsim::from_bits<float>(a[l]); if (x > m) m = x; } return m; }
+LHIP_DEV float wave_maxf_pos(float v) { return wave_maxf(v); }
+LHIP_DEV double wave_maxd(double v) { uint64_t a[64]; wsim::exchange(8, wsim::bits_of(v), a); double m = wsim::from_bits<double>(a[0]); for (int l = 1; l < 64; l++) { const double x = wsim::from_bits<double>(a[l]); if (x > m) m = x; } return m; }
+LHIP_DEV double wave_sumd(double v) { uint64_t a[64]; wsim::exchange(9, wsim::bits_of(v), a); double s = 0; for (int l = 0; l < 64; l++) s += wsim::from_bits<double>(a[l]); return s; }   // order-insensitive uses only
+LHIP_DEV int wave_bcast(int v, int src) { uint64_t a[64]; wsim::exchange(10, (uint64_t)(uint32_t)v, a); return (int)(uint32_t)a[src]; }
+LHIP_DEV uint64_t wave_ballot(int p) { uint64_t a[64]; wsim::exchange(11, p ? 1u : 0u, a); uint64_t m = 0; for (int l = 0; l < 64; l++) m |= a[l] << l; return m; }
+LHIP_DEV int wave_any(int p) { return wave_ballot(p) != 0; }
+LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { uint64_t a[64]; wsim::exchange(12, (uint64_t)(uint32_t)v, a); int pre = 0, tot = 0; for (int l = 0; l < 64; l++) { if (l < lane) pre += (int)(uint32_t)a[l]; tot += (int)(uint32_t)a[l]; } *total = tot; return pre; }
+LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }                 // lanes run one at a time: plain read-modify-write
+LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
+LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return wave_ballot(v != 0); }
+LHIP_DEV int uni(int v) { return v; }                                      // an assertion on the device; nothing to move here
+LHIP_DEV double unid(double v) { return v; }
+LHIP_DEV int fresh_lane(int lane) { return lane; }
+LHIP_DEV unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+LHIP_DEV double wave_shr1d(double v, double first) { uint64_t a[64]; wsim::exchange(13, wsim::bits_of(v), a); const int me = wsim::my_lane(); return me == 0 ? first : wsim::from_bits<double>(a[me - 1]); }
+// the device's systolic fold, literally: 64 steps of "add my K values onto the sum handed over by lane - 1"
+template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) {
+    double carry = 0.0, s = 0.0;
+    for (int st = 0; st < 64; st++) {
+        s = carry;
+        for (int k = 0; k < K; k++) s += p[k];
+        carry = wave_shr1d(s, 0.0);
+    }
+    uint64_t a[64]; wsim::exchange(14, wsim::bits_of(s), a);
+    return wsim::from_bits<double>(a[63]);
+}
 #else
 extern "C" __device__ float __ockl_wfred_max_f32(float);
 extern "C" __device__ double __ockl_wfred_max_f64(double);
@@ -64,6 +172,8 @@ LHIP_DEV double wave_maxd(double v) { return __ockl_wfred_max_f64(v); }
 // tree sum: NOT order-exact; only for order-insensitive decisions
 LHIP_DEV double wave_sumd(double v) { return __ockl_wfred_add_f64(v); }
 LHIP_DEV int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }   // src must be wave-uniform
+LHIP_DEV uint64_t wave_ballot(int p) { return __ballot(p); }
+LHIP_DEV unsigned mul24(unsigned a, unsigned b) { return __umul24(a, b); }
 LHIP_DEV int wave_any(int p) { return __any(p); }
 // exclusive prefix sum over the 64 lanes (integers: exact in any order); *total = sum over all lanes.
 // Kogge-Stone inside each row of 16 lanes with DPP row shifts, then the row totals are broadcast into the later rows

@@ -1,0 +1,106 @@
+"""The wave programs themselves without a GPU: the kernel bodies of lamejs_amd/csrc compiled for the host with NL = 64,
+the 64 lanes of a wave running as fibers that meet at every wave primitive (ballots, DPP-style reductions and scans,
+lane broadcasts, the systolic folds -- lhip_wave.h, -DLHIP_WAVESIM).  Unlike the one-lane simulation (test_hostsim_parity.py)
+this executes exactly the lane-parallel code paths the GPU runs; it is ~100 x slower, hence the small cases.  Test-only."""
+import ctypes
+import hashlib
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_case_pcm
+from oracle_py import oracle_encode
+
+
+@pytest.fixture(scope="module")
+def wsim():
+    import lamejs_amd
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    lib = lamejs_amd.load_library(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim.so")
+    assert b"HOST SIMULATION" in lib.lhip_version()
+    return lib
+
+
+def _encode(lib, ch, kbps, L, R, chunk, sr=44100):
+    import lamejs_amd
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib)
+    out = b""
+    for p in range(0, len(L), chunk):
+        out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
+    out += enc.flush()
+    assert enc.flush() == b""
+    enc.close()
+    return out
+
+
+def test_wavesim_matches_small_goldens(wsim, golden):
+    """Every golden of at most 60 frames (reference output, all sample-rate families)."""
+    n = 0
+    for case in golden:
+        if case.get("outside_envelope") or case["corpus"] == "wavfull" or case["nsamples"] > 1152 * 60:
+            continue
+        L, R = load_case_pcm(case)
+        mp3 = _encode(wsim, case["channels"], case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100))
+        assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
+        n += 1
+    assert n >= 5
+
+
+@pytest.mark.parametrize("corpus,ch,sr,kbps,nfr,chunk", [
+    ("sine", 1, 44100, 128, 14, 1152 * 14),        # BASELINE config shapes
+    ("sine", 2, 44100, 128, 10, 1152 * 3),
+    ("bursts", 2, 44100, 320, 24, 4000),           # attacks: short / start / stop blocks, subblock gain
+    ("bursts", 1, 48000, 64, 24, 1152 * 24),
+    ("bursts", 1, 32000, 192, 24, 777),
+    ("bursts", 2, 22050, 64, 24, 1152 * 24),       # MPEG-2: one granule per frame, scale_bitcount_lsf
+    ("bursts", 1, 8000, 16, 24, 5000),             # MPEG-2.5
+    ("bursts", 1, 48000, 40, 30, 1152 * 30),       # resampled 48 -> 24 kHz in front of the encoder
+])
+def test_wavesim_matches_oracle(wsim, corpus, ch, sr, kbps, nfr, chunk):
+    import pcm
+    L, R = pcm.CORPORA[corpus](1152 * nfr + 313, ch, seed=4000 + nfr + kbps)
+    got = _encode(wsim, ch, kbps, L, R, chunk, sr)
+    assert got == oracle_encode(ch, sr, kbps, L, R)
+
+
+def test_wavesim_quiet_and_edge_material(wsim):
+    """Digital silence, near-silence (analog-silence rule, sparse spectra: the path-dependent table_select leftovers),
+    full-scale square wave, and a stream that is shorter than one frame."""
+    rng = np.random.default_rng(7)
+    n = 1152 * 10
+    cases = [np.zeros(n, np.int16), rng.integers(-3, 4, n).astype(np.int16),
+             (np.where((np.arange(n) // 40) % 2 == 0, 32767, -32768)).astype(np.int16), rng.integers(-2000, 2000, 700).astype(np.int16)]
+    quiet_then_loud = np.concatenate([rng.integers(-2, 3, 1152 * 5), rng.integers(-20000, 20000, 1152 * 5)]).astype(np.int16)
+    cases.append(quiet_then_loud)
+    for x in cases:
+        assert _encode(wsim, 1, 128, x, None, 1152 * 4) == oracle_encode(1, 44100, 128, x)
+    assert _encode(wsim, 2, 128, cases[1], cases[4][:n], 3000) == oracle_encode(2, 44100, 128, cases[1], cases[4][:n])
+
+
+def test_wavesim_seed_repair_path(wsim):
+    """Poor speculative bin-search seed: validation (memo replay with ballots / lane broadcasts) flags frames, the repair
+    passes converge to the reference's bytes."""
+    import lamejs_amd, pcm
+    L, R = pcm.bursts(1152 * 10, 2, seed=77)
+    want = oracle_encode(2, 44100, 128, L, R)
+    wsim.lhip_debug_set_spec_seed.argtypes = [ctypes.c_int, ctypes.c_int]
+    try:
+        assert wsim.lhip_debug_set_spec_seed(255, 1) == 0
+        enc = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=wsim)
+        got = enc.encodeBuffer(L, R)
+        stats = enc.last_batch_stats()
+        got += enc.flush()
+        assert stats["repaired_frames"] > 0, stats
+        assert got == want
+    finally:
+        wsim.lhip_debug_set_spec_seed(180, 4)
+
+
+def test_wavesim_batch_streams(wsim):
+    import lamejs_amd, pcm
+    streams = [pcm.bursts(1152 * (4 + i), 1, seed=2000 + i)[0] for i in range(3)]
+    encs = [lamejs_amd.Mp3Encoder(1, 44100, 128, lib=wsim) for _ in streams]
+    got = lamejs_amd.encode_streams(encs, streams)
+    for s, g in zip(streams, got):
+        assert g == oracle_encode(1, 44100, 128, s)
