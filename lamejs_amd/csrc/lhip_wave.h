@@ -49,8 +49,24 @@ template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) { double s =
 namespace lhip {
 namespace wsim {
 enum { NLANES = 64, STACK = 1 << 20 };
+// Context switch between the scheduler and a lane fiber.  x86-64: six callee-saved registers and the stack pointer (glibc's
+// swapcontext also saves the signal mask -- a system call per switch, and a wave program switches ~10^4 times per frame);
+// elsewhere ucontext.
+#if defined(__x86_64__)
+#define WSIM_ASM_SWITCH 1
+extern "C" void lhip_wsim_switch(void** save_sp, void* load_sp);
+asm(".text\n.globl lhip_wsim_switch\n.type lhip_wsim_switch,@function\nlhip_wsim_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size lhip_wsim_switch,.-lhip_wsim_switch\n");
+#endif
 struct Ctx {
+#ifdef WSIM_ASM_SWITCH
+    void* main_sp = nullptr; void* lane_sp[NLANES];
+#else
     ucontext_t main_ctx, lane_ctx[NLANES];
+#endif
     char* stacks = nullptr;
     int cur = 0, done[NLANES];
     unsigned gen[NLANES];
@@ -59,7 +75,25 @@ struct Ctx {
     std::function<void(int)> body;
 };
 inline Ctx*& current() { static thread_local Ctx* c = nullptr; return c; }
-inline void trampoline(int lane) { Ctx* c = current(); c->body(lane); c->done[lane] = 1; swapcontext(&c->lane_ctx[lane], &c->main_ctx); }
+inline void to_scheduler(Ctx* c, int lane) {
+#ifdef WSIM_ASM_SWITCH
+    lhip_wsim_switch(&c->lane_sp[lane], c->main_sp);
+#else
+    swapcontext(&c->lane_ctx[lane], &c->main_ctx);
+#endif
+}
+inline void to_lane(Ctx* c, int lane) {
+#ifdef WSIM_ASM_SWITCH
+    lhip_wsim_switch(&c->main_sp, c->lane_sp[lane]);
+#else
+    swapcontext(&c->main_ctx, &c->lane_ctx[lane]);
+#endif
+}
+#ifdef WSIM_ASM_SWITCH
+inline void trampoline() { Ctx* c = current(); const int lane = c->cur; c->body(lane); c->done[lane] = 1; to_scheduler(c, lane); abort(); }
+#else
+inline void trampoline(int lane) { Ctx* c = current(); c->body(lane); c->done[lane] = 1; to_scheduler(c, lane); }
+#endif
 // run `body(lane)` for the 64 lanes of one wave
 template <class F> inline void run(F&& body) {
     static thread_local Ctx ctx;
@@ -69,15 +103,25 @@ template <class F> inline void run(F&& body) {
     c->body = body;
     for (int l = 0; l < NLANES; l++) {
         c->done[l] = 0; c->gen[l] = 0;
+#ifdef WSIM_ASM_SWITCH
+        // initial frame: six zeroed callee-saved registers, then the "return address" = trampoline; the stack is laid out so
+        // that it is 16-byte aligned + 8 at the trampoline's entry, as after a call
+        uintptr_t top = ((uintptr_t)(c->stacks + (size_t)(l + 1) * STACK)) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 8);
+        *--sp = (void*)(void (*)())trampoline;
+        for (int r = 0; r < 6; r++) *--sp = nullptr;
+        c->lane_sp[l] = sp;
+#else
         getcontext(&c->lane_ctx[l]);
         c->lane_ctx[l].uc_stack.ss_sp = c->stacks + (size_t)l * STACK;
         c->lane_ctx[l].uc_stack.ss_size = STACK;
         c->lane_ctx[l].uc_link = &c->main_ctx;
         makecontext(&c->lane_ctx[l], (void (*)())trampoline, 1, l);
+#endif
     }
     for (;;) {
         int alive = 0;
-        for (int l = 0; l < NLANES; l++) if (!c->done[l]) { c->cur = l; swapcontext(&c->main_ctx, &c->lane_ctx[l]); alive += !c->done[l]; }
+        for (int l = 0; l < NLANES; l++) if (!c->done[l]) { c->cur = l; to_lane(c, l); alive += !c->done[l]; }
         if (!alive) break;
     }
     current() = nullptr;
@@ -87,7 +131,7 @@ inline void exchange(int tag, uint64_t v, uint64_t (&all)[NLANES]) {
     Ctx* c = current();
     const int me = c->cur, par = (int)(c->gen[me] & 1u);
     c->slot[par][me] = v; c->tag[par][me] = tag; c->gen[me]++;
-    swapcontext(&c->lane_ctx[me], &c->main_ctx);
+    to_scheduler(c, me);
     c->cur = me;
     for (int l = 0; l < NLANES; l++) {
         // lanes before me in the round have already run on to their next primitive (one generation ahead, other parity)

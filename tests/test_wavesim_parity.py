@@ -1,9 +1,10 @@
 """The wave programs themselves without a GPU: the kernel bodies of lamejs_amd/csrc compiled for the host with NL = 64,
 the 64 lanes of a wave running as fibers that meet at every wave primitive (ballots, DPP-style reductions and scans,
 lane broadcasts, the systolic folds -- lhip_wave.h, -DLHIP_WAVESIM).  Unlike the one-lane simulation (test_hostsim_parity.py)
-this executes exactly the lane-parallel code paths the GPU runs; it is ~100 x slower, hence the small cases.  Test-only."""
+this executes exactly the lane-parallel code paths the GPU runs; it is ~20 x slower, hence the smaller cases.  Test-only."""
 import ctypes
 import hashlib
+import os
 import subprocess
 
 import numpy as np
@@ -11,6 +12,8 @@ import pytest
 
 from conftest import ROOT, load_case_pcm
 from oracle_py import oracle_encode
+
+FULL = os.environ.get("LAMEJS_WAVESIM_FULL") == "1"      # the long variant (~4 min): goldens up to 110 frames, 16 random cases
 
 
 @pytest.fixture(scope="module")
@@ -35,16 +38,16 @@ def _encode(lib, ch, kbps, L, R, chunk, sr=44100):
 
 
 def test_wavesim_matches_small_goldens(wsim, golden):
-    """Every golden of at most 60 frames (reference output, all sample-rate families)."""
+    """Every golden of at most 40 frames (110 with LAMEJS_WAVESIM_FULL=1): reference output, all sample-rate families."""
     n = 0
     for case in golden:
-        if case.get("outside_envelope") or case["corpus"] == "wavfull" or case["nsamples"] > 1152 * 60:
+        if case.get("outside_envelope") or case["corpus"] == "wavfull" or case["nsamples"] > 1152 * (110 if FULL else 40):
             continue
         L, R = load_case_pcm(case)
         mp3 = _encode(wsim, case["channels"], case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100))
         assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
         n += 1
-    assert n >= 5
+    assert n >= (15 if FULL else 4)
 
 
 @pytest.mark.parametrize("corpus,ch,sr,kbps,nfr,chunk", [
@@ -104,3 +107,15 @@ def test_wavesim_batch_streams(wsim):
     got = lamejs_amd.encode_streams(encs, streams)
     for s, g in zip(streams, got):
         assert g == oracle_encode(1, 44100, 128, s)
+
+
+def test_wavesim_random_material(wsim):
+    """A short sweep of the seeded random material the GPU fuzz uses (tones, coloured noise, clicks, silence gaps, level
+    steps) over MPEG-1, MPEG-2/2.5 and resampling configurations."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    n1, n2, n3 = (6, 6, 4) if FULL else (2, 2, 1)
+    assert fuzz_gpu.run(n1, 2024, lib=wsim, verbose=False) == []
+    assert fuzz_gpu.run(n2, 31, lib=wsim, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []
+    assert fuzz_gpu.run(n3, 5, lib=wsim, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []
