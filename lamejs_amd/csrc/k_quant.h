@@ -1805,12 +1805,10 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             }
             wave_sync();
         }
-#ifndef LHIP_HOSTSIM
         if (PAIR) {                                   // both waves have published this granule: take the other channel's bits
-            __syncthreads();
+            wg_barrier();
             ResvSize = uni(ResvSize - (mbox[2 * gr] + mbox[2 * gr + 1]));
         }
-#endif
     }
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
 #ifdef LHIP_PHASE_PROF

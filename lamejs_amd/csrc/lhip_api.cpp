@@ -710,7 +710,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB(T, W, dSD, b, lane_, LB));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
-        for (int b = 0; b < nfs; b++) WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, 0, lane_, LQ, QT));
+#ifdef LHIP_WAVESIM
+        // small stereo batches: the two-waves-per-frame latency kernel (kb_quant<1>), as run_batch chooses on the device
+        static QuantLds LQ2[2]; static int mbox[4];
+        static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : 12; }();
+        const bool pair = (C == 2 && nfs <= pair_max);
+#define QUANT_RUN(chain_) do { if (pair) wsim::run_block(2, [&](int wave_, int lane_) { kb_quant<1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); }); \
+                               else WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT)); } while (0)
+#else
+#define QUANT_RUN(chain_) WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
+#endif
+        for (int b = 0; b < nfs; b++) QUANT_RUN(0);
         for (;;) {
             W.nflagged[0] = 0; W.nflagged[1] = 0;
             for (int b = 0; b < nfs; b++) kb_validate_fast(T, W, dSD, b);
@@ -718,11 +728,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             const int nf = W.nflagged[0];
             if (nf == 0) break;
             repaired += nf; iters++;
-            for (int b = 0; b < nfs; b++) WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, 1, lane_, LQ, QT));
+            for (int b = 0; b < nfs; b++) QUANT_RUN(1);
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
         for (int b = 0; b < nfs; b++) WAVE_RUN(kb_bits(T, W, dSD, b, lane_, LBi));
         for (int s = 0; s < S; s++) WAVE_RUN(kb_save(T, W, dSD, dIO, s, lane_));
+#undef QUANT_RUN
 #undef WAVE_RUN
     }
 #else

@@ -26,6 +26,7 @@ LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 // see the device version
 LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return v; }
+LHIP_DEV void wg_barrier() {}                  // multi-wave workgroups only exist on the device and in the wave simulation
 LHIP_DEV int uni(int v) { return v; }
 LHIP_DEV int fresh_lane(int lane) { return lane; }
 LHIP_DEV double unid(double v) { return v; }
@@ -48,7 +49,7 @@ template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) { double s =
 #include <functional>
 namespace lhip {
 namespace wsim {
-enum { NLANES = 64, STACK = 1 << 20 };
+enum { NLANES = 64, MAXWAVES = 2, NFIB = NLANES * MAXWAVES, STACK = 1 << 20 };   // a workgroup of up to two waves
 // Context switch between the scheduler and a lane fiber.  x86-64: six callee-saved registers and the stack pointer (glibc's
 // swapcontext also saves the signal mask -- a system call per switch, and a wave program switches ~10^4 times per frame);
 // elsewhere ucontext.
@@ -63,16 +64,17 @@ asm(".text\n.globl lhip_wsim_switch\n.type lhip_wsim_switch,@function\nlhip_wsim
 #endif
 struct Ctx {
 #ifdef WSIM_ASM_SWITCH
-    void* main_sp = nullptr; void* lane_sp[NLANES];
+    void* main_sp = nullptr; void* lane_sp[NFIB];
 #else
-    ucontext_t main_ctx, lane_ctx[NLANES];
+    ucontext_t main_ctx, lane_ctx[NFIB];
 #endif
     char* stacks = nullptr;
-    int cur = 0, done[NLANES];
-    unsigned gen[NLANES];
-    uint64_t slot[2][NLANES];
-    int tag[2][NLANES];
-    std::function<void(int)> body;
+    int cur = 0, nfib = NLANES, done[NFIB];
+    unsigned gen[NFIB], bar_gen[NFIB];
+    long bar_arrived = 0;
+    uint64_t slot[2][NFIB];
+    int tag[2][NFIB];
+    std::function<void(int)> body;          // argument: fiber index = wave * 64 + lane
 };
 inline Ctx*& current() { static thread_local Ctx* c = nullptr; return c; }
 inline void to_scheduler(Ctx* c, int lane) {
@@ -94,15 +96,16 @@ inline void trampoline() { Ctx* c = current(); const int lane = c->cur; c->body(
 #else
 inline void trampoline(int lane) { Ctx* c = current(); c->body(lane); c->done[lane] = 1; to_scheduler(c, lane); }
 #endif
-// run `body(lane)` for the 64 lanes of one wave
-template <class F> inline void run(F&& body) {
+// run `body(wave, lane)` for the 64 x nwaves lanes of one workgroup; the waves only meet at block_barrier()
+template <class F> inline void run_block(int nwaves, F&& body) {
     static thread_local Ctx ctx;
     Ctx* c = &ctx;
-    if (!c->stacks) c->stacks = (char*)malloc((size_t)NLANES * STACK);
+    if (!c->stacks) c->stacks = (char*)malloc((size_t)NFIB * STACK);
     current() = c;
-    c->body = body;
-    for (int l = 0; l < NLANES; l++) {
-        c->done[l] = 0; c->gen[l] = 0;
+    c->nfib = NLANES * nwaves; c->bar_arrived = 0;
+    c->body = [&body](int f) { body(f / NLANES, f % NLANES); };
+    for (int l = 0; l < c->nfib; l++) {
+        c->done[l] = 0; c->gen[l] = 0; c->bar_gen[l] = 0;
 #ifdef WSIM_ASM_SWITCH
         // initial frame: six zeroed callee-saved registers, then the "return address" = trampoline; the stack is laid out so
         // that it is 16-byte aligned + 8 at the trampoline's entry, as after a call
@@ -121,35 +124,48 @@ template <class F> inline void run(F&& body) {
     }
     for (;;) {
         int alive = 0;
-        for (int l = 0; l < NLANES; l++) if (!c->done[l]) { c->cur = l; to_lane(c, l); alive += !c->done[l]; }
+        for (int l = 0; l < c->nfib; l++) if (!c->done[l]) { c->cur = l; to_lane(c, l); alive += !c->done[l]; }
         if (!alive) break;
     }
     current() = nullptr;
 }
+// run `body(lane)` for the 64 lanes of one wave
+template <class F> inline void run(F&& body) { run_block(1, [&body](int, int lane) { body(lane); }); }
 // deposit v under `tag`, wait for the other lanes, return everybody's deposits
 inline void exchange(int tag, uint64_t v, uint64_t (&all)[NLANES]) {
     Ctx* c = current();
-    const int me = c->cur, par = (int)(c->gen[me] & 1u);
+    const int me = c->cur, base = me - me % NLANES, par = (int)(c->gen[me] & 1u);
     c->slot[par][me] = v; c->tag[par][me] = tag; c->gen[me]++;
     to_scheduler(c, me);
     c->cur = me;
     for (int l = 0; l < NLANES; l++) {
-        // lanes before me in the round have already run on to their next primitive (one generation ahead, other parity)
-        const bool gen_ok = (c->gen[l] == c->gen[me]) || (l < me && c->gen[l] == c->gen[me] + 1);
-        if (!gen_ok || c->tag[par][l] != tag) {
-            fprintf(stderr, "wavesim: lanes diverged at a wave primitive (lane %d tag %d vs lane %d tag %d, gen %u/%u, done %d)\n",
-                    me, tag, l, c->tag[par][l], c->gen[me], c->gen[l], c->done[l]);
+        // the other lanes of my wave have deposited this primitive; some may already have run on to their next one (one
+        // generation ahead, other parity): the lanes before me in the round, or -- after a block barrier -- the ones after me
+        const int f = base + l;
+        const bool gen_ok = (c->gen[f] == c->gen[me]) || (c->gen[f] == c->gen[me] + 1);
+        if (!gen_ok || c->tag[par][f] != tag) {
+            fprintf(stderr, "wavesim: lanes diverged at a wave primitive (fiber %d tag %d vs fiber %d tag %d, gen %u/%u, done %d)\n",
+                    me, tag, f, c->tag[par][f], c->gen[me], c->gen[f], c->done[f]);
             abort();
         }
-        all[l] = c->slot[par][l];
+        all[l] = c->slot[par][f];
     }
 }
-inline int my_lane() { return current()->cur; }
+// workgroup barrier (__syncthreads): every fiber of the block arrives, then all continue
+inline void block_barrier() {
+    Ctx* c = current();
+    const int me = c->cur;
+    c->bar_arrived++;
+    const long target = (long)(++c->bar_gen[me]) * c->nfib;
+    while (c->bar_arrived < target) { to_scheduler(c, me); c->cur = me; }
+}
+inline int my_lane() { return current()->cur % NLANES; }
 template <class T> inline uint64_t bits_of(T v) { uint64_t u = 0; memcpy(&u, &v, sizeof v); return u; }
 template <class T> inline T from_bits(uint64_t u) { T v; memcpy(&v, &u, sizeof v); return v; }
 }  // namespace wsim
 struct Wave { int lane; };
 LHIP_DEV void wave_sync() { uint64_t a[64]; wsim::exchange(1, 0, a); }
+LHIP_DEV void wg_barrier() { wsim::block_barrier(); }                  // __syncthreads of a multi-wave workgroup
 LHIP_DEV int wave_sum(int v) { uint64_t a[64]; wsim::exchange(2, (uint64_t)(uint32_t)v, a); int s = 0; for (int l = 0; l < 64; l++) s += (int)(uint32_t)a[l]; return s; }
 LHIP_DEV int wave_max(int v) { uint64_t a[64]; wsim::exchange(3, (uint64_t)(uint32_t)v, a); int m = (int)(uint32_t)a[0]; for (int l = 1; l < 64; l++) if ((int)(uint32_t)a[l] > m) m = (int)(uint32_t)a[l]; return m; }
 LHIP_DEV int wave_min(int v) { uint64_t a[64]; wsim::exchange(4, (uint64_t)(uint32_t)v, a); int m = (int)(uint32_t)a[0]; for (int l = 1; l < 64; l++) if ((int)(uint32_t)a[l] < m) m = (int)(uint32_t)a[l]; return m; }
@@ -218,6 +234,7 @@ LHIP_DEV double wave_sumd(double v) { return __ockl_wfred_add_f64(v); }
 LHIP_DEV int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }   // src must be wave-uniform
 LHIP_DEV uint64_t wave_ballot(int p) { return __ballot(p); }
 LHIP_DEV unsigned mul24(unsigned a, unsigned b) { return __umul24(a, b); }
+LHIP_DEV void wg_barrier() { __syncthreads(); }
 LHIP_DEV int wave_any(int p) { return __any(p); }
 // exclusive prefix sum over the 64 lanes (integers: exact in any order); *total = sum over all lanes.
 // Kogge-Stone inside each row of 16 lanes with DPP row shifts, then the row totals are broadcast into the later rows

@@ -52,7 +52,8 @@ def test_wavesim_matches_small_goldens(wsim, golden):
 
 @pytest.mark.parametrize("corpus,ch,sr,kbps,nfr,chunk", [
     ("sine", 1, 44100, 128, 14, 1152 * 14),        # BASELINE config shapes
-    ("sine", 2, 44100, 128, 10, 1152 * 3),
+    ("sine", 2, 44100, 128, 10, 1152 * 3),         # stereo calls of <= 12 frames: the two-waves-per-frame kernel (workgroup barrier)
+    ("bursts", 2, 44100, 128, 30, 1152 * 30),      # one larger stereo call: the one-wave-per-frame kernel
     ("bursts", 2, 44100, 320, 24, 4000),           # attacks: short / start / stop blocks, subblock gain
     ("bursts", 1, 48000, 64, 24, 1152 * 24),
     ("bursts", 1, 32000, 192, 24, 777),
