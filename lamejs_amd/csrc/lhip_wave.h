@@ -182,8 +182,17 @@ LHIP_DEV int wave_excl_scan(int v, int lane, int* total) { uint64_t a[64]; wsim:
 LHIP_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }                 // lanes run one at a time: plain read-modify-write
 LHIP_DEV void lds_max(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return wave_ballot(v != 0); }
-LHIP_DEV int uni(int v) { return v; }                                      // an assertion on the device; nothing to move here
-LHIP_DEV double unid(double v) { return v; }
+// uni(): on the device v_readfirstlane, i.e. "this value is wave-uniform" -- which silently takes lane 0's value if it is
+// not.  With LAMEJS_WAVESIM_CHECK_UNI=1 the simulation verifies the claim (a rendezvous per call: slow, for sweeps).
+inline bool wsim_check_uni() { static const bool on = [] { const char* e = getenv("LAMEJS_WAVESIM_CHECK_UNI"); return e && e[0] == '1'; }(); return on; }
+LHIP_DEV int uni(int v) {
+    if (wsim_check_uni()) {
+        uint64_t a[64]; wsim::exchange(15, (uint64_t)(uint32_t)v, a);
+        for (int l = 1; l < 64; l++) if (a[l] != a[0]) { fprintf(stderr, "wavesim: uni() of a non-uniform value (lane 0: %d, lane %d: %d)\n", (int)(uint32_t)a[0], l, (int)(uint32_t)a[l]); abort(); }
+    }
+    return v;
+}
+LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
 LHIP_DEV int fresh_lane(int lane) { return lane; }
 LHIP_DEV unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 LHIP_DEV double wave_shr1d(double v, double first) { uint64_t a[64]; wsim::exchange(13, wsim::bits_of(v), a); const int me = wsim::my_lane(); return me == 0 ? first : wsim::from_bits<double>(a[me - 1]); }
