@@ -1,15 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- 1152-sample frames/s of the MI355X-native lamejs encode path (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch: the BASELINE config-2 workload (mono 44.1 kHz,
-128 kbps CBR, 1e5 synthetic sine+noise frames in ONE stream) per GPU, Int16 PCM resident in HBM when
-the timed region starts, MP3 bytes left in HBM.  With N > 1 GPUs every rank encodes its own stream
-(seed 12345 + rank): independent streams, no data-path collective ("weak" scaling); RCCL is used once,
-untimed, to broadcast the table blob and to gather output digests.
+A "step" = one pass of the hot path over one batch per GPU; the default workload is the configuration north_star's
+target is quoted on (SURVEY.md 8d "Config 3" = BASELINE configs[2]): stereo 44.1 kHz, 128 kbps CBR, 1e5 synthetic
+sine+noise frames in ONE stream per GPU, Int16 PCM resident in HBM when the timed region starts, MP3 bytes left in HBM.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, algorithmic
-bytes / measured kernel time vs HBM peak) and `cpu_baseline` (the CPU oracle -- a plain-C port of the
-reference -- timed on one host core on a bounded sample).
+    --config 2   BASELINE configs[1]: mono 128 kbps, 1e5 frames, one stream per GPU          (seed 12345 + rank)
+    --config 3   BASELINE configs[2]: stereo 128 kbps, 1e5 frames, one stream per GPU        (default)
+    --config 4   BASELINE configs[3]: stereo 320 kbps, 1e5 frames per GPU ("8 x 1e5 over 8 GPUs" with --gpus 8)
+    --config 5   BASELINE configs[4]: 128 independent mono 128 kbps streams x 1000 frames per GPU (1024 with --gpus 8; seed 1000 + s)
+
+With N > 1 GPUs every rank encodes its own stream(s): independent streams, no data-path collective ("weak" scaling);
+RCCL is used outside the timed region only: one broadcast of the table blob, one gather of the MP3 bytes to rank 0
+(north_star: "a single RCCL broadcast/gather ... for input/output buffers only").
+
+Every stream's FULL output is compared (md5 + length) with tests/golden/full_md5.json, produced from the unmodified
+reference by tests/tools/gen_full_md5.sh; a prefix is additionally byte-compared with the CPU oracle.
+
+Prints ONE JSON line (rank 0): the contract fields for the chosen config, `roofline` (dominant kernel: algorithmic bytes /
+measured kernel time vs HBM peak, PMC traffic), `roofline_compute` (the same kernel against the VALU issue ceiling of its
+measured instruction mix), `cpu_baseline` (the plain-C oracle on a bounded sample, one host core; plus the Node reference's
+figures measured where /root/reference exists) and, at N = 1, `other_configs`: configs 2, 4, 5 and the `bursts` material.
 """
 import argparse
 import ctypes
@@ -27,181 +38,337 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SR = 44100
 
+PRESETS = {
+    2: dict(label="BASELINE configs[1]", ch=1, kbps=128, streams=1, frames=100000, corpus="sine", seed0=12345),
+    3: dict(label="BASELINE configs[2]", ch=2, kbps=128, streams=1, frames=100000, corpus="sine", seed0=12345),
+    4: dict(label="BASELINE configs[3]", ch=2, kbps=320, streams=1, frames=100000, corpus="sine", seed0=12345),
+    5: dict(label="BASELINE configs[4]", ch=1, kbps=128, streams=128, frames=1000, corpus="sine", seed0=1000),
+    # second material (SURVEY.md 8d config 2 note): quiet noise with full-scale bursts -- ATH adjustment, attacks, short blocks
+    "bursts": dict(label="bursts material", ch=2, kbps=128, streams=1, frames=100000, corpus="bursts", seed0=777),
+}
+
+
+def alg_bytes_per_frame(ch, kbps):
+    return 1152 * ch * 2 + 144000.0 * kbps / SR     # Int16 PCM in + MP3 bytes out: 5026 B stereo 128k
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=100000, help="frames per step per GPU (BASELINE: 1e5)")
-    ap.add_argument("--cpu-frames", type=int, default=40000, help="bounded sample for the CPU baseline (0 = skip)")
-    ap.add_argument("--channels", type=int, default=1, help="1 = BASELINE configs[1] (the metric's configuration); 2 = configs[2]/[3]")
-    ap.add_argument("--kbps", type=int, default=128)
-    ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU in one batch launch (BASELINE configs[4]: 128 x 1000 frames)")
-    ap.add_argument("--check-frames", type=int, default=2000, help="prefix checked against the CPU oracle")
+    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]) or 'bursts'")
+    ap.add_argument("--frames", type=int, default=0, help="override frames per stream (parity table then only covers a prefix check)")
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--check-frames", type=int, default=2000, help="prefix byte-compared with the CPU oracle (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs (they are only run at N = 1)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the MP3 bytes to rank 0 (N > 1)")
     args = ap.parse_args()
 
-    CH, KBPS = args.channels, args.kbps
-    ALG_BYTES_PER_FRAME = 1152 * CH * 2 + 144000.0 * KBPS / SR   # Int16 PCM in + MP3 bytes out: 2722 B mono 128k
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    sim = os.environ.get("LAMEJS_BENCH_HOSTSIM") == "1"       # tests only: gloo + the host simulation behind the same C ABI
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if sim:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if sim:
+        dev = torch.device("cpu")
+        dev_ord = 0
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dev_ord = local_rank
+
+    def dsync():
+        if not sim:
+            torch.cuda.synchronize()
 
     import lamejs_amd
     import pcm
 
     lib = lamejs_amd.load_library()
-    nfr = args.frames
-    nsamp = 1152 * nfr
-
-    # table blob: rank 0 builds it with the host JavaScript, everyone receives it over RCCL (setup, untimed)
-    if world > 1:
-        from lamejs_amd.shard import broadcast_blob
-        blob = broadcast_blob(dist, lamejs_amd.tables_blob(CH, SR, KBPS) if rank == 0 else None, dev, rank)
+    if sim:
+        assert b"HOST SIMULATION" in lib.lhip_version()
     else:
-        blob = lamejs_amd.tables_blob(CH, SR, KBPS)
+        lib.lhip_set_hip_stream(dev_ord, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    lib.lhip_kernel_times.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
 
-    NS = args.streams
-    # rank r owns streams r*NS .. r*NS+NS-1 (lamejs_amd.shard); one stream: seed 12345 + rank (configs[1..3]), many: 1000 + s (configs[4])
-    seeds = [12345 + rank] if NS == 1 else [1000 + rank * NS + i for i in range(NS)]
-    pcs = [pcm.sine(nsamp, CH, seed=sd_) for sd_ in seeds]
-    L, R = pcs[0]
-    d_l = [torch.from_numpy(p[0]).to(dev) for p in pcs]      # Int16 PCM resident in HBM
-    d_r = [torch.from_numpy(p[1]).to(dev) for p in pcs] if CH == 2 else d_l
-    out_cap = (nfr + 4) * (144000 * KBPS // SR + 1)
-    d_out = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(NS)]
+    table = {}
+    tpath = ROOT / "tests" / "golden" / "full_md5.json"
+    if tpath.exists():
+        for e in json.loads(tpath.read_text())["entries"]:
+            table[(e["corpus"], e["channels"], e["kbps"], e["frames"], e["seed"])] = (e["md5"], e["bytes"])
 
-    cfg = lamejs_amd._Config(CH, SR, KBPS, local_rank)
-    bbuf = ctypes.create_string_buffer(blob, len(blob))
+    pcm_cache = {}
 
-    def new_stream():
-        h = ctypes.c_void_p()
-        rc = lib.lhip_create(ctypes.byref(cfg), bbuf, len(blob), ctypes.byref(h))
-        assert rc == 0, lib.lhip_last_error()
-        return h
+    def get_pcm(corpus, nsamp, ch, seed):
+        # stereo 128k and stereo 320k share the PCM; the mono stream is the same generator with one channel
+        key = (corpus, nsamp, ch, seed)
+        if key not in pcm_cache:
+            L, R = pcm.CORPORA[corpus](nsamp, ch, seed=seed)
+            dl = torch.from_numpy(L).to(dev)
+            dr = torch.from_numpy(R).to(dev) if ch == 2 else dl
+            pcm_cache[key] = (L, R, dl, dr)
+        return pcm_cache[key]
 
-    lib.lhip_set_hip_stream(local_rank, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    HN = ctypes.c_void_p * NS
-    SN = ctypes.c_size_t * NS
-    wr = (ctypes.c_int64 * NS)()
-    a_l = HN(*[t.data_ptr() for t in d_l]); a_r = HN(*[t.data_ptr() for t in d_r]); a_o = HN(*[t.data_ptr() for t in d_out])
-    a_n = SN(*([nsamp] * NS)); a_c = SN(*([out_cap] * NS))
+    class Workload:
+        def __init__(self, key):
+            p = dict(PRESETS[key])
+            self.key = key
+            self.ch, self.kbps, self.corpus = p["ch"], p["kbps"], p["corpus"]
+            self.ns = args.streams or p["streams"]
+            self.nfr = args.frames or p["frames"]
+            self.full = (self.nfr == p["frames"])
+            self.label = p["label"]
+            self.seeds = [p["seed0"] + rank * self.ns + i for i in range(self.ns)]     # one stream: seed0 + rank; config 5: 1000 + global stream index
+            self.nsamp = 1152 * self.nfr
+            # table blob: rank 0 builds it with the host JavaScript, everyone receives it over RCCL (setup, untimed)
+            if world > 1:
+                from lamejs_amd.shard import broadcast_blob
+                self.blob = broadcast_blob(dist, lamejs_amd.tables_blob(self.ch, SR, self.kbps) if rank == 0 else None, dev, rank)
+            else:
+                self.blob = lamejs_amd.tables_blob(self.ch, SR, self.kbps)
+            self.bbuf = ctypes.create_string_buffer(self.blob, len(self.blob))
+            self.cfg = lamejs_amd._Config(self.ch, SR, self.kbps, dev_ord)
+            self.pcs = [get_pcm(self.corpus, self.nsamp, self.ch, s) for s in self.seeds]
+            self.out_cap = (self.nfr + 4) * (144000 * self.kbps // SR + 1)
+            self.d_out = [torch.empty(self.out_cap, dtype=torch.uint8, device=dev) for _ in range(self.ns)]
+            NS = self.ns
+            self.HN = ctypes.c_void_p * NS
+            SN = ctypes.c_size_t * NS
+            self.wr = (ctypes.c_int64 * NS)()
+            self.a_l = self.HN(*[p_[2].data_ptr() for p_ in self.pcs])
+            self.a_r = self.HN(*[p_[3].data_ptr() for p_ in self.pcs])
+            self.a_o = self.HN(*[t.data_ptr() for t in self.d_out])
+            self.a_n = SN(*([self.nsamp] * NS))
+            self.a_c = SN(*([self.out_cap] * NS))
+            self.handles = []
 
-    def step(hs):
-        rc = lib.lhip_encode_batch_device(HN(*hs), NS, a_l, a_r, a_n, a_o, a_c, wr, 0)
-        assert rc == 0, lib.lhip_last_error()
-        return wr[0]
+        def new_streams(self):
+            hs = []
+            for _ in range(self.ns):
+                h = ctypes.c_void_p()
+                rc = lib.lhip_create(ctypes.byref(self.cfg), self.bbuf, len(self.blob), ctypes.byref(h))
+                assert rc == 0, lib.lhip_last_error()
+                hs.append(h)
+            self.handles.append(hs)
+            return hs
 
-    def new_streams():
-        return [new_stream() for _ in range(NS)]
+        def step(self, hs):
+            rc = lib.lhip_encode_batch_device(self.HN(*hs), self.ns, self.a_l, self.a_r, self.a_n, self.a_o, self.a_c, self.wr, 0)
+            assert rc == 0, lib.lhip_last_error()
 
-    streams = [new_streams() for _ in range(args.warmup + args.steps)]
-    for w in range(args.warmup):
-        step(streams[w])
-    torch.cuda.synchronize()
-    lib.lhip_kernel_timing(0)
+        def close(self):
+            for hs in self.handles:
+                for h in hs:
+                    lib.lhip_destroy(h)
+            self.handles = []
 
+        def timed(self, steps, warmup):
+            """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+            sets = [self.new_streams() for _ in range(warmup + steps)]
+            for w in range(warmup):
+                self.step(sets[w])
+            dsync()
+            if world > 1:
+                dist.barrier()
+            dsync()
+            t0 = time.perf_counter()
+            for s in range(steps):
+                self.step(sets[warmup + s])
+            dsync()
+            if world > 1:
+                dist.barrier()
+            dsync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+            lib.lhip_last_batch_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+            self.frames_per_step, self.repaired, self.repair_iters = a.value, b.value, c.value
+            self.nbytes = [int(self.wr[i]) for i in range(self.ns)]
+            return dt
+
+        def outputs(self):
+            return [self.d_out[i][: self.nbytes[i]].cpu().numpy().tobytes() for i in range(self.ns)]
+
+        def check(self, outs):
+            """(bit_exact_full, bit_exact_prefix_vs_oracle, md5s).  Full: every stream's md5 + length equals the committed reference
+            table (None if the table has no entry for this shape); prefix: the first frames of stream 0 byte-compared with the oracle."""
+            md5s = [hashlib.md5(o).hexdigest() for o in outs]
+            full = None
+            if self.full:
+                ent = [table.get((self.corpus, self.ch, self.kbps, self.nfr, s)) for s in self.seeds]
+                if all(e is not None for e in ent):
+                    full = all(e[0] == m and e[1] == len(o) for e, m, o in zip(ent, md5s, outs))
+            prefix = None
+            if args.check_frames > 0:
+                from oracle_py import oracle_encode
+                k = min(args.check_frames, self.nfr - 2)
+                L, R = self.pcs[0][0], self.pcs[0][1]
+                ref = oracle_encode(self.ch, SR, self.kbps, L[: 1152 * k], R[: 1152 * k] if self.ch == 2 else None, flush=False)
+                prefix = bool(outs[0][: len(ref)] == ref)
+            return full, prefix, md5s
+
+        def kernel_times(self):
+            """one extra, untimed step with HIP events around every kernel on the launch stream"""
+            kern = {}
+            hs = self.new_streams()
+            nk = lib.lhip_kernel_timing(1)
+            self.step(hs)
+            dsync()
+            for i in range(nk):
+                name = ctypes.c_char_p(); ms = ctypes.c_double(); cnt = ctypes.c_int64()
+                lib.lhip_kernel_times(i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(cnt))
+                if cnt.value:
+                    kern[name.value.decode()] = {"ms": round(ms.value, 4), "launches": cnt.value}
+            lib.lhip_kernel_timing(0)
+            return kern
+
+        def describe(self):
+            shape = f"{'stereo' if self.ch == 2 else 'mono'} 44.1kHz {self.kbps}kbps CBR, {self.ns} stream(s) x {self.nfr} synthetic {self.corpus} frames per GPU"
+            return f"{self.label}: {shape}" if self.full and not args.streams else shape
+
+    key = args.config if args.config in PRESETS else int(args.config)
+    wl = Workload(key)
+    dt = wl.timed(args.steps, args.warmup)
+    outs = wl.outputs()
+    full, prefix, md5s = wl.check(outs)
+    kern = wl.kernel_times() if not sim else {}
+
+    # ---- N > 1: verdicts of all ranks; RCCL gather of the MP3 bytes to rank 0 (untimed), re-hashed there ----
+    verdicts = [(rank, md5s, full, prefix, wl.nbytes)]
+    gathered_ok = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nbytes = 0
-    for s in range(args.steps):
-        nbytes = step(streams[args.warmup + s])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        allv = [None] * world
+        dist.all_gather_object(allv, verdicts[0])
+        verdicts = allv
+        if not args.no_gather:
+            nmax = max(max(v[4]) for v in verdicts)
+            mine = torch.zeros(wl.ns * nmax, dtype=torch.uint8, device=dev)
+            for i in range(wl.ns):
+                mine[i * nmax: i * nmax + wl.nbytes[i]] = wl.d_out[i][: wl.nbytes[i]]
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+            if rank == 0:
+                gathered_ok = True
+                for r in range(world):
+                    host = parts[r].cpu().numpy()
+                    for i in range(wl.ns):
+                        nb = verdicts[r][4][i]
+                        if hashlib.md5(host[i * nmax: i * nmax + nb].tobytes()).hexdigest() != verdicts[r][1][i]:
+                            gathered_ok = False
 
-    a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    lib.lhip_last_batch_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-    frames_per_step = a.value
-    mp3 = d_out[0][:nbytes].cpu().numpy().tobytes()
-
-    # parity spot check against the CPU oracle on a prefix (bit-exact) -- checker only, outside the timed region
-    parity = None
-    if args.check_frames > 0:
-        from oracle_py import oracle_encode
-        k = min(args.check_frames, nfr - 2)
-        ref = oracle_encode(CH, SR, KBPS, L[: 1152 * k], R[: 1152 * k] if CH == 2 else None, flush=False)
-        parity = bool(mp3[: len(ref)] == ref)
-
-    # per-kernel timing pass (untimed extra step with HIP events on the launch stream)
-    kern = {}
-    extra = new_streams()
-    nk = lib.lhip_kernel_timing(1)
-    step(extra)
-    torch.cuda.synchronize()
-    for i in range(nk):
-        name = ctypes.c_char_p(); ms = ctypes.c_double(); cnt = ctypes.c_int64()
-        lib.lhip_kernel_times.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
-        lib.lhip_kernel_times(i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(cnt))
-        if cnt.value:
-            kern[name.value.decode()] = {"ms": round(ms.value, 4), "launches": cnt.value}
-    lib.lhip_kernel_timing(0)
-    dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
-
-    digests = [hashlib.md5(mp3).hexdigest()]
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, digests[0])
-        digests = gathered
-
+    line = None
     if rank == 0:
-        total_frames = frames_per_step * args.steps * world
+        total_frames = wl.frames_per_step * args.steps * world
         value = total_frames / dt
+        all_full = [v[2] for v in verdicts]
         line = {
-            "metric": f"1152-sample frames/s encoded (44.1kHz {KBPS}kbps CBR); bit-exact",
+            "metric": f"1152-sample frames/s encoded (44.1kHz {wl.kbps}kbps CBR); bit-exact",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: mono 44.1kHz 128kbps CBR, {nfr} synthetic sine+noise frames, one stream per GPU" if (CH, KBPS, NS) == (1, 128, 1)
-                                    else f"{'stereo' if CH == 2 else 'mono'} 44.1kHz {KBPS}kbps CBR, {NS} stream(s) x {nfr} synthetic sine+noise frames per GPU"),
-                       "frames_per_step_per_gpu": frames_per_step, "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
-                       "bit_exact_prefix_vs_oracle": parity, "seed_repaired_frames": b.value, "output_md5_per_rank": digests},
+            "config": {"workload": wl.describe(), "frames_per_step_per_gpu": wl.frames_per_step,
+                       "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
+                       "bit_exact_full": (None if any(f is None for f in all_full) else all(all_full)),
+                       "bit_exact_full_note": "md5 + length of every stream's whole output vs tests/golden/full_md5.json (unmodified reference under node)",
+                       "bit_exact_prefix_vs_oracle": (None if any(v[3] is None for v in verdicts) else all(v[3] for v in verdicts)),
+                       "seed_repaired_frames": wl.repaired, "repair_iterations": wl.repair_iters,
+                       "output_md5_per_rank": [v[1][0] if len(v[1]) == 1 else hashlib.md5("".join(v[1]).encode()).hexdigest() for v in verdicts],
+                       "rccl_gather_of_outputs_rehashed_ok": gathered_ok},
             "kernels_ms": kern,
         }
+        dom = max(kern, key=lambda k_: kern[k_]["ms"]) if kern else None
         if dom:
             kt = kern[dom]["ms"] / max(kern[dom]["launches"], 1) / 1000.0
-            alg = ALG_BYTES_PER_FRAME * frames_per_step
+            alg = alg_bytes_per_frame(wl.ch, wl.kbps) * wl.frames_per_step
             ach = alg / kt / 1e9
-            # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-            # runs, gfx950 FETCH_SIZE x2 correction) -- measured offline on this exact workload, committed under profiles/
+            # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+            # gfx950 FETCH_SIZE x2 correction) and its instruction mix -- measured offline on this exact workload, under profiles/
             traffic = None
-            pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic_mono128_1e5.json"
-            if (CH, KBPS, nfr, NS) == (1, 128, 100000, 1) and pmc.exists():
+            prof = {}
+            pf = ROOT / "profiles" / f"r02_pmc_config{key}.json"
+            if wl.full and pf.exists():
                 try:
-                    traffic = json.loads(pmc.read_text())["kernels"]["g_" + dom]["hbm_bytes_per_launch"]
+                    prof = json.loads(pf.read_text())
+                    traffic = prof["traffic"]["g_" + dom]["hbm_bytes_per_launch"]
                 except (KeyError, ValueError):
                     traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_unit": "bytes/launch",
                                 "algorithmic_bytes_per_launch": int(alg),
-                                "note": "path is latency/issue bound (SURVEY.md 8d): the HBM fraction is small by construction; "
-                                        "traffic from profiles/r01_pmc_hbm_traffic_mono128_1e5.json"}
-        if args.cpu_frames > 0 and world == 1:       # the CPU baseline is reported at N = 1 only
-            from oracle_py import oracle_encode
-            k = min(args.cpu_frames, nfr)
-            t1 = time.perf_counter()
-            oracle_encode(CH, SR, KBPS, L[: 1152 * k], R[: 1152 * k] if CH == 2 else None)
-            cdt = time.perf_counter() - t1
-            line["cpu_baseline"] = {"value": round(k / cdt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
-                                    "sample": f"first {k} frames of the same stream, plain-C oracle (oracle/), 1 thread"}
+                                "note": "neither HBM nor MFMA bounds this path (SURVEY.md 8d): the HBM fraction is small by construction; "
+                                        "see roofline_compute for the limiter (VALU issue)"}
+            rc = prof.get("compute", {}).get("g_" + dom)
+            if rc:
+                # issue ceiling of the kernel's own instruction mix: sum over classes of (wave-instructions x measured cycles per
+                # instruction per SIMD, tools/ubench_issue.hip) = SIMD-cycles of pure issue; peak rate = 1024 SIMDs x clock / mean cycles
+                cyc = rc["issue_cycles_per_launch"]; insts = rc["valu_insts_per_launch"]
+                simds, clk = 1024, rc.get("clock_ghz", 2.4)
+                peak = simds * clk * 1e9 / (cyc / insts)
+                line["roofline_compute"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(insts / kt / 1e9, 2), "peak": round(peak / 1e9, 2),
+                                            "unit": "G wave-instructions/s", "frac": round(insts / kt / peak, 4),
+                                            "mean_cycles_per_valu_inst": round(cyc / insts, 3), "source": f"profiles/r02_pmc_config{key}.json + profiles/r02_ubench_issue.json"}
+
+    # ---- the other configurations (N = 1 only): each is its own short run, md5-checked like the main one ----
+    if world == 1 and not args.no_extras and not args.frames and not args.streams:
+        others = {}
+        for k2 in (2, 3, 4, 5, "bursts"):
+            if k2 == key:
+                continue
+            w2 = Workload(k2)
+            dt2 = w2.timed(2, 1)
+            o2 = w2.outputs()
+            f2, p2, m2 = w2.check(o2)
+            others[f"config{k2}" if isinstance(k2, int) else k2] = {
+                "workload": w2.describe(), "value": round(w2.frames_per_step * 2 / dt2, 1), "unit": "frames/s", "ms_per_step": round(1000.0 * dt2 / 2, 3),
+                "frames_per_step": w2.frames_per_step, "bit_exact_full": f2, "bit_exact_prefix_vs_oracle": p2,
+                "seed_repaired_frames": w2.repaired, "repair_iterations": w2.repair_iters,
+                "output_md5": m2[0] if len(m2) == 1 else hashlib.md5("".join(m2).encode()).hexdigest()}
+            w2.close()
+            del w2
+        line["other_configs"] = others
+
+    if rank == 0 and args.cpu_seconds > 0 and world == 1:       # the CPU baseline is reported at N = 1 only
+        from oracle_py import oracle_encode
+        L, R = wl.pcs[0][0], wl.pcs[0][1]
+        k = min(2000, wl.nfr)
+        t1 = time.perf_counter()
+        oracle_encode(wl.ch, SR, wl.kbps, L[: 1152 * k], R[: 1152 * k] if wl.ch == 2 else None)
+        rate = k / (time.perf_counter() - t1)
+        k = int(min(wl.nfr, max(2000, rate * args.cpu_seconds)))                # ~cpu_seconds of CPU work
+        t1 = time.perf_counter()
+        oracle_encode(wl.ch, SR, wl.kbps, L[: 1152 * k], R[: 1152 * k] if wl.ch == 2 else None)
+        cdt = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": round(k / cdt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                "sample": f"first {k} frames of the same stream, plain-C oracle (oracle/), 1 thread, on this host"}
+        rn = ROOT / "profiles" / "r02_reference_node_cpu.jsonl"
+        if rn.exists():
+            for l_ in rn.read_text().splitlines():
+                try:
+                    e = json.loads(l_)
+                except ValueError:
+                    continue
+                if e.get("channels") == wl.ch and e.get("kbps") == wl.kbps:
+                    line["cpu_baseline"]["reference_node"] = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1,
+                                                              "what": e.get("what"), "frames": e.get("frames"), "host": e.get("host"),
+                                                              "note": "unmodified lamejs under Node.js (tests/tools/time_reference.js); measured in the build container "
+                                                                      "(/root/reference does not exist on the GPU box), NOT on this host"}
+    if rank == 0:
         print(json.dumps(line))
+    wl.close()
     if world > 1:
         dist.destroy_process_group()
 

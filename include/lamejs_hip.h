@@ -51,6 +51,12 @@ typedef struct lhip_config {
 /* number of usable HIP devices (0 if none / runtime unavailable) */
 int lhip_device_count(void);
 
+/* Restrict the devices the library may place streams on: bit d of `mask` = HIP device d.  A later
+ * lhip_create with cfg.device == -1 then deals streams round-robin over the allowed devices (independent streams are the
+ * path's multi-GPU axis); an explicit cfg.device outside the mask is refused.  mask == 0 restores the default (every
+ * device; device -1 = the calling thread's current HIP device).  Returns the number of allowed devices or <0. */
+int lhip_set_devices(uint64_t mask);
+
 /* Create an encoder stream.  `tables` is the LHTB blob produced by lamejs_amd/js/tables.js for
  * (channels, samplerate, kbps); it is validated against cfg, uploaded to HBM (shared between
  * streams with identical blobs) and may be freed by the caller on return.  Returns 0 or <0. */

@@ -14,7 +14,11 @@
 
 namespace lhip {
 
-struct BitsLds { uint32_t w[272]; };
+// largest legal frame: 320 kbps at 32 kHz (or 160 kbps at 8 kHz) = 1440 bytes (+1 padding byte at 44.1 kHz rates) =
+// 361 words, and kb_bits also touches word nwords (a straddling put_bits); lhip_create checks the configuration's
+// frame size against BITS_LDS_WORDS.
+enum { BITS_LDS_WORDS = 368 };
+struct BitsLds { uint32_t w[BITS_LDS_WORDS]; };
 
 // write the low n bits of val at bit position pos (MSB-first stream); n <= 32
 LHIP_DEV void put_bits(uint32_t* w, int pos, uint32_t val, int n) {

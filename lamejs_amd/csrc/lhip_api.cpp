@@ -19,6 +19,7 @@
 #include <vector>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <memory>
 #include <cstring>
 #include <cstdlib>
@@ -296,11 +297,14 @@ __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const Stream
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
 enum { KT_LOAD, KT_PREP, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
 static const char* const g_kt_names[KT_N] = {"load", "prep", "psyA", "scan", "psyB", "polyphase", "mdct", "quant", "validate", "repair", "bits", "save"};
-static bool g_kt_on = false;
+// The switch is process-wide (bench.py turns it on for one extra, untimed step); the events of a batch belong to the calling
+// thread (a batch runs entirely inside one run_batch call), the accumulators are shared by all devices and guarded by g_kt_mu.
+static std::atomic<bool> g_kt_on{false};
+static std::mutex g_kt_mu;
 static double g_kt_ms[KT_N];
 static int64_t g_kt_calls[KT_N];
 struct KtPending { int id; hipEvent_t a, b; };
-static std::vector<KtPending> g_kt_pending;
+static thread_local std::vector<KtPending> g_kt_pending;
 static void kt_begin(int id, void* st) {
     if (!g_kt_on) return;
     KtPending p; p.id = id;
@@ -310,6 +314,7 @@ static void kt_begin(int id, void* st) {
 }
 static void kt_end(void* st) { if (g_kt_on && !g_kt_pending.empty()) hipEventRecord(g_kt_pending.back().b, (hipStream_t)st); }
 static void kt_collect() {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
     for (auto& p : g_kt_pending) {
         float ms = 0.f;
         hipEventSynchronize(p.b);
@@ -345,7 +350,7 @@ __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase 
 // ===========================================================================================
 // tables (shared between streams with identical blobs)
 // ===========================================================================================
-static int g_spec_start = 180, g_spec_step = 4;   // seed assumed by the speculative quantization pass (test hook)
+static std::atomic<int> g_spec_start{180}, g_spec_step{4};   // seed assumed by the speculative quantization pass (test hook)
 struct lhtb_entry { char name[32]; uint32_t dtype, count, offset, pad; };
 
 struct TableSet {
@@ -355,7 +360,6 @@ struct TableSet {
     void* d_blob = nullptr;
     void* d_extra = nullptr;
     int device = 0;
-    int refs = 0;
     int base_frame_bytes = 0;
     ~TableSet() { rt::dfree(d_blob); rt::dfree(d_extra); }
 };
@@ -491,6 +495,10 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     T.bo_l = T.s3off_l + 4 * CBANDS; T.bo_s = T.bo_l + SBMAX_l;
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
+    // kb_bits assembles a frame in BitsLds (and zeroes one word past its last one): the largest frame of this configuration must fit
+    if ((8 * (ts.base_frame_bytes + (T.frac_SpF != 0 ? 1 : 0)) + 31) / 32 + 1 > (int)BITS_LDS_WORDS) {
+        set_err("configuration outside the supported envelope (frame larger than the bit-packing buffer)"); return false;
+    }
     return true;
 }
 
@@ -851,6 +859,17 @@ extern "C" {
 
 int lhip_device_count(void) { return rt::device_count(); }
 
+static std::atomic<uint64_t> g_dev_mask{0};
+static std::atomic<unsigned> g_dev_rr{0};
+int lhip_set_devices(uint64_t mask) {
+    const int n = rt::device_count();
+    if (n <= 0) { set_err("no HIP device available (this library has no CPU fallback)"); return LHIP_ERR_INTERNAL; }
+    const uint64_t all = n >= 64 ? ~0ull : ((1ull << n) - 1);
+    if (mask & ~all) { set_err("lhip_set_devices: mask names a device that does not exist"); return LHIP_ERR_INTERNAL; }
+    g_dev_mask = mask; g_dev_rr = 0;
+    return mask ? __builtin_popcountll(mask) : n;
+}
+
 const char* lhip_last_error(void) { return g_err.c_str(); }
 const char* lhip_version(void) {
 #ifdef LHIP_HOSTSIM
@@ -865,19 +884,31 @@ int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes,
     *out = nullptr;
     if (rt::device_count() <= 0) { set_err("no HIP device available (this library has no CPU fallback)"); return LHIP_ERR_INTERNAL; }
     int dev = cfg->device;
+    const uint64_t mask = g_dev_mask;
+    if (mask) {
+        if (dev >= 0 && !((mask >> dev) & 1)) { set_err("device excluded by lhip_set_devices"); return LHIP_ERR_INTERNAL; }
+        if (dev < 0) {                       // deal streams round-robin over the allowed devices
+            unsigned k = g_dev_rr++ % (unsigned)__builtin_popcountll(mask);
+            for (dev = 0; dev < 64; dev++) if ((mask >> dev) & 1) { if (k == 0) break; k--; }
+        }
+    }
 #ifndef LHIP_HOSTSIM
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) { set_err("hipGetDevice failed"); return LHIP_ERR_INTERNAL; } }
 #else
     if (dev < 0) dev = 0;
 #endif
+    if (dev >= rt::device_count()) { set_err("no such HIP device"); return LHIP_ERR_INTERNAL; }
     Context* ctx = get_context(dev);
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(dev)) return LHIP_ERR_INTERNAL;
     std::string key((const char*)tables, tables_bytes);
     std::shared_ptr<TableSet> ts;
     auto it = ctx->tables.find(key);
-    if (it != ctx->tables.end()) ts = it->second;
-    else {
+    if (it != ctx->tables.end()) {
+        ts = it->second;
+        // the same checks build_tables makes of the blob against the requested configuration
+        if (ts->T.channels_out != (cfg->channels == 1 ? 1 : 2) || ts->T.in_samplerate != cfg->samplerate) { set_err("tables blob does not match the requested configuration"); return LHIP_ERR_INTERNAL; }
+    } else {
         ts = std::make_shared<TableSet>();
         ts->device = dev;
         if (!build_tables(*ts, tables, tables_bytes, *cfg, ctx->stream)) return LHIP_ERR_INTERNAL;
@@ -906,8 +937,14 @@ int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes,
 
 void lhip_destroy(lhip_stream* s) {
     if (!s || s->magic != 0x4c484950) return;
-    rt::set_device(s->ctx->device);
+    Context* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    rt::set_device(ctx->device);
+    std::shared_ptr<TableSet> ts = s->ts;
     delete s;
+    // the cache entry goes with the last stream that uses it (one reference is the map's, one is `ts` here)
+    if (ts.use_count() == 2)
+        for (auto it = ctx->tables.begin(); it != ctx->tables.end(); ++it) if (it->second == ts) { ctx->tables.erase(it); break; }
 }
 
 size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples) {
@@ -1062,6 +1099,7 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
 
 int lhip_kernel_timing(int enable) {
 #ifndef LHIP_HOSTSIM
+    std::lock_guard<std::mutex> lk(g_kt_mu);
     g_kt_on = enable != 0;
     for (int i = 0; i < KT_N; i++) { g_kt_ms[i] = 0; g_kt_calls[i] = 0; }
     return KT_N;
@@ -1073,6 +1111,7 @@ int lhip_kernel_timing(int enable) {
 int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* launches) {
 #ifndef LHIP_HOSTSIM
     if (idx < 0 || idx >= KT_N) return -1;
+    std::lock_guard<std::mutex> lk(g_kt_mu);
     if (name) *name = g_kt_names[idx];
     if (total_ms) *total_ms = g_kt_ms[idx];
     if (launches) *launches = g_kt_calls[idx];

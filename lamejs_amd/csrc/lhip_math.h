@@ -212,7 +212,7 @@ LHIP_DEV double v8_pow_from_parts(double y, double t1, double t2) {
     double r = (z * tt1) / ((tt1 - 2.0) - (w + z * w));
     z = 1.0 - (r - z);
     j = (int32_t)d_hi(z);
-    j += (n << 20);
+    j += (int32_t)((uint32_t)n << 20);          // n may be negative: shift the bit pattern, not the signed value
     if ((j >> 20) <= 0) {
         // subnormal result: scale by 2^n in two exact steps (scalbn)
         const double twom54 = 5.55111512312578270212e-17;
@@ -220,7 +220,7 @@ LHIP_DEV double v8_pow_from_parts(double y, double t1, double t2) {
         int32_t kk = ((hz & 0x7ff00000) >> 20) + n;
         if (kk <= -54) return tiny * tiny;
         kk += 54;
-        z = d_with_hi(z, (uint32_t)((hz & 0x800fffff) | (kk << 20)));
+        z = d_with_hi(z, (uint32_t)((hz & 0x800fffff) | (int32_t)((uint32_t)kk << 20)));
         return z * twom54;
     }
     return d_with_hi(z, (uint32_t)j);

@@ -70,9 +70,8 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
     void* blob; size_t nblob;
     if (napi_get_buffer_info(env, argv[0], &blob, &nblob) != napi_ok) { napi_throw_type_error(env, NULL, "tables must be a Buffer"); return NULL; }
     lhip_config cfg; cfg.device = -1;
-    napi_get_value_int32(env, argv[1], &cfg.channels);
-    napi_get_value_int32(env, argv[2], &cfg.samplerate);
-    napi_get_value_int32(env, argv[3], &cfg.kbps);
+    if (argc < 4 || napi_get_value_int32(env, argv[1], &cfg.channels) != napi_ok || napi_get_value_int32(env, argv[2], &cfg.samplerate) != napi_ok ||
+        napi_get_value_int32(env, argv[3], &cfg.kbps) != napi_ok) { napi_throw_type_error(env, NULL, "channels, samplerate and kbps must be numbers"); return NULL; }
     if (argc > 4) { napi_valuetype vt; napi_typeof(env, argv[4], &vt); if (vt == napi_number) napi_get_value_int32(env, argv[4], &cfg.device); }
     lhip_stream* s = NULL;
     if (p_create(&cfg, blob, nblob, &s) != 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
@@ -92,15 +91,18 @@ static napi_value make_i8(napi_env env, const uint8_t* src, size_t n) {
 static napi_value js_encode(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
     napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
-    lhip_stream* s; napi_get_value_external(env, argv[0], (void**)&s);
+    lhip_stream* s = NULL;
+    if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&s) != napi_ok || !s) { napi_throw_type_error(env, NULL, "first argument must be a stream handle"); return NULL; }
     napi_typedarray_type tt; size_t nl = 0, nr = 0; void *dl = NULL, *dr = NULL;
     if (napi_get_typedarray_info(env, argv[1], &tt, &nl, &dl, NULL, NULL) != napi_ok || tt != napi_int16_array) { napi_throw_type_error(env, NULL, "left must be an Int16Array"); return NULL; }
-    napi_valuetype vt; napi_typeof(env, argv[2], &vt);
+    napi_valuetype vt = napi_undefined;
+    if (argc > 2) napi_typeof(env, argv[2], &vt);
     if (vt != napi_null && vt != napi_undefined) {
         if (napi_get_typedarray_info(env, argv[2], &tt, &nr, &dr, NULL, NULL) != napi_ok || tt != napi_int16_array || nr != nl) { napi_throw_type_error(env, NULL, "right must be an Int16Array of the same length"); return NULL; }
     }
     size_t cap = p_max_out(s, nl);
     uint8_t* out = (uint8_t*)malloc(cap ? cap : 1);
+    if (!out) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     int64_t n = p_encode(s, (const int16_t*)dl, (const int16_t*)dr, nl, out, cap);
     /* the reference swallows negative codes and returns an empty array (index.js:128-129) */
     napi_value r = make_i8(env, out, n > 0 ? (size_t)n : 0);
@@ -111,9 +113,11 @@ static napi_value js_encode(napi_env env, napi_callback_info info) {
 static napi_value js_flush(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1];
     napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
-    lhip_stream* s; napi_get_value_external(env, argv[0], (void**)&s);
+    lhip_stream* s = NULL;
+    if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&s) != napi_ok || !s) { napi_throw_type_error(env, NULL, "first argument must be a stream handle"); return NULL; }
     size_t cap = p_max_out(s, 4 * 1152);
-    uint8_t* out = (uint8_t*)malloc(cap);
+    uint8_t* out = (uint8_t*)malloc(cap ? cap : 1);
+    if (!out) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     int64_t n = p_flush(s, out, cap);
     napi_value r = make_i8(env, out, n > 0 ? (size_t)n : 0);
     free(out);

@@ -25,9 +25,9 @@ def load_case_pcm(case):
     import pcm
 
     ch, n = case["channels"], case["nsamples"]
-    if case["corpus"] == "wavexcerpt":
-        L = np.fromfile(ROOT / "tests" / "golden" / "left44100_excerpt.s16", dtype="<i2")[:n]
-        R = np.fromfile(ROOT / "tests" / "golden" / "right44100_excerpt.s16", dtype="<i2")[:n] if ch == 2 else None
+    if case["corpus"] in ("wavexcerpt", "wavfull"):     # the reference's own fixtures (testdata/Left44100.wav, Right44100.wav) as raw s16le
+        L = np.fromfile(ROOT / "tests" / "golden" / "left44100_full.s16", dtype="<i2")[:n]
+        R = np.fromfile(ROOT / "tests" / "golden" / "right44100_full.s16", dtype="<i2")[:n] if ch == 2 else None
     else:
         L, R = pcm.CORPORA[case["corpus"]](n, ch)
     h = hashlib.md5()

@@ -55,8 +55,6 @@ def test_device_math_matches_v8(lib):
 def test_gpu_matches_reference_goldens(lib, golden):
     n = 0
     for case in golden:
-        if case["corpus"] == "wavfull":
-            continue
         if case.get("outside_envelope"):
             continue
         L, R = load_case_pcm(case)
@@ -64,7 +62,24 @@ def test_gpu_matches_reference_goldens(lib, golden):
         assert len(mp3) == case["mp3_len"], case
         assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
         n += 1
-    assert n >= 62
+    assert n >= 65
+
+
+def test_gpu_reference_fixture_md5s(lib, golden):
+    """the three md5s of the reference's own fixtures (testdata/Left44100.wav [+ Right44100.wav], 287 x 1152-sample
+    calls + flush = 288 frames) -- the values Tests.js' outputs have -- reproduced on the GPU through the C ABI."""
+    want = {(1, 128): "5a522d307c7593e9cb57bfd31ff2a18c", (2, 128): "444bd5a0b7af22b0498d2a3fdd77b359", (2, 320): "910219d73827803a67e6e1a89a0794a5"}
+    seen = 0
+    for case in golden:
+        if case["corpus"] != "wavfull":
+            continue
+        assert case["mp3_md5"] == want[(case["channels"], case["kbps"])]
+        L, R = load_case_pcm(case)
+        for chunk in (1152, len(L)):                    # the reference's call pattern, and one batch call
+            mp3 = _encode(case["channels"], case["kbps"], L, R, chunk)
+            assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], (case, chunk)
+        seen += 1
+    assert seen == 3
 
 
 def test_gpu_matches_oracle_seeded(lib):
@@ -247,3 +262,11 @@ def test_gpu_stereo_both_quant_paths(lib, kbps):
     small = _encode(2, kbps, L, R, 1152 * 300)
     assert big == want, "persistent kernel differs from the oracle: " + _first_diff(big, want)
     assert small == want, "pair kernel differs from the oracle: " + _first_diff(small, want)
+
+
+def test_gpu_largest_frames_dense_noise(lib):
+    """Full-scale noise at the configurations with the largest frames (1440 bytes): every byte of the frame carries Huffman data."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import large_frames
+    assert large_frames.run(nframes=40) == []

@@ -35,7 +35,7 @@ def _encode(lib, ch, kbps, L, R, chunk, sr=44100):
 def test_hostsim_matches_goldens(sim, golden):
     n = 0
     for case in golden:
-        if case["corpus"] == "wavfull" or case["nsamples"] > 1152 * 300:
+        if case["nsamples"] > 1152 * 300:
             continue
         if case.get("outside_envelope"):
             continue
@@ -43,7 +43,7 @@ def test_hostsim_matches_goldens(sim, golden):
         mp3 = _encode(sim, case["channels"], case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100))
         assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
         n += 1
-    assert n >= 50
+    assert n >= 53
 
 
 def test_hostsim_batch_streams_match_single(sim):
@@ -84,3 +84,19 @@ def test_hostsim_random_material(sim):
     assert fuzz_gpu.run(42, 2024, lib=sim, verbose=False) == []
     assert fuzz_gpu.run(48, 31, lib=sim, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []      # MPEG-2 / 2.5
     assert fuzz_gpu.run(42, 5, lib=sim, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []  # integer-ratio resampling in front
+
+
+def test_hostsim_asan_largest_frames():
+    """The kernel bodies under AddressSanitizer on dense noise at the configurations with the largest frames (1440 bytes at
+    32 kHz / 320 kbps): the bit-packing buffer once held 1088 bytes (an out-of-bounds LDS write on the device, found by review,
+    invisible to sine goldens whose main data stays short).  Also byte-compared with the oracle."""
+    import os, shutil, sys
+    gcc = shutil.which("gcc")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip() if gcc else ""
+    if not asan or not os.path.isabs(asan):
+        pytest.skip("libasan not available")
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "asan"], check=True, capture_output=True)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "large_frames.py"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim_asan.so")],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

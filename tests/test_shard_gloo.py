@@ -48,3 +48,33 @@ def test_two_ranks_gloo(tmp_path, ch, kbps, n_streams):
         L, R = pcm.sine(1152 * (3 + 2 * i) + 77 * i, ch, seed=100 + i)
         want = hashlib.md5(oracle_encode(ch, 44100, kbps, L, R)).hexdigest()
         assert got[str(i)] == want, f"stream {i}"
+
+
+@pytest.mark.parametrize("cfg,extra,ch,kbps", [("3", ["--frames", "7"], 2, 128), ("4", ["--frames", "5"], 2, 320), ("5", ["--streams", "3", "--frames", "5"], 1, 128)])
+def test_bench_py_two_ranks_gloo(cfg, extra, ch, kbps):
+    """bench.py ITSELF with world_size 2 (its rank seeds, table broadcast, barrier-bracketed timing with the max over ranks,
+    verdict gather, gather of the MP3 bytes to rank 0): gloo + the host simulation of the kernels behind the same C ABI
+    (LAMEJS_BENCH_HOSTSIM=1), a handful of frames per stream.  Every rank's stream must equal the oracle's bytes."""
+    if not HOSTSIM.exists():
+        pytest.skip("host simulation not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, LAMEJS_HIP_LIB=str(HOSTSIM), LAMEJS_BENCH_HOSTSIM="1", MASTER_ADDR="127.0.0.1")
+    port = 31500 + (os.getpid() % 2000) + int(cfg)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", cfg,
+                        "--cpu-seconds", "0"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "frames/s"
+    c = line["config"]
+    assert c["bit_exact_prefix_vs_oracle"] is True and c["rccl_gather_of_outputs_rehashed_ok"] is True
+    ns = int(extra[extra.index("--streams") + 1]) if "--streams" in extra else 1
+    nfr = int(extra[extra.index("--frames") + 1])
+    assert line["value"] > 0 and c["frames_per_step_per_gpu"] == ns * (nfr - 1)
+    for rank in range(2):
+        md5s = []
+        for i in range(ns):
+            seed = (12345 + rank) if cfg != "5" else 1000 + rank * ns + i
+            L, R = pcm.sine(1152 * nfr, ch, seed=seed)
+            md5s.append(hashlib.md5(oracle_encode(ch, 44100, kbps, L, R, flush=False)).hexdigest())
+        want = md5s[0] if ns == 1 else hashlib.md5("".join(md5s).encode()).hexdigest()
+        assert c["output_md5_per_rank"][rank] == want, (rank, c)

@@ -1,8 +1,8 @@
 /*
  * TEST TOOL (needs /root/reference): generates tests/golden/* by running the UNMODIFIED reference
  * encoder (src/js/index.js via tests/tools/ref_harness.js refPublic) on
- *   - an excerpt of the reference's own fixtures testdata/Left44100.wav / Right44100.wav
- *     (first 60 x 1152 samples, stored as raw s16le so the GPU box can read them), and
+ *   - the reference's own fixtures testdata/Left44100.wav / Right44100.wav (the 287 x 1152 samples Tests.js encodes, stored as
+ *     raw s16le so that the GPU box, which has no /root/reference, can read them; the 60-frame excerpt cases are a prefix), and
  *   - the synthetic corpora of tests/tools/pcm_gen.js (regenerated bit-identically by tests/pcm.py).
  * Outputs: golden.json (per case: parameters, md5 of PCM, md5 + length of the MP3, and for the small
  * cases the MP3 bytes themselves as files) .  usage: node tests/tools/gen_golden.js
@@ -35,17 +35,18 @@ const cases = [];
 const WL = gen.readWav(fs.readFileSync(path.join(REF, 'testdata/Left44100.wav'))).samples;
 const WR = gen.readWav(fs.readFileSync(path.join(REF, 'testdata/Right44100.wav'))).samples;
 const NEX = 60 * 1152;
-fs.writeFileSync(path.join(OUT, 'left44100_excerpt.s16'), Buffer.from(WL.buffer, WL.byteOffset, NEX * 2));
-fs.writeFileSync(path.join(OUT, 'right44100_excerpt.s16'), Buffer.from(WR.buffer, WR.byteOffset, NEX * 2));
+const NFULL = Math.floor(WL.length / 1152) * 1152;
+fs.writeFileSync(path.join(OUT, 'left44100_full.s16'), Buffer.from(WL.buffer, WL.byteOffset, NFULL * 2));
+fs.writeFileSync(path.join(OUT, 'right44100_full.s16'), Buffer.from(WR.buffer, WR.byteOffset, NFULL * 2));
 for (const [ch, kbps] of [[1, 128], [2, 128], [2, 320]]) {
     const L = WL.subarray(0, NEX), R = ch == 2 ? WR.subarray(0, NEX) : null;
     const mp3 = encode(L, R, ch, kbps, 1152);
     const name = `wavexcerpt_${ch}_${kbps}.mp3`;
     fs.writeFileSync(path.join(OUT, name), mp3);
     cases.push({ corpus: 'wavexcerpt', channels: ch, kbps, nsamples: NEX, chunk: 1152, pcm_md5: pcmMd5(L, R), mp3_md5: md5(mp3), mp3_len: mp3.length, mp3_file: name });
-    const nfull = Math.floor(WL.length / 1152) * 1152;
-    const full = encode(WL.subarray(0, nfull), ch == 2 ? WR.subarray(0, nfull) : null, ch, kbps, 1152);
-    cases.push({ corpus: 'wavfull', channels: ch, kbps, nsamples: nfull, chunk: 1152, mp3_md5: md5(full), mp3_len: full.length });
+    const LF = WL.subarray(0, NFULL), RF = ch == 2 ? WR.subarray(0, NFULL) : null;
+    const full = encode(LF, RF, ch, kbps, 1152);
+    cases.push({ corpus: 'wavfull', channels: ch, kbps, nsamples: NFULL, chunk: 1152, pcm_md5: pcmMd5(LF, RF), mp3_md5: md5(full), mp3_len: full.length });
 }
 /* 2. synthetic corpora */
 const synth = [
