@@ -187,7 +187,7 @@ LHIP_DEV double athAdjust(const Tables& T, const PowBase& pb10, double a, double
     if (w < 0) w = 0.;
     u *= w;
     u += athFloor + o - p;
-    return v8_pow_from_parts(0.1 * u, pb10.t1, pb10.t2);
+    return v8_pow_base(pb10, 0.1 * u);
 }
 
 LHIP_DEV int sbgain(const GI& g, int w) {   // subblock_gain[w] without a dynamically indexed register array
@@ -464,56 +464,48 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     PH_MARK(L, PH_Q_MASK, tm_);
     const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
-    // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here).
-    // The previous values are only fetched when some band is cached.
     const int need_old = (m_cached != 0);
+    const float istep_f = Q.ipow20[g.global_gain];     // the Float32Array value itself; `istep` above is its f64 image
+    // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here); the two
+    // truncations of every line are q_floor_prod / q_floor_fma (lhip_math.h)
+    float xa[NPL], xb[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        xa[j] = 0.f; xb[j] = 0.f;
+        if (p < 576) { struct F2 { float x, y; }; const F2 xx = *(const F2*)(L.xrpow + p); xa[j] = xx.x; xb[j] = xx.y; }   // 8-byte aligned: p is even
+    }
+    int ra[NPL], rb[NPL];
+    q_floor_prod(xa, xb, istep_f, ra, rb);                                 // 0 <= x <= 8206: truncation == ToInt32
+    float aa[NPL], ab[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        aa[j] = Q.adj43[ra[j] < QT_N ? ra[j] : QT_N - 1]; ab[j] = Q.adj43[rb[j] < QT_N ? rb[j] : QT_N - 1];
+        if (may_big) {                                                     // rare: large quantized values
+            if (ra[j] >= QT_N) aa[j] = T.adj43[ra[j]];
+            if (rb[j] >= QT_N) ab[j] = T.adj43[rb[j]];
+        }
+    }
+    // no masking at the end of the spectrum: zero xrpow quantizes to (int)(0 + adj43[0]) = 0 (see above)
+    q_floor_fma(xa, xb, istep_f, aa, ab, vx, vy);
     if (!need_old && m_zo == 0) {
         // the common round (every bin-search round and most others): no cached band, no 0/1 shortcut
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             const int p = 2 * (lane + LHIP_NL * j);
-            float xa = 0.f, xb = 0.f;
-            if (p < 576) { struct F2 { float x, y; }; const F2 xx = *(const F2*)(L.xrpow + p); xa = xx.x; xb = xx.y; }
-            const double qa = (double)xa * istep, qb = (double)xb * istep;
-            const int ra = (int)qa, rb = (int)qb;                          // 0 <= x <= 8206: truncation == ToInt32
-            float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
-            if (may_big) {                                                 // rare: large quantized values
-                if (ra >= QT_N) aa = T.adj43[ra];
-                if (rb >= QT_N) ab = T.adj43[rb];
-            }
-            // no masking at the end of the spectrum: zero xrpow quantizes to (int)(0 + adj43[0]) = 0 (see above)
-            const int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
-            vx[j] = va; vy[j] = vb;
-            if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
+            if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)vx[j] | ((uint32_t)vy[j] << 16);
         }
     } else {
-        float xa[NPL], xb[NPL]; int sf[NPL]; uint32_t oldw[NPL];
+        // the previous values are only fetched when some band is cached
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             const int p = 2 * (lane + LHIP_NL * j);
-            xa[j] = 0.f; xb[j] = 0.f; sf[j] = 0; oldw[j] = 0;
-            if (p < 576) {
-                sf[j] = l2s[p];
-                struct F2 { float x, y; };
-                const F2 xx = *(const F2*)(L.xrpow + p);       // 8-byte aligned: p is even and xrpow is
-                xa[j] = xx.x; xb[j] = xx.y;
-                if (need_old) oldw[j] = *(const uint32_t*)(ix + p);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NPL; j++) {
-            const int p = 2 * (lane + LHIP_NL * j);
-            const double qa = (double)xa[j] * istep, qb = (double)xb[j] * istep;
-            const int ra = (int)qa, rb = (int)qb;
-            float aa = Q.adj43[ra < QT_N ? ra : QT_N - 1], ab = Q.adj43[rb < QT_N ? rb : QT_N - 1];
-            if (may_big) {
-                if (ra >= QT_N) aa = T.adj43[ra];
-                if (rb >= QT_N) ab = T.adj43[rb];
-            }
-            const int cached = (int)((m_cached >> sf[j]) & 1), zo = (int)((m_zo >> sf[j]) & 1);
-            int va = (int)(qa + (double)aa), vb = (int)(qb + (double)ab);
+            int sf = 0; uint32_t oldw = 0;
+            if (p < 576) { sf = l2s[p]; if (need_old) oldw = *(const uint32_t*)(ix + p); }
+            const int cached = (int)((m_cached >> sf) & 1), zo = (int)((m_zo >> sf) & 1);
+            int va = vx[j], vb = vy[j];
             if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
-            const int oa = (int)(oldw[j] & 0xffffu), ob = (int)(oldw[j] >> 16);
+            const int oa = (int)(oldw & 0xffffu), ob = (int)(oldw >> 16);
             va = cached ? oa : va;
             vb = cached ? ob : vb;
             vx[j] = va; vy[j] = vb;
@@ -739,7 +731,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         const int mr0 = (p < a1) ? m : 0, mr1 = (p >= a1 && p < a2) ? m : 0, mr2 = (p >= a2) ? m : 0;
         m0 = m0 > mr0 ? m0 : mr0; m1 = m1 > mr1 ? m1 : mr1; m2 = m2 > mr2 ? m2 : mr2;
     }
-    m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
+    { int mm[3] = {m0, m1, m2}; wave_max_n(mm); m0 = mm[0]; m1 = mm[1]; m2 = mm[2]; }
     // Data-driven length sums: every region publishes the pool offsets of its (up to three) candidate tables and
     // its row stride; a pair then costs three byte gathers whatever its region's table group is, and all regions
     // are handled in ONE pass.  Region r is planned (and later finished) by lane r, branch-free: there is no
@@ -803,12 +795,10 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     }
     // unpack to (A|B<<16), (C|N<<16) per region: wave totals stay below 2^16 (<= 288 pairs x 21 bits = 6048)
 #define FLD(A, R) ((uint32_t)(((A) >> (FB * (R))) & FM))
-    const int q0 = wave_sum((int)(FLD(accA, 0) | (FLD(accB, 0) << 16)));
-    const int q1 = wave_sum((int)(FLD(accC, 0) | (FLD(accN, 0) << 16)));
-    const int q2 = wave_sum((int)(FLD(accA, 1) | (FLD(accB, 1) << 16)));
-    const int q3 = wave_sum((int)(FLD(accC, 1) | (FLD(accN, 1) << 16)));
-    const int q4 = wave_sum((int)(FLD(accA, 2) | (FLD(accB, 2) << 16)));
-    const int q5 = wave_sum((int)(FLD(accC, 2) | (FLD(accN, 2) << 16)));
+    int qq[6] = {(int)(FLD(accA, 0) | (FLD(accB, 0) << 16)), (int)(FLD(accC, 0) | (FLD(accN, 0) << 16)), (int)(FLD(accA, 1) | (FLD(accB, 1) << 16)),
+                 (int)(FLD(accC, 1) | (FLD(accN, 1) << 16)), (int)(FLD(accA, 2) | (FLD(accB, 2) << 16)), (int)(FLD(accC, 2) | (FLD(accN, 2) << 16))};
+    wave_sum_n(qq);                       // six packed sums reduced side by side
+    const int q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3], q4 = qq[4], q5 = qq[5];
 #undef FLD
     PH_MARK(L, PH_C_SUMS, tm_);
     // finish (Takehiro.js count_bit_noESC / _from2 / _from3 / count_bit_ESC tie-breaking): lane r picks the cheapest
@@ -996,7 +986,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
             noise = noise / (double)L.xmin[sfb];
             L.distort[sfb] = (float)noise;
-            noise = v8_log10(noise > 1E-20 ? noise : 1E-20);
+            noise = v8_log10_pos(noise > 1E-20 ? noise : 1E-20);      // operand >= 1e-20 (a NaN compares false and becomes 1e-20 too)
             if (use_pn) L.pn_noise_log[sfb] = (float)noise;
         }
         if (noise > 0.0) {
@@ -1284,6 +1274,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         best.max_noise = unid(best.max_noise); best.over_count = uni(best.over_count); best.over_SSD = uni(best.over_SSD); best.bits = uni(best.bits);
 #endif
         int asg = 0;
+        const int cnt1_seen = pn.sfb_count1;                  // what this evaluation's 0/1 shortcut is decided with
         const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site
         // memo of the bin search: collected in LDS and written to the side record in one burst when the search ends (a global
         // store per step would sit in front of every later memory wait of the wave -- the VMEM counter retires in order)
@@ -1328,7 +1319,17 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             w.part2_3_length = nBits;
             if (nBits > huff_bits && w.global_gain <= maxggain) { w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
-            if (best.over_count == 0) { st = ST_B; continue; }   // the reference re-counts at the same gain first
+            if (best.over_count == 0) {
+                // The reference's second loop (Quantize.js:1004-1013) starts by counting again at the SAME gain.  That evaluation
+                // has the same inputs as the one just made -- spectrum, gain, scalefactors, the noise cache (only calc_noise
+                // writes it) -- except PrevNoise.sfb_count1, which the one just made has rewritten and which steers the 0/1
+                // shortcut of quantize_xrpow.  If it was rewritten with the value it had, the second evaluation is the first
+                // one again (same bits, same assignments, same spectrum) and is not made.
+                st = ST_B;
+                if (pn.sfb_count1 != cnt1_seen) continue;
+                if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
+                if (w.global_gain > maxggain) break;
+            }
         } else {   // ST_B
             w.part2_3_length = nBits;
             if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }

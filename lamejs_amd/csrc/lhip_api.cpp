@@ -193,6 +193,17 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
 }
 
+// op 8: records of 21 doubles [istep, xa0..4, xb0..4, adj_a0..4, adj_b0..4] (f32 values) -> [0, floor(x istep) x 10, floor(x istep + adj) x 10]
+LHIP_DEV void math_op8(const double* in, double* out) {
+    float xa[5], xb[5], ja[5], jb[5]; int ra[5], rb[5], va[5], vb[5];
+    const float istep = (float)in[0];
+    for (int k = 0; k < 5; k++) { xa[k] = (float)in[1 + k]; xb[k] = (float)in[6 + k]; ja[k] = (float)in[11 + k]; jb[k] = (float)in[16 + k]; }
+    q_floor_prod(xa, xb, istep, ra, rb);
+    q_floor_fma(xa, xb, istep, ja, jb, va, vb);
+    out[0] = 0;
+    for (int k = 0; k < 5; k++) { out[1 + k] = ra[k]; out[6 + k] = rb[k]; out[11 + k] = va[k]; out[16 + k] = vb[k]; }
+}
+
 // ===========================================================================================
 // kernel launch layer
 // ===========================================================================================
@@ -331,17 +342,19 @@ static void kt_collect() {
 
 __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase pb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (op == 8) { if (21 * i + 21 <= n) math_op8(in + 21 * i, out + 21 * i); return; }
     if (i >= n) return;
     const double x = in[i];
     double r = 0;
     switch (op) {
         case 0: r = v8_log10(x); break;
-        case 1: r = v8_pow_from_parts(x, pb.t1, pb.t2); break;
+        case 1: r = v8_pow_base(pb, x); break;
         case 2: r = d_sqrt(x); break;
         case 3: r = 1.0 / x; break;
         case 4: r = (double)(float)x; break;
         case 5: r = (double)js_toint32(x); break;
         case 6: r = x / 3.0 + x * 0.1; break;
+        case 7: r = v8_log10_pos(x); break;
     }
     out[i] = r;
 }
@@ -1139,15 +1152,17 @@ int lhip_debug_math(int op, const double* in, double* out, size_t n) {
     return 0;
 #else
     const PowBase pb = pow_log2_parts(10.0);
+    if (op == 8) { for (size_t i = 0; 21 * i + 21 <= n; i++) math_op8(in + 21 * i, out + 21 * i); return 0; }
     for (size_t i = 0; i < n; i++) {
         const double x = in[i];
         switch (op) {
             case 0: out[i] = v8_log10(x); break;
-            case 1: out[i] = v8_pow_from_parts(x, pb.t1, pb.t2); break;
+            case 1: out[i] = v8_pow_base(pb, x); break;
             case 2: out[i] = d_sqrt(x); break;
             case 3: out[i] = 1.0 / x; break;
             case 4: out[i] = (double)(float)x; break;
             case 5: out[i] = (double)js_toint32(x); break;
+            case 7: out[i] = v8_log10_pos(x); break;
             default: out[i] = x / 3.0 + x * 0.1; break;
         }
     }

@@ -31,15 +31,18 @@ LHIP_DEV double d_trunc_lo(double x) { return d_make(d_hi(x), 0u); }
 
 // ECMAScript ToInt32 for the values this path produces (finite, |x| < 2^31 in practice).
 LHIP_DEV int32_t js_toint32(double d) {
-    if (!(d == d)) return 0;
-    if (d >= -2147483648.0 && d <= 2147483647.0) return (int32_t)d;
-    // out-of-range: wrap modulo 2^32 (never reached by in-envelope inputs; kept for fidelity)
-    if (d_abs(d) > 1.0e300) return 0;
-    double t = (d < 0) ? -(double)(uint64_t)(-d) : (double)(uint64_t)d;
-    double q = t / 4294967296.0;
-    double fl = (double)(int64_t)q; if (fl > q) fl -= 1.0;
-    double m = t - fl * 4294967296.0;
-    return (int32_t)(uint32_t)m;
+    if (d >= -2147483648.0 && d <= 2147483647.0) return (int32_t)d;        // the only case frame material produces (NaN compares false)
+    // ECMAScript ToInt32 for every other double: the integer part modulo 2^32, from the bits (NaN and the infinities give 0)
+    const uint32_t hi = d_hi(d), lo = d_lo(d);
+    const int32_t e = (int32_t)((hi >> 20) & 0x7ffu);
+    if (e == 0x7ff) return 0;
+    const uint64_t mant = (((uint64_t)(hi & 0x000fffffu) | 0x00100000ull) << 32) | lo;     // |d| = mant * 2^(e - 1075), e >= 1054 here
+    const int32_t sh = e - 1075;
+    uint32_t m = 0;
+    if (sh >= 32) m = 0;
+    else if (sh >= 0) m = (uint32_t)(mant << sh);
+    else m = (uint32_t)(mant >> (-sh));
+    return (int32_t)((hi >> 31) ? (0u - m) : m);
 }
 
 // natural logarithm, fdlibm method: x = 2^k (1+f); log(1+f) = f - s*(f - R(s^2)) ..., Remez poly
@@ -119,8 +122,107 @@ LHIP_DEV double v8_log10(double x) {
     return z + y * log10_2hi;
 }
 
+// ---- the two truncations of quantize_lines_xrpow (Takehiro.js:125-165) -----------------------------------------------------
+//     rx = (int)(x * istep)                 x, istep: Float32Array values, the product is formed in f64 (exact: 24 x 24 bits)
+//     ix = (int)(x * istep + adj43[rx])     adj43: Float32Array value in (0, 0.5); one f64 rounding
+// with 0 <= x * istep <= 8206 (count_bits' guard).  On the device they are ONE f32 instruction each under round-toward-zero
+// (v_mul_f32 / v_fma_f32, then the truncating v_cvt_i32_f32) instead of f64 conversions, multiply and add (quarter-rate ops):
+//   * floor(trunc24(p)) == floor(p) for an exact value 0 <= p < 2^24, because floor(p) is itself a 24-bit number <= p;
+//   * the exact sum S = x * istep + adj is a multiple of g = min(ulp(x) ulp(istep), ulp(adj)) >= 2^-25 resp. 2^(E - 46) (E the
+//     exponent sum), while the f64 rounding error of S is at most 2^(E + 2 - 53) and at most 2^-40: smaller than g, so RN64(S)
+//     cannot reach the next integer above S unless S is that integer; hence floor(RN64(S)) == floor(S) == floor(trunc24(S)).
+// FP_ROUND's single-precision field is switched inside the asm statement, so no other instruction can see the changed mode (the
+// f64 field is untouched).  Host builds evaluate the reference's f64 expressions literally; tests: device math op 8.
+template <int N> LHIP_DEV void q_floor_prod(const float (&xa)[N], const float (&xb)[N], float istep, int (&ra)[N], int (&rb)[N]) {
+#ifdef LHIP_HOSTSIM
+    for (int j = 0; j < N; j++) { ra[j] = (int)((double)xa[j] * (double)istep); rb[j] = (int)((double)xb[j] * (double)istep); }
+#else
+    static_assert(N == 5, "device form is written for 5 pairs per lane");
+    float a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\t"
+                 "v_mul_f32 %0, %10, %20\n\tv_mul_f32 %1, %11, %20\n\tv_mul_f32 %2, %12, %20\n\tv_mul_f32 %3, %13, %20\n\tv_mul_f32 %4, %14, %20\n\t"
+                 "v_mul_f32 %5, %15, %20\n\tv_mul_f32 %6, %16, %20\n\tv_mul_f32 %7, %17, %20\n\tv_mul_f32 %8, %18, %20\n\tv_mul_f32 %9, %19, %20\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4)
+                 : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xa[4]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(xb[4]), "v"(istep));
+    ra[0] = (int)a0; ra[1] = (int)a1; ra[2] = (int)a2; ra[3] = (int)a3; ra[4] = (int)a4;
+    rb[0] = (int)b0; rb[1] = (int)b1; rb[2] = (int)b2; rb[3] = (int)b3; rb[4] = (int)b4;
+#endif
+}
+template <int N> LHIP_DEV void q_floor_fma(const float (&xa)[N], const float (&xb)[N], float istep, const float (&ja)[N], const float (&jb)[N],
+                                           int (&va)[N], int (&vb)[N]) {
+#ifdef LHIP_HOSTSIM
+    for (int j = 0; j < N; j++) {
+        va[j] = (int)((double)xa[j] * (double)istep + (double)ja[j]);
+        vb[j] = (int)((double)xb[j] * (double)istep + (double)jb[j]);
+    }
+#else
+    static_assert(N == 5, "device form is written for 5 pairs per lane");
+    float a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\t"
+                 "v_fma_f32 %0, %10, %20, %21\n\tv_fma_f32 %1, %11, %20, %22\n\tv_fma_f32 %2, %12, %20, %23\n\tv_fma_f32 %3, %13, %20, %24\n\tv_fma_f32 %4, %14, %20, %25\n\t"
+                 "v_fma_f32 %5, %15, %20, %26\n\tv_fma_f32 %6, %16, %20, %27\n\tv_fma_f32 %7, %17, %20, %28\n\tv_fma_f32 %8, %18, %20, %29\n\tv_fma_f32 %9, %19, %20, %30\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4)
+                 : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xa[4]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(xb[4]), "v"(istep),
+                   "v"(ja[0]), "v"(ja[1]), "v"(ja[2]), "v"(ja[3]), "v"(ja[4]), "v"(jb[0]), "v"(jb[1]), "v"(jb[2]), "v"(jb[3]), "v"(jb[4]));
+    va[0] = (int)a0; va[1] = (int)a1; va[2] = (int)a2; va[3] = (int)a3; va[4] = (int)a4;
+    vb[0] = (int)b0; vb[1] = (int)b1; vb[2] = (int)b2; vb[3] = (int)b3; vb[4] = (int)b4;
+#endif
+}
+
+// v8_log10 for positive normal operands, +inf and NaN (x >= 2^-1022 or NaN) without data-dependent branches: in a wave program
+// every two-sided `if` on a per-lane value costs exec-mask bookkeeping on the (per-CU) scalar unit and both sides run anyway.
+// Same operations in the same order as v8_log10 / v8_log above -- the four return expressions of v8_log's main path and the two
+// of its short series (|f| < 2^-20 after range reduction; the f == 0 returns are the short-series expressions with R = 0, bit
+// for bit) -- selected per lane.  Zero, negative and subnormal operands are NOT handled (callers clamp: calc_noise passes
+// max(noise, 1e-20)).  Bit-identical to v8_log10 on its domain (tests: device math op 7, 60 M operands on the host).
+LHIP_DEV double v8_log10_pos(double x) {
+    const double ivln10 = 4.34294481903251816668e-01, log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int32_t hx = (int32_t)d_hi(x);
+    const bool infnan = hx >= 0x7ff00000;
+    // log10: x = 2^k10 * m, operand of log in [0.5, 2)
+    const int32_t k10 = (hx >> 20) - 1023;
+    const int32_t i10 = (int32_t)(((uint32_t)k10 & 0x80000000u) >> 31);
+    const double y = (double)(k10 + i10);
+    hx = (hx & 0x000fffff) | ((0x3ff - i10) << 20);
+    // log of that operand
+    int32_t k = (hx >> 20) - 1023;                          // -1 or 0
+    hx &= 0x000fffff;
+    const int32_t i = (hx + 0x95f64) & 0x100000;
+    const double xm = d_make((uint32_t)(hx | (i ^ 0x3ff00000)), d_lo(x));
+    k += (i >> 20);                                         // -1, 0, 1
+    const double f = xm - 1.0;
+    const bool small = (0x000fffff & (2 + hx)) < 3;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const int32_t i2 = (hx - 0x6147a) | (0x6b851 - hx);
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double ff = f * f;
+    const double hfsq = 0.5 * ff;
+    const double Rs = ff * (0.5 - 0.33333333333333333 * f);
+    const bool big = i2 > 0, k0 = k == 0;
+    const double v = s * (big ? hfsq + R : f - R);
+    const double dl = dk * ln2_lo, dh = dk * ln2_hi;
+    // k == 0:  f - R' with R' = Rs | hfsq - v | v ;  k != 0:  dh - ((R'' ) - f) with R'' = Rs - dl | hfsq - (v + dl) | v - dl
+    const double r0 = small ? Rs : (big ? hfsq - v : v);
+    const double r1 = small ? Rs - dl : (big ? hfsq - (v + dl) : v - dl);
+    const double lg = k0 ? f - r0 : dh - (r1 - f);
+    const double zz = y * log10_2lo + ivln10 * lg;
+    const double res = zz + y * log10_2hi;
+    return infnan ? x + x : res;
+}
+
 // ---- pow(x, y), x > 0 finite normal (x == 10 on this path), |y| < 2^31 ----
-struct PowBase { double t1, t2; };   // log2(x) = t1 + t2, t1 with a zeroed low word
+struct PowBase { double t1, t2, x; };   // log2(x) = t1 + t2, t1 with a zeroed low word; the base itself (x > 1, finite) for the special cases of y
 
 // x-dependent half (host side, once per table set).  Valid for positive normal x, any y with |y| <= 2^31.
 static inline PowBase pow_log2_parts(double x) {
@@ -167,8 +269,28 @@ static inline PowBase pow_log2_parts(double x) {
     pb.t1 = (((z_h + z_l) + dp_h[k]) + t);
     pb.t1 = mk(hi_of(pb.t1), 0);
     pb.t2 = z_l - (((pb.t1 - t) - dp_h[k]) - z_h);
+    pb.x = x;
     (void)lo_of;
     return pb;
+}
+
+LHIP_DEV double v8_pow_from_parts(double y, double t1, double t2);
+// Math.pow(x, y) for the base the parts were made from (finite, x > 1): the special cases of y that the engine answers before its
+// general algorithm (ieee754::pow: y = +-0, NaN, +-inf, +-1, 2, 0.5, |y| > 2^31), then the general algorithm.
+LHIP_DEV double v8_pow_base(const PowBase& pb, double y) {
+    const int32_t hy = (int32_t)d_hi(y);
+    const uint32_t ly = d_lo(y);
+    const int32_t iy = hy & 0x7fffffff;
+    if ((iy | (int32_t)ly) == 0) return 1.0;
+    if (iy > 0x7ff00000 || (iy == 0x7ff00000 && ly != 0)) return pb.x + y;                 // NaN
+    if (ly == 0) {
+        if (iy == 0x7ff00000) return hy >= 0 ? y : 0.0;                                    // |x| > 1: +inf -> inf, -inf -> 0
+        if (iy == 0x3ff00000) return hy < 0 ? 1.0 / pb.x : pb.x;
+        if (hy == 0x40000000) return pb.x * pb.x;
+        if (hy == 0x3fe00000) return d_sqrt(pb.x);
+    }
+    if (iy > 0x41e00000) return hy > 0 ? 1.0e300 * 1.0e300 : 1.0e-300 * 1.0e-300;          // |y| > 2^31 with x > 1: overflow / underflow
+    return v8_pow_from_parts(y, pb.t1, pb.t2);
 }
 
 // y-dependent half: 2^(y * (t1 + t2)) with the engine's exact operation order (including its

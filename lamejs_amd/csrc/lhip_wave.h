@@ -9,6 +9,8 @@ namespace lhip {
 struct Wave { int lane; };
 LHIP_DEV void wave_sync() {}
 LHIP_DEV int wave_sum(int v) { return v; }
+template <int N> LHIP_DEV void wave_sum_n(int (&v)[N]) { (void)v; }
+template <int N> LHIP_DEV void wave_max_n(int (&v)[N]) { (void)v; }
 LHIP_DEV int wave_max(int v) { return v; }
 LHIP_DEV int wave_min(int v) { return v; }
 LHIP_DEV int wave_or(int v) { return v; }
@@ -167,7 +169,11 @@ struct Wave { int lane; };
 LHIP_DEV void wave_sync() { uint64_t a[64]; wsim::exchange(1, 0, a); }
 LHIP_DEV void wg_barrier() { wsim::block_barrier(); }                  // __syncthreads of a multi-wave workgroup
 LHIP_DEV int wave_sum(int v) { uint64_t a[64]; wsim::exchange(2, (uint64_t)(uint32_t)v, a); int s = 0; for (int l = 0; l < 64; l++) s += (int)(uint32_t)a[l]; return s; }
+template <int N> LHIP_DEV void wave_sum_n(int (&v)[N]);
+template <int N> LHIP_DEV void wave_max_n(int (&v)[N]);
 LHIP_DEV int wave_max(int v) { uint64_t a[64]; wsim::exchange(3, (uint64_t)(uint32_t)v, a); int m = (int)(uint32_t)a[0]; for (int l = 1; l < 64; l++) if ((int)(uint32_t)a[l] > m) m = (int)(uint32_t)a[l]; return m; }
+template <int N> LHIP_DEV void wave_sum_n(int (&v)[N]) { for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]); }
+template <int N> LHIP_DEV void wave_max_n(int (&v)[N]) { for (int i = 0; i < N; i++) v[i] = wave_max(v[i]); }
 LHIP_DEV int wave_min(int v) { uint64_t a[64]; wsim::exchange(4, (uint64_t)(uint32_t)v, a); int m = (int)(uint32_t)a[0]; for (int l = 1; l < 64; l++) if ((int)(uint32_t)a[l] < m) m = (int)(uint32_t)a[l]; return m; }
 LHIP_DEV int wave_or(int v) { uint64_t a[64]; wsim::exchange(5, (uint64_t)(uint32_t)v, a); uint32_t m = 0; for (int l = 0; l < 64; l++) m |= (uint32_t)a[l]; return (int)m; }
 LHIP_DEV uint64_t wave_or64(uint64_t v) { uint64_t a[64]; wsim::exchange(6, v, a); uint64_t m = 0; for (int l = 0; l < 64; l++) m |= a[l]; return m; }
@@ -220,12 +226,43 @@ LHIP_DEV void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-LHIP_DEV int wave_sum(int v) { return __reduce_add_sync(~0ull, v); }
-LHIP_DEV int wave_max(int v) { return __reduce_max_sync(~0ull, v); }
-LHIP_DEV int wave_min(int v) { return __reduce_min_sync(~0ull, v); }
-LHIP_DEV int wave_or(int v) { return (int)__reduce_or_sync(~0ull, (unsigned)v); }
+// Integer reductions over the 64 lanes (all lanes active: the kernels call them under wave-uniform control flow): four DPP row
+// shifts leave each row's total in its last lane, row_bcast:15 / row_bcast:31 carry the totals into the later rows, lane 63 ends
+// up with the wave's total, one v_readlane moves it to an SGPR (wave-uniform for the compiler).  Seven VALU instructions and no
+// scalar code -- HIP's __reduce_*_sync wrap the same DPP steps in mask checks (~20 SALU instructions and several branches each),
+// and the scalar unit is shared by the whole CU.  `IDENT` is what a lane receives when its DPP source does not exist.
+#define LHIP_DPP_REDUCE(OP, IDENT)                                                                     \
+    int x = v;                                                                                         \
+    x = OP(x, __builtin_amdgcn_update_dpp(IDENT, x, 0x111, 0xf, 0xf, false));   /* row_shr:1 */        \
+    x = OP(x, __builtin_amdgcn_update_dpp(IDENT, x, 0x112, 0xf, 0xf, false));   /* row_shr:2 */        \
+    x = OP(x, __builtin_amdgcn_update_dpp(IDENT, x, 0x114, 0xf, 0xf, false));   /* row_shr:4 */        \
+    x = OP(x, __builtin_amdgcn_update_dpp(IDENT, x, 0x118, 0xf, 0xf, false));   /* row_shr:8 */        \
+    x = OP(x, __builtin_amdgcn_update_dpp(IDENT, x, 0x142, 0xa, 0xf, false));   /* row_bcast:15 -> rows 1, 3 */ \
+    x = OP(x, __builtin_amdgcn_update_dpp(IDENT, x, 0x143, 0xc, 0xf, false));   /* row_bcast:31 -> rows 2, 3 */ \
+    return __builtin_amdgcn_readlane(x, 63);
+LHIP_DEV int dpp_op_add(int a, int b) { return a + b; }
+LHIP_DEV int dpp_op_max(int a, int b) { return a > b ? a : b; }
+LHIP_DEV int dpp_op_min(int a, int b) { return a < b ? a : b; }
+LHIP_DEV int dpp_op_or(int a, int b) { return a | b; }
+// N independent reductions side by side: step s of every value before step s + 1 of any, so that the two wait states a DPP read
+// needs after the VALU write of its source are filled by the other chains instead of s_nop (which costs an issue slot like any
+// other instruction).
+#define LHIP_DPP_REDUCE_N(OP, IDENT)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = OP(v[i], __builtin_amdgcn_update_dpp(IDENT, v[i], 0x111, 0xf, 0xf, false)); \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = OP(v[i], __builtin_amdgcn_update_dpp(IDENT, v[i], 0x112, 0xf, 0xf, false)); \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = OP(v[i], __builtin_amdgcn_update_dpp(IDENT, v[i], 0x114, 0xf, 0xf, false)); \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = OP(v[i], __builtin_amdgcn_update_dpp(IDENT, v[i], 0x118, 0xf, 0xf, false)); \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = OP(v[i], __builtin_amdgcn_update_dpp(IDENT, v[i], 0x142, 0xa, 0xf, false)); \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = OP(v[i], __builtin_amdgcn_update_dpp(IDENT, v[i], 0x143, 0xc, 0xf, false)); \
+    _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = __builtin_amdgcn_readlane(v[i], 63);
+template <int N> LHIP_DEV void wave_sum_n(int (&v)[N]) { LHIP_DPP_REDUCE_N(dpp_op_add, 0) }
+template <int N> LHIP_DEV void wave_max_n(int (&v)[N]) { LHIP_DPP_REDUCE_N(dpp_op_max, (int)0x80000000) }
+LHIP_DEV int wave_sum(int v) { LHIP_DPP_REDUCE(dpp_op_add, 0) }
+LHIP_DEV int wave_max(int v) { LHIP_DPP_REDUCE(dpp_op_max, (int)0x80000000) }
+LHIP_DEV int wave_min(int v) { LHIP_DPP_REDUCE(dpp_op_min, 0x7fffffff) }
+LHIP_DEV int wave_or(int v) { LHIP_DPP_REDUCE(dpp_op_or, 0) }
 LHIP_DEV uint64_t wave_or64(uint64_t v) {
-    const unsigned lo = __reduce_or_sync(~0ull, (unsigned)v), hi = __reduce_or_sync(~0ull, (unsigned)(v >> 32));
+    const unsigned lo = (unsigned)wave_or((int)(unsigned)v), hi = (unsigned)wave_or((int)(unsigned)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
 // Float reductions go through the device library's DPP wavefront reductions: the result lands in an SGPR,
@@ -236,7 +273,7 @@ LHIP_DEV uint64_t wave_or64(uint64_t v) {
 LHIP_DEV float wave_maxf(float v) { return __ockl_wfred_max_f32(v); }
 // maximum of values that are all >= +0 (no NaN, no -0): IEEE order == integer order of the bit patterns, and the integer
 // reduction is one fused DPP max per step where the f32 one spends three more on canonicalising its operands
-LHIP_DEV float wave_maxf_pos(float v) { return __int_as_float(__reduce_max_sync(~0ull, __float_as_int(v))); }
+LHIP_DEV float wave_maxf_pos(float v) { return __int_as_float(wave_max(__float_as_int(v))); }
 LHIP_DEV double wave_maxd(double v) { return __ockl_wfred_max_f64(v); }
 // tree sum: NOT order-exact; only for order-insensitive decisions
 LHIP_DEV double wave_sumd(double v) { return __ockl_wfred_add_f64(v); }

@@ -588,6 +588,7 @@ void lo_math(int op, const double* in, double* out, size_t n) {
             case 3: out[i] = 1.0 / x; break;
             case 4: out[i] = (double)(float)x; break;
             case 5: out[i] = (double)js_toint32(x); break;
+            case 7: out[i] = v8_log10(x); break;      /* the device's branch-free variant must equal plain log10 on its domain */
             default: out[i] = x / 3.0 + x * 0.1; break;
         }
     }

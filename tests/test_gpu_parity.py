@@ -33,23 +33,75 @@ def _encode(ch, kbps, L, R, chunk, sr=44100):
     return out
 
 
+def _math_cases(n=400000):
+    """Operands per device-math op, including the edge classes the frame material never produces (subnormals, zeros, infinities,
+    NaN, negative operands of log10, |x| beyond 2^31 / 2^53 for ToInt32, pow(10, y) that overflows / underflows to subnormals)."""
+    rng = np.random.default_rng(7)
+    pos = np.exp((rng.random(n) - 0.5) * 120.0)
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.uint64).view(np.float64)
+    sub = bits(rng.integers(1, 1 << 52, 4000, dtype=np.uint64))                                   # positive subnormals
+    near1 = bits((np.uint64(0x3FF) << np.uint64(52)) + rng.integers(0, 1 << 33, 20000, dtype=np.uint64) - np.uint64(1 << 32))   # |x - 1| tiny: the short log series
+    anyf = bits(rng.integers(0, 1 << 63, 60000, dtype=np.uint64) | (rng.integers(0, 2, 60000, dtype=np.uint64) << np.uint64(63)))  # any bit pattern (NaNs, infs included)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 2.0 ** 31, -(2.0 ** 31), 2.0 ** 31 - 1,
+                        2.0 ** 32, 2.0 ** 32 + 5, -(2.0 ** 32) - 7, 2.0 ** 53, 2.0 ** 63, -(2.0 ** 63), 1e300, -1e300, 0.5, 1.5, 2.5, -0.5, -1.5, 4294967295.5, 308.25, -323.3, 400.0, -400.0])
+    big = (rng.random(40000) - 0.5) * 2.0 ** rng.integers(20, 80, 40000)
+    cases = {0: np.concatenate([pos, sub, near1, anyf, special]),                               # log10
+             1: np.concatenate([(rng.random(n) - 0.5) * 60.0, (rng.random(40000) - 0.5) * 700.0, special, sub]),   # pow(10, y): into overflow / subnormal results
+             2: np.concatenate([pos, sub, special[special >= 0]]),                             # sqrt
+             3: np.concatenate([pos * np.where(rng.random(n) < 0.5, -1, 1), sub, special]),     # 1/x
+             4: np.concatenate([pos * 1e-3, sub, anyf, special, pos * 1e38, pos * 1e-42]),      # f32 rounding incl. f32 overflow / subnormal results
+             5: np.concatenate([(rng.random(n) - 0.5) * 1e6, big, special, anyf]),              # ToInt32 incl. |x| >= 2^31
+             6: np.concatenate([pos, special]),
+             7: np.concatenate([pos, near1, bits(rng.integers(1 << 52, 0x7FF << 52, 200000, dtype=np.uint64)), np.array([np.inf, np.nan, 1.0, 2.2250738585072014e-308, 1e-20, 1.7976931348623157e308])])}
+    return cases
+
+
 def test_device_math_matches_v8(lib):
-    """log10 / pow(10,.) / sqrt / division / f32 rounding / no-FMA on the device vs the pinned oracle math."""
+    """log10 / pow(10,.) / sqrt / division / f32 rounding / ToInt32 / no-FMA on the device vs the pinned oracle math, bit for bit,
+    including every special-operand branch (op 7: the branch-free log10 of the quantizer on its domain, x >= 2^-1022 | inf | NaN)."""
     import oracle_py
     o = oracle_py._load()
     o.lo_math.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-    rng = np.random.default_rng(7)
-    n = 400000
-    pos = np.exp((rng.random(n) - 0.5) * 120.0)
-    cases = {0: pos, 1: (rng.random(n) - 0.5) * 60.0, 2: pos, 3: pos * np.where(rng.random(n) < 0.5, -1, 1),
-             4: pos * 1e-3, 5: (rng.random(n) - 0.5) * 1e6, 6: pos}
-    for op, x in cases.items():
+    for op, x in _math_cases().items():
         x = np.ascontiguousarray(x, dtype=np.float64)
+        n = len(x)
         a = np.empty(n); b = np.empty(n)
         assert lib.lhip_debug_math(op, x.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n) == 0
         o.lo_math(op, x.ctypes.data, b.ctypes.data, n)
-        bad = np.nonzero(a.view(np.uint64) != b.view(np.uint64))[0]
-        assert bad.size == 0, f"op {op}: {bad.size} mismatches, first x={x[bad[0]]!r} gpu={a[bad[0]]!r} ref={b[bad[0]]!r}"
+        nan_both = np.isnan(a) & np.isnan(b)             # NaN payloads are not part of the contract (JS has one NaN)
+        bad = np.nonzero((a.view(np.uint64) != b.view(np.uint64)) & ~nan_both)[0]
+        assert bad.size == 0, f"op {op}: {bad.size} mismatches, first x={x[bad[0]]!r} ({x[bad[0]].hex()}) gpu={a[bad[0]]!r} ref={b[bad[0]]!r}"
+
+
+def test_device_quantize_truncations(lib):
+    """quantize_lines_xrpow's two truncations, (int)(x istep) and (int)(x istep + adj43[.]) in f64 (Takehiro.js:125-165), are ONE f32
+    instruction each under round-toward-zero on the device (lhip_math.h q_floor_prod / q_floor_fma).  2.1 M operand triples,
+    a third of them constructed so that x istep + adj lands within a few f32 ulps of an integer (where the rounding mode decides)."""
+    rng = np.random.default_rng(11)
+    nrec = 100000
+    rec = np.zeros((nrec, 21))
+    istep = (2.0 ** (rng.random(nrec) * 50 - 10)).astype(np.float32)
+    tgt = rng.random((nrec, 10)) * np.where(rng.random((nrec, 10)) < 0.5, 8206.0, 40.0)          # wanted x * istep
+    adj = (0.25 + 0.25 * rng.random((nrec, 10))).astype(np.float32)
+    near = rng.random((nrec, 10)) < 0.35
+    k = np.floor(tgt) + 1.0
+    tgt = np.where(near, k - adj.astype(np.float64) + (rng.integers(-3, 4, (nrec, 10)) * np.spacing(np.maximum(k, 1).astype(np.float32)).astype(np.float64) * 0.5), tgt)
+    x = (np.maximum(tgt, 0) / istep[:, None].astype(np.float64)).astype(np.float32)
+    keep = (x.astype(np.float64) * istep[:, None].astype(np.float64)) <= 8206.0
+    x = np.where(keep, x, np.float32(0))
+    rec[:, 0] = istep; rec[:, 1:11] = x; rec[:, 11:21] = adj
+    flat = np.ascontiguousarray(rec.reshape(-1))
+    out = np.empty_like(flat)
+    assert lib.lhip_debug_math(8, flat.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), flat.size) == 0
+    out = out.reshape(nrec, 21)
+    p = x.astype(np.float64) * istep[:, None].astype(np.float64)                                 # exact (24 x 24 bits)
+    want_r = np.floor(p)
+    want_v = np.floor(p + adj.astype(np.float64))                                                # one f64 rounding, as the reference
+    assert np.array_equal(out[:, 1:11], want_r), "floor(x * istep) differs"
+    bad = np.argwhere(out[:, 11:21] != want_v)
+    assert bad.size == 0, f"{len(bad)} mismatches, first: x={x[tuple(bad[0])]!r} istep={istep[bad[0][0]]!r} adj={adj[tuple(bad[0])]!r} got={out[bad[0][0], 11 + bad[0][1]]} want={want_v[tuple(bad[0])]}"
+    frac = (p + adj) - np.floor(p + adj)
+    assert ((frac < 1e-4) | (frac > 1 - 1e-4)).sum() > 100000          # the adversarial third really is near integers
 
 
 def test_gpu_matches_reference_goldens(lib, golden):

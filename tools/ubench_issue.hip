@@ -4,9 +4,13 @@
 // the chip's ceiling (4 cycles per wave64 VALU instruction) or 39 % (2 cycles)?  The MI355X guide measures v_fma_f32 at 2
 // cycles; g_quant's mix is f64 arithmetic, conversions, 32-bit integer/logic, DPP moves and LDS gathers.  Every class below is
 // run as an unrolled block of INDEPENDENT instructions (8 accumulator chains, so dependent-issue latency is not what is
-// measured) by W waves per SIMD on every CU, and reported as
-//     cycles per wave-instruction per SIMD = elapsed shader cycles * 1 / (W * instructions per wave)
-// with the shader clock taken from s_memtime inside the kernel (not an assumed 2.4 GHz).
+// measured) by W waves per SIMD (grid = 4 W waves x CUs: W = 1, 2, 4 as workgroups of 256 W threads, W = 5, 6, 8 as twice as many
+// workgroups of 128 W threads), each launch long enough (2-45 ms) for the clock to settle, and reported in WALL-CLOCK terms from
+// hipEvents around the launch:
+//     G wave-instructions/s over the whole chip, and shader cycles per wave-instruction per SIMD (clock = s_memtime ticks per
+//     s_memrealtime microsecond inside the kernel: s_memtime ticks are shader cycles, the real-time counter runs at 100 MHz).
+// (The per-workgroup in-kernel duration is NOT used for rates: workgroups of one launch do not all run concurrently -- with W >= 2
+// the launch takes up to 3x one workgroup's duration -- so only the launch's wall time says what the chip sustained.)
 //
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/_build/ubench_issue tools/ubench_issue.hip ; run: tools/_build/ubench_issue [json]
 #include <hip/hip_runtime.h>
@@ -18,7 +22,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-enum { ITER = 2000, UNROLL = 32 };   // instructions per wave = ITER * UNROLL (* ops per macro)
+enum { ITER = 30000, UNROLL = 32 };   // instructions per wave = ITER * UNROLL (* ops per macro)
 
 // 8 independent 32-bit chains a0..a7, 8 independent 64-bit chains d0..d7
 #define REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
@@ -35,16 +39,18 @@ enum { ITER = 2000, UNROLL = 32 };   // instructions per wave = ITER * UNROLL (*
         __syncthreads();                                                                                     \
         const unsigned la = (threadIdx.x & 63) * 4;   /* conflict-free LDS address */                        \
         (void)la; (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)s5; (void)s6; (void)s7;                                                  \
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                      \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                          \
         for (int it = 0; it < iters; it++) {
 #define KERNEL_END()                                                                                         \
         }                                                                                                    \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                          \
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                      \
         unsigned r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7;                           \
         r ^= __float_as_uint(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);                                        \
         r ^= (unsigned)__double_as_longlong(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);                         \
         if (r == 0x12345678u) out[0] = r;                                                                    \
-        if (threadIdx.x == 0) atomicMax(cyc + 0, t1 - t0);                                                   \
+        if (threadIdx.x == 0) { atomicMax(cyc + 0, t1 - t0); atomicMax(cyc + 1, r1 - r0); }                  \
     }
 
 #define A32(op, i) asm volatile(op " %0, %0, %1" : "+v"(a##i) : "v"(a0 | 1u));
@@ -256,6 +262,21 @@ KERNEL_BEGIN(k_ds_u8_valu_1to3)
 #undef M
 KERNEL_END()
 
+// The quantization kernel's measured mix (profiles/r02_pmc_*: per 16 VALU = 5 int32, 2 f64, 1 cvt, 8 moves/compares/selects;
+// 10.5 SALU, 1.3 LDS reads, ~2 branches), as independent instructions: the issue ceiling of THAT mix at a given occupancy.
+KERNEL_BEGIN(k_quant_mix)
+#define M(i) asm volatile( \
+    "v_add_u32 %0, %0, %4\n s_add_u32 %3, %3, 3\n v_and_b32 %0, %0, %4\n s_lshl_b32 %3, %3, 1\n v_lshlrev_b32 %0, 1, %0\n s_and_b32 %3, %3, 0xffff\n" \
+    "v_fma_f64 %1, %1, %5, %1\n s_add_u32 %3, %3, 5\n v_mov_b32 %2, %0\n s_cmp_lt_u32 %3, 77\n v_cmp_lt_u32 vcc, %0, %4\n s_cselect_b32 %3, %3, 9\n" \
+    "v_cndmask_b32 %2, %2, %4, vcc\n v_cvt_f64_u32 %1, %2\n s_add_u32 %3, %3, 1\n v_mul_f64 %1, %1, %5\n v_add_u32 %0, %0, %2\n s_xor_b32 %3, %3, 21\n" \
+    "v_mov_b32 %2, %0\n v_max_i32 %0, %0, %4\n s_add_u32 %3, %3, 7\n v_cmp_gt_u32 vcc, %0, %4\n v_cndmask_b32 %2, %2, %4, vcc\n s_lshr_b32 %3, %3, 1\n" \
+    "v_mov_b32 %2, %2\n v_bfe_u32 %0, %0, 1, 20\n ds_read_b32 %2, %6 offset:" #i "*256" \
+    : "+v"(a##i), "+v"(d##i), "+v"(f##i), "+s"(s##i) : "v"(a0 | 1u), "v"(1.0000001), "v"(la) : "vcc", "scc");
+    REP8(M)
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#undef M
+KERNEL_END()
+
 struct Case { const char* name; void (*fn)(unsigned*, unsigned long long*, int); int ops_per_iter; const char* cls; };
 #define C(name, ops, cls) {#name, name, ops, cls}
 static const Case cases[] = {
@@ -268,6 +289,7 @@ static const Case cases[] = {
     C(k_sqrt_f64, 32, "trans64"), C(k_rcp_f64, 32, "trans64"),
     C(k_salu_add, 32, "salu"), C(k_valu_salu_1to1, 64, "mix"), C(k_f64_int_1to1, 64, "mix"),
     C(k_ds_read_b32, 32, "lds"), C(k_ds_read_u8, 32, "lds"), C(k_ds_read_b64, 32, "lds"), C(k_ds_write_b32, 32, "lds"), C(k_ds_u8_valu_1to3, 32, "mix"),
+    C(k_quant_mix, 8 * 16, "quantmix(VALU only counted: 16 VALU + 10 SALU + 1 LDS per group)"),
 };
 
 int main(int argc, char** argv) {
@@ -276,31 +298,42 @@ int main(int argc, char** argv) {
     const int cus = prop.multiProcessorCount;
     unsigned* out; unsigned long long* cyc;
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&cyc, 64));
-    std::string js = "{\"device\": \"" + std::string(prop.gcnArchName) + "\", \"cus\": " + std::to_string(cus) + ", \"unit\": \"shader cycles per wave64 instruction per SIMD (independent instructions)\", \"cases\": {";
-    printf("%-22s %-9s  cycles/inst/SIMD at 1, 2, 4 waves per SIMD   (clock MHz at 4)\n", "instruction", "class");
+    std::string js = "{\"device\": \"" + std::string(prop.gcnArchName) + "\", \"cus\": " + std::to_string(cus) +
+                     ", \"unit\": \"G wave64 instructions per second, whole chip, wall clock (hipEvents around the launch); independent instructions\", \"waves_per_simd\": [1, 2, 4, 5, 6, 8], \"cases\": {";
+    const int wps[6] = {1, 2, 4, 5, 6, 8};
+    printf("%-22s %-9s  G wave-inst/s at 1, 2, 4, 5, 6, 8 waves/SIMD | cycles/inst/SIMD at 4 and 8 | shader MHz at 4\n", "instruction", "class");
     bool first = true;
     for (const Case& c : cases) {
-        double res[3] = {0, 0, 0}; double mhz = 0;
-        const int wps[3] = {1, 2, 4};
-        for (int k = 0; k < 3; k++) {
-            const int threads = 64 * 4 * wps[k];          // one block per CU, wps waves on each of the 4 SIMDs
-            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-            hipLaunchKernelGGL(c.fn, dim3(cus), dim3(threads), 0, 0, out, cyc, 50);      // warm-up
+        double rate[6], nsi[6], tick_mhz[6], ev[6], inker[6];
+        for (int k = 0; k < 6; k++) {
+            const int w = wps[k];
+            const int blocks_per_cu = w <= 4 ? 1 : 2, threads = 64 * 4 * w / blocks_per_cu;
+            hipLaunchKernelGGL(c.fn, dim3(cus * blocks_per_cu), dim3(threads), 0, 0, out, cyc, 2000);      // warm-up (clock ramp)
             CK(hipMemset(cyc, 0, 64));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             CK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(c.fn, dim3(cus), dim3(threads), 0, 0, out, cyc, (int)ITER);
+            hipLaunchKernelGGL(c.fn, dim3(cus * blocks_per_cu), dim3(threads), 0, 0, out, cyc, (int)ITER);
             CK(hipEventRecord(e1, 0));
             CK(hipDeviceSynchronize());
-            unsigned long long hc = 0; CK(hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost));
-            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-            const double insts = (double)ITER * c.ops_per_iter;
-            res[k] = (double)hc / (insts * wps[k]);        // s_memtime ticks = shader cycles (MI355X guide)
-            mhz = (double)hc / (ms * 1e3);
+            float ev_ms = 0; CK(hipEventElapsedTime(&ev_ms, e0, e1));
             CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+            ev[k] = ev_ms;
+            unsigned long long hc[2] = {0, 0}; CK(hipMemcpy(hc, cyc, 16, hipMemcpyDeviceToHost));
+            const double insts = (double)ITER * c.ops_per_iter;     // per wave
+            const double ksecs = (double)hc[1] / 100e6;             // one workgroup's duration (s_memrealtime: 100 MHz)
+            const double secs = ev_ms * 1e-3;                       // the launch
+            tick_mhz[k] = (double)hc[0] / (ksecs * 1e6);            // shader clock while the kernel ran
+            rate[k] = insts * w * 4 * cus / secs / 1e9;
+            nsi[k] = secs * tick_mhz[k] * 1e6 / (insts * w);        // shader cycles per wave-instruction per SIMD
+            inker[k] = ksecs * 1e3;
         }
-        printf("%-22s %-9s  %6.2f %6.2f %6.2f   (%.0f)\n", c.name + 2, c.cls, res[0], res[1], res[2], mhz);
-        char buf[256];
-        snprintf(buf, sizeof buf, "%s\"%s\": {\"class\": \"%s\", \"w1\": %.3f, \"w2\": %.3f, \"w4\": %.3f}", first ? "" : ", ", c.name + 2, c.cls, res[0], res[1], res[2]);
+        printf("%-22s %-9.9s  %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f | %6.3f %6.3f | %6.0f\n", c.name + 2, c.cls, rate[0], rate[1], rate[2], rate[3], rate[4], rate[5], nsi[2], nsi[5], tick_mhz[2]);
+        printf("      kernel ms by hipEvents / by s_memrealtime inside the kernel: ");
+        for (int k = 0; k < 6; k++) printf(" %.3f/%.3f", ev[k], inker[k]);
+        printf("\n");
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s\"%s\": {\"class\": \"%s\", \"ginst_per_s\": [%.1f, %.1f, %.1f, %.1f, %.1f, %.1f], \"cycles_per_inst_per_simd\": [%.4f, %.4f, %.4f, %.4f, %.4f, %.4f], \"shader_mhz_w4\": %.0f}",
+                 first ? "" : ", ", c.name + 2, c.cls, rate[0], rate[1], rate[2], rate[3], rate[4], rate[5], nsi[0], nsi[1], nsi[2], nsi[3], nsi[4], nsi[5], tick_mhz[2]);
         js += buf; first = false;
     }
     js += "}}\n";
