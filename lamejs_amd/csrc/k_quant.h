@@ -57,7 +57,8 @@ LHIP_DEV void uni_gi(GI& g) {
 #define PH_NOW() 0ull
 #endif
 enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL,
-       PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N, PH_DRAIN = 29 /* 22..28 belong to psyA's stamps */ };
+       PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N, PH_DRAIN = 29 /* 22..28 belong to psyA's stamps */,
+       PH_N_LINES = 30, PH_N_FOLD = 31 /* calc_noise: per-line terms / systolic fold; PH_N_TERMS is then the per-band part */ };
 
 // Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
 // inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
@@ -941,6 +942,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             if (j == nend - 1) lastm |= 1u << (k & 31);
             lastb[k] = bnd; prevb = bnd;
         }
+        PH_MARK(L, PH_N_LINES, tm_);
         // NLN <= 32 on the device; the one-lane host build folds everything in a single pass below
         const int nsteps = (LHIP_NL == 1) ? 1 : (maxlen + NLN - 1) / NLN + 1;
 #if LHIP_NL == 1
@@ -971,6 +973,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         for (int k = 0; k < NLN; k++) if ((lastm >> k) & 1u) L.nsum[lastb[k]] = tq[k];
 #endif
         wave_sync();
+        PH_MARK(L, PH_N_FOLD, tm_);
     }
     int over = 0, ssd = 0;
     double max_noise = -20.0;

@@ -322,3 +322,13 @@ def test_gpu_largest_frames_dense_noise(lib):
     sys.path.insert(0, str(ROOT / "tests" / "tools"))
     import large_frames
     assert large_frames.run(nframes=40) == []
+
+
+@pytest.mark.parametrize("ch,sr,kbps,nfr", [(2, 44100, 128, 600), (1, 22050, 64, 600), (2, 48000, 192, 300), (1, 8000, 16, 300)])
+def test_gpu_stage_taps(lib, ch, sr, kbps, nfr):
+    """Stage-level differential check on the device (tests/stage_taps.py): per granule and channel, the MDCT output, block types,
+    masking ratios (en / thm of long and short bands), ATH.adjust and the quantizer's global_gain / part2_3_length / part2_length
+    must equal the oracle's taps bit for bit -- on the `bursts` material (attacks, short blocks, ATH adjustment), MPEG-1 and LSF."""
+    import pcm, stage_taps
+    L, R = pcm.bursts(1152 * nfr, ch, seed=92)
+    assert stage_taps.compare_stages(None, ch, sr, kbps, L, R) == []

@@ -100,3 +100,13 @@ def test_hostsim_asan_largest_frames():
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "large_frames.py"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim_asan.so")],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("ch,sr,kbps,nfr", [(2, 44100, 128, 40), (1, 22050, 64, 40)])
+def test_hostsim_stage_taps(sim, ch, sr, kbps, nfr):
+    """Stage-level differential check of the kernel logic (host simulation) against the oracle's taps: MDCT output, block types,
+    masking ratios, ATH.adjust and the quantizer's gain / lengths per granule -- see tests/stage_taps.py (the GPU tier runs the
+    same comparison on the device)."""
+    import pcm, stage_taps
+    L, R = pcm.bursts(1152 * nfr, ch, seed=91)
+    assert stage_taps.compare_stages(sim, ch, sr, kbps, L, R) == []

@@ -20,6 +20,9 @@ for corpus, ch, kbps in [("sine", 1, 128), ("sine", 2, 128)]:
     for i, n in enumerate(names):
         if buf[32 + i]:
             print(f"   {n:9s} {100.0 * buf[i] / tot:5.1f}%  calls/frame {buf[32 + i] / nfr:7.2f}  cycles/call {buf[i] / buf[32 + i]:9.0f}")
+    for i, n in ((30, "n_lines"), (31, "n_fold")):
+        if buf[32 + i]:
+            print(f"   {n:9s} {100.0 * buf[i] / tot:5.1f}%  calls/frame {buf[32 + i] / nfr:7.2f}  cycles/call {buf[i] / buf[32 + i]:9.0f}")
     if buf[61]:
         print(f"   drain     {100.0 * buf[29] / tot:5.1f}%  calls/frame {buf[61] / nfr:7.2f}  cycles/call {buf[29] / buf[61]:9.0f}")
     if buf[54]:
