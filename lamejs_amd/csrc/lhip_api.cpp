@@ -32,6 +32,8 @@ using namespace lhip;
 // ===========================================================================================
 static thread_local std::string g_err;
 static thread_local int64_t g_stat_frames = 0, g_stat_repaired = 0, g_stat_iters = 0;
+struct Context;
+static thread_local Context* g_stat_pending = nullptr;      // the last batch was enqueued without synchronisation: its repair statistics are still on the device
 static void set_err(const std::string& e) { g_err = e; }
 
 #ifdef LHIP_HOSTSIM
@@ -288,18 +290,85 @@ __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pair(QArgs a_unused) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     kb_quant<1>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
 }
-__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_validate(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int nslow) {
+// ---- seed-chain validation + repair without the host (persistent, grid barriers) ------------------------------------------
+// One launch replaces the host's loop "validate -> read the flagged count back -> repair -> ...": every workgroup walks the same
+// phases, separated by grid barriers, until a validation pass flags nothing.  Counters per iteration live in two parity slots of
+// W.nflagged (zeroed for the next-but-one iteration by workgroup 0); the verdicts of all waves are the same because they read
+// the counters after the barrier.  Launched cooperatively when the grid has more than one workgroup (co-residency is what a grid
+// barrier needs); a single workgroup (batches of up to 64 frames) needs no cross-workgroup barrier at all.
+enum { FX_NFLAG = 0, FX_NSLOW = 1, FX_WORK_REPAIR = 2, FX_WORK_SLOW = 3, FX_PARITY_STRIDE = 8, FX_BAR = 24, FX_STATS = 32 };
+LHIP_DEV void grid_barrier(int32_t* bar, int nblocks) {
+    __syncthreads();
+    if (nblocks > 1 && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                    // this workgroup's records / flags -> L2 and beyond
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
+            __hip_atomic_store(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // this CU's L1 must not serve stale records
+    }
+    __syncthreads();
+}
+// one workgroup per CU at most (2 waves per SIMD): the register budget is 256 VGPRs, nothing needs to spill
+__global__ __launch_bounds__(64 * QWAVES, 2) void g_fixup(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
-    q_load_tabs(T, Q, threadIdx.x, 64 * QWAVES);
-    __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), idx = blockIdx.x * QWAVES + wv;
-    if (idx >= nslow) return;
-    kb_validate(T, pb, W, SD, W.slow_list[idx], threadIdx.x & 63, L[wv], Q);    // only the frames the memo-only pass left undecided
-}
-__global__ __launch_bounds__(256) void g_validate_fast(Tables T, Workspace W, const StreamDesc* SD, int nfs) {
-    const int fslot = blockIdx.x * 256 + threadIdx.x;
-    if (fslot < nfs) kb_validate_fast(T, W, SD, fslot);
+    const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int nfs = A->nfs, nblocks = gridDim.x, nthr = 64 * QWAVES;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int32_t* base = A->W.nflagged;
+    bool tabs = false;
+    int repaired = 0, iters = 0, failed = 0;
+    for (int it = 0;; it++) {
+        int32_t* ctr = base + FX_PARITY_STRIDE * (it & 1);
+        Workspace W = A->W;
+        W.nflagged = ctr;                                                     // kb_validate(_fast) count into this iteration's slots
+        if (blockIdx.x == 0 && threadIdx.x < FX_PARITY_STRIDE) base[FX_PARITY_STRIDE * ((it + 1) & 1) + threadIdx.x] = 0;   // next iteration's
+        // V: memo-only replay, one thread per frame slot
+        for (int f = blockIdx.x * nthr + threadIdx.x; f < nfs; f += nblocks * nthr) kb_validate_fast(A->T, W, A->SD, f);
+        grid_barrier(base + FX_BAR, nblocks);
+        // (the counters are read by every lane and asserted wave-uniform: every decision below must be scalar control flow)
+        const int nslow = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr + FX_NSLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // Static work split over all waves of the grid (the work of these phases is rare and tiny).  NOT an atomic dispenser: a
+        // `for (;;) { i = next_frame_slot(ctr); if (i >= n) break; ... }` loop nested in this iteration loop was compiled into an
+        // exec-masked loop whose first-active-lane read of the dispensed index span forever on hardware (seen on ROCm 7.2, gfx950).
+        const int gw = blockIdx.x * QWAVES + wv, nw = nblocks * QWAVES;
+        if (nslow > 0) {                                                      // frames whose replay asked for a gain never evaluated
+            if (!tabs) { q_load_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
+            for (int i = gw; i < nslow; i += nw)
+                kb_validate(A->T, A->pb, W, A->SD, __builtin_amdgcn_readfirstlane(W.slow_list[i]), lane, L[wv], Q);
+            grid_barrier(base + FX_BAR, nblocks);
+        }
+        const int nflag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr + FX_NFLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (nflag == 0) break;
+        repaired += nflag; iters++;
+        if (iters > nfs + 2) { failed = 1; break; }                           // cannot happen: every pass finalises at least the first flagged frame
+        // R: re-quantize the flagged frames with the chain-implied seeds; 64 frame slots per step, lane = slot
+        if (!tabs) { q_load_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
+        for (int b0 = 64 * gw; b0 < nfs; b0 += 64 * nw) {
+            int flagged = 0;
+            const int f = b0 + lane;
+            if (f < nfs) {
+                const StreamDesc* sd = A->SD + W.fslot_stream[f];
+                const int k = f - sd->fslot0 - 1;
+                if (k >= 0) flagged = W.seed_flag[sd->out_slot0 + k] == 1;
+            }
+            uint64_t m = __ballot(flagged);
+            while (m) {
+                const int l = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                kb_quant(A->T, A->pb, W, A->SD, b0 + l, 1, lane, L[wv], Q);
+            }
+        }
+        grid_barrier(base + FX_BAR, nblocks);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { base[FX_STATS + 0] = repaired; base[FX_STATS + 1] = iters; base[FX_STATS + 2] = failed; }
 }
 __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ BitsLds L;
@@ -335,9 +404,12 @@ static void kt_collect() {
     }
     g_kt_pending.clear();
 }
-#define LAUNCHB(id, kern, nblk, nthr, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); \
+// LAMEJS_HIP_TRACE=1: synchronise after every launch and name it on stderr (locating a kernel that does not come back)
+static const bool g_trace = []() { const char* e = getenv("LAMEJS_HIP_TRACE"); return e && e[0] == '1'; }();
+#define TRACE_SYNC(kern, st) do { if (g_trace) { fprintf(stderr, "[lhip] %s launched...", #kern); fflush(stderr); hipError_t t_ = hipStreamSynchronize((hipStream_t)(st)); fprintf(stderr, " %s\n", hipGetErrorString(t_)); } } while (0)
+#define LAUNCHB(id, kern, nblk, nthr, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); TRACE_SYNC(kern, st); \
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
-#define LAUNCH(id, kern, nblk, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); \
+#define LAUNCH(id, kern, nblk, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); TRACE_SYNC(kern, st); \
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
 
 __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase pb) {
@@ -647,7 +719,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
-    ENS(seed_flag, FR * 4); ENS(nflagged, 64); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
+    ENS(seed_flag, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
     ENS(prof, 512);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
@@ -658,7 +730,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
-    W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 8; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
+    W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 16; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
@@ -704,7 +776,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
     W.fslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_gm);
     if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
-    if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
+    if (!rt::dzero(ctx->nflagged.p, 256, st)) return false;
     if (!rt::dzero(ctx->prof.p, 512, st)) return false;
     const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ctx->desc.p + o_sd);
     const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ctx->desc.p + o_io);
@@ -773,6 +845,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // stream while polyphase + MDCT (which need neither) keep the chip busy.  With per-kernel timing on, everything stays
     // on the launch stream so that the HIP events bracket each kernel.
     bool forked = false;
+    struct AuxJoin {           // an error return between fork and join must not leave g_scan_ath running on the shared workspace
+        void* aux = nullptr;
+        ~AuxJoin() { if (aux) (void)hipStreamSynchronize((hipStream_t)aux); }
+    } aux_guard;
     if (!g_kt_on) {
         if (!ctx->aux_stream) {
             hipStream_t a; hipEvent_t e1, e2;
@@ -782,6 +858,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (ctx->aux_stream && hipEventRecord((hipEvent_t)ctx->ev_fork, (hipStream_t)st) == hipSuccess &&
             hipStreamWaitEvent((hipStream_t)ctx->aux_stream, (hipEvent_t)ctx->ev_fork, 0) == hipSuccess) {
             LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, ctx->aux_stream, T, W, dSD);
+            aux_guard.aux = ctx->aux_stream;
             HIPCK(hipEventRecord((hipEvent_t)ctx->ev_join, (hipStream_t)ctx->aux_stream));
             forked = true;
         }
@@ -789,7 +866,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (!forked) LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
-    if (forked) HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0));
+    if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
@@ -806,28 +883,30 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
       if (pair) LAUNCHB(KT_QUANT, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
     if (nfr > 0) {
-        for (;;) {
-            if (!rt::dzero(ctx->nflagged.p, 64, st)) return false;
-            LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
-            int32_t nf2[2] = {0, 0};
-            if (!rt::d2h(nf2, W.nflagged, 8, st)) return false;
-            if (!rt::sync(st)) return false;
-            int32_t nf = nf2[0];
-            if (nf2[1] > 0) {       // frames whose replay asked for a gain the speculative pass never evaluated
-                LAUNCHB(KT_VALIDATE, g_validate, (nf2[1] + QWAVES - 1) / QWAVES, 64 * QWAVES, st, T, ts.pb10, W, dSD, nf2[1]);
-                if (!rt::d2h(&nf, W.nflagged, 4, st)) return false;
-                if (!rt::sync(st)) return false;
-            }
-            if (nf == 0) break;
-            repaired += nf; iters++;
-            if (!rt::dzero(ctx->nflagged.p, 4, st)) return false;
-            { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 2;
-              if (pair) LAUNCHB(KT_REPAIR, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_REPAIR, g_quant, qgrid, 64 * QWAVES, st, qa); }
-            if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
+        // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
+        QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
+        int fgrid = (nfs + 63) / 64;
+        if (fgrid > ctx->num_cus) fgrid = ctx->num_cus;
+        if (fgrid < 1) fgrid = 1;
+        if (fgrid == 1) LAUNCHB(KT_VALIDATE, g_fixup, 1, 64 * QWAVES, st, qa);
+        else {
+            kt_begin(KT_VALIDATE, st);
+            void* kargs[] = {(void*)&qa};
+            hipError_t e_ = hipLaunchCooperativeKernel((const void*)g_fixup, dim3(fgrid), dim3(64 * QWAVES), kargs, 0, (hipStream_t)st);
+            kt_end(st);
+            TRACE_SYNC(g_fixup_cooperative, st);
+            if (e_ != hipSuccess) { set_err(std::string("g_fixup (cooperative launch): ") + hipGetErrorString(e_)); return false; }
         }
     }
     LAUNCH(KT_BITS, g_bits, nfs, st, T, W, dSD);
     LAUNCH(KT_SAVE, g_save, S, st, T, W, dSD, dIO);
+#endif
+#ifndef LHIP_HOSTSIM
+    // repair statistics live on the device; they travel with the final synchronisation when there is one, else they are fetched
+    // when somebody asks (lhip_last_batch_stats)
+    int32_t fx[3] = {0, 0, 0};
+    const bool fetch_fx = nfr > 0 && (!dev_io || want_sync || g_kt_on);
+    if (fetch_fx && !rt::d2h(fx, (const int32_t*)ctx->nflagged.p + FX_STATS, sizeof fx, st)) return false;
 #endif
     // ---- outputs ----
     if (!dev_io) {
@@ -860,6 +939,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         s->frame_num += j.F;
         j.written = j.bytes;
     }
+#ifndef LHIP_HOSTSIM
+    g_stat_pending = nullptr;
+    if (fetch_fx) {
+        repaired = fx[0]; iters = fx[1];
+        if (fx[2]) { set_err("seed-chain repair did not converge"); return false; }
+    } else if (nfr > 0) g_stat_pending = ctx;
+#endif
     g_stat_frames = nfr; g_stat_repaired = repaired; g_stat_iters = iters;
     ctx->lastW = W; ctx->lastC = C; ctx->have_last = true;
     return true;
@@ -1080,6 +1166,18 @@ int lhip_set_hip_stream(int device, void* hip_stream) {
 }
 
 void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations) {
+#ifndef LHIP_HOSTSIM
+    if (g_stat_pending) {                      // asynchronous batch: wait for it and fetch the device-side counters
+        Context* ctx = g_stat_pending;
+        g_stat_pending = nullptr;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        int32_t fx[3] = {0, 0, 0};
+        if (rt::set_device(ctx->device) && rt::d2h(fx, (const int32_t*)ctx->nflagged.p + FX_STATS, sizeof fx, ctx->stream) && rt::sync(ctx->stream)) {
+            g_stat_repaired = fx[0]; g_stat_iters = fx[1];
+            if (fx[2]) set_err("seed-chain repair did not converge");
+        }
+    }
+#endif
     if (frames) *frames = g_stat_frames;
     if (repaired_frames) *repaired_frames = g_stat_repaired;
     if (repair_iterations) *repair_iterations = g_stat_iters;
