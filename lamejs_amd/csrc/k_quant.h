@@ -58,7 +58,8 @@ LHIP_DEV void uni_gi(GI& g) {
 #endif
 enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL,
        PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N, PH_DRAIN = 29 /* 22..28 belong to psyA's stamps */,
-       PH_N_LINES = 30, PH_N_FOLD = 31 /* calc_noise: per-line terms / systolic fold; PH_N_TERMS is then the per-band part */ };
+       PH_N_LINES = 30, PH_N_FOLD = 31 /* calc_noise: per-line terms / systolic fold; PH_N_TERMS is then the per-band part */,
+       PH_B_TRIG = 22, PH_B_AMP = 23, PH_B_BREAK = 24, PH_B_BITCOUNT = 25 /* balance_noise parts (profiling builds: these slots are psyA's otherwise) */ };
 
 // Read-only tables staged once per workgroup in LDS (shared by the waves of the block): everything the
 // inner loops gather from -- avoids ~1 us HBM/L2 round trips inside serially dependent code.
@@ -1103,27 +1104,42 @@ LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantL
     return !wave_any(z);
 }
 
-// multiply xrpow of the flagged bands (bit sfb of m_amp) by `amp`, tracking xrpow_max
+// multiply xrpow of the flagged bands (bit sfb of m_amp) by `amp`, tracking xrpow_max.  Branch-free: an unflagged pair is
+// multiplied by 1.0 (exact through the f32 -> f64 -> f32 round trip) and takes part in the maximum like the flagged ones --
+// xrpow_max already bounds every unflagged line, so the update `if (max > xrpow_max)` sees the same verdict.
 LHIP_DEV void q_amplify_flagged(GI& g, double amp, uint64_t m_amp, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     float m = 0.f;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
-    for (int p = 2 * lane; p < 576; p += 2 * LHIP_NL) {        // pairs never straddle a band
-        if ((m_amp >> l2s[p]) & 1) {
-            struct F2 { float x, y; };
-            F2 xx = *(const F2*)(L.xrpow + p);
-            xx.x = (float)((double)xx.x * amp); xx.y = (float)((double)xx.y * amp);
-            *(F2*)(L.xrpow + p) = xx;
-            if (xx.x > m) m = xx.x;
-            if (xx.y > m) m = xx.y;
-        }
+    struct F2 { float x, y; };
+    F2 xx[NPL]; int bnd[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {                             // pairs never straddle a band
+        const int p = 2 * (lane + LHIP_NL * j);
+        xx[j].x = 0.f; xx[j].y = 0.f; bnd[j] = 0;
+        if (p < 576) { xx[j] = *(const F2*)(L.xrpow + p); bnd[j] = l2s[p]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        const double a = ((m_amp >> bnd[j]) & 1) ? amp : 1.0;
+        xx[j].x = (float)((double)xx[j].x * a); xx[j].y = (float)((double)xx[j].y * a);
+        if (p < 576) *(F2*)(L.xrpow + p) = xx[j];
+        if (xx[j].x > m) m = xx[j].x;
+        if (xx[j].y > m) m = xx[j].y;
     }
     m = wave_maxf_pos(m);
     if ((double)m > g.xrpow_max) g.xrpow_max = m;
     wave_sync();
 }
 
-LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+// amp_scalefac_bands (Quantize.js:597-669) + loop_break (453-460) + the scalefactor statistics scale_bitcount starts with
+// (Takehiro.js:980-1005), in ONE pass over the bands: the amplification decision, the incremented scalefactor, "is any band
+// still at zero" and, for MPEG-1 long blocks, "could the pretab be subtracted" / the two range maxima all look at the same
+// scalefac[sfb].  *all_nonzero = loop_break's verdict; *pre_bad / *m12 feed q_scale_bitcount_from (values BEFORE a preflag
+// subtraction, which that function applies itself when it is due).
+LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, int* all_nonzero, int* pre_bad, int* m12_out,
+                                   int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     const double ifqstep34 = (g.scalefac_scale == 0) ? 1.29683955465100964055 : 1.68179283050742922612;
     float tr = 0.f;
@@ -1145,8 +1161,45 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
         if (!((double)L.distort[sfb] < trigger)) m_amp |= 1ull << sfb;
     m_amp = wave_lane_bits(m_amp);
     if (T.noise_shaping_amp == 2 && m_amp) m_amp = 1ull << __builtin_ctzll(m_amp);     // amplify exactly one band
-    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if ((m_amp >> sfb) & 1) scalefac[sfb]++;
-    q_amplify_flagged(g, ifqstep34, m_amp, lane, L, Q);
+    int z = 0, bad = 0, m12 = 0;
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
+        const int v = scalefac[sfb] + (int)((m_amp >> sfb) & 1);
+        scalefac[sfb] = v;
+        if (v + sbgain(g, L.window[sfb]) == 0) z = 1;
+        if (sfb >= 11 && sfb < SBPSY_l && v < Q.pretab[sfb]) bad = 1;
+        m12 |= (sfb < g.sfbdivide) ? v : (v << 8);
+    }
+    {   // three one-bit / small-field facts in one OR reduction: bits 0-15 m12, bit 16 z, bit 17 bad
+        const int r = wave_or(m12 | (z << 16) | (bad << 17));
+        *m12_out = r & 0xffff; *all_nonzero = !((r >> 16) & 1); *pre_bad = (r >> 17) & 1;
+    }
+    { unsigned long long tt_ = PH_NOW(); (void)tt_; q_amplify_flagged(g, ifqstep34, m_amp, lane, L, Q); PH_MARK(L, PH_B_TRIG, tt_); }
+}
+
+// scale_bitcount (MPEG-1) continuing from the statistics of q_amp_scalefac_bands: pre_bad = some band 11..20 is below its
+// pretab entry, m12 = OR of the scalefactors of part 1 | part 2 << 8.  Same result as q_scale_bitcount on the same scalefactors.
+LHIP_DEV int q_scale_bitcount_from(const QuantTabs& Q, GI& g, int32_t* scalefac, int pre_bad, int m12, int lane) {
+    lane = fresh_lane(lane);
+    const int sh = (g.block_type == SHORT_TYPE) ? 24 : 16;
+    if (g.block_type != SHORT_TYPE && 0 == g.preflag && !pre_bad) {
+        g.preflag = 1;
+        wave_sync();
+        LHIP_LANE_ONCE(sfb, 11, SBPSY_l) scalefac[sfb] -= Q.pretab[sfb];
+        wave_sync();
+        m12 = 0;                                              // the statistics change with the subtraction: take them again
+        LHIP_LANE_ONCE(sfb, 0, g.sfbmax) { const int v = scalefac[sfb]; m12 |= (sfb < g.sfbdivide) ? v : (v << 8); }
+        m12 = wave_or(m12);
+    }
+    const int m1 = m12 & 0xff, m2 = m12 >> 8;
+    int best = 0x7fffffff;
+    LHIP_LANE_ONCE(k, 0, 16) {
+        const uint32_t e = Q.sbc[k];
+        if (m1 < (int)(e & 0xffu) && m2 < (int)((e >> 8) & 0xffu)) { const int v = (int)((e >> sh) & 0xffu) * 16 + k; if (v < best) best = v; }
+    }
+    best = wave_min(best);
+    g.part2_length = LARGE_BITS;
+    if (best != 0x7fffffff) { g.part2_length = best >> 4; g.scalefac_compress = best & 15; }
+    return g.part2_length == LARGE_BITS;
 }
 
 LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
@@ -1213,10 +1266,14 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
 
 // balance_noise (Quantize.js:793-846); returns 1 to continue the outer loop
 LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
-    q_amp_scalefac_bands(T, g, scalefac, lane, L, Q);
-    int status = q_loop_break(g, scalefac, lane, L, Q);
+    unsigned long long tb_ = PH_NOW(); (void)tb_;
+    int all_nonzero, pre_bad, m12;
+    q_amp_scalefac_bands(T, g, scalefac, &all_nonzero, &pre_bad, &m12, lane, L, Q);
+    PH_MARK(L, PH_B_AMP, tb_);
+    int status = all_nonzero;                                  // loop_break (Quantize.js:453-460)
     if (status) return 0;
-    status = q_scale_bitcount_any(T, Q, g, scalefac, lane);
+    status = T.mode_gr == 2 ? q_scale_bitcount_from(Q, g, scalefac, pre_bad, m12, lane) : q_scale_bitcount_lsf(g, scalefac, lane);
+    PH_MARK(L, PH_B_BITCOUNT, tb_);
     if (!status) return 1;
     if (T.noise_shaping > 1) {
         if (0 == g.scalefac_scale) {
