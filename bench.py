@@ -313,14 +313,18 @@ def main():
                                         "see roofline_compute for the limiter (VALU issue)"}
             rc = prof.get("compute", {}).get("g_" + dom)
             if rc:
-                # issue ceiling of the kernel's own instruction mix: sum over classes of (wave-instructions x measured cycles per
-                # instruction per SIMD, tools/ubench_issue.hip) = SIMD-cycles of pure issue; peak rate = 1024 SIMDs x clock / mean cycles
-                cyc = rc["issue_cycles_per_launch"]; insts = rc["valu_insts_per_launch"]
-                simds, clk = 1024, rc.get("clock_ghz", 2.4)
-                peak = simds * clk * 1e9 / (cyc / insts)
-                line["roofline_compute"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(insts / kt / 1e9, 2), "peak": round(peak / 1e9, 2),
-                                            "unit": "G wave-instructions/s", "frac": round(insts / kt / peak, 4),
-                                            "mean_cycles_per_valu_inst": round(cyc / insts, 3), "source": f"profiles/r02_pmc_config{key}.json + profiles/r02_ubench_issue.json"}
+                # The limiter of this kernel is instruction issue (VALU, with the per-CU scalar unit 60 % busy beside it), so the
+                # roofline that says something is: VALU wave-instructions per second (PMC count of this exact workload / the kernel
+                # time measured now) against the rate an independent-instruction stream of the kernel's own measured class mix
+                # sustains on this chip (tools/ubench_issue.hip `quant_mix`): at the kernel's occupancy and at full occupancy.
+                insts = rc["valu_insts_per_launch"]
+                ce = dict(zip(rc["issue_ceiling_ginst_per_s"]["waves_per_simd"], rc["issue_ceiling_ginst_per_s"]["valu_ginst_per_s"]))
+                occ = rc.get("occupancy_waves_per_simd", 4)
+                ach = insts / kt / 1e9
+                line["roofline_compute"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(ach, 1), "peak": ce[8], "unit": "G VALU wave-instructions/s",
+                                            "frac": round(ach / ce[8], 4), "peak_at_kernel_occupancy": ce[occ], "frac_at_kernel_occupancy": round(ach / ce[occ], 4),
+                                            "occupancy_waves_per_simd": occ, "valu_insts_per_launch": insts, "salu_insts_per_launch": rc["salu_insts_per_launch"],
+                                            "source": f"profiles/r02_pmc_config{key}.json (PMC of this workload) + profiles/r02_ubench_issue.json (ceiling of that mix)"}
 
     # ---- the other configurations (N = 1 only): each is its own short run, md5-checked like the main one ----
     if world == 1 and not args.no_extras and not args.frames and not args.streams:
