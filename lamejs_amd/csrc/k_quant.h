@@ -154,6 +154,7 @@ struct QuantLds {
         struct { int32_t bs_tab[BS_TAB_MAX], bs_asg[BS_TAB_MAX]; } memo;   // bin-search memo, flushed to the side record before the first calc_noise
     };
     alignas(8) uint32_t rdesc[4][2];   // per Huffman region: offsets of its candidate length tables | row stride
+    int32_t gkeep[24];                 // the mutable scalars of the kept quantization (cod_info) while the outer loop runs on cod_info_w
     double ath_pseudo[6];
 #ifdef LHIP_PHASE_PROF
     unsigned int prof[64];           // per-frame cycle sums fit 32 bits
@@ -1299,6 +1300,30 @@ LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // 
     return better;
 }
 
+// The kept quantization's scalars live in LDS while the outer loop runs (only part2_3_length is read there): the loop carries
+// one GrInfo (the working copy) in scalar registers instead of two, which is most of what used to spill.  Fields the loop never
+// changes (block type, band limits, max_nonzero_coeff) are the same in both copies and are not stored.
+LHIP_DEV void gi_keep_store(QuantLds& L, const GI& w, int lane) {
+    if (lane == 0) {
+        int32_t* k = L.gkeep;
+        k[0] = w.part2_3_length; k[1] = w.big_values; k[2] = w.count1; k[3] = w.global_gain; k[4] = w.scalefac_compress;
+        k[5] = w.table_select[0]; k[6] = w.table_select[1]; k[7] = w.table_select[2];
+        k[8] = w.subblock_gain[0]; k[9] = w.subblock_gain[1]; k[10] = w.subblock_gain[2]; k[11] = w.subblock_gain[3];
+        k[12] = w.region0_count; k[13] = w.region1_count; k[14] = w.preflag; k[15] = w.scalefac_scale; k[16] = w.count1table_select;
+        k[17] = w.part2_length; k[18] = w.count1bits;
+        union { double d; int32_t i[2]; } u; u.d = w.xrpow_max; k[19] = u.i[0]; k[20] = u.i[1];
+    }
+}
+LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
+    const int32_t* k = L.gkeep;
+    g.part2_3_length = uni(k[0]); g.big_values = uni(k[1]); g.count1 = uni(k[2]); g.global_gain = uni(k[3]); g.scalefac_compress = uni(k[4]);
+    g.table_select[0] = uni(k[5]); g.table_select[1] = uni(k[6]); g.table_select[2] = uni(k[7]);
+    g.subblock_gain[0] = uni(k[8]); g.subblock_gain[1] = uni(k[9]); g.subblock_gain[2] = uni(k[10]); g.subblock_gain[3] = uni(k[11]);
+    g.region0_count = uni(k[12]); g.region1_count = uni(k[13]); g.preflag = uni(k[14]); g.scalefac_scale = uni(k[15]); g.count1table_select = uni(k[16]);
+    g.part2_length = uni(k[17]); g.count1bits = uni(k[18]);
+    union { double d; int32_t i[2]; } u; u.i[0] = uni(k[19]); u.i[1] = uni(k[20]); g.xrpow_max = u.d;
+}
+
 // outer_loop (Quantize.js:871-1052).  g = kept copy (cod_info); seeds in/out via start/step.
 // bin_search_StepSize (Quantize.js:322-381) + outer_loop (Quantize.js:871-1052) as ONE state machine, so that the
 // three big building blocks -- count_bits, calc_noise, balance_noise -- are each instantiated exactly once
@@ -1324,11 +1349,12 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     w.global_gain = bs_start;
     // outer-loop state
     int best_part2_3_length = 9999999, age = 0, maxggain = 255, huff_bits = 0, first = 1;
+    int kept_p23 = g.part2_3_length;                        // cod_info.part2_3_length (the one kept field the loop reads)
     const int search_limit = 3;
     int st = ST_BS, nbs = 0;
     for (;;) {
 #ifndef LHIP_NO_FORCE_UNI
-        uni_gi(w); uni_gi(g); st = uni(st); CurrentStep = uni(CurrentStep); flagGoneOver = uni(flagGoneOver); Direction = uni(Direction);
+        uni_gi(w); kept_p23 = uni(kept_p23); st = uni(st); CurrentStep = uni(CurrentStep); flagGoneOver = uni(flagGoneOver); Direction = uni(Direction);
         best_part2_3_length = uni(best_part2_3_length); age = uni(age); maxggain = uni(maxggain); huff_bits = uni(huff_bits); first = uni(first);
         pn.gain = uni(pn.gain); pn.sfb_count1 = uni(pn.sfb_count1);
         best.max_noise = unid(best.max_noise); best.over_count = uni(best.over_count); best.over_SSD = uni(best.over_SSD); best.bits = uni(best.bits);
@@ -1401,9 +1427,10 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         if (first) keep = 1;
         else keep = q_quant_compare(best, ni);
         if (keep) {
-            if (!first) best_part2_3_length = g.part2_3_length;   // value BEFORE the copy (reference quirk)
+            if (!first) best_part2_3_length = kept_p23;           // value BEFORE the copy (reference quirk)
             best = ni;
-            g = w;
+            gi_keep_store(L, w, lane);                            // cod_info = cod_info_w
+            kept_p23 = w.part2_3_length;
             for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
             LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sfb[i] = L.sfw[i];
             wave_sync();
@@ -1421,6 +1448,8 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         if (huff_bits <= 0) break;
         st = ST_A;
     }
+    wave_sync();
+    { const GI inv = w; g = inv; gi_keep_load(L, g); }       // the invariant fields are the working copy's, the rest comes back from LDS
 }
 
 // ---------------------------------------------------------------------------------------------
