@@ -30,6 +30,7 @@ static size_t (*p_max_out)(const lhip_stream*, size_t);
 static int (*p_encode_batch)(lhip_stream* const*, size_t, const int16_t* const*, const int16_t* const*, const size_t*, uint8_t* const*, const size_t*, int64_t*);
 static int (*p_flush_batch)(lhip_stream* const*, size_t, uint8_t* const*, const size_t*, int64_t*);
 static const char* (*p_last_error)(void);
+static int (*p_set_devices)(uint64_t);
 
 static int load_lib(napi_env env) {
     if (g_lib) return 1;
@@ -48,7 +49,7 @@ static int load_lib(napi_env env) {
 #define SYM(v, n) *(void**)(&v) = dlsym(g_lib, n); if (!v) { napi_throw_error(env, NULL, "lamejs_amd: missing symbol " n); return 0; }
     SYM(p_device_count, "lhip_device_count") SYM(p_create, "lhip_create") SYM(p_encode, "lhip_encode") SYM(p_flush, "lhip_flush")
     SYM(p_destroy, "lhip_destroy") SYM(p_max_out, "lhip_max_output_bytes") SYM(p_last_error, "lhip_last_error")
-    SYM(p_encode_batch, "lhip_encode_batch") SYM(p_flush_batch, "lhip_flush_batch")
+    SYM(p_encode_batch, "lhip_encode_batch") SYM(p_flush_batch, "lhip_flush_batch") SYM(p_set_devices, "lhip_set_devices")
 #undef SYM
     return 1;
 }
@@ -60,6 +61,20 @@ static napi_value js_device_count(napi_env env, napi_callback_info info) {
     napi_value r;
     if (!load_lib(env)) return NULL;
     napi_create_int32(env, p_device_count(), &r);
+    return r;
+}
+
+/* setDevices(mask: number) -> number of allowed devices: restricts where later encoders are placed (lhip_set_devices); encoders
+ * created without an explicit device are then dealt round-robin over the allowed GPUs */
+static napi_value js_set_devices(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    if (!load_lib(env)) return NULL;
+    double m = 0;
+    if (argc < 1 || napi_get_value_double(env, argv[0], &m) != napi_ok || m < 0 || m >= 18446744073709551616.0) { napi_throw_type_error(env, NULL, "mask must be a non-negative number"); return NULL; }
+    const int n = p_set_devices((uint64_t)m);
+    if (n < 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
+    napi_value r; napi_create_int32(env, n, &r);
     return r;
 }
 
@@ -182,7 +197,8 @@ static napi_value init(napi_env env, napi_value exports) {
     napi_property_descriptor d[] = {
         {"deviceCount", 0, js_device_count, 0, 0, 0, napi_default, 0}, {"create", 0, js_create, 0, 0, 0, napi_default, 0},
         {"encode", 0, js_encode, 0, 0, 0, napi_default, 0}, {"flush", 0, js_flush, 0, 0, 0, napi_default, 0},
-        {"encodeBatch", 0, js_encode_batch, 0, 0, 0, napi_default, 0}, {"flushBatch", 0, js_flush_batch, 0, 0, 0, napi_default, 0}};
+        {"encodeBatch", 0, js_encode_batch, 0, 0, 0, napi_default, 0}, {"flushBatch", 0, js_flush_batch, 0, 0, 0, napi_default, 0},
+        {"setDevices", 0, js_set_devices, 0, 0, 0, napi_default, 0}};
     napi_define_properties(env, exports, 6, d);
     return exports;
 }

@@ -75,9 +75,13 @@ module.exports.deviceCount = function () { return loadAddon().deviceCount(); };
  *   encodeBatch(encoders, lefts[, rights]) one launch for all the encoders' new samples -> Int8Array per encoder, the same
  *                                         bytes each encoder's own encodeBuffer() would have returned
  *   flushBatch(encoders)                  likewise for flush()
+ *   setDevices(mask)                      let the library deal new encoders round-robin over the GPUs named by the bit mask
  * The encoders of one call must share (channels, samplerate, kbps) and the device.
  */
 module.exports.setDevice = function (d) { defaultDevice = d | 0; };
+/* setDevices(mask): bit d = HIP device d may be used; encoders constructed with the default device (-1) are then dealt round-robin
+ * over the allowed GPUs by the library (lhip_set_devices); returns how many devices are allowed.  mask 0 restores the default. */
+module.exports.setDevices = function (mask) { defaultDevice = -1; return loadAddon().setDevices(mask); };
 module.exports.encodeBatch = function (encoders, lefts, rights) {
     const hs = encoders.map((e) => e._lhip.handle);
     const L = lefts.map((a) => (a instanceof Int16Array ? a : Int16Array.from(a)));

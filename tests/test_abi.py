@@ -46,3 +46,18 @@ def test_configs_outside_the_envelope_fail_loudly(golden):
     for c in outside:
         with pytest.raises(lamejs_amd.LhipError, match="resampl"):
             lamejs_amd.tables_blob(c["channels"], c.get("samplerate", 44100), c["kbps"])
+
+
+def test_set_devices_argument_handling():
+    """lhip_set_devices without a GPU: fails loudly (no device to allow); with one: rejects masks naming absent devices."""
+    import ctypes
+    import lamejs_amd
+    lib = lamejs_amd.load_library()
+    lib.lhip_set_devices.restype = ctypes.c_int
+    lib.lhip_set_devices.argtypes = [ctypes.c_uint64]
+    n = lib.lhip_device_count()
+    if n <= 0:
+        assert lib.lhip_set_devices(1) < 0 and b"no HIP device" in lib.lhip_last_error()
+    else:
+        assert lib.lhip_set_devices(1 << 63) < 0
+        assert lib.lhip_set_devices(0) == n
