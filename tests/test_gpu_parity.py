@@ -338,39 +338,60 @@ def test_gpu_async_batch_and_device_mask(lib):
     """lhip_encode_batch_device(sync=0) returns after enqueueing (the seed-chain validation / repair runs on the device): several
     batches are enqueued back to back on a HIP stream without any host synchronisation in between, the outputs are read after ONE
     synchronisation and equal the oracle's; lhip_last_batch_stats fetches the device-side repair counters lazily.  Also
-    lhip_set_devices: a mask that allows device 0 deals default-device streams there, a mask naming an absent device is refused."""
-    import torch
+    lhip_set_devices: a mask that allows device 0 deals default-device streams there, a mask naming an absent device is refused.
+    (Device memory and the stream come straight from the HIP runtime the library itself uses -- no torch in this process.)"""
+    import time
     import lamejs_amd, pcm
     from oracle_py import oracle_encode
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+
+    def dmalloc(n):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), n) == 0
+        return p
+
     lib.lhip_set_devices.restype = ctypes.c_int
     lib.lhip_set_devices.argtypes = [ctypes.c_uint64]
     assert lib.lhip_set_devices(1) == 1
+    bufs = []
     try:
-        dev = torch.device("cuda", 0)
-        st = torch.cuda.Stream(device=dev)
-        lib.lhip_set_hip_stream(0, ctypes.c_void_p(st.cuda_stream))
+        assert hip.hipSetDevice(0) == 0
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+        lib.lhip_set_hip_stream(0, st)
         ch, kbps, nfr, nb = 2, 128, 700, 4
-        L, R = pcm.bursts(1152 * nfr * nb, ch, seed=555)
-        dl, dr = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+        n = 1152 * nfr * nb
+        L, R = pcm.bursts(n, ch, seed=555)
+        dl, dr = dmalloc(2 * n), dmalloc(2 * n)
+        bufs += [dl, dr]
+        assert hip.hipMemcpy(dl, L.ctypes.data, 2 * n, 1) == 0 and hip.hipMemcpy(dr, R.ctypes.data, 2 * n, 1) == 0
         cap = (nfr + 4) * 420
-        outs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(nb)]
+        outs = [dmalloc(cap) for _ in range(nb)]
+        bufs += outs
         enc = lamejs_amd.Mp3Encoder(ch, 44100, kbps, device=-1)          # placed by the mask
         H = (ctypes.c_void_p * 1)(enc._h)
         written = []
-        torch.cuda.synchronize()
-        import time
         t0 = time.perf_counter()
         for b in range(nb):
-            off = 1152 * nfr * b
-            a_l = (ctypes.c_void_p * 1)(dl.data_ptr() + 2 * off); a_r = (ctypes.c_void_p * 1)(dr.data_ptr() + 2 * off)
-            a_o = (ctypes.c_void_p * 1)(outs[b].data_ptr()); a_n = (ctypes.c_size_t * 1)(1152 * nfr); a_c = (ctypes.c_size_t * 1)(cap)
+            off = 2 * 1152 * nfr * b
+            a_l = (ctypes.c_void_p * 1)(dl.value + off); a_r = (ctypes.c_void_p * 1)(dr.value + off)
+            a_o = (ctypes.c_void_p * 1)(outs[b].value); a_n = (ctypes.c_size_t * 1)(1152 * nfr); a_c = (ctypes.c_size_t * 1)(cap)
             wr = (ctypes.c_int64 * 1)()
             assert lib.lhip_encode_batch_device(H, 1, a_l, a_r, a_n, a_o, a_c, wr, 0) == 0, lib.lhip_last_error()
             written.append(int(wr[0]))
         t_enq = time.perf_counter() - t0
-        st.synchronize()
+        assert hip.hipStreamSynchronize(st) == 0
         t_all = time.perf_counter() - t0
-        got = b"".join(outs[b][: written[b]].cpu().numpy().tobytes() for b in range(nb))
+        got = b""
+        for b in range(nb):
+            h = np.empty(written[b], dtype=np.uint8)
+            assert hip.hipMemcpy(h.ctypes.data, outs[b], written[b], 2) == 0
+            got += h.tobytes()
         want = oracle_encode(ch, 44100, kbps, L, R, flush=False)
         assert got == want
         assert t_enq < 0.8 * t_all, (t_enq, t_all)      # the calls returned while the GPU was still working
@@ -381,3 +402,5 @@ def test_gpu_async_batch_and_device_mask(lib):
     finally:
         lib.lhip_set_hip_stream(0, None)
         lib.lhip_set_devices(0)
+        for p in bufs:
+            hip.hipFree(p)
