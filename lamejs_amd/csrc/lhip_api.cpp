@@ -290,6 +290,10 @@ __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pair(QArgs a_unused) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     kb_quant<1>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
 }
+__global__ __launch_bounds__(256) void g_validate_fast(Tables T, Workspace W, const StreamDesc* SD, int nfs) {
+    const int fslot = blockIdx.x * 256 + threadIdx.x;
+    if (fslot < nfs) kb_validate_fast(T, W, SD, fslot);
+}
 // ---- seed-chain validation + repair without the host (persistent, grid barriers) ------------------------------------------
 // One launch replaces the host's loop "validate -> read the flagged count back -> repair -> ...": every workgroup walks the same
 // phases, separated by grid barriers, until a validation pass flags nothing.  Counters per iteration live in two parity slots of
@@ -330,9 +334,13 @@ __global__ __launch_bounds__(64 * QWAVES, 2) void g_fixup(QArgs a_unused) {
         Workspace W = A->W;
         W.nflagged = ctr;                                                     // kb_validate(_fast) count into this iteration's slots
         if (blockIdx.x == 0 && threadIdx.x < FX_PARITY_STRIDE) base[FX_PARITY_STRIDE * ((it + 1) & 1) + threadIdx.x] = 0;   // next iteration's
-        // V: memo-only replay, one thread per frame slot
-        for (int f = blockIdx.x * nthr + threadIdx.x; f < nfs; f += nblocks * nthr) kb_validate_fast(A->T, W, A->SD, f);
-        grid_barrier(base + FX_BAR, nblocks);
+        // V: memo-only replay, one thread per frame slot.  The first pass has been made by g_validate_fast, a plain launch in front
+        // of this kernel (it needs no LDS, so it runs at full occupancy; the kernel boundary orders it): in the usual case -- nothing
+        // flagged -- this kernel reads two counters and ends without a single grid barrier.
+        if (it > 0) {
+            for (int f = blockIdx.x * nthr + threadIdx.x; f < nfs; f += nblocks * nthr) kb_validate_fast(A->T, W, A->SD, f);
+            grid_barrier(base + FX_BAR, nblocks);
+        }
         // (the counters are read by every lane and asserted wave-uniform: every decision below must be scalar control flow)
         const int nslow = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr + FX_NSLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         // Static work split over all waves of the grid (the work of these phases is rare and tiny).  NOT an atomic dispenser: a
@@ -885,6 +893,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (nfr > 0) {
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
+        LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
         int fgrid = (nfs + 63) / 64;
         if (fgrid > ctx->num_cus) fgrid = ctx->num_cus;
         if (fgrid < 1) fgrid = 1;
