@@ -159,7 +159,7 @@ LHIP_DEV void poly_slot(const Tables& T, const float* xt, float* out, int j) {
     }
     for (int i = 0; i < 32; i++) out[j * 32 + i] = a[i];
 }
-LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, int wave_idx, int nitems, int lane, PolyLds& L) {
+LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int wave_idx, int nitems, int lane, PolyLds& L) {
     const int C = T.channels_out, ngs = W.ngslots;
     const int item0 = wave_idx * POLY_PER_WAVE;
     const int nit = (nitems - item0) < POLY_PER_WAVE ? (nitems - item0) : POLY_PER_WAVE;
@@ -179,13 +179,24 @@ LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc
     for (int ps = 0; ps < npass; ps++) {
         const int itA = together ? 0 : ps, cnt = together ? nit : 1;
         const int item = item0 + itA, ch = item / ngs, gs = item - ch * ngs;
-        const StreamDesc sd = SD[W.gslot_stream[gs]];
+        const int stg = W.gslot_stream[gs];
+        const StreamDesc sd = SD[stg];
         const int q = gs - sd.gslot0 - 1;
         if (q < 0) continue;                                   // carry slot: nothing to compute
-        const float* src = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 286 - POLY_BIAS;
+        const PcmSrc P = pcm_source(T, W, sd, IO[stg], ch);
+        const int s0 = 576 * q + 286 - POLY_BIAS;              // segment index of staging slot 0 (slots below `lo` lie before the segment)
         const int n_need = POLY_N1 + 576 * (cnt - 1);
         wave_sync();
-        for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? src[n] : 0.f;
+        if (!P.plane && s0 + lo >= P.mf) {                     // wave-uniform usual case: everything staged is new Int16 input
+            const int16_t* src = P.src + (s0 - P.mf);
+            for (int n = lane; n < n_need; n += LHIP_NL) {
+                float v = 0.f;
+                if (n >= lo) { v = (float)src[n]; if (P.do_scale) v = (float)((double)v * P.scale); }
+                L.xs[(n & 31) * POLY_ROW + (n >> 5)] = v;
+            }
+        } else {
+            for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? pcm_at(P, s0 + n) : 0.f;
+        }
         wave_sync();
         for (int u = lane; u < 18 * cnt; u += LHIP_NL) {
             const int it = u / 18, j = u - 18 * it;

@@ -113,19 +113,38 @@ struct PsyALds {
 #define PSY_FLUSH() do {} while (0)
 #endif
 // one wave per (granule slot >= 1 of a stream, channel)
-LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int ch, int lane, PsyALds& L) {
+LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int gslot, int ch, int lane, PsyALds& L) {
     const int C = T.channels_out;
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
     const int q = gslot - sd.gslot0 - 1;              // local psy call index
     if (q < 0) return;                                // carry slot: nothing to compute
-    const float* buf = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off + 576 * q + 304;
+    // The call's 1024-sample window (segment index 576 q + 304 onwards) is converted ONCE into the long FHT buffer: the high-pass,
+    // the short windowing and the long windowing all read it from LDS; the long windowing then runs in place (every lane takes its
+    // samples into registers before anybody writes).  The caller's Int16 is read coalesced, 2 bytes per sample, exactly once.
+    {
+        const PcmSrc P = pcm_source(T, W, sd, IO[st], ch);
+        const int b0 = 576 * q + 304;
+        if (!P.plane && b0 >= P.mf) {
+            // the usual case, wave-uniform: the whole window lies in this call's new samples -- no per-sample decisions
+            const int16_t* src = P.src + (b0 - P.mf);
+            for (int i = lane; i < BLKSIZE; i += LHIP_NL) {
+                float v = (float)src[i];
+                if (P.do_scale) v = (float)((double)v * P.scale);
+                L.fz[i] = v;
+            }
+        } else {
+            for (int i = lane; i < BLKSIZE; i += LHIP_NL) L.fz[i] = pcm_at(P, b0 + i);
+        }
+        wave_sync();
+    }
+#define buf(i) L.fz[i]
     const int64_t o = (int64_t)gslot * C + ch;
     PSY_STAMP(0);
 
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
     {
-        const float* fir = buf + 397;                 // 576 - 350 - 21 + 192
+        const float* fir = L.fz + 397;                // 576 - 350 - 21 + 192
         // all nine sub-block outputs of a lane first (their loads are independent and overlap), the maxima after
         enum { KP = (64 + LHIP_NL - 1) / LHIP_NL };
         float pk[9];
@@ -156,47 +175,65 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
 
     PSY_STAMP(1);
     // --- windowing + first radix-4 stage (FFT.js:185-221 long, 140-180 short) ---
-    for (int jj = lane; jj < BLKSIZE / 8; jj += LHIP_NL) {
-        const int i = T.fft_rv_tbl[jj] & 0xff;
-        float* x = L.fz + 4 * jj;
-        double f0, f1, f2, f3, w;
-        f0 = (double)T.window[i] * (double)buf[i];
-        w = (double)T.window[i + 0x200] * (double)buf[i + 0x200];
-        f1 = f0 - w; f0 = f0 + w;
-        f2 = (double)T.window[i + 0x100] * (double)buf[i + 0x100];
-        w = (double)T.window[i + 0x300] * (double)buf[i + 0x300];
-        f3 = f2 - w; f2 = f2 + w;
-        x[0] = (float)(f0 + f2); x[2] = (float)(f0 - f2); x[1] = (float)(f1 + f3); x[3] = (float)(f1 - f3);
-        f0 = (double)T.window[i + 0x001] * (double)buf[i + 0x001];
-        w = (double)T.window[i + 0x201] * (double)buf[i + 0x201];
-        f1 = f0 - w; f0 = f0 + w;
-        f2 = (double)T.window[i + 0x101] * (double)buf[i + 0x101];
-        w = (double)T.window[i + 0x301] * (double)buf[i + 0x301];
-        f3 = f2 - w; f2 = f2 + w;
-        x[BLKSIZE / 2 + 0] = (float)(f0 + f2); x[BLKSIZE / 2 + 2] = (float)(f0 - f2);
-        x[BLKSIZE / 2 + 1] = (float)(f1 + f3); x[BLKSIZE / 2 + 3] = (float)(f1 - f3);
-    }
     for (int it = lane; it < 3 * (BLKSIZE_s / 8); it += LHIP_NL) {
         const int b = it / (BLKSIZE_s / 8), j = it - b * (BLKSIZE_s / 8);
         const int k = (576 / 3) * (b + 1);
         const int i = T.fft_rv_tbl[j << 2] & 0xff;
         float* x = L.fs[b] + 4 * j;
         double f0, f1, f2, f3, w;
-        f0 = (double)T.window_s[i] * (double)buf[i + k];
-        w = (double)T.window_s[0x7f - i] * (double)buf[i + k + 0x80];
+        f0 = (double)T.window_s[i] * (double)buf(i + k);
+        w = (double)T.window_s[0x7f - i] * (double)buf(i + k + 0x80);
         f1 = f0 - w; f0 = f0 + w;
-        f2 = (double)T.window_s[i + 0x40] * (double)buf[i + k + 0x40];
-        w = (double)T.window_s[0x3f - i] * (double)buf[i + k + 0xc0];
+        f2 = (double)T.window_s[i + 0x40] * (double)buf(i + k + 0x40);
+        w = (double)T.window_s[0x3f - i] * (double)buf(i + k + 0xc0);
         f3 = f2 - w; f2 = f2 + w;
         x[0] = (float)(f0 + f2); x[2] = (float)(f0 - f2); x[1] = (float)(f1 + f3); x[3] = (float)(f1 - f3);
-        f0 = (double)T.window_s[i + 0x01] * (double)buf[i + k + 0x01];
-        w = (double)T.window_s[0x7e - i] * (double)buf[i + k + 0x81];
+        f0 = (double)T.window_s[i + 0x01] * (double)buf(i + k + 0x01);
+        w = (double)T.window_s[0x7e - i] * (double)buf(i + k + 0x81);
         f1 = f0 - w; f0 = f0 + w;
-        f2 = (double)T.window_s[i + 0x41] * (double)buf[i + k + 0x41];
-        w = (double)T.window_s[0x3e - i] * (double)buf[i + k + 0xc1];
+        f2 = (double)T.window_s[i + 0x41] * (double)buf(i + k + 0x41);
+        w = (double)T.window_s[0x3e - i] * (double)buf(i + k + 0xc1);
         f3 = f2 - w; f2 = f2 + w;
         x[BLKSIZE_s / 2 + 0] = (float)(f0 + f2); x[BLKSIZE_s / 2 + 2] = (float)(f0 - f2);
         x[BLKSIZE_s / 2 + 1] = (float)(f1 + f3); x[BLKSIZE_s / 2 + 3] = (float)(f1 - f3);
+    }
+    {   // long window, in place: all samples of the lane's items first, then -- after everybody has read -- the butterflies
+        enum { KL = (BLKSIZE / 8 + LHIP_NL - 1) / LHIP_NL };
+        float xin[KL][8];
+#pragma unroll
+        for (int u = 0; u < KL; u++) {
+            const int jj = lane + LHIP_NL * u;
+            if (jj < BLKSIZE / 8) {
+                const int i = T.fft_rv_tbl[jj] & 0xff;
+                xin[u][0] = buf(i); xin[u][1] = buf(i + 0x200); xin[u][2] = buf(i + 0x100); xin[u][3] = buf(i + 0x300);
+                xin[u][4] = buf(i + 0x001); xin[u][5] = buf(i + 0x201); xin[u][6] = buf(i + 0x101); xin[u][7] = buf(i + 0x301);
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < KL; u++) {
+            const int jj = lane + LHIP_NL * u;
+            if (jj < BLKSIZE / 8) {
+                const int i = T.fft_rv_tbl[jj] & 0xff;
+                float* x = L.fz + 4 * jj;
+                double f0, f1, f2, f3, w;
+                f0 = (double)T.window[i] * (double)xin[u][0];
+                w = (double)T.window[i + 0x200] * (double)xin[u][1];
+                f1 = f0 - w; f0 = f0 + w;
+                f2 = (double)T.window[i + 0x100] * (double)xin[u][2];
+                w = (double)T.window[i + 0x300] * (double)xin[u][3];
+                f3 = f2 - w; f2 = f2 + w;
+                x[0] = (float)(f0 + f2); x[2] = (float)(f0 - f2); x[1] = (float)(f1 + f3); x[3] = (float)(f1 - f3);
+                f0 = (double)T.window[i + 0x001] * (double)xin[u][4];
+                w = (double)T.window[i + 0x201] * (double)xin[u][5];
+                f1 = f0 - w; f0 = f0 + w;
+                f2 = (double)T.window[i + 0x101] * (double)xin[u][6];
+                w = (double)T.window[i + 0x301] * (double)xin[u][7];
+                f3 = f2 - w; f2 = f2 + w;
+                x[BLKSIZE / 2 + 0] = (float)(f0 + f2); x[BLKSIZE / 2 + 2] = (float)(f0 - f2);
+                x[BLKSIZE / 2 + 1] = (float)(f1 + f3); x[BLKSIZE / 2 + 3] = (float)(f1 - f3);
+            }
+        }
     }
     wave_sync();
 
@@ -335,6 +372,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     PSY_STAMP(7);
     PSY_FLUSH();
+#undef buf
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -56,6 +56,12 @@ LHIP_DEV void uni_gi(GI& g) {
 #define PH_MARK(L, id, t) do {} while (0)
 #define PH_NOW() 0ull
 #endif
+// balance_noise sub-phase marks share the accumulator slots of psyA's stamps: only with -DLHIP_PROF_BALANCE
+#ifdef LHIP_PROF_BALANCE
+#define PH_MARKB(L, id, t) PH_MARK(L, id, t)
+#else
+#define PH_MARKB(L, id, t) do {} while (0)
+#endif
 enum { PH_INIT, PH_XRPOW, PH_XMIN, PH_QUANTIZE, PH_COUNT, PH_NOISE, PH_BALANCE, PH_SFSTORE, PH_HUFFDIV, PH_PUBLISH, PH_COPY, PH_TOTAL,
        PH_C_LOAD, PH_C_QUADS, PH_C_MAX, PH_C_SUMS, PH_C_FIN, PH_N_WALK, PH_N_TERMS, PH_N_SUMS, PH_Q_MASK, PH_Q_LINES, PH_N, PH_DRAIN = 29 /* 22..28 belong to psyA's stamps */,
        PH_N_LINES = 30, PH_N_FOLD = 31 /* calc_noise: per-line terms / systolic fold; PH_N_TERMS is then the per-band part */,
@@ -1174,7 +1180,7 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
         const int r = wave_or(m12 | (z << 16) | (bad << 17));
         *m12_out = r & 0xffff; *all_nonzero = !((r >> 16) & 1); *pre_bad = (r >> 17) & 1;
     }
-    { unsigned long long tt_ = PH_NOW(); (void)tt_; q_amplify_flagged(g, ifqstep34, m_amp, lane, L, Q); PH_MARK(L, PH_B_TRIG, tt_); }
+    { unsigned long long tt_ = PH_NOW(); (void)tt_; q_amplify_flagged(g, ifqstep34, m_amp, lane, L, Q); PH_MARKB(L, PH_B_TRIG, tt_); }
 }
 
 // scale_bitcount (MPEG-1) continuing from the statistics of q_amp_scalefac_bands: pre_bad = some band 11..20 is below its
@@ -1270,11 +1276,11 @@ LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane
     unsigned long long tb_ = PH_NOW(); (void)tb_;
     int all_nonzero, pre_bad, m12;
     q_amp_scalefac_bands(T, g, scalefac, &all_nonzero, &pre_bad, &m12, lane, L, Q);
-    PH_MARK(L, PH_B_AMP, tb_);
+    PH_MARKB(L, PH_B_AMP, tb_);
     int status = all_nonzero;                                  // loop_break (Quantize.js:453-460)
     if (status) return 0;
     status = T.mode_gr == 2 ? q_scale_bitcount_from(Q, g, scalefac, pre_bad, m12, lane) : q_scale_bitcount_lsf(g, scalefac, lane);
-    PH_MARK(L, PH_B_BITCOUNT, tb_);
+    PH_MARKB(L, PH_B_BITCOUNT, tb_);
     if (!status) return 1;
     if (T.noise_shaping > 1) {
         if (0 == g.scalefac_scale) {

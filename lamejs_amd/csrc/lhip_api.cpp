@@ -66,30 +66,6 @@ static bool sync(void* st) { HIPCK(hipStreamSynchronize((hipStream_t)st)); retur
 // ===========================================================================================
 // device-resident per-stream state (what the reference carries from frame to frame)
 // ===========================================================================================
-enum { RS_TAPS = 33 };                       // BLACKSIZE of the reference for an integer ratio (filter_l = 32)
-
-struct StreamState {
-    float pcm_tail[2][MF_NEEDED];
-    float sb[2][SB_STRIDE];
-    float E[2][E_STRIDE];
-    float ecb_s[2][EBS_STRIDE];
-    float peaks[2][PK_STRIDE];
-    float loud[2];
-    int32_t last_attack[2], tent[2];
-    double ath_adjust, ath_limit;
-    int32_t seed[2][2];
-    float rs_old[2][RS_TAPS - 1];   // resampling streams: the last 32 (scaled) input samples
-};
-
-struct StreamIO {          // per stream, per launch (device array parallel to StreamDesc)
-    StreamState* state;
-    const int16_t* src[2]; // new samples (device addresses)
-    uint8_t* out;          // where this stream's frames go (device address)
-    int32_t n_new, mf_size;    // samples appended to the encoder's buffer by this call / already buffered
-    int32_t n_in, rs_p0;       // resampling streams: input samples of this call; input position (relative to this call's
-                               // first sample, >= -32) of tap 0 of the first new output sample
-};
-
 // load carried state into the stream's carry slots and build its sample segment (tail + new samples)
 LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
     const int C = T.channels_out;
@@ -97,8 +73,10 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const StreamIO io = IO[st];
     const StreamState* S = io.state;
     for (int ch = 0; ch < C; ch++) {
-        float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
-        for (int i = lane; i < io.mf_size; i += LHIP_NL) seg[i] = S->pcm_tail[ch][i];
+        if (T.rs_ratio != 1) {                                   // resampling: the segment is materialised (PcmSrc::plane)
+            float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
+            for (int i = lane; i < io.mf_size; i += LHIP_NL) seg[i] = S->pcm_tail[ch][i];
+        }
         const int64_t o = (int64_t)sd.gslot0 * C + ch;
         for (int i = lane; i < SB_STRIDE; i += LHIP_NL) W.sb[o * SB_STRIDE + i] = S->sb[ch][i];
         for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[ch][i];
@@ -159,8 +137,17 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const int frame = 576 * T.mode_gr;
     const int total = io.mf_size + io.n_new, keep = total - frame * F;
     for (int ch = 0; ch < C; ch++) {
-        const float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
-        for (int i = lane; i < keep; i += LHIP_NL) S->pcm_tail[ch][i] = seg[frame * F + i];
+        // new tail = segment[frame * F ...): read through the same accessor the kernels use.  In place: a chunk of 64 is read
+        // completely before it is written, and later chunks only read positions above everything written so far
+        const PcmSrc P = pcm_source(T, W, sd, io, ch);
+        for (int base = 0; base < keep; base += LHIP_NL) {
+            const int i = base + lane;
+            float v = 0.f;
+            if (i < keep) v = pcm_at(P, frame * F + i);
+            wave_sync();
+            if (i < keep) S->pcm_tail[ch][i] = v;
+            wave_sync();
+        }
         if (F == 0) continue;
         const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * C + ch;
         for (int i = lane; i < SB_STRIDE; i += LHIP_NL) S->sb[ch][i] = W.sb[o * SB_STRIDE + i];
@@ -212,10 +199,10 @@ LHIP_DEV void math_op8(const double* in, double* out) {
 #ifndef LHIP_HOSTSIM
 __global__ __launch_bounds__(64) void g_load(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_load(T, W, SD, IO, blockIdx.x, threadIdx.x); }
 __global__ __launch_bounds__(64) void g_save(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_save(T, W, SD, IO, blockIdx.x, threadIdx.x); }
-__global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD) {
+__global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) {
     __shared__ PsyALds L;
     const int C = T.channels_out;
-    kb_psyA(T, W, SD, blockIdx.x / C, blockIdx.x % C, threadIdx.x, L);
+    kb_psyA(T, W, SD, IO, blockIdx.x / C, blockIdx.x % C, threadIdx.x, L);
 }
 __global__ __launch_bounds__(256) void g_prep(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nstreams) {
     kb_prep(T, W, SD, IO, nstreams, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
@@ -228,9 +215,9 @@ __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const Stream
     __shared__ PsyBLds L;
     kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-__global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, int nitems) {
+__global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nitems) {
     __shared__ PolyLds L;
-    kb_polyphase(T, W, SD, blockIdx.x, nitems, threadIdx.x, L);
+    kb_polyphase(T, W, SD, IO, blockIdx.x, nitems, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ MdctLds L;
@@ -721,7 +708,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
     const size_t GC = (size_t)ngs * C, FR = (size_t)(nfr > 0 ? nfr : 1);
 #define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
-    ENS(pcm, (size_t)pcm_plane * C * 4 + 64);
+    ENS(pcm, T.rs_ratio != 1 ? (size_t)pcm_plane * C * 4 + 64 : 64);
     ENS(peaks, GC * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GC * EBL_STRIDE * 4); ENS(mask_idx, GC * EBL_STRIDE * 4);
     ENS(eb_s, GC * EBS_STRIDE * 4); ENS(ecb_s, GC * EBS_STRIDE * 4); ENS(att_raw, GC * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GC * 4); ENS(last_attack, GC * 4);
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
@@ -802,14 +789,14 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         static PsyALds LA; static PsyBLds LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
         q_load_tabs(T, QT, 0, 1);
         for (int s = 0; s < S; s++) WAVE_RUN(kb_load(T, W, dSD, dIO, s, lane_));
-        kb_prep(T, W, dSD, dIO, S, 0, 1);
-        for (int b = 0; b < ngs * C; b++) WAVE_RUN(kb_psyA(T, W, dSD, b / C, b % C, lane_, LA));
+        if (T.rs_ratio != 1) kb_prep(T, W, dSD, dIO, S, 0, 1);
+        for (int b = 0; b < ngs * C; b++) WAVE_RUN(kb_psyA(T, W, dSD, dIO, b / C, b % C, lane_, LA));
         for (int b = 0; b < ngs; b++) kb_scan_raw(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB(T, W, dSD, b, lane_, LB));
-        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, b, ngs * C, lane_, LP));
+        for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
 #ifdef LHIP_WAVESIM
         // small stereo batches: the two-waves-per-frame latency kernel (kb_quant<1>), as run_batch chooses on the device
@@ -839,13 +826,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
 #else
     LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);
-    {
+    if (T.rs_ratio != 1) {          // only the resampler materialises samples; otherwise the consumers convert the caller's Int16 themselves
         int64_t nb = (in_total / C + 255) / 256;
         if (nb > 8192) nb = 8192;
         if (nb < 1) nb = 1;
         LAUNCHB(KT_PREP, g_prep, (int)nb, 256, st, T, W, dSD, dIO, S);
     }
-    LAUNCH(KT_PSYA, g_psyA, ngs * C, st, T, W, dSD);
+    LAUNCH(KT_PSYA, g_psyA, ngs * C, st, T, W, dSD, dIO);
     LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
@@ -872,7 +859,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         }
     }
     if (!forked) LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
-    LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, ngs * C);
+    LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, dIO, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
     LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);

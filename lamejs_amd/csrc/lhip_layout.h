@@ -34,6 +34,50 @@ struct StreamDesc {
     int64_t frame_num0;     // absolute index of the first frame of this batch
 };
 
+enum { RS_TAPS = 33 };                       // BLACKSIZE of the reference for an integer ratio (filter_l = 32)
+
+struct StreamState {
+    float pcm_tail[2][MF_NEEDED];
+    float sb[2][SB_STRIDE];
+    float E[2][E_STRIDE];
+    float ecb_s[2][EBS_STRIDE];
+    float peaks[2][PK_STRIDE];
+    float loud[2];
+    int32_t last_attack[2], tent[2];
+    double ath_adjust, ath_limit;
+    int32_t seed[2][2];
+    float rs_old[2][RS_TAPS - 1];   // resampling streams: the last 32 (scaled) input samples
+};
+
+struct StreamIO {          // per stream, per launch (device array parallel to StreamDesc)
+    StreamState* state;
+    const int16_t* src[2]; // new samples (device addresses)
+    uint8_t* out;          // where this stream's frames go (device address)
+    int32_t n_new, mf_size;    // samples appended to the encoder's buffer by this call / already buffered
+    int32_t n_in, rs_p0;       // resampling streams: input samples of this call; input position (relative to this call's
+                               // first sample, >= -32) of tap 0 of the first new output sample
+};
+
+// Where the samples of a stream's segment (carried tail ++ this call's new samples) come from.  Without resampling nothing is
+// materialised: a sample below `mf` is the carried tail (scaled f32, StreamState), the others are converted from the caller's
+// Int16 on the fly -- Lame.js:1554-1560 is one multiply, `(float)((double)(float)s16 * scale)` -- so the psychoacoustics and the
+// filterbank read 2 bytes per sample instead of a 4-byte copy that another kernel had to write first.  Resampling
+// configurations (integer-ratio FIR in front, g_prep) read the f32 plane that kernel fills.
+struct PcmSrc {
+    const float* plane;      // != nullptr: materialised segment (resampling configurations)
+    const float* tail;       // carried samples [0, mf)
+    const int16_t* src;      // new samples [mf, ...)
+    int mf, do_scale;
+    double scale;
+};
+LHIP_DEV float pcm_at(const PcmSrc& P, int s) {
+    if (P.plane) return P.plane[s];
+    if (s < P.mf) return P.tail[s];
+    float v = (float)P.src[s - P.mf];
+    if (P.do_scale) v = (float)((double)v * P.scale);
+    return v;
+}
+
 // All slot arrays of a launch (device pointers).  C = channels_out.
 struct Workspace {
     int nstreams, nframes_total, nfslots, ngslots;   // slots include one carry slot per stream
@@ -77,5 +121,13 @@ struct Workspace {
     int32_t mode_gr;            // granules per frame (2: MPEG-1, 1: MPEG-2/2.5 LSF)
     int32_t spec_start, spec_step;   // seed assumed by the speculative pass (Quantize.js reset values 180 / 4)
 };
+
+LHIP_DEV PcmSrc pcm_source(const Tables& T, const Workspace& W, const StreamDesc& sd, const StreamIO& io, int ch) {
+    PcmSrc P;
+    P.plane = T.rs_ratio != 1 ? W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off : nullptr;
+    P.tail = io.state->pcm_tail[ch]; P.src = io.src[ch]; P.mf = io.mf_size;
+    P.do_scale = !(T.scale == 0.0) && !(T.scale == 1.0); P.scale = T.scale;
+    return P;
+}
 
 }  // namespace lhip

@@ -25,7 +25,7 @@ for corpus, ch, kbps in [("sine", 1, 128), ("sine", 2, 128)]:
             print(f"   {n:9s} {100.0 * buf[i] / tot:5.1f}%  calls/frame {buf[32 + i] / nfr:7.2f}  cycles/call {buf[i] / buf[32 + i]:9.0f}")
     if buf[61]:
         print(f"   drain     {100.0 * buf[29] / tot:5.1f}%  calls/frame {buf[61] / nfr:7.2f}  cycles/call {buf[29] / buf[61]:9.0f}")
-    if False and buf[54]:
+    if buf[54]:
         pn = ["hpf_peaks", "window+r4", "fht", "energies", "loudness", "partitions", "tonal+spread"]
         tp = sum(buf[22 + i] for i in range(7))
         print(f"   psyA: {tp / buf[54]:.0f} cycles per (granule, channel) wave")
