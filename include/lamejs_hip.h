@@ -91,7 +91,9 @@ int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* cons
  * Work is enqueued on the HIP stream set by lhip_set_hip_stream (default: the null stream) and the
  * call returns after enqueueing unless `sync` is non-zero: nothing in the pipeline waits for the host (the bin-search seed chain
  * is validated and repaired by a persistent kernel on the device), so with sync == 0 the output bytes and lhip_last_batch_stats
- * are only valid after the stream has been synchronised (lhip_last_batch_stats does that itself). */
+ * are only valid after the stream has been synchronised (lhip_last_batch_stats does that itself).  The input buffers are read by
+ * kernels up to the end of the batch (the samples are converted where they are consumed, there is no staging copy), so with
+ * sync == 0 they must stay valid and unchanged until then as well. */
 int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const int16_t* const* d_left,
                              const int16_t* const* d_right, const size_t* nsamples, uint8_t* const* d_out,
                              const size_t* out_cap, int64_t* written, int sync);

@@ -145,26 +145,39 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
     {
         const float* fir = L.fz + 397;                // 576 - 350 - 21 + 192
-        // all nine sub-block outputs of a lane first (their loads are independent and overlap), the maxima after
+        // Each lane filters NINE CONSECUTIVE outputs: they share 30 input samples, read and widened once (a lane that took
+        // output lane + 64 k of each sub-block instead would read 198).  The magnitudes go through LDS (the short FHT buffers are
+        // free until the windowing) so that lane l then holds value l of each 64-sample sub-block for the nine wave maxima.
+        // Per output the sums are formed exactly as in PsyModel.js:1051-1069 (same operands, same order).
+        enum { HO = (576 + LHIP_NL - 1) / LHIP_NL };      // outputs per lane: 9
+        float* mag = &L.fs[0][0];
+        {
+            double x[HO + 21];
+#pragma unroll
+            for (int t = 0; t < HO + 21; t++) { const int n = HO * lane + t; x[t] = (n < 576 + 21) ? (double)fir[n] : 0.0; }
+#pragma unroll
+            for (int k = 0; k < HO; k++) {
+                double sum1 = x[k + 10], sum2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 9; j += 2) {
+                    sum1 += T.hpf_fircoef[j] * (x[k + j] + x[k + 21 - j]);
+                    sum2 += T.hpf_fircoef[j + 1] * (x[k + j + 1] + x[k + 21 - j - 1]);
+                }
+                float v = (float)(sum1 + sum2);
+                v = v < 0 ? -v : v;
+                if (HO * lane + k < 576) mag[HO * lane + k] = v;
+            }
+        }
+        wave_sync();
         enum { KP = (64 + LHIP_NL - 1) / LHIP_NL };
         float pk[9];
 #pragma unroll
         for (int sbk = 0; sbk < 9; sbk++) {
             float m = 1.0f;
-            for (int u = 0; u < KP; u++) {
-                const int i = sbk * 64 + lane + LHIP_NL * u;
-                double sum1 = (double)fir[i + 10], sum2 = 0.0;
-#pragma unroll
-                for (int j = 0; j < 9; j += 2) {
-                    sum1 += T.hpf_fircoef[j] * ((double)fir[i + j] + (double)fir[i + 21 - j]);
-                    sum2 += T.hpf_fircoef[j + 1] * ((double)fir[i + j + 1] + (double)fir[i + 21 - j - 1]);
-                }
-                float v = (float)(sum1 + sum2);
-                v = v < 0 ? -v : v;
-                if (m < v) m = v;
-            }
+            for (int u = 0; u < KP; u++) { const float v = mag[sbk * 64 + lane + LHIP_NL * u]; if (m < v) m = v; }
             pk[sbk] = m;
         }
+        wave_sync();                                  // the magnitudes are dead: the short windowing refills L.fs
 #pragma unroll
         for (int sbk = 0; sbk < 9; sbk++) pk[sbk] = wave_maxf(pk[sbk]);
         if (lane == 0) {
