@@ -633,7 +633,8 @@ struct PsyBLds {
 };
 
 LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, double m1, double m2, int b) {
-    // PsyModel.js:403-473 (long blocks)
+    // PsyModel.js:403-473 (long blocks).  Every logarithm here has a positive, finite, normal operand -- `ratio` lies in
+    // [1, ma_max_i2) and m1 / m2 in (1, ma_max_m) on the paths that take it -- so the branch-free v8_log10_pos applies (lhip_math.h)
     double ratio;
     if (m2 > m1) {
         if (m2 < (m1 * T.ma_max_i2)) ratio = m2 / m1;
@@ -645,16 +646,16 @@ LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, dou
     m1 += m2;
     if ((b + 3) <= 3 + 3) {
         if (ratio >= T.ma_max_i1) return m1;
-        const int i = js_toint32(v8_log10(ratio) * 16.0);
+        const int i = js_toint32(v8_log10_pos(ratio) * 16.0);
         return m1 * L.mt2[i];
     }
-    const int i = js_toint32(v8_log10(ratio) * 16.0);
+    const int i = js_toint32(v8_log10_pos(ratio) * 16.0);
     m2 = ath_cb;
     if (m1 < T.ma_max_m * m2) {
         if (m1 > m2) {
             double f = 1.0;
             if (i <= 13) f = L.mt3[i];
-            const double r = v8_log10(m1 / m2) * (10.0 / 15.0);
+            const double r = v8_log10_pos(m1 / m2) * (10.0 / 15.0);
             return m1 * ((L.mt1[i] - f) * r + f);
         }
         if (i > 13) return m1;

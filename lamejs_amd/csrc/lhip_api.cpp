@@ -881,6 +881,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
         LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
+        // one workgroup per CU at most: the memo-miss re-validation (a few hundred frames per 1e5 on steady material) is spread over
+        // all of them -- a quarter-chip grid was tried and doubled this stage's time
         int fgrid = (nfs + 63) / 64;
         if (fgrid > ctx->num_cus) fgrid = ctx->num_cus;
         if (fgrid < 1) fgrid = 1;
