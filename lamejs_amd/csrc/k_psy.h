@@ -16,15 +16,6 @@
 namespace lhip {
 
 // ---------------------------------------------------------------------------------------------
-// kb_prep: Int16 -> scaled Float32 (Lame.js:1506-1560).  One element per thread, grid-stride.
-// ---------------------------------------------------------------------------------------------
-LHIP_DEV void kb_prep_elem(const Tables& T, float* dst, const int16_t* src, int64_t i) {
-    float v = (float)src[i];
-    if (!(T.scale == 0.0) && !(T.scale == 1.0)) v = (float)((double)v * T.scale);
-    dst[i] = v;
-}
-
-// ---------------------------------------------------------------------------------------------
 // FHT butterflies, one radix-4 pass over n points held in LDS (FFT.js:45-112).
 // Work item t in [0, n/8): block m = t / kx, index i = t % kx inside the block.
 // ---------------------------------------------------------------------------------------------

@@ -114,7 +114,8 @@ LHIP_DEV void kb_resample_elem(const Tables& T, float* dst, const int16_t* src, 
     dst[t] = (float)xvalue;
 }
 
-// Int16 -> scaled f32 for the new samples of every stream: grid-stride over (stream, channel, sample)
+// Resampling configurations only: the new output-rate samples of every stream, grid-stride over (stream, channel, sample).
+// (Without resampling nothing is materialised: the consumers convert the caller's Int16 where they stage it, PcmSrc.)
 LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int nstreams, int64_t tid, int64_t nthreads) {
     const int C = T.channels_out;
     for (int st = 0; st < nstreams; st++) {
@@ -122,8 +123,7 @@ LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD,
         const int64_t off = SD[st].pcm_off + io.mf_size;
         for (int ch = 0; ch < C; ch++) {
             float* dst = W.pcm + (int64_t)ch * W.pcm_plane + off;
-            if (T.rs_ratio == 1) { for (int64_t i = tid; i < io.n_new; i += nthreads) kb_prep_elem(T, dst, io.src[ch], i); }
-            else for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, io.src[ch], io.state->rs_old[ch], io.rs_p0, i);
+            for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, io.src[ch], io.state->rs_old[ch], io.rs_p0, i);
         }
     }
 }
