@@ -735,6 +735,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     int m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
+        if (2 * LHIP_NL * j >= i) continue;                         // wave-uniform: every pair of this round of lanes lies beyond big_values
         const int p = 2 * (lane + LHIP_NL * j);
         const int m = (p < i) ? (vx[j] > vy[j] ? vx[j] : vy[j]) : 0;
         const int mr0 = (p < a1) ? m : 0, mr1 = (p >= a1 && p < a2) ? m : 0, mr2 = (p >= a2) ? m : 0;
