@@ -19,10 +19,10 @@ namespace lhip {
 // consecutive banks, and the whole index except `+ j` is a compile-time constant.
 enum { POLY_PER_WAVE = 3, POLY_BIAS = 320, POLY_N1 = 32 * 17 + 256 + POLY_BIAS + 1, POLY_N = POLY_N1 + 576 * (POLY_PER_WAVE - 1),
        POLY_ROW = 73 /* odd, >= POLY_N / 32 + 1 */, POLY_ITEM = 32 * POLY_ROW };
-#define XT(off) ((double)xt[(((off) + POLY_BIAS) & 31) * POLY_ROW + (((off) + POLY_BIAS) >> 5)])
+#define XT(off) ((double)xt[(((off) + POLY_BIAS) & 31) * ROW + (((off) + POLY_BIAS) >> 5)])
 
 // One 32-band slot.  xt = transposed window base of this lane's slot; a[] lives in registers.
-LHIP_DEV void window_subband(const double* W, const float* xt, float* a) {
+template <int ROW> LHIP_DEV void window_subband(lhip_ctab W, const float* xt, float* a) {
     // reference pointers: p = x - d, q = x - 62 + d with d = i + 15 (NewMDCT.js:540-583)
 #pragma unroll
     for (int d = 0; d < 15; d++) {
@@ -46,6 +46,7 @@ LHIP_DEV void window_subband(const double* W, const float* xt, float* a) {
         w = t - s;
         a[2 * d] = (float)(t + s);
         a[2 * d + 1] = (float)(W[wp + 7] * w);
+        LHIP_SCHED_FENCE();                       // keep one d's coefficient loads from being hoisted over the others (register pressure)
     }
     const int wp = 10 + 18 * 15;
     {
@@ -145,9 +146,11 @@ LHIP_DEV void window_subband(const double* W, const float* xt, float* a) {
 // 1121-sample window), so ONE transposed staging of 2273 samples serves all three and lane u = item * 18 + slot simply
 // reads at column offset u (576 = 18 rows of 32).  Waves that straddle a stream boundary take the items one by one.
 struct PolyLds { float xs[POLY_ITEM]; };
-LHIP_DEV void poly_slot(const Tables& T, const float* xt, float* out, int j) {
+static_assert(POLY_ITEM >= 18 * POLY_PER_WAVE * 33, "the polyphase output is staged in the PCM area");
+// one slot: 32 band values, sign and low-pass scaling applied, stored with stride 1 at `out`
+template <int ROW> LHIP_DEV void poly_slot(const Tables& T, const float* xt, float* out, int j) {
     float a[32];
-    window_subband(T.enwindow, xt, a);
+    window_subband<ROW>(LHIP_CTAB(T.enwindow), xt, a);
     if (j & 1)
         for (int band = 1; band < 32; band += 2) a[band] = (float)((double)a[band] * -1);
     for (int band = 0; band < 32; band++) {
@@ -157,7 +160,7 @@ LHIP_DEV void poly_slot(const Tables& T, const float* xt, float* out, int j) {
             a[ob] = (float)((double)a[ob] * af);
         }
     }
-    for (int i = 0; i < 32; i++) out[j * 32 + i] = a[i];
+    for (int i = 0; i < 32; i++) out[i] = a[i];
 }
 LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int wave_idx, int nitems, int lane, PolyLds& L) {
     const int C = T.channels_out, ngs = W.ngslots;
@@ -198,14 +201,35 @@ LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc
             for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? pcm_at(P, s0 + n) : 0.f;
         }
         wave_sync();
+#if LHIP_NL == 1
         for (int u = lane; u < 18 * cnt; u += LHIP_NL) {
             const int it = u / 18, j = u - 18 * it;
-            poly_slot(T, L.xs + u, W.sb + ((int64_t)(gs + it) * C + ch) * SB_STRIDE, j);
+            float a[32];
+            poly_slot<POLY_ROW>(T, L.xs + u, a, j);
+            float* out = W.sb + ((int64_t)(gs + it) * C + ch) * SB_STRIDE + j * 32;
+            for (int i = 0; i < 32; i++) out[i] = a[i];
         }
+#else
+        // every lane holds one slot (32 values); stored from the registers, a lane would write 128 bytes at a 128-byte stride from
+        // its neighbours'.  Through LDS (the PCM window is no longer needed; rows padded to 33 against bank conflicts) the wave
+        // writes each item's 2304 bytes as consecutive 256-byte rows instead.
+        {
+            const int u = lane, it = u / 18, j = u - 18 * it;      // 18 * cnt <= 54 < 64: one slot per lane
+            float a[32];
+            if (u < 18 * cnt) poly_slot<POLY_ROW>(T, L.xs + u, a, j);
+            wave_sync();
+            if (u < 18 * cnt) for (int i = 0; i < 32; i++) L.xs[u * 33 + i] = a[i];
+            wave_sync();
+            for (int k = 0; k < cnt; k++) {
+                float* out = W.sb + ((int64_t)(gs + k) * C + ch) * SB_STRIDE;
+                for (int i = lane; i < SB_STRIDE; i += LHIP_NL) out[i] = L.xs[(18 * k + (i >> 5)) * 33 + (i & 31)];
+            }
+        }
+#endif
     }
 }
 
-LHIP_DEV void mdct_short3(const double* ws, float* io) {
+LHIP_DEV void mdct_short3(lhip_ctab ws, float* io) {
     for (int l = 0; l < 3; l++, io++) {
         double tc0, tc1, tc2, ts0, ts1, ts2;
         ts0 = (double)io[6] * ws[0] - (double)io[15];
@@ -231,7 +255,7 @@ LHIP_DEV void mdct_short3(const double* ws, float* io) {
     }
 }
 
-LHIP_DEV void mdct_long18(const double* cx, float* out, const float* in) {
+LHIP_DEV void mdct_long18(lhip_ctab cx, float* out, const float* in) {
     double ct, st;
 #define I(k) ((double)in[k])
     {
@@ -285,70 +309,72 @@ LHIP_DEV void mdct_long18(const double* cx, float* out, const float* in) {
 
 struct MdctLds { float xr[2][576]; };
 
+// windowing + MDCT of one band of one granule: band0 / band1 = previous / current polyphase output of that band, slot r at
+// [r * RS]; enc = the band's 18 spectral lines
+template <int RS> LHIP_DEV void mdct_band(const Tables& T, const float* band0, const float* band1, int type, int band, float* enc) {
+    lhip_ctab win = LHIP_CTAB(T.mdct_win);
+#define B0(r) ((double)band0[(r) * RS])
+#define B1(r) ((double)band1[(r) * RS])
+    if ((double)T.amp_filter[band] < 1e-12) {
+        for (int k = 0; k < 18; k++) enc[k] = 0.f;
+    } else if (type == SHORT_TYPE) {
+        lhip_ctab ws = win + 2 * 36;
+        float v[18];
+        for (int k = -3; k < 0; k++) {
+            const double w = ws[k + 3];
+            v[k * 3 + 9] = (float)(B0(9 + k) * w - B0(8 - k));
+            v[k * 3 + 18] = (float)(B0(14 - k) * w + B0(15 + k));
+            v[k * 3 + 10] = (float)(B0(15 + k) * w - B0(14 - k));
+            v[k * 3 + 19] = (float)(B1(2 - k) * w + B1(3 + k));
+            v[k * 3 + 11] = (float)(B1(3 + k) * w - B1(2 - k));
+            v[k * 3 + 20] = (float)(B1(8 - k) * w + B1(9 + k));
+        }
+        mdct_short3(ws, v);
+        for (int k = 0; k < 18; k++) enc[k] = v[k];
+    } else {
+        float work[18], o18[18];
+        lhip_ctab wt = win + type * 36;
+        lhip_ctab tantab = win + 2 * 36 + 3;
+        for (int k = -9; k < 0; k++) {
+            const double a = wt[k + 27] * B1(k + 9) + wt[k + 36] * B1(8 - k);
+            const double b = wt[k + 9] * B0(k + 9) - wt[k + 18] * B0(8 - k);
+            work[k + 9] = (float)(a - b * tantab[k + 9]);
+            work[k + 18] = (float)(a * tantab[k + 9] + b);
+        }
+        mdct_long18(win + 2 * 36 + 12, o18, work);
+        for (int k = 0; k < 18; k++) enc[k] = o18[k];
+    }
+#undef B0
+#undef B1
+}
+// alias-reduction butterflies between band - 1 and band (non-short blocks, band >= 1); enc = the band's lines
+LHIP_DEV void alias_band(const Tables& T, float* enc) {
+    lhip_ctab ca = LHIP_CTAB(T.mdct_win) + 2 * 36 + 20;
+    lhip_ctab cs = LHIP_CTAB(T.mdct_win) + 2 * 36 + 28;
+    for (int k = 7; k >= 0; --k) {
+        const double bu = (double)enc[k] * ca[k] + (double)enc[-1 - k] * cs[k];
+        const double bd = (double)enc[k] * cs[k] - (double)enc[-1 - k] * ca[k];
+        enc[-1 - k] = (float)bu;
+        enc[k] = (float)bd;
+    }
+}
+
 // one wave per granule slot >= 1; lane = ch * 32 + band
 LHIP_DEV void kb_mdct(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int lane, MdctLds& L) {
     const int C = T.channels_out;
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
     if (gslot - sd.gslot0 - 1 < 0) return;
-    const double* win = T.mdct_win;
     LHIP_LANE_ONCE(it, 0, C * 32) {                            // C <= 2: at most one (channel, band) per lane
         const int ch = it >> 5, band = it & 31;
-        const float* band0 = W.sb + ((int64_t)(gslot - 1) * C + ch) * SB_STRIDE;   // previous granule (or carry)
-        const float* band1 = W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE;
-        const int type = W.blocktype[(int64_t)gslot * C + ch];
         const int ob = T.mdct_order[band];
-        float* enc = L.xr[ch] + 18 * band;
-#define B0(r) ((double)band0[(r) * 32 + ob])
-#define B1(r) ((double)band1[(r) * 32 + ob])
-        if ((double)T.amp_filter[band] < 1e-12) {
-            for (int k = 0; k < 18; k++) enc[k] = 0.f;
-        } else if (type == SHORT_TYPE) {
-            const double* ws = win + 2 * 36;
-            float v[18];
-            for (int k = -3; k < 0; k++) {
-                const double w = ws[k + 3];
-                v[k * 3 + 9] = (float)(B0(9 + k) * w - B0(8 - k));
-                v[k * 3 + 18] = (float)(B0(14 - k) * w + B0(15 + k));
-                v[k * 3 + 10] = (float)(B0(15 + k) * w - B0(14 - k));
-                v[k * 3 + 19] = (float)(B1(2 - k) * w + B1(3 + k));
-                v[k * 3 + 11] = (float)(B1(3 + k) * w - B1(2 - k));
-                v[k * 3 + 20] = (float)(B1(8 - k) * w + B1(9 + k));
-            }
-            mdct_short3(ws, v);
-            for (int k = 0; k < 18; k++) enc[k] = v[k];
-        } else {
-            float work[18], o18[18];
-            const double* wt = win + type * 36;
-            const double* tantab = win + 2 * 36 + 3;
-            for (int k = -9; k < 0; k++) {
-                const double a = wt[k + 27] * B1(k + 9) + wt[k + 36] * B1(8 - k);
-                const double b = wt[k + 9] * B0(k + 9) - wt[k + 18] * B0(8 - k);
-                work[k + 9] = (float)(a - b * tantab[k + 9]);
-                work[k + 18] = (float)(a * tantab[k + 9] + b);
-            }
-            mdct_long18(win + 2 * 36 + 12, o18, work);
-            for (int k = 0; k < 18; k++) enc[k] = o18[k];
-        }
-#undef B0
-#undef B1
+        mdct_band<32>(T, W.sb + ((int64_t)(gslot - 1) * C + ch) * SB_STRIDE + ob, W.sb + ((int64_t)gslot * C + ch) * SB_STRIDE + ob,
+                      W.blocktype[(int64_t)gslot * C + ch], band, L.xr[ch] + 18 * band);
     }
     wave_sync();
-    // alias-reduction butterflies between band-1 and band (non-short blocks); disjoint element pairs
-    LHIP_LANE_ONCE(it, 0, C * 32) {                            // C <= 2: at most one (channel, band) per lane
+    LHIP_LANE_ONCE(it, 0, C * 32) {                            // disjoint element pairs
         const int ch = it >> 5, band = it & 31;
-        const int type = W.blocktype[(int64_t)gslot * C + ch];
-        if (type != SHORT_TYPE && band != 0) {
-            float* enc = L.xr[ch] + 18 * band;
-            const double* ca = win + 2 * 36 + 20;
-            const double* cs = win + 2 * 36 + 28;
-            for (int k = 7; k >= 0; --k) {
-                const double bu = (double)enc[k] * ca[k] + (double)enc[-1 - k] * cs[k];
-                const double bd = (double)enc[k] * cs[k] - (double)enc[-1 - k] * ca[k];
-                enc[-1 - k] = (float)bu;
-                enc[k] = (float)bd;
-            }
-        }
+        if (W.blocktype[(int64_t)gslot * C + ch] != SHORT_TYPE && band != 0) alias_band(T, L.xr[ch] + 18 * band);
     }
     wave_sync();
     for (int ch = 0; ch < C; ch++)

@@ -197,12 +197,19 @@ LHIP_DEV void math_op8(const double* in, double* out) {
 // kernel launch layer
 // ===========================================================================================
 #ifndef LHIP_HOSTSIM
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.  Kernels whose
+// neighbouring work items read the same data (a granule and its successor: overlapping PCM windows, the polyphase output that
+// two MDCT granules share, the carried thresholds) number their items so that neighbours run on ONE XCD, back to back:
+// item = (b % 8) * ceil(n / 8) + b / 8.  Launch XCD_GRID(n) workgroups; -1 = no item for this workgroup.
+#define XCD_GRID(n) (8 * (((n) + 7) / 8))
+static __device__ __forceinline__ int xcd_item(int b, int n) { const int it = (b & 7) * ((n + 7) >> 3) + (b >> 3); return it < n && (b >> 3) < ((n + 7) >> 3) ? it : -1; }
 __global__ __launch_bounds__(64) void g_load(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_load(T, W, SD, IO, blockIdx.x, threadIdx.x); }
 __global__ __launch_bounds__(64) void g_save(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_save(T, W, SD, IO, blockIdx.x, threadIdx.x); }
 __global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) {
     __shared__ PsyALds L;
     const int C = T.channels_out;
-    kb_psyA(T, W, SD, IO, blockIdx.x / C, blockIdx.x % C, threadIdx.x, L);
+    const int it = xcd_item(blockIdx.x, W.ngslots * C);
+    if (it >= 0) kb_psyA(T, W, SD, IO, it / C, it % C, threadIdx.x, L);
 }
 __global__ __launch_bounds__(256) void g_prep(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nstreams) {
     kb_prep(T, W, SD, IO, nstreams, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
@@ -213,15 +220,18 @@ __global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, co
 __global__ __launch_bounds__(ATH_NT) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
 __global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ PsyBLds L;
-    kb_psyB(T, W, SD, blockIdx.x, threadIdx.x, L);
+    const int it = xcd_item(blockIdx.x, W.ngslots);
+    if (it >= 0) kb_psyB(T, W, SD, it, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nitems) {
     __shared__ PolyLds L;
-    kb_polyphase(T, W, SD, IO, blockIdx.x, nitems, threadIdx.x, L);
+    const int it = xcd_item(blockIdx.x, (nitems + POLY_PER_WAVE - 1) / POLY_PER_WAVE);
+    if (it >= 0) kb_polyphase(T, W, SD, IO, it, nitems, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ MdctLds L;
-    kb_mdct(T, W, SD, blockIdx.x, threadIdx.x, L);
+    const int it = xcd_item(blockIdx.x, W.ngslots);
+    if (it >= 0) kb_mdct(T, W, SD, it, threadIdx.x, L);
 }
 // quantization kernels: 8 waves (= 8 frames) per workgroup share one copy of the lookup tables in LDS
 #ifdef LHIP_PHASE_PROF
@@ -832,7 +842,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (nb < 1) nb = 1;
         LAUNCHB(KT_PREP, g_prep, (int)nb, 256, st, T, W, dSD, dIO, S);
     }
-    LAUNCH(KT_PSYA, g_psyA, ngs * C, st, T, W, dSD, dIO);
+    LAUNCH(KT_PSYA, g_psyA, XCD_GRID(ngs * C), st, T, W, dSD, dIO);
     LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
@@ -859,10 +869,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         }
     }
     if (!forked) LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
-    LAUNCH(KT_POLY, g_poly, (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE, st, T, W, dSD, dIO, ngs * C);
-    LAUNCH(KT_MDCT, g_mdct, ngs, st, T, W, dSD);
+    LAUNCH(KT_POLY, g_poly, XCD_GRID((ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE), st, T, W, dSD, dIO, ngs * C);
+    LAUNCH(KT_MDCT, g_mdct, XCD_GRID(ngs), st, T, W, dSD);
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
-    LAUNCH(KT_PSYB, g_psyB, ngs, st, T, W, dSD);
+    LAUNCH(KT_PSYB, g_psyB, XCD_GRID(ngs), st, T, W, dSD);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;

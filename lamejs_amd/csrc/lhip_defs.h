@@ -31,6 +31,19 @@
 #define LHIP_NL 64
 #endif
 
+// Immutable f64 tables read at wave-uniform, compile-time-constant offsets (filterbank windows): through a pointer to the
+// constant address space the compiler may use the scalar unit's loads (s_load, operands in SGPRs) instead of one vector
+// memory load per lane -- the tables are written once, before any kernel that reads them is launched.
+#ifdef LHIP_HOSTSIM
+typedef const double* lhip_ctab;
+#define LHIP_CTAB(p) (p)
+#define LHIP_SCHED_FENCE() ((void)0)
+#else
+#define LHIP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)     /* the instruction scheduler moves nothing across this point */
+typedef const double __attribute__((address_space(4)))* lhip_ctab;
+#define LHIP_CTAB(p) ((lhip_ctab)(uintptr_t)(p))
+#endif
+
 // `for (v = lo + lane; v < n; v += NL)` where the author knows n - lo <= NL (band loops: at most 39 bands) but the
 // compiler does not: at most one iteration per lane.  Left as a loop, the compiler emits a generic loop nest (with a
 // 16-fold unrolled body and the spills that come with it) for every one of them.  `lane` must be in scope.
