@@ -73,26 +73,28 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     return lib
 
 
-def tables_blob(channels: int, samplerate: int, kbps: int) -> bytes:
+def tables_blob(channels: int, samplerate: int, kbps: int, joint: bool = False) -> bytes:
     """The LHTB table blob for a configuration.
 
     Built by the host-side JavaScript ``lamejs_amd/js/tables.js`` (so every transcendental comes
     from the same engine the reference uses).  Blobs for the BASELINE configurations are generated
     at build time into ``lamejs_amd/tables/``; other configurations are generated on demand when
-    ``node`` is available.
+    ``node`` is available.  ``joint``: the reference's joint-stereo mode (an extension: its own
+    ``Mp3Encoder`` never selects it, index.js:105); only meaningful for two channels.
     """
-    f = _TABLE_DIR / f"t_{channels}_{samplerate}_{kbps}.bin"
+    joint = bool(joint) and channels == 2
+    f = _TABLE_DIR / f"t_{channels}_{samplerate}_{kbps}{'_joint' if joint else ''}.bin"
     gen = _PKG / "js" / "tables.js"
     if not f.exists() or f.stat().st_mtime < gen.stat().st_mtime:      # a cached blob older than its generator is stale
         _TABLE_DIR.mkdir(exist_ok=True)
         try:
-            subprocess.run(["node", str(_PKG / "js" / "tables.js"), str(channels), str(samplerate), str(kbps), str(f)],
+            subprocess.run(["node", str(_PKG / "js" / "tables.js"), str(channels), str(samplerate), str(kbps), str(f)] + (["joint"] if joint else []),
                            check=True, capture_output=True, text=True)
         except (OSError, subprocess.CalledProcessError) as e:  # pragma: no cover
             msg = getattr(e, "stderr", "") or str(e)
             if isinstance(e, OSError) and f.exists():      # no node on this machine: use the blob that was shipped
                 return f.read_bytes()
-            raise LhipError(f"no table blob for ({channels},{samplerate},{kbps}) and node could not build it: {msg}")
+            raise LhipError(f"no table blob for ({channels},{samplerate},{kbps}{',joint' if joint else ''}) and node could not build it: {msg}")
     return f.read_bytes()
 
 

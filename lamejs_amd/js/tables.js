@@ -30,7 +30,7 @@ const SBMAX_l = 22, SBMAX_s = 13, SBPSY_l = 21, SBPSY_s = 12, PSFB21 = 6, PSFB12
 const CBANDS = 64, BLKSIZE = 1024, BLKSIZE_s = 256, HBLKSIZE = 513;
 const IXMAX_VAL = 8206, PRECALC_SIZE = IXMAX_VAL + 2, Q_MAX = 256 + 1, Q_MAX2 = 116;
 const FLOAT_MAX = 3.4028235e+38;
-const MODE_STEREO = 0, MODE_MONO = 3;
+const MODE_STEREO = 0, MODE_JOINT_STEREO = 1, MODE_MONO = 3;
 
 function f32(n) { return new Float32Array(n); }
 function i32(n) { return new Int32Array(n); }
@@ -69,10 +69,12 @@ function suggestedSampleFreq(lowpassfreq, in_rate) {
     return s;
 }
 
-function resolveParams(channels, samplerate, kbps) {
+function resolveParams(channels, samplerate, kbps, opts) {
     const p = {};
     p.channels_in = channels;
     p.mode = (channels == 1) ? MODE_MONO : MODE_STEREO;      /* index.js:105, Lame.js:759-761 */
+    /* extension (SURVEY.md 8f #3): the reference's joint-stereo path, which its Mp3Encoder never selects (index.js:105) */
+    if (opts && opts.jointStereo && channels == 2) p.mode = MODE_JOINT_STEREO;
     p.channels_out = (p.mode == MODE_MONO) ? 1 : 2;
     p.in_samplerate = samplerate;
     let brate = kbps;
@@ -216,6 +218,10 @@ function resolveParams(channels, samplerate, kbps) {
     p.ATHlower = -row[10] / 10.;
     p.ATHcurve = row[11];
     p.interChRatio = row[12];
+    /* Presets.js:288-292 (nsmsfix); Lame.js:1322: < 0 -> 0; PsyModel.js:2738-2744: 0 -> NS_MSFIX (3.5), or 1.0 with safejoint */
+    p.msfix = row[4];
+    if (p.msfix < 0) p.msfix = 0;
+    if (!(Math.abs(p.msfix) > 0.0)) p.msfix = ((exp_nspsytune & 2) != 0) ? 1.0 : 3.5;
     p.mask_adjust = maskingadjust;
     p.mask_adjust_short = maskingadjust_short;
     /* CBRNewIterationLoop.js:56-65: masking_lower = 10^(0.1 * mask_adjust[_short]) */
@@ -236,7 +242,7 @@ function resolveParams(channels, samplerate, kbps) {
     p.ATH_useAdjust = 3;
     p.ATH_aaSensitivityP = Math.pow(10.0, 0.0 / -10.0);
     /* short_block_allowed -> coupled for (joint) stereo (Lame.js:1302-1317) */
-    p.short_blocks_coupled = (p.mode == MODE_STEREO) ? 1 : 0;
+    p.short_blocks_coupled = (p.mode == MODE_STEREO || p.mode == MODE_JOINT_STEREO) ? 1 : 0;
     p.exp_nspsytune = exp_nspsytune | 1;
     p.ATHtype = 4;
     p.athaa_loudapprox = 2;
@@ -351,7 +357,7 @@ function buildTables(p) {
     };
     const bval = f32(CBANDS), bval_width = f32(CBANDS), norm = f32(CBANDS);
 
-    function init_numline(numlines, bo, bm, bo_w, blksize, scalepos, deltafreq, sbmax) {
+    function init_numline(numlines, bo, bm, bo_w, mld, blksize, scalepos, deltafreq, sbmax) {
         const b_frq = f32(CBANDS + 1);
         const sample_freq_frac = sfreq0 / (sbmax > 15 ? 2 * 576 : 2 * 192);
         const partition = i32(HBLKSIZE);
@@ -379,6 +385,10 @@ function buildTables(p) {
             const f_tmp = sample_freq_frac * end;
             bo_w[sfb] = (f_tmp - b_frq[bo[sfb]]) / (b_frq[bo[sfb] + 1] - b_frq[bo[sfb]]);
             if (bo_w[sfb] < 0) bo_w[sfb] = 0; else if (bo_w[sfb] > 1) bo_w[sfb] = 1;
+            /* stereo demasking threshold of the band (PsyModel.js:2432-2438) */
+            let arg = freq2bark(sfreq * scalepos[sfb] * deltafreq);
+            arg = (Math.min(arg, 15.5) / 15.5);
+            mld[sfb] = Math.pow(10.0, 1.25 * (1 - Math.cos(Math.PI * arg)) - 2.5);
         }
         j = 0;
         for (let k = 0; k < ni; k++) {
@@ -416,11 +426,12 @@ function buildTables(p) {
     T.numlines_l = i32(CBANDS); T.numlines_s = i32(CBANDS); T.rnumlines_l = f32(CBANDS);
     T.bo_l = i32(SBMAX_l); T.bm_l = i32(SBMAX_l); T.bo_s = i32(SBMAX_s); T.bm_s = i32(SBMAX_s);
     T.bo_l_weight = f32(SBMAX_l); T.bo_s_weight = f32(SBMAX_s);
+    T.mld_l = f32(SBMAX_l); T.mld_s = f32(SBMAX_s);
     T.s3ind = i32(2 * CBANDS); T.s3ind_s = i32(2 * CBANDS);
     T.ATH_cb_l = f32(CBANDS); T.ATH_cb_s = f32(CBANDS);
 
     const bvl_a = 13, bvl_b = 24, snr_l_a = 0, snr_l_b = 0, snr_s_a = -8.25, snr_s_b = -4.5;
-    T.npart_l = init_numline(T.numlines_l, T.bo_l, T.bm_l, T.bo_l_weight, BLKSIZE, p.sfb_l,
+    T.npart_l = init_numline(T.numlines_l, T.bo_l, T.bm_l, T.bo_l_weight, T.mld_l, BLKSIZE, p.sfb_l,
         BLKSIZE / (2.0 * 576), SBMAX_l);
     for (let i = 0; i < T.npart_l; i++) {
         let snr = snr_l_a;
@@ -444,7 +455,7 @@ function buildTables(p) {
             T.ATH_cb_l[i] = x;
         }
     }
-    T.npart_s = init_numline(T.numlines_s, T.bo_s, T.bm_s, T.bo_s_weight, BLKSIZE_s, p.sfb_s,
+    T.npart_s = init_numline(T.numlines_s, T.bo_s, T.bm_s, T.bo_s_weight, T.mld_s, BLKSIZE_s, p.sfb_s,
         BLKSIZE_s / (2.0 * 192), SBMAX_s);
     {
         let j = 0;
@@ -578,8 +589,8 @@ function huffmanEntries() {
         ['t32l', I(C.ht[32].hlen)], ['t33l', I(C.ht[33].hlen)]];
 }
 
-function buildBlob(channels, samplerate, kbps) {
-    const p = resolveParams(channels, samplerate, kbps);
+function buildBlob(channels, samplerate, kbps, opts) {
+    const p = resolveParams(channels, samplerate, kbps, opts);
     const T = buildTables(p);
     const cfg_i = {
         channels_out: p.channels_out, mode: p.mode, mode_gr: p.mode_gr, version: p.version,
@@ -601,7 +612,8 @@ function buildBlob(channels, samplerate, kbps) {
         interChRatio: p.interChRatio, masking_lower_long: p.masking_lower_long,
         masking_lower_short: p.masking_lower_short, ATH_aaSensitivityP: p.ATH_aaSensitivityP,
         ATH_floor: T.ATH_floor, decay: T.decay, ma_max_i1: T.ma_max_i1, ma_max_i2: T.ma_max_i2,
-        ma_max_m: T.ma_max_m, VO_SCALE: T.VO_SCALE, resample_ratio: p.resample_ratio
+        ma_max_m: T.ma_max_m, VO_SCALE: T.VO_SCALE, resample_ratio: p.resample_ratio,
+        msfix: p.msfix, ATHlower: p.ATHlower
     };
     const entries = [];
     entries.push(['cfg_i_names', Int32Array.from(Buffer.from(Object.keys(cfg_i).join(',') + '\0', 'ascii'))]);
@@ -619,6 +631,7 @@ function buildBlob(channels, samplerate, kbps) {
     push('numlines_l', T.numlines_l); push('numlines_s', T.numlines_s); push('rnumlines_l', T.rnumlines_l);
     push('bo_l', T.bo_l); push('bm_l', T.bm_l); push('bo_s', T.bo_s); push('bm_s', T.bm_s);
     push('bo_l_weight', T.bo_l_weight); push('bo_s_weight', T.bo_s_weight);
+    push('mld_l', T.mld_l); push('mld_s', T.mld_s);
     push('s3ind', T.s3ind); push('s3ind_s', T.s3ind_s); push('s3_ll', T.s3_ll); push('s3_ss', T.s3_ss);
     push('window', T.window); push('window_s', T.window_s); push('fht_twiddle', T.fht_twiddle);
     push('fht_costab', D(C.fht_costab)); push('fft_rv_tbl', I(C.fft_rv_tbl));
@@ -641,9 +654,9 @@ function buildBlob(channels, samplerate, kbps) {
 module.exports = { buildBlob, resolveParams, buildTables, packBlob };
 
 if (require.main === module) {
-    /* CLI: node tables.js <channels> <samplerate> <kbps> <out.bin> */
-    const [ch, sr, kb, out] = process.argv.slice(2);
-    const r = buildBlob(+ch, +sr, +kb);
+    /* CLI: node tables.js <channels> <samplerate> <kbps> <out.bin> [joint] */
+    const [ch, sr, kb, out, joint] = process.argv.slice(2);
+    const r = buildBlob(+ch, +sr, +kb, { jointStereo: joint === 'joint' });
     require('fs').writeFileSync(out, r.blob);
     console.log('wrote', out, r.blob.length, 'bytes');
 }

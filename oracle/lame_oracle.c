@@ -82,13 +82,14 @@ static int lo_load_cfg(lo_cfg* c, const void* blob_in, size_t nbytes) {
     CD(resample_ratio);
     CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
     CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
+    CD(msfix); CD(ATHlower);
 #define AF(f) c->f = (const float*)lo_arr(b, #f, 2, NULL)
 #define AI(f) c->f = (const int32_t*)lo_arr(b, #f, 1, NULL)
 #define AD(f) c->f = (const double*)lo_arr(b, #f, 3, NULL)
     AF(rs_blackfilt);
     AF(amp_filter); AF(ATH_l); AF(ATH_s); AF(ATH_psfb21); AF(ATH_psfb12); AF(ATH_cb_l); AF(ATH_cb_s); AF(eql_w);
     AF(pow43); AF(adj43); AF(ipow20); AF(pow20); AF(longfact); AF(shortfact); AF(rnumlines_l); AF(bo_l_weight);
-    AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s);
+    AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s); AF(mld_l); AF(mld_s);
     AI(sfb_l); AI(sfb_s); AI(psfb21); AI(psfb12); AI(bv_scf); AI(numlines_l); AI(numlines_s); AI(bo_l); AI(bm_l);
     AI(bo_s); AI(bm_s); AI(s3ind); AI(s3ind_s); AI(fft_rv_tbl); AI(mdct_order); AI(pretab); AI(scfsi_band);
     AI(slen1_n); AI(slen2_n); AI(slen1_tab); AI(slen2_tab); AI(scale_short); AI(scale_long); AI(huf_tbl_noESC);
@@ -192,7 +193,7 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
     lo_put(&w, (uint32_t)e->padding, 1);
     lo_put(&w, (uint32_t)c->extension, 1);
     lo_put(&w, (uint32_t)c->mode, 2);
-    lo_put(&w, 0, 2);                                   /* mode_ext: always LR_LR on this path */
+    lo_put(&w, (uint32_t)e->mode_ext, 2);               /* BitStream.js:279; 0 unless joint stereo chose M/S for this frame */
     lo_put(&w, (uint32_t)c->copyright, 1);
     lo_put(&w, (uint32_t)c->original, 1);
     lo_put(&w, (uint32_t)c->emphasis, 2);
@@ -360,7 +361,9 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
 
 static int lo_encode_frame(lo_enc* e, uint8_t* out) {
     const lo_cfg* c = &e->c;
-    lo_ratio masking[2][2];
+    lo_ratio masking[2][2], masking_MS[2][2];
+    double pe[2][2] = {{0, 0}, {0, 0}}, pe_MS[2][2] = {{0, 0}, {0, 0}}, ms_ener_ratio[2] = {.5, .5};
+    float tot_ener[2][4];
     int gr, ch, n;
     const float* inbuf[2] = {e->mfbuf[0], e->mfbuf[1]};
 
@@ -386,7 +389,11 @@ static int lo_encode_frame(lo_enc* e, uint8_t* out) {
         const float* bufp[2];
         for (ch = 0; ch < c->channels_out; ch++) bufp[ch] = inbuf[ch] + 576 + gr * 576 - 272;
         if (c->channels_out == 1) bufp[1] = bufp[0];
-        lo_psycho_anal(e, bufp, gr, masking, blocktype);
+        lo_psycho_anal(e, bufp, gr, masking, masking_MS, pe[gr], pe_MS[gr], tot_ener[gr], blocktype);
+        if (c->mode == 1) {                             /* Encoder.js:482-486 */
+            ms_ener_ratio[gr] = D(tot_ener[gr][2]) + D(tot_ener[gr][3]);
+            if (ms_ener_ratio[gr] > 0) ms_ener_ratio[gr] = D(tot_ener[gr][3]) / ms_ener_ratio[gr];
+        }
         for (ch = 0; ch < c->channels_out; ch++) {
             e->tt[gr][ch].block_type = blocktype[ch];
             e->tt[gr][ch].mixed_block_flag = 0;
@@ -394,16 +401,31 @@ static int lo_encode_frame(lo_enc* e, uint8_t* out) {
     }
     lo_adjust_ATH(e);
     lo_mdct_sub48(e, inbuf[0], inbuf[1]);
+    /* M/S or L/R for this frame (Encoder.js:520-561): M/S if its perceptual entropy is not larger and the two channels
+     * have the same block type in the first and in the last granule */
+    e->mode_ext = 0;
+    if (c->mode == 1) {
+        double sum_pe_MS = 0., sum_pe_LR = 0.;
+        for (gr = 0; gr < c->mode_gr; gr++)
+            for (ch = 0; ch < c->channels_out; ch++) { sum_pe_MS += pe_MS[gr][ch]; sum_pe_LR += pe[gr][ch]; }
+        if (sum_pe_MS <= 1.00 * sum_pe_LR) {
+            const lo_gr *gi0 = e->tt[0], *gi1 = e->tt[c->mode_gr - 1];
+            if (gi0[0].block_type == gi0[1].block_type && gi1[0].block_type == gi1[1].block_type) e->mode_ext = 2;
+        }
+    }
     if (e->tap) {
         e->tap->ath_adjust = e->ATH_adjust;
         for (gr = 0; gr < c->mode_gr; gr++)
             for (ch = 0; ch < c->channels_out; ch++) {
                 memcpy(e->tap->xr[gr][ch], e->tt[gr][ch].xr, sizeof e->tt[gr][ch].xr);
                 e->tap->block_type[gr][ch] = e->tt[gr][ch].block_type;
-                e->tap->ratio[gr][ch] = masking[gr][ch];
+                e->tap->ratio[gr][ch] = (e->mode_ext == 2) ? masking_MS[gr][ch] : masking[gr][ch];
+                e->tap->pe[gr][ch] = pe[gr][ch]; e->tap->pe_MS[gr][ch] = pe_MS[gr][ch];
             }
+        e->tap->mode_ext = e->mode_ext;
+        e->tap->ms_ener_ratio[0] = ms_ener_ratio[0]; e->tap->ms_ener_ratio[1] = ms_ener_ratio[1];
     }
-    lo_iteration_loop(e, masking);
+    lo_iteration_loop(e, (e->mode_ext == 2) ? masking_MS : masking, ms_ener_ratio);
     n = lo_format_frame(e, out);
     e->frame_num++;
     return n;
@@ -416,6 +438,7 @@ lo_enc* lo_create(const void* blob, size_t nbytes) {
     if (lo_load_cfg(&e->c, blob, nbytes) != 0) { free(e); return NULL; }
     e->mf_size = 576 - 48;                 /* ENCDELAY - MDCTDELAY zeros in front */
     e->mf_samples_to_encode = 576 + 1152;  /* ENCDELAY + POSTDELAY */
+    e->masking_lower = 1;                  /* Lame.js:175 */
     e->OldValue[0] = e->OldValue[1] = 180;
     e->CurrentStep[0] = e->CurrentStep[1] = 4;
     e->slot_lag = e->c.frac_SpF;

@@ -59,11 +59,12 @@ typedef struct {
     double resample_ratio;
     const float* rs_blackfilt;                  /* [2*bpc+1][filter_l+1] */
     double scale, attackthre, attackthre_s, interChRatio, masking_lower_long, masking_lower_short,
-        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE;
+        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE,
+        msfix, ATHlower;                          /* joint stereo only (PsyModel.js:1336-1341) */
     /* tables */
     const float *amp_filter, *ATH_l, *ATH_s, *ATH_psfb21, *ATH_psfb12, *ATH_cb_l, *ATH_cb_s, *eql_w,
         *pow43, *adj43, *ipow20, *pow20, *longfact, *shortfact, *rnumlines_l, *bo_l_weight, *bo_s_weight,
-        *s3_ll, *s3_ss, *window, *window_s;
+        *s3_ll, *s3_ss, *window, *window_s, *mld_l, *mld_s;
     const int32_t *sfb_l, *sfb_s, *psfb21, *psfb12, *bv_scf, *numlines_l, *numlines_s, *bo_l, *bm_l, *bo_s,
         *bm_s, *s3ind, *s3ind_s, *fft_rv_tbl, *mdct_order, *pretab, *scfsi_band, *slen1_n, *slen2_n,
         *slen1_tab, *slen2_tab, *scale_short, *scale_long, *huf_tbl_noESC, *version_bytes, *ht_xlen,
@@ -117,6 +118,8 @@ typedef struct lo_enc {
     int lastAttacks[4];
     int blocktype_old[2];
     float loudness_sq[2][2], loudness_sq_save[2];
+    float tot_ener[4];                          /* LameInternalFlags.js:271; chn 2, 3 = mid, side */
+    int mode_ext;                               /* Encoder.js:520-561: 0 = L/R, 2 = M/S, per frame */
     double ATH_adjust, ATH_adjustLimit;
     /* quantizer state */
     int OldValue[2], CurrentStep[2];
@@ -137,6 +140,8 @@ typedef struct lo_tap {
     double ath_adjust;             /* after adjust_ATH of this frame */
     float l3_xmin[2][2][SFBMAX];
     int global_gain[2][2], part2_3_length[2][2], part2_length[2][2];
+    int mode_ext;                  /* joint stereo: the frame's M/S decision */
+    double pe[2][2], pe_MS[2][2], ms_ener_ratio[2];
 } lo_tap;
 
 #endif

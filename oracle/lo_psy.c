@@ -272,7 +272,111 @@ static void lo_compute_masking_s(lo_enc* e, float fftenergy_s[3][HBLKSIZE_s], fl
 
 /* One psy call: analyses the granule that starts 576 samples after the one being coded.
  * buf[ch] = mfbuf[ch] + (576 + 576*gr - 272).  Writes masking for (gr,ch) and block types. */
-static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_ratio masking[2][2], int blocktype_d[2]) {
+
+/* perceptual entropy (PsyModel.js:845-905).  Dead for the output of the L/R path (on_pe's additions collapse with the reservoir
+ * disabled); live in joint stereo, where the M/S decision compares the sums (Encoder.js:540-560). */
+static double lo_pecalc_s(const lo_ratio* mr, double masking_lower) {
+    static const double regcoef_s[] = {11.8, 13.6, 17.2, 32, 46.5, 51.3, 57.5, 67.1, 71.5, 84.6, 97.6, 130};
+    double pe_s = 1236.28 / 4;
+    int sb, sblock;
+    for (sb = 0; sb < SBMAX_s - 1; sb++)
+        for (sblock = 0; sblock < 3; sblock++) {
+            double thm = mr->thm.s[sb][sblock];
+            if (thm > 0.0) {
+                double x = thm * masking_lower, en = mr->en.s[sb][sblock];
+                if (en > x) {
+                    if (en > x * 1e10) pe_s += regcoef_s[sb] * (10.0 * 2.30258509299404568402);
+                    else pe_s += regcoef_s[sb] * v8_log10(en / x);
+                }
+            }
+        }
+    return pe_s;
+}
+static double lo_pecalc_l(const lo_ratio* mr, double masking_lower) {
+    static const double regcoef_l[] = {6.8, 5.8, 5.8, 6.4, 6.5, 9.9, 12.1, 14.4, 15, 18.9, 21.6, 26.9, 34.2, 40.2, 46.8, 56.5,
+                                       60.7, 73.9, 85.7, 93.4, 126.1};
+    double pe_l = 1124.23 / 4;
+    int sb;
+    for (sb = 0; sb < SBMAX_l - 1; sb++) {
+        double thm = mr->thm.l[sb];
+        if (thm > 0.0) {
+            double x = thm * masking_lower, en = mr->en.l[sb];
+            if (en > x) {
+                if (en > x * 1e10) pe_l += regcoef_l[sb] * (10.0 * 2.30258509299404568402);
+                else pe_l += regcoef_l[sb] * v8_log10(en / x);
+            }
+        }
+    }
+    return pe_l;
+}
+
+#define LO_MAX(a, b) ((a) > (b) ? (a) : (b))      /* Math.max / Math.min on non-NaN operands */
+#define LO_MIN(a, b) ((a) < (b) ? (a) : (b))
+/* M/S thresholds after Johnston & Ferreira (PsyModel.js:548-582) */
+static void lo_msfix1(lo_enc* e) {
+    const lo_cfg* c = &e->c;
+    int sb, sblock;
+    for (sb = 0; sb < SBMAX_l; sb++) {
+        double mld, rmid, rside;
+        if (D(e->thm[0].l[sb]) > 1.58 * D(e->thm[1].l[sb]) || D(e->thm[1].l[sb]) > 1.58 * D(e->thm[0].l[sb])) continue;
+        mld = D(c->mld_l[sb]) * D(e->en[3].l[sb]);
+        rmid = LO_MAX(D(e->thm[2].l[sb]), LO_MIN(D(e->thm[3].l[sb]), mld));
+        mld = D(c->mld_l[sb]) * D(e->en[2].l[sb]);
+        rside = LO_MAX(D(e->thm[3].l[sb]), LO_MIN(D(e->thm[2].l[sb]), mld));
+        e->thm[2].l[sb] = (float)rmid;
+        e->thm[3].l[sb] = (float)rside;
+    }
+    for (sb = 0; sb < SBMAX_s; sb++)
+        for (sblock = 0; sblock < 3; sblock++) {
+            double mld, rmid, rside;
+            if (D(e->thm[0].s[sb][sblock]) > 1.58 * D(e->thm[1].s[sb][sblock]) || D(e->thm[1].s[sb][sblock]) > 1.58 * D(e->thm[0].s[sb][sblock])) continue;
+            mld = D(c->mld_s[sb]) * D(e->en[3].s[sb][sblock]);
+            rmid = LO_MAX(D(e->thm[2].s[sb][sblock]), LO_MIN(D(e->thm[3].s[sb][sblock]), mld));
+            mld = D(c->mld_s[sb]) * D(e->en[2].s[sb][sblock]);
+            rside = LO_MAX(D(e->thm[3].s[sb][sblock]), LO_MIN(D(e->thm[2].s[sb][sblock]), mld));
+            e->thm[2].s[sb][sblock] = (float)rmid;
+            e->thm[3].s[sb][sblock] = (float)rside;
+        }
+}
+/* PsyModel.js:591-636 (note: the long-block scaling uses msfix2, the short-block one msfix; both are 2 x the setting) */
+static void lo_ns_msfix(lo_enc* e, double msfix, double athadjust) {
+    const lo_cfg* c = &e->c;
+    double msfix2 = msfix, athlower = v8_pow(10, athadjust);
+    int sb, sblock;
+    msfix *= 2.0;
+    msfix2 *= 2.0;
+    for (sb = 0; sb < SBMAX_l; sb++) {
+        double ath = D(c->ATH_cb_l[c->bm_l[sb]]) * athlower;
+        double thmLR = LO_MIN(LO_MAX(D(e->thm[0].l[sb]), ath), LO_MAX(D(e->thm[1].l[sb]), ath));
+        double thmM = LO_MAX(D(e->thm[2].l[sb]), ath), thmS = LO_MAX(D(e->thm[3].l[sb]), ath);
+        if (thmLR * msfix < thmM + thmS) {
+            double f = thmLR * msfix2 / (thmM + thmS);
+            thmM *= f;
+            thmS *= f;
+        }
+        e->thm[2].l[sb] = (float)LO_MIN(thmM, D(e->thm[2].l[sb]));
+        e->thm[3].l[sb] = (float)LO_MIN(thmS, D(e->thm[3].l[sb]));
+    }
+    athlower *= (D(BLKSIZE_s) / BLKSIZE);
+    for (sb = 0; sb < SBMAX_s; sb++)
+        for (sblock = 0; sblock < 3; sblock++) {
+            double ath = D(c->ATH_cb_s[c->bm_s[sb]]) * athlower;
+            double thmLR = LO_MIN(LO_MAX(D(e->thm[0].s[sb][sblock]), ath), LO_MAX(D(e->thm[1].s[sb][sblock]), ath));
+            double thmM = LO_MAX(D(e->thm[2].s[sb][sblock]), ath), thmS = LO_MAX(D(e->thm[3].s[sb][sblock]), ath);
+            if (thmLR * msfix < thmM + thmS) {
+                double f = thmLR * msfix / (thmM + thmS);
+                thmM *= f;
+                thmS *= f;
+            }
+            e->thm[2].s[sb][sblock] = (float)LO_MIN(D(e->thm[2].s[sb][sblock]), thmM);
+            e->thm[3].s[sb][sblock] = (float)LO_MIN(D(e->thm[3].s[sb][sblock]), thmS);
+        }
+}
+
+/* masking_MS / pe / pe_MS / tot_ener are only filled (and only meaningful) in joint stereo; tot_ener[chn] is the total of
+ * the PREVIOUS call (PsyModel.js:1206, one granule of delay like the maskings) */
+static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_ratio masking[2][2], lo_ratio masking_MS[2][2],
+                           double pe[2], double pe_MS[2], float tot_ener[4], int blocktype_d[2]) {
     const lo_cfg* c = &e->c;
     float wsamp_L[2][BLKSIZE];
     float wsamp_S[2][3][BLKSIZE_s];
@@ -281,7 +385,7 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
     float ns_hpfsmpl[2][576];
     int32_t mask_idx_l[CBANDS + 2];
     int chn, i, j, b, sb, sblock, k;
-    const int numchn = c->channels_out;
+    const int numchn = (c->mode == 1) ? 4 : c->channels_out;        /* chn 2, 3 = mid, side (PsyModel.js:1031-1034) */
 
     /* fs/4 high-pass for attack detection */
     for (chn = 0; chn < c->channels_out; chn++) {
@@ -296,6 +400,10 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
         }
         masking[gr_out][chn].en = e->en[chn];
         masking[gr_out][chn].thm = e->thm[chn];
+        if (numchn > 2) {
+            masking_MS[gr_out][chn].en = e->en[chn + 2];
+            masking_MS[gr_out][chn].thm = e->thm[chn + 2];
+        }
     }
 
     for (chn = 0; chn < numchn; chn++) {
@@ -314,6 +422,12 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
             attack_intensity[i] = (float)(D(en_subshort[i]) / D(e->last_en_subshort[chn][i + 4]));
             en_short[0] += D(en_subshort[i]);
         }
+        if (chn == 2)                                   /* PsyModel.js:1113-1121: mid / side of the high-passed samples */
+            for (i = 0; i < 576; i++) {
+                const double l = ns_hpfsmpl[0][i], r = ns_hpfsmpl[1][i];
+                ns_hpfsmpl[0][i] = (float)(l + r);
+                ns_hpfsmpl[1][i] = (float)(l - r);
+            }
         {
             const float* pf = ns_hpfsmpl[chn & 1];
             for (i = 0; i < 9; i++) {
@@ -351,11 +465,27 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
             if (ns_attacks[2] != 0 && ns_attacks[1] != 0) ns_attacks[2] = 0;
             if (ns_attacks[3] != 0 && ns_attacks[2] != 0) ns_attacks[3] = 0;
         }
-        uselongblock[chn] = ns_uselongblock;
+        if (chn < 2) uselongblock[chn] = ns_uselongblock;
+        else if (ns_uselongblock == 0) uselongblock[0] = uselongblock[1] = 0;      /* PsyModel.js:1198-1204 */
+        tot_ener[chn] = e->tot_ener[chn];
 
-        /* FFTs + energies (compute_ffts) */
-        lo_fft_long(c, wsamp_L[chn & 1], buf[chn]);
-        lo_fft_short(c, wsamp_S[chn & 1], buf[chn]);
+        /* FFTs + energies (compute_ffts, PsyModel.js:251-327) */
+        if (chn < 2) {
+            lo_fft_long(c, wsamp_L[chn & 1], buf[chn]);
+            lo_fft_short(c, wsamp_S[chn & 1], buf[chn]);
+        } else if (chn == 2) {                          /* mid / side spectra from the L / R ones */
+            for (j = BLKSIZE - 1; j >= 0; --j) {
+                const double l = wsamp_L[0][j], r = wsamp_L[1][j];
+                wsamp_L[0][j] = (float)((l + r) * SQRT2 * 0.5);
+                wsamp_L[1][j] = (float)((l - r) * SQRT2 * 0.5);
+            }
+            for (b = 2; b >= 0; --b)
+                for (j = BLKSIZE_s - 1; j >= 0; --j) {
+                    const double l = wsamp_S[0][b][j], r = wsamp_S[1][b][j];
+                    wsamp_S[0][b][j] = (float)((l + r) * SQRT2 * 0.5);
+                    wsamp_S[1][b][j] = (float)((l - r) * SQRT2 * 0.5);
+                }
+        }
         {
             const float* wl = wsamp_L[chn & 1];
             fftenergy[0] = wl[0];
@@ -373,8 +503,13 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
                     fftenergy_s[b][BLKSIZE_s / 2 - j] = (float)((re * re + im * im) * 0.5);
                 }
             }
-            /* loudness approximation for the ATH auto-adjust (athaa_loudapprox == 2) */
-            {
+            {                                           /* total energy (PsyModel.js:300-307) */
+                double tot = 0.0;
+                for (j = 11; j < HBLKSIZE; j++) tot += D(fftenergy[j]);
+                e->tot_ener[chn] = (float)tot;
+            }
+            /* loudness approximation for the ATH auto-adjust (athaa_loudapprox == 2); not for mid / side */
+            if (chn < 2) {
                 double lp = 0.0;
                 e->loudness_sq[gr_out][chn] = e->loudness_sq_save[chn];
                 for (i = 0; i < BLKSIZE / 2; ++i) lp += D(fftenergy[i]) * D(c->eql_w[i]);
@@ -464,7 +599,7 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
     }
 
     /* inter-channel masking (stereo only, ratio > 0) */
-    if (c->mode == 0 && c->interChRatio > 0.0 && c->channels_out > 1) {
+    if ((c->mode == 0 || c->mode == 1) && c->interChRatio > 0.0 && c->channels_out > 1) {
         double r_ = c->interChRatio;
         for (sb = 0; sb < SBMAX_l; sb++) {
             double l = e->thm[0].l[sb], r = e->thm[1].l[sb];
@@ -477,6 +612,11 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
                 e->thm[0].s[sb][sblock] = (float)(D(e->thm[0].s[sb][sblock]) + r * r_);
                 e->thm[1].s[sb][sblock] = (float)(D(e->thm[1].s[sb][sblock]) + l * r_);
             }
+    }
+
+    if (c->mode == 1) {                                 /* PsyModel.js:1336-1342 */
+        lo_msfix1(e);
+        if (fabs(c->msfix) > 0.0) lo_ns_msfix(e, c->msfix, c->ATHlower * e->ATH_adjust);
     }
 
     /* block_type_set */
@@ -493,6 +633,22 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
         }
         blocktype_d[chn] = e->blocktype_old[chn];
         e->blocktype_old[chn] = blocktype[chn];
+    }
+    /* perceptual entropy of the granule handed back (PsyModel.js:1352-1380): the maskings are the delayed ones */
+    for (chn = 0; chn < numchn; chn++) {
+        int type;
+        const lo_ratio* mr;
+        if (chn > 1) {
+            type = (blocktype_d[0] == SHORT_TYPE || blocktype_d[1] == SHORT_TYPE) ? SHORT_TYPE : NORM_TYPE;
+            mr = &masking_MS[gr_out][chn - 2];
+        } else {
+            type = blocktype_d[chn];
+            mr = &masking[gr_out][chn];
+        }
+        {
+            const double v = (type == SHORT_TYPE) ? lo_pecalc_s(mr, e->masking_lower) : lo_pecalc_l(mr, e->masking_lower);
+            if (chn > 1) pe_MS[chn - 2] = v; else pe[chn] = v;
+        }
     }
 }
 

@@ -980,7 +980,7 @@ static int lo_frame_bits(const lo_enc* e) {
     return 8 * bytes;
 }
 
-static void lo_iteration_loop(lo_enc* e, lo_ratio ratio[2][2]) {
+static void lo_iteration_loop(lo_enc* e, lo_ratio ratio[2][2], const double ms_ener_ratio[2]) {
     const lo_cfg* c = &e->c;
     float l3_xmin[SFBMAX];
     float xrpow[576];
@@ -991,7 +991,7 @@ static void lo_iteration_loop(lo_enc* e, lo_ratio ratio[2][2]) {
     /* ResvFrameBegin with the reservoir disabled: ResvMax = 0 */
     for (gr = 0; gr < c->mode_gr; gr++) {
         /* on_pe + ResvMaxBits(cbr = gr): add_bits/extra_bits collapse to 0 */
-        int ResvSize = e->ResvSize, tbits, bits = 0;
+        int ResvSize = e->ResvSize, tbits, bits = 0, max_bits;
         if (gr != 0) ResvSize += mean_bits;
         tbits = mean_bits;
         if (ResvSize * 10 > 0) tbits += ResvSize;
@@ -1004,6 +1004,40 @@ static void lo_iteration_loop(lo_enc* e, lo_ratio ratio[2][2]) {
             for (ch = 0; ch < c->channels_out; ++ch) {
                 targ_bits[ch] = js_toint32(D(targ_bits[ch]) * MAX_BITS_PER_GRANULE);
                 targ_bits[ch] = js_toint32(D(targ_bits[ch]) / bits);
+            }
+        }
+        if (e->mode_ext == 2) {
+            /* ms_convert (Quantize.js:76-83) */
+            int i;
+            for (i = 0; i < 576; ++i) {
+                const double l = e->tt[gr][0].xr[i], r = e->tt[gr][1].xr[i];
+                e->tt[gr][0].xr[i] = (float)((l + r) * (SQRT2 * 0.5));
+                e->tt[gr][1].xr[i] = (float)((l - r) * (SQRT2 * 0.5));
+            }
+            /* reduce_side (QuantizePVT.js:486-534): bits move from the side to the mid channel; targ_bits is an Int32Array there */
+            {
+                double fac = .33 * (.5 - ms_ener_ratio[gr]) / .5;
+                int move_bits;
+                max_bits = tbits < MAX_BITS_PER_GRANULE ? tbits : MAX_BITS_PER_GRANULE;      /* on_pe: tbits + extra_bits (= 0), capped */
+                if (fac < 0) fac = 0;
+                if (fac > .5) fac = .5;
+                move_bits = js_toint32(fac * .5 * (targ_bits[0] + targ_bits[1]));
+                if (move_bits > MAX_BITS_PER_CHANNEL - targ_bits[0]) move_bits = MAX_BITS_PER_CHANNEL - targ_bits[0];
+                if (move_bits < 0) move_bits = 0;
+                if (targ_bits[1] >= 125) {
+                    if (targ_bits[1] - move_bits > 125) {
+                        if (targ_bits[0] < mean_bits) targ_bits[0] += move_bits;
+                        targ_bits[1] -= move_bits;
+                    } else {
+                        targ_bits[0] += targ_bits[1] - 125;
+                        targ_bits[1] = 125;
+                    }
+                }
+                move_bits = targ_bits[0] + targ_bits[1];
+                if (move_bits > max_bits) {
+                    targ_bits[0] = js_toint32(D(max_bits * targ_bits[0]) / move_bits);
+                    targ_bits[1] = js_toint32(D(max_bits * targ_bits[1]) / move_bits);
+                }
             }
         }
         for (ch = 0; ch < c->channels_out; ch++) {

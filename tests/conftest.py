@@ -19,6 +19,12 @@ def golden():
     return json.loads((ROOT / "tests" / "golden" / "golden.json").read_text())["cases"]
 
 
+@pytest.fixture(scope="session")
+def golden_joint():
+    """Joint-stereo goldens (SURVEY.md 8f #3): the reference's modules driven with gfp.mode = JOINT_STEREO (tests/tools/gen_golden_joint.js)."""
+    return json.loads((ROOT / "tests" / "golden" / "golden_joint.json").read_text())["cases"]
+
+
 def load_case_pcm(case):
     """PCM of a golden case: committed excerpt for the reference's fixtures, regenerated for synthetic corpora."""
     import hashlib

@@ -57,4 +57,15 @@ def bursts(nsamples: int, channels: int, seed: int = 777):
     return L.astype(np.int16), R.astype(np.int16)
 
 
-CORPORA = {"sine": sine, "bursts": bursts}
+def _centre(gen):
+    """Strongly correlated channels (so that joint stereo codes M/S): L = A + (B >> 3), R = A - (B >> 3); tests/tools/gen_golden_joint.js."""
+    def f(nsamples: int, channels: int):
+        a, b = gen(nsamples, 2)
+        d = b.astype(np.int32) >> 3
+        L = np.clip(a.astype(np.int32) + d, -32768, 32767).astype(np.int16)
+        R = np.clip(a.astype(np.int32) - d, -32768, 32767).astype(np.int16)
+        return L, R
+    return f
+
+
+CORPORA = {"sine": sine, "bursts": bursts, "centre_sine": _centre(sine), "centre_bursts": _centre(bursts)}

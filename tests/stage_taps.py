@@ -15,7 +15,8 @@ from oracle_py import _load as _load_oracle
 SFBMAX = 39
 TAP = np.dtype([("xr", "<f4", (2, 2, 576)), ("block_type", "<i4", (2, 2)), ("ratio", "<f4", (2, 2, 122)), ("ath_adjust", "<f8"),
                 ("l3_xmin", "<f4", (2, 2, SFBMAX)), ("global_gain", "<i4", (2, 2)), ("part2_3_length", "<i4", (2, 2)),
-                ("part2_length", "<i4", (2, 2))], align=True)
+                ("part2_length", "<i4", (2, 2)), ("mode_ext", "<i4"), ("pe", "<f8", (2, 2)), ("pe_MS", "<f8", (2, 2)),
+                ("ms_ener_ratio", "<f8", (2,))], align=True)
 
 # struct GrSide (lamejs_amd/csrc/lhip_defs.h), 32-bit fields in declaration order
 _GRSIDE_FIELDS = (["part2_3_length", "part2_length", "big_values", "count1", "global_gain", "scalefac_compress", "block_type"] +

@@ -26,12 +26,18 @@ const configs = [[1, 44100, 128], [2, 44100, 128], [2, 44100, 320], [1, 44100, 6
     /* MPEG-2 / MPEG-2.5 (LSF) rates */
     [1, 22050, 64], [2, 24000, 96], [1, 16000, 32], [2, 16000, 48], [1, 11025, 24], [1, 8000, 16], [2, 12000, 32], [1, 22050, 160], [2, 22050, 128],
     /* integer-ratio resampling (in_samplerate = k * out_samplerate) */
-    [1, 44100, 32], [2, 44100, 48], [1, 48000, 24], [2, 48000, 64], [1, 32000, 16], [2, 32000, 8], [1, 16000, 8], [2, 24000, 16], [1, 48000, 40], [1, 48000, 8]];
-for (const [ch, sr, kb] of configs) {
+    [1, 44100, 32], [2, 44100, 48], [1, 48000, 24], [2, 48000, 64], [1, 32000, 16], [2, 32000, 8], [1, 16000, 8], [2, 24000, 16], [1, 48000, 40], [1, 48000, 8],
+    /* joint stereo (extension flag; reference driven with gfp.mode = JOINT_STEREO) */
+    [2, 44100, 128, 1], [2, 44100, 96, 1], [2, 48000, 192, 1], [2, 32000, 64, 1], [2, 44100, 320, 1], [2, 22050, 64, 1], [2, 16000, 32, 1]];
+for (const [ch, sr, kb, joint] of configs) {
     let r;
-    try { r = tables.buildBlob(ch, sr, kb); } catch (e) { console.log('skip', ch, sr, kb, e.message); continue; }
-    const e = refEncoder(ch, sr, kb), gfp = e.gfp, gfc = e.gfc, p = r.params, T = r.tables;
-    const tag = ch + '/' + sr + '/' + kb + ' ';
+    const opts = { jointStereo: !!joint };
+    try { r = tables.buildBlob(ch, sr, kb, opts); } catch (e) { console.log('skip', ch, sr, kb, e.message); continue; }
+    const e = refEncoder(ch, sr, kb, opts), gfp = e.gfp, gfc = e.gfc, p = r.params, T = r.tables;
+    const tag = ch + '/' + sr + '/' + kb + (joint ? '/joint ' : ' ');
+    cmpS(tag + 'msfix', p.msfix, gfp.msfix);
+    cmp(tag + 'mld_l', T.mld_l, gfc.mld_l);
+    cmp(tag + 'mld_s', T.mld_s, gfc.mld_s);
     cmpS(tag + 'out_samplerate', p.out_samplerate, gfp.out_samplerate);
     cmpS(tag + 'mode', p.mode, gfp.mode.ordinal());
     cmpS(tag + 'channels_out', p.channels_out, gfc.channels_out);

@@ -11,7 +11,9 @@ const path = require('path');
 const REF = process.env.LAMEJS_REF || '/root/reference';
 const S = path.join(REF, 'src', 'js');
 
-function refEncoder(channels, samplerate, kbps) {
+/* opts.jointStereo: gfp.mode = JOINT_STEREO instead of the STEREO that index.js:105 hard-codes -- still the unmodified reference
+ * code, only driven with the one setting its public wrapper does not offer (SURVEY.md 8f #3) */
+function refEncoder(channels, samplerate, kbps, opts) {
     const Lame = require(path.join(S, 'Lame.js'));
     const Presets = require(path.join(S, 'Presets.js'));
     const GainAnalysis = require(path.join(S, 'GainAnalysis.js'));
@@ -45,7 +47,7 @@ function refEncoder(channels, samplerate, kbps) {
     gfp.num_channels = channels;
     gfp.in_samplerate = samplerate;
     gfp.brate = kbps;
-    gfp.mode = MPEGMode.STEREO;
+    gfp.mode = (opts && opts.jointStereo && channels == 2) ? MPEGMode.JOINT_STEREO : MPEGMode.STEREO;
     gfp.quality = 3;
     gfp.bWriteVbrTag = false;
     gfp.disable_reservoir = true;
