@@ -154,7 +154,8 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
         PUT(T.out_samplerate < 16000 ? 0xffe : 0xfff, 12) PUT(T.version, 1)       // BitStream.js:262-267
         PUT(4 - 3, 2) PUT(!T.error_protection ? 1 : 0, 1)
         PUT(T.bitrate_index, 4) PUT(T.samplerate_index, 2) PUT(padding, 1) PUT(T.extension, 1)
-        PUT(T.mode, 2) PUT(0, 2) PUT(T.copyright, 1) PUT(T.original, 1) PUT(T.emphasis, 2)
+        PUT(T.mode, 2) PUT(T.mode == 1 ? side[0].mode_ext : 0, 2)                  // mode_ext: the frame's M/S decision in joint stereo (BitStream.js:279)
+        PUT(T.copyright, 1) PUT(T.original, 1) PUT(T.emphasis, 2)
         if (GR == 2) {
             PUT(0, 9)
             PUT(0, C == 2 ? 3 : 5)

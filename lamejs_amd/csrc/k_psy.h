@@ -103,9 +103,11 @@ struct PsyALds {
 #define PSY_STAMP(i) do {} while (0)
 #define PSY_FLUSH() do {} while (0)
 #endif
-// one wave per (granule slot >= 1 of a stream, channel)
+// one wave per (granule slot >= 1 of a stream, psy channel).  ch = 0, 1: L, R.  Joint stereo adds ch = 2, 3 (mid, side) in a second
+// launch: their high-passed samples and their spectra are linear combinations of the L / R ones (PsyModel.js:1113-1121, 258-273),
+// which the L / R waves leave in W.hpf / W.fht; everything from the energies on is the same code for all four.
 LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int gslot, int ch, int lane, PsyALds& L) {
-    const int C = T.channels_out;
+    const int C = T.channels_out, Cp = T.psy_channels;
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
     const int q = gslot - sd.gslot0 - 1;              // local psy call index
@@ -113,7 +115,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     // The call's 1024-sample window (segment index 576 q + 304 onwards) is converted ONCE into the long FHT buffer: the high-pass,
     // the short windowing and the long windowing all read it from LDS; the long windowing then runs in place (every lane takes its
     // samples into registers before anybody writes).  The caller's Int16 is read coalesced, 2 bytes per sample, exactly once.
-    {
+    if (ch < 2) {
         const PcmSrc P = pcm_source(T, W, sd, IO[st], ch);
         const int b0 = 576 * q + 304;
         if (!P.plane && b0 >= P.mf) {
@@ -130,7 +132,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         wave_sync();
     }
 #define buf(i) L.fz[i]
-    const int64_t o = (int64_t)gslot * C + ch;
+    const int64_t o = (int64_t)gslot * Cp + ch;
     PSY_STAMP(0);
 
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
@@ -142,7 +144,14 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         // Per output the sums are formed exactly as in PsyModel.js:1051-1069 (same operands, same order).
         enum { HO = (576 + LHIP_NL - 1) / LHIP_NL };      // outputs per lane: 9
         float* mag = &L.fs[0][0];
-        {
+        if (ch >= 2) {
+            const float* hl = W.hpf + (int64_t)gslot * 2 * 576;
+            for (int i = lane; i < 576; i += LHIP_NL) {
+                const double l = hl[i], r = hl[576 + i];
+                float v = (ch == 2) ? (float)(l + r) : (float)(l - r);
+                mag[i] = v < 0 ? -v : v;
+            }
+        } else {
             double x[HO + 21];
 #pragma unroll
             for (int t = 0; t < HO + 21; t++) { const int n = HO * lane + t; x[t] = (n < 576 + 21) ? (double)fir[n] : 0.0; }
@@ -155,6 +164,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
                     sum2 += T.hpf_fircoef[j + 1] * (x[k + j + 1] + x[k + 21 - j - 1]);
                 }
                 float v = (float)(sum1 + sum2);
+                if (Cp == 4 && HO * lane + k < 576) W.hpf[((int64_t)gslot * 2 + ch) * 576 + HO * lane + k] = v;
                 v = v < 0 ? -v : v;
                 if (HO * lane + k < 576) mag[HO * lane + k] = v;
             }
@@ -178,6 +188,16 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
 
     PSY_STAMP(1);
+    if (ch >= 2) {
+        // mid / side spectra from the L / R ones (compute_ffts, PsyModel.js:258-273): (l + r) * SQRT2 * 0.5, rounded to f32
+        const float* fl = W.fht + (int64_t)gslot * 2 * FHT_STRIDE;
+        for (int i = lane; i < FHT_STRIDE; i += LHIP_NL) {
+            const double l = fl[i], r = fl[FHT_STRIDE + i];
+            const float v = (ch == 2) ? (float)((l + r) * LHIP_SQRT2 * 0.5) : (float)((l - r) * LHIP_SQRT2 * 0.5);
+            if (i < BLKSIZE) L.fz[i] = v; else (&L.fs[0][0])[i - BLKSIZE] = v;
+        }
+        wave_sync();
+    } else {
     // --- windowing + first radix-4 stage (FFT.js:185-221 long, 140-180 short) ---
     for (int it = lane; it < 3 * (BLKSIZE_s / 8); it += LHIP_NL) {
         const int b = it / (BLKSIZE_s / 8), j = it - b * (BLKSIZE_s / 8);
@@ -254,6 +274,11 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             off += kx - 1;
         }
     }
+    if (Cp == 4) {                                    // joint stereo: the spectra the mid / side waves combine
+        float* fo = W.fht + ((int64_t)gslot * 2 + ch) * FHT_STRIDE;
+        for (int i = lane; i < FHT_STRIDE; i += LHIP_NL) fo[i] = (i < BLKSIZE) ? L.fz[i] : (&L.fs[0][0])[i - BLKSIZE];
+    }
+    }   // ch < 2
 
     PSY_STAMP(3);
     // --- energies (PsyModel.js:274-296), written over the lower halves of the transform buffers ---
@@ -295,9 +320,19 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         double pr[K];
 #pragma unroll
         for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (double)PSYA_FE(L)[i] * (double)T.eql_w[i]; }
-        double lp = wave_seq_sum<K>(pr);
-        lp *= T.VO_SCALE;
-        if (lane == 0) W.loud[o] = (float)lp;
+        if (ch < 2) {                                 // no loudness for mid / side (PsyModel.js:319)
+            double lp = wave_seq_sum<K>(pr);
+            lp *= T.VO_SCALE;
+            if (lane == 0) W.loud[(int64_t)gslot * C + ch] = (float)lp;
+        }
+        if (Cp == 4) {
+            // total energy: lines 11 .. 512 summed in ascending order (PsyModel.js:300-307); the leading zeros change nothing
+#pragma unroll
+            for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (i >= 11) ? (double)PSYA_FE(L)[i] : 0.0; }
+            double tot = wave_seq_sum<K>(pr);
+            tot += (double)PSYA_FE(L)[BLKSIZE / 2];
+            if (lane == 0) W.tot_ener[(int64_t)gslot * 4 + ch] = (float)tot;
+        }
     }
 
     PSY_STAMP(5);
@@ -414,12 +449,12 @@ LHIP_DEV int attack_flags_raw(const Tables& T, const float* cur, const float* pr
 
 // raw attack flags of one psy call, all channels (parallel over granule slots)
 LHIP_DEV void kb_scan_raw(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot) {
-    const int C = T.channels_out;
+    const int Cp = T.psy_channels;
     const StreamDesc sd = SD[W.gslot_stream[gslot]];
     if (gslot - sd.gslot0 - 1 < 0) return;
-    for (int ch = 0; ch < C; ch++) {
-        const int64_t o = (int64_t)gslot * C + ch;
-        W.att_raw[o] = attack_flags_raw(T, W.peaks + o * PK_STRIDE, W.peaks + (o - C) * PK_STRIDE, ch);
+    for (int ch = 0; ch < Cp; ch++) {
+        const int64_t o = (int64_t)gslot * Cp + ch;
+        W.att_raw[o] = attack_flags_raw(T, W.peaks + o * PK_STRIDE, W.peaks + (o - Cp) * PK_STRIDE, ch);
     }
 }
 
@@ -443,21 +478,22 @@ LHIP_DEV int last_attack_after(const Workspace& W, int C, int gcarry, int gslot,
 
 // per granule slot: attack clean-up -> uselongblock (coupled), lastAttacks (parallel over granule slots)
 LHIP_DEV void kb_scan_attack(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot) {
-    const int C = T.channels_out;
+    const int C = T.channels_out, Cp = T.psy_channels;
     const StreamDesc sd = SD[W.gslot_stream[gslot]];
     if (gslot - sd.gslot0 - 1 < 0) return;
     int ul[2] = {1, 1};
-    for (int ch = 0; ch < C; ch++) {
-        const int last = last_attack_after(W, C, sd.gslot0, gslot - 1, ch);
-        const int raw = W.att_raw[(int64_t)gslot * C + ch];
+    for (int ch = 0; ch < Cp; ch++) {
+        const int last = last_attack_after(W, Cp, sd.gslot0, gslot - 1, ch);
+        const int raw = W.att_raw[(int64_t)gslot * Cp + ch];
         int a0 = raw & 1, a1 = (raw >> 1) & 1, a2 = (raw >> 2) & 1, a3 = (raw >> 3) & 1;
         if (a0 != 0 && last != 0) a0 = 0;
         if ((a0 + a1 + a2 + a3) != 0) {            // lastAttacks == 3 never happens
-            ul[ch] = 0;
+            if (ch < 2) ul[ch] = 0;
+            else ul[0] = ul[1] = 0;                 // an attack in mid or side switches both channels (PsyModel.js:1198-1204)
             if (a1 != 0 && a0 != 0) a1 = 0;
             if (a2 != 0 && a1 != 0) a2 = 0;
         }
-        W.ul_tmp[(int64_t)gslot * C + ch] = a2;    // lastAttacks after this call (published below)
+        W.ul_tmp[(int64_t)gslot * Cp + ch] = a2;   // lastAttacks after this call (published below)
     }
     if (T.short_blocks_coupled && !(ul[0] != 0 && ul[1] != 0)) ul[0] = ul[1] = 0;
     for (int ch = 0; ch < C; ch++) W.uselong[(int64_t)gslot * C + ch] = ul[ch];
@@ -492,8 +528,9 @@ LHIP_DEV void kb_scan_blocktype(const Tables& T, const Workspace& W, const Strea
         }
         W.blocktype[(int64_t)gslot * C + ch] = old;
         W.tent[(int64_t)gslot * C + ch] = bt;
-        W.last_attack[(int64_t)gslot * C + ch] = W.ul_tmp[(int64_t)gslot * C + ch];
     }
+    const int Cp = T.psy_channels;
+    for (int ch = 0; ch < Cp; ch++) W.last_attack[(int64_t)gslot * Cp + ch] = W.ul_tmp[(int64_t)gslot * Cp + ch];
 }
 
 // ATH auto-adjust recurrence (Encoder.js:166-243), one 1024-thread workgroup per stream.
@@ -618,9 +655,9 @@ LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc*
 // ---------------------------------------------------------------------------------------------
 struct PsyBLds {
     double mt1[25], mt2[10], mt3[14], mtab[9];     // mask_add tables: looked up inside a serially dependent chain
-    float thr_l[2][CBANDS + 2];
-    float thr_s[2][3][CBANDS + 2];
-    float E[2][E_STRIDE];
+    float thr_l[4][CBANDS + 2];                    // psy channels: L, R and -- joint stereo -- mid, side
+    float thr_s[4][3][CBANDS + 2];
+    float E[4][E_STRIDE];
 };
 
 LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, double m1, double m2, int b) {
@@ -656,8 +693,8 @@ LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, dou
 }
 
 
-LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLds& L) {
-    const int C = T.channels_out;
+LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLds& L) {
+    const int C = T.channels_out, Cp = T.psy_channels;
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
     const int q = gslot - sd.gslot0 - 1;
@@ -672,8 +709,8 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
 
-    for (int ch = 0; ch < C; ch++) {
-        const int64_t o = (int64_t)gslot * C + ch;
+    for (int ch = 0; ch < Cp; ch++) {
+        const int64_t o = (int64_t)gslot * Cp + ch;
         const float* eb_l = W.eb_l + o * EBL_STRIDE;
         const int32_t* midx = W.mask_idx + o * EBL_STRIDE;
         // long-block spreading with additive masking (PsyModel.js:1274-1320); thr = ecb (pcfact == 0)
@@ -693,11 +730,11 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
             L.thr_l[ch][b] = (float)ecb;
         }
         // short-block limiting by the two previous sub-blocks (compute_masking_s, 762-775)
-        const int pshort = W.prev_short[o];
+        const int pshort = W.prev_short[(int64_t)gslot * C + (ch & 1)];      // blocktype_old[chn & 1] (PsyModel.js:767)
         for (int it = lane; it < 3 * T.npart_s; it += LHIP_NL) {
             const int sblock = it / T.npart_s, b = it - sblock * T.npart_s;
             const float* e0 = W.ecb_s + o * EBS_STRIDE;
-            const float* em = W.ecb_s + (o - C) * EBS_STRIDE;       // previous psy call (or carry)
+            const float* em = W.ecb_s + (o - Cp) * EBS_STRIDE;      // previous psy call (or carry)
             const float ecb = e0[sblock * CBANDS + b];
             const float nb1 = sblock >= 1 ? e0[(sblock - 1) * CBANDS + b] : em[2 * CBANDS + b];
             const float nb2 = sblock >= 2 ? e0[(sblock - 2) * CBANDS + b] : em[(sblock + 1) * CBANDS + b];
@@ -713,8 +750,8 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
 
-    for (int ch = 0; ch < C; ch++) {
-        const int64_t o = (int64_t)gslot * C + ch;
+    for (int ch = 0; ch < Cp; ch++) {
+        const int64_t o = (int64_t)gslot * Cp + ch;
         const float* eb_l = W.eb_l + o * EBL_STRIDE;
         float* Eo = L.E[ch];
         // convert_partition2scalefac_l (PsyModel.js:692-734): lane per scalefactor band
@@ -787,7 +824,7 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     wave_sync();
     // inter-channel masking (PsyModel.js:525-543): stereo mode with ratio > 0
-    if (T.mode == 0 && T.interChRatio > 0.0 && C > 1) {
+    if ((T.mode == 0 || T.mode == 1) && T.interChRatio > 0.0 && C > 1) {
         const double r_ = T.interChRatio;
         float nl[2] = {0.f, 0.f};
         for (int i = lane; i < SBMAX_l + 3 * SBMAX_s; i += LHIP_NL) {
@@ -800,8 +837,48 @@ LHIP_DEV void kb_psyB(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
         wave_sync();
     }
-    for (int ch = 0; ch < C; ch++)
-        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[((int64_t)gslot * C + ch) * E_STRIDE + i] = L.E[ch][i];
+    if (Cp == 4) {
+        // joint stereo (PsyModel.js:1336-1342): msfix1 (548-582), then ns_msfix (591-636) with the ATH.adjust the previous frame left.
+        // One lane per band (thm.l then thm.s are contiguous in E, and so are en.l / en.s); both steps only touch the band's own
+        // four thresholds, so they run back to back in the lane.
+        const double msfix = T.msfix;
+        const bool do_ns = d_abs(msfix) > 0.0;
+        const double athlower_l = do_ns ? v8_pow_base(pb10, T.ATHlower * ath_adjust) : 0.0;
+        const double athlower_s = athlower_l * ((double)BLKSIZE_s / BLKSIZE);
+        for (int i = lane; i < SBMAX_l + 3 * SBMAX_s; i += LHIP_NL) {
+            const int it = E_THM_L + i, ie = E_EN_L + i;
+            const bool lng = i < SBMAX_l;
+            const int sb = lng ? i : (i - SBMAX_l) / 3;
+            float t0 = L.E[0][it], t1 = L.E[1][it], t2 = L.E[2][it], t3 = L.E[3][it];
+            if (!((double)t0 > 1.58 * (double)t1 || (double)t1 > 1.58 * (double)t0)) {
+                const double m = lng ? (double)T.mld_l[sb] : (double)T.mld_s[sb];
+                double mld = m * (double)L.E[3][ie];
+                const double lo1 = (double)t3 < mld ? (double)t3 : mld;
+                const double rmid = (double)t2 > lo1 ? (double)t2 : lo1;
+                mld = m * (double)L.E[2][ie];
+                const double lo2 = (double)t2 < mld ? (double)t2 : mld;
+                const double rside = (double)t3 > lo2 ? (double)t3 : lo2;
+                t2 = (float)rmid; t3 = (float)rside;
+            }
+            if (do_ns) {
+                const double ath = lng ? (double)T.ATH_cb_l[T.bm_l[sb]] * athlower_l : (double)T.ATH_cb_s[T.bm_s[sb]] * athlower_s;
+                const double a0 = (double)t0 > ath ? (double)t0 : ath, a1 = (double)t1 > ath ? (double)t1 : ath;
+                const double thmLR = a0 < a1 ? a0 : a1;
+                double thmM = (double)t2 > ath ? (double)t2 : ath, thmS = (double)t3 > ath ? (double)t3 : ath;
+                if (thmLR * (msfix * 2.0) < thmM + thmS) {
+                    const double f = thmLR * (msfix * 2.0) / (thmM + thmS);
+                    thmM *= f;
+                    thmS *= f;
+                }
+                t2 = (float)(thmM < (double)t2 ? thmM : (double)t2);
+                t3 = (float)(thmS < (double)t3 ? thmS : (double)t3);
+            }
+            L.E[2][it] = t2; L.E[3][it] = t3;
+        }
+        wave_sync();
+    }
+    for (int ch = 0; ch < Cp; ch++)
+        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[((int64_t)gslot * Cp + ch) * E_STRIDE + i] = L.E[ch][i];
 }
 
 }  // namespace lhip

@@ -214,8 +214,23 @@ LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, c
 // ---------------------------------------------------------------------------------------------
 // xr_wb != nullptr: lines zeroed by the analog-silence rule are also zeroed in HBM, so that a later pass over the
 // same granule (kb_validate) can skip the rule (`skip_silence`); the rule is idempotent.
+// Where the lines come from: the channel's own MDCT output, or -- frames that joint stereo codes M/S -- mid / side of both
+// channels' outputs (ms_convert, Quantize.js:76-83).  M/S granules are never written back (the L / R lines must survive for the
+// other channel and for later passes), so they never skip the silence rule either.
+struct XrSrc { const float* a; const float* b; int side; };       // b == nullptr: a is the spectrum; else a = left, b = right
+LHIP_DEV XrSrc xr_source(const Workspace& W, int C, int gslot, int ch, int ms) {
+    XrSrc X;
+    if (!ms) { X.a = W.xr + ((int64_t)gslot * C + ch) * 576; X.b = nullptr; X.side = 0; }
+    else { X.a = W.xr + (int64_t)gslot * C * 576; X.b = X.a + 576; X.side = ch; }
+    return X;
+}
+LHIP_DEV float xr_at(const XrSrc& X, int i) {
+    if (!X.b) return X.a[i];
+    const double l = X.a[i], r = X.b[i];
+    return X.side ? (float)((l - r) * (LHIP_SQRT2 * 0.5)) : (float)((l + r) * (LHIP_SQRT2 * 0.5));
+}
 LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath_adjust, GI& g, int block_type,
-                                const float* xr_g, float* xr_wb, int skip_silence, int lane, QuantLds& L, const QuantTabs& Q) {
+                                const XrSrc& xr_g, float* xr_wb, int skip_silence, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     unsigned long long tmi_ = PH_NOW(); (void)tmi_;
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
@@ -249,7 +264,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         for (int d = lane; d < 576; d += LHIP_NL) {
             const int sw = Q.l2s_short[d], sfb = sw / 3, win = sw - 3 * sfb;
             const int st = Q.sfb_s[sfb], w = Q.sfb_s[sfb + 1] - st;
-            L.xr[d] = xr_g[3 * (st + (d - 3 * st - win * w)) + win];
+            L.xr[d] = xr_at(xr_g, 3 * (st + (d - 3 * st - win * w)) + win);
         }
     } else {
         nsfb = SBMAX_l;
@@ -257,7 +272,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
             L.width[i] = T.sfb_l[i + 1] - T.sfb_l[i]; L.window[i] = 3; L.start[i] = T.sfb_l[i];
         }
         if (lane == 0) L.start[SBMAX_l] = 576;
-        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_g[d];
+        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_at(xr_g, d);
     }
     LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.sfw[i] = 0; L.sfb[i] = 0; }
     wave_sync();
@@ -1788,7 +1803,98 @@ LHIP_DEV int frame_padding(const Tables& T, const StreamDesc& sd, int k) {
     return (m - T.frac_SpF) < 0 ? 1 : 0;
 }
 
-LHIP_DEV void targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize, int* targ) {
+// perceptual entropy of one channel of one psy call (pecalc_l / pecalc_s, PsyModel.js:845-905) from the maskings E (layout E_*)
+LHIP_DEV double q_pecalc(const float* E, int is_short, double masking_lower) {
+    const double regcoef_s[12] = {11.8, 13.6, 17.2, 32, 46.5, 51.3, 57.5, 67.1, 71.5, 84.6, 97.6, 130};
+    const double regcoef_l[21] = {6.8, 5.8, 5.8, 6.4, 6.5, 9.9, 12.1, 14.4, 15, 18.9, 21.6, 26.9, 34.2, 40.2, 46.8, 56.5, 60.7, 73.9, 85.7, 93.4, 126.1};
+    const double LOG10 = 2.30258509299404568402;
+    double pe;
+    if (is_short) {
+        pe = 1236.28 / 4;
+        for (int sb = 0; sb < SBMAX_s - 1; sb++)
+            for (int sblock = 0; sblock < 3; sblock++) {
+                const double thm = E[E_THM_S + sb * 3 + sblock];
+                if (thm > 0.0) {
+                    const double x = thm * masking_lower, en = E[E_EN_S + sb * 3 + sblock];
+                    if (en > x) {
+                        if (en > x * 1e10) pe += regcoef_s[sb] * (10.0 * LOG10);
+                        else pe += regcoef_s[sb] * v8_log10(en / x);
+                    }
+                }
+            }
+    } else {
+        pe = 1124.23 / 4;
+        for (int sb = 0; sb < SBMAX_l - 1; sb++) {
+            const double thm = E[E_THM_L + sb];
+            if (thm > 0.0) {
+                const double x = thm * masking_lower, en = E[E_EN_L + sb];
+                if (en > x) {
+                    if (en > x * 1e10) pe += regcoef_l[sb] * (10.0 * LOG10);
+                    else pe += regcoef_l[sb] * v8_log10(en / x);
+                }
+            }
+        }
+    }
+    return pe;
+}
+
+// Joint stereo: M/S or L/R for frame k of the stream (Encoder.js:520-561).  M/S when the perceptual entropy of the mid / side pair,
+// summed over the frame's granules, is not larger than that of left / right, and both channels have the same block type in the
+// first and in the last granule.  The entropies belong to the psy calls of this frame: maskings of the call before (slot - 1),
+// block types of the granule, and the masking_lower the previous frame's last channel left behind (gfc.masking_lower; 1 before
+// the first frame -- Lame.js:175).  Returns mode_ext: 0 or 2 (wave-uniform).
+LHIP_DEV int q_ms_decision(const Tables& T, const Workspace& W, const StreamDesc& sd, int k, int lane, QuantLds& L) {
+    const int GR = T.mode_gr;
+    const int bt_prev = W.blocktype[(int64_t)(sd.gslot0 + GR * k) * 2 + 1];         // carry slot for k == 0: -1 on a fresh stream
+    const double ml = bt_prev < 0 ? 1.0 : (bt_prev != SHORT_TYPE ? T.masking_lower_long : T.masking_lower_short);
+    wave_sync();
+    LHIP_LANE_ONCE(it, 0, 4 * GR) {                                                  // lane = granule * 4 + psy channel
+        const int gr = it >> 2, chn = it & 3;
+        const int gs = sd.gslot0 + 1 + GR * k + gr;
+        const int bt0 = W.blocktype[(int64_t)gs * 2], bt1 = W.blocktype[(int64_t)gs * 2 + 1];
+        const int type = chn < 2 ? (chn ? bt1 : bt0) : ((bt0 == SHORT_TYPE || bt1 == SHORT_TYPE) ? SHORT_TYPE : NORM_TYPE);
+        L.nsum[it] = q_pecalc(W.E + ((int64_t)(gs - 1) * 4 + chn) * E_STRIDE, type == SHORT_TYPE, ml);
+    }
+    wave_sync();
+    double sum_ms = 0., sum_lr = 0.;
+    for (int gr = 0; gr < GR; gr++)
+        for (int ch = 0; ch < 2; ch++) { sum_ms += L.nsum[4 * gr + 2 + ch]; sum_lr += L.nsum[4 * gr + ch]; }
+    wave_sync();
+    int ms = 0;
+    if (sum_ms <= 1.00 * sum_lr) {
+        const int g0 = sd.gslot0 + 1 + GR * k, g1 = g0 + GR - 1;
+        if (W.blocktype[(int64_t)g0 * 2] == W.blocktype[(int64_t)g0 * 2 + 1] && W.blocktype[(int64_t)g1 * 2] == W.blocktype[(int64_t)g1 * 2 + 1]) ms = 2;
+    }
+    return uni(ms);
+}
+
+// reduce_side (QuantizePVT.js:486-534): M/S granules move bits from the side to the mid channel by the energy ratio; the
+// reference's targ_bits is an Int32Array, so every store truncates
+LHIP_DEV void q_reduce_side(int* targ, double ms_ener_ratio, int mean_bits, int max_bits) {
+    double fac = .33 * (.5 - ms_ener_ratio) / .5;
+    if (fac < 0) fac = 0;
+    if (fac > .5) fac = .5;
+    int move_bits = js_toint32(fac * .5 * (targ[0] + targ[1]));
+    if (move_bits > MAX_BITS_PER_CHANNEL - targ[0]) move_bits = MAX_BITS_PER_CHANNEL - targ[0];
+    if (move_bits < 0) move_bits = 0;
+    if (targ[1] >= 125) {
+        if (targ[1] - move_bits > 125) {
+            if (targ[0] < mean_bits) targ[0] += move_bits;
+            targ[1] -= move_bits;
+        } else {
+            targ[0] += targ[1] - 125;
+            targ[1] = 125;
+        }
+    }
+    move_bits = targ[0] + targ[1];
+    if (move_bits > max_bits) {
+        targ[0] = js_toint32((double)(max_bits * targ[0]) / move_bits);
+        targ[1] = js_toint32((double)(max_bits * targ[1]) / move_bits);
+    }
+}
+
+// returns max_bits of on_pe (tbits + extra_bits, extra_bits = 0 here, capped at the per-granule limit)
+LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize, int* targ) {
     // on_pe + ResvMaxBits(cbr = gr) with the reservoir disabled (QuantizePVT.js:421-484, Reservoir.js:190-229)
     const int C = T.channels_out;
     int rs = ResvSize, tbits, bits = 0;
@@ -1805,6 +1911,7 @@ LHIP_DEV void targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize
             targ[ch] = js_toint32((double)targ[ch] * MAX_BITS_PER_GRANULE);
             targ[ch] = js_toint32((double)targ[ch] / bits);
         }
+    return tbits < MAX_BITS_PER_GRANULE ? tbits : MAX_BITS_PER_GRANULE;
 }
 
 // One wave per frame slot.  chain == 0: speculative reset seed (exact for the first frame of a stream
@@ -1838,18 +1945,27 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     }
     int ResvSize = 0;
     int gr0_bt0 = 0, gr0_bt1 = 0;
+    const int Cp = T.psy_channels;
+    const int mode_ext = (T.mode == 1) ? q_ms_decision(T, W, sd, k, lane, L) : 0;      // joint stereo: this frame M/S (2) or L/R (0)
     for (int gr = 0; gr < T.mode_gr; gr++) {
         const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
         int targ[2] = {0, 0};
-        targ_bits_for(T, mean_bits, gr, ResvSize, targ);
-        const int targ0 = targ[0], targ1 = targ[1];
+        const int max_bits = targ_bits_for(T, mean_bits, gr, ResvSize, targ);
+        if (mode_ext == 2) {
+            // Encoder.js:482-486: side / (mid + side) of the total energies the psy call of this granule handed back (one call of delay)
+            const float* te = W.tot_ener + (int64_t)(gslot - 1) * 4;
+            double r = (double)te[2] + (double)te[3];
+            if (r > 0) r = (double)te[3] / r;
+            q_reduce_side(targ, r, mean_bits, max_bits);
+        }
+        const int targ0 = uni(targ[0]), targ1 = uni(targ[1]);
         for (int ch = 0; ch < C; ch++) {
             if (PAIR && ch != my_ch) continue;
             GI g;
             const int bt = W.blocktype[(int64_t)gslot * C + ch];
             const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
-            const float* ratio = W.E + ((int64_t)(gslot - 1) * C + ch) * E_STRIDE;   // thresholds of the previous psy call
-            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, W.xr + ((int64_t)gslot * C + ch) * 576, W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
+            const float* ratio = W.E + ((int64_t)(gslot - 1) * Cp + ch + mode_ext) * E_STRIDE;   // thresholds of the previous psy call (mid / side: channels 2, 3)
+            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, xr_source(W, C, gslot, ch, mode_ext == 2), mode_ext == 2 ? nullptr : W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
             int active = 0, bs_gain = 0;
             const Seed used = ch == 0 ? seed0 : seed1;
             const int targ_ch = ch == 0 ? targ0 : targ1;
@@ -1891,6 +2007,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 out->sfbmax = g.sfbmax; out->sfbdivide = g.sfbdivide;
                 out->active = active; out->bs_start = used.start; out->bs_step_in = used.step; out->bs_gain = bs_gain;
                 out->targ_bits = targ_ch;
+                out->mode_ext = mode_ext;
                 out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
             }
             LHIP_LANE_ONCE(i, 0, SFBMAX) out->scalefac[i] = L.sfb[i];
@@ -1965,8 +2082,9 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
 #endif
                 if (nBits < 0) {
                     if (!inited) {
+                        const int ms = uni(rec->mode_ext) == 2;        // M/S granules were not written back: the silence rule runs again
                         q_init_outer_loop(T, pb10, ath_adjust, g, W.blocktype[(int64_t)gslot * C + ch],
-                                          W.xr + ((int64_t)gslot * C + ch) * 576, nullptr, 1, lane, L, Q);
+                                          xr_source(W, C, gslot, ch, ms), nullptr, ms ? 0 : 1, lane, L, Q);
                         q_init_xrpow(g, lane, L, Q);
                         // max_nonzero_coeff is set by calc_xmin in the reference before the bin search
                         if (g.block_type != SHORT_TYPE) {

@@ -79,17 +79,23 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
         const int64_t o = (int64_t)sd.gslot0 * C + ch;
         for (int i = lane; i < SB_STRIDE; i += LHIP_NL) W.sb[o * SB_STRIDE + i] = S->sb[ch][i];
-        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[ch][i];
-        for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[ch][i];
-        for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[ch][i];
         if (lane == 0) {
             W.loud[o] = S->loud[ch];
-            W.last_attack[o] = S->last_attack[ch];
             W.tent[o] = S->tent[ch];
+            W.blocktype[o] = S->last_bt[ch];
             W.seed[((int64_t)sd.fslot0 * C + ch) * 2 + 0] = S->seed[ch][0];
             W.seed[((int64_t)sd.fslot0 * C + ch) * 2 + 1] = S->seed[ch][1];
         }
     }
+    const int Cp = T.psy_channels;
+    for (int chn = 0; chn < Cp; chn++) {                         // psy channels: L, R and -- joint stereo -- mid, side
+        const int64_t o = (int64_t)sd.gslot0 * Cp + chn;
+        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[chn][i];
+        for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[chn][i];
+        for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[chn][i];
+        if (lane == 0) W.last_attack[o] = S->last_attack[chn];
+    }
+    if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) W.tot_ener[(int64_t)sd.gslot0 * 4 + i] = S->tot_ener[i];
     if (lane == 0) { W.ath_adjust[sd.fslot0] = S->ath_adjust; W.ath_limit[sd.fslot0] = S->ath_limit; }
 }
 
@@ -151,16 +157,24 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
         if (F == 0) continue;
         const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * C + ch;
         for (int i = lane; i < SB_STRIDE; i += LHIP_NL) S->sb[ch][i] = W.sb[o * SB_STRIDE + i];
-        for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[ch][i] = W.E[o * E_STRIDE + i];
-        for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[ch][i] = W.ecb_s[o * EBS_STRIDE + i];
-        for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[ch][i] = W.peaks[o * PK_STRIDE + i];
         if (lane == 0) {
             S->loud[ch] = W.loud[o];
-            S->last_attack[ch] = W.last_attack[o];
             S->tent[ch] = W.tent[o];
+            S->last_bt[ch] = W.blocktype[o];
             const Seed s = seed_before(W, sd, C, F, 0, ch);
             S->seed[ch][0] = s.start; S->seed[ch][1] = s.step;
         }
+    }
+    if (F > 0) {
+        const int Cp = T.psy_channels;
+        for (int chn = 0; chn < Cp; chn++) {
+            const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * Cp + chn;
+            for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[chn][i] = W.E[o * E_STRIDE + i];
+            for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[chn][i] = W.ecb_s[o * EBS_STRIDE + i];
+            for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = W.peaks[o * PK_STRIDE + i];
+            if (lane == 0) S->last_attack[chn] = W.last_attack[o];
+        }
+        if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) S->tot_ener[i] = W.tot_ener[(int64_t)(sd.gslot0 + T.mode_gr * F) * 4 + i];
     }
     if (lane == 0 && F > 0) { S->ath_adjust = W.ath_adjust[sd.fslot0 + F]; S->ath_limit = W.ath_limit[sd.fslot0 + F]; }
     if (T.rs_ratio != 1) {
@@ -205,11 +219,12 @@ LHIP_DEV void math_op8(const double* in, double* out) {
 static __device__ __forceinline__ int xcd_item(int b, int n) { const int it = (b & 7) * ((n + 7) >> 3) + (b >> 3); return it < n && (b >> 3) < ((n + 7) >> 3) ? it : -1; }
 __global__ __launch_bounds__(64) void g_load(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_load(T, W, SD, IO, blockIdx.x, threadIdx.x); }
 __global__ __launch_bounds__(64) void g_save(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_save(T, W, SD, IO, blockIdx.x, threadIdx.x); }
-__global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) {
+// psy channels chn0 .. chn0 + nch - 1 of every granule slot: (0, C) for L / R; joint stereo then runs (2, 2) for mid / side, which
+// read what the L / R pass left in W.fht / W.hpf
+__global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int chn0, int nch) {
     __shared__ PsyALds L;
-    const int C = T.channels_out;
-    const int it = xcd_item(blockIdx.x, W.ngslots * C);
-    if (it >= 0) kb_psyA(T, W, SD, IO, it / C, it % C, threadIdx.x, L);
+    const int it = xcd_item(blockIdx.x, W.ngslots * nch);
+    if (it >= 0) kb_psyA(T, W, SD, IO, it / nch, chn0 + it % nch, threadIdx.x, L);
 }
 __global__ __launch_bounds__(256) void g_prep(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nstreams) {
     kb_prep(T, W, SD, IO, nstreams, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
@@ -218,10 +233,10 @@ __global__ __launch_bounds__(64) void g_scan_raw(Tables T, Workspace W, const St
 __global__ __launch_bounds__(64) void g_scan_attack(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_attack(T, W, SD, g); }
 __global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_blocktype(T, W, SD, g); }
 __global__ __launch_bounds__(ATH_NT) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
-__global__ __launch_bounds__(64) void g_psyB(Tables T, Workspace W, const StreamDesc* SD) {
+__global__ __launch_bounds__(64) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD) {
     __shared__ PsyBLds L;
     const int it = xcd_item(blockIdx.x, W.ngslots);
-    if (it >= 0) kb_psyB(T, W, SD, it, threadIdx.x, L);
+    if (it >= 0) kb_psyB(T, pb, W, SD, it, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nitems) {
     __shared__ PolyLds L;
@@ -510,6 +525,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     CD(resample_ratio);
     CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
     CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
+    CD(msfix); CD(ATHlower);
 #undef CI
 #undef CD
 #define AF(f) T.f = (const float*)arr(#f, 2, nullptr)
@@ -518,7 +534,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     AF(rs_blackfilt);
     AF(amp_filter); AF(ATH_l); AF(ATH_s); AF(ATH_psfb21); AF(ATH_psfb12); AF(ATH_cb_l); AF(ATH_cb_s); AF(eql_w);
     AF(pow43); AF(adj43); AF(ipow20); AF(pow20); AF(longfact); AF(shortfact); AF(rnumlines_l); AF(bo_l_weight);
-    AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s);
+    AF(bo_s_weight); AF(s3_ll); AF(s3_ss); AF(window); AF(window_s); AF(mld_l); AF(mld_s);
     AI(sfb_l); AI(sfb_s); AI(psfb21); AI(psfb12); AI(bv_scf); AI(numlines_l); AI(numlines_s); AI(bo_l); AI(bm_l);
     AI(bo_s); AI(bm_s); AI(s3ind); AI(s3ind_s); AI(fft_rv_tbl); AI(mdct_order); AI(pretab); AI(scfsi_band);
     AI(slen1_n); AI(slen2_n); AI(slen1_tab); AI(slen2_tab); AI(scale_short); AI(scale_long); AI(huf_tbl_noESC);
@@ -531,6 +547,9 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
 #undef AI
 #undef AD
     if (!ok) return false;
+    // MPEGMode: 0 stereo, 1 joint stereo (an extension -- the reference's Mp3Encoder never asks for it, index.js:105), 3 mono
+    if (!((T.mode == 0 && T.channels_out == 2) || (T.mode == 1 && T.channels_out == 2) || (T.mode == 3 && T.channels_out == 1))) { set_err("configuration outside the supported envelope (channel mode)"); return false; }
+    T.psy_channels = (T.mode == 1) ? 4 : T.channels_out;
     // ---- envelope checks: fail loudly rather than produce different bytes than the reference ----
     if (T.channels_out != (cfg.channels == 1 ? 1 : 2) || T.in_samplerate != cfg.samplerate || T.brate <= 0) { set_err("tables blob does not match the requested configuration"); return false; }
     // resampling (Lame.js:1849): only integer decimation ratios, where the reference's filter is a fixed 33-tap FIR
@@ -614,9 +633,9 @@ struct Context {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener;
     // last batch (for debug taps)
-    Workspace lastW; int lastC = 0; bool have_last = false;
+    Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
     int num_cus = 256;
     // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
     // beside the filterbank kernels, which do not depend on it
@@ -716,13 +735,15 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     memset(&W, 0, sizeof W);
     W.spec_start = g_spec_start; W.spec_step = g_spec_step; W.mode_gr = T.mode_gr;
     W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
-    const size_t GC = (size_t)ngs * C, FR = (size_t)(nfr > 0 ? nfr : 1);
+    const int Cp = T.psy_channels;
+    const size_t GC = (size_t)ngs * C, GP = (size_t)ngs * Cp, FR = (size_t)(nfr > 0 ? nfr : 1);
 #define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
     ENS(pcm, T.rs_ratio != 1 ? (size_t)pcm_plane * C * 4 + 64 : 64);
-    ENS(peaks, GC * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GC * EBL_STRIDE * 4); ENS(mask_idx, GC * EBL_STRIDE * 4);
-    ENS(eb_s, GC * EBS_STRIDE * 4); ENS(ecb_s, GC * EBS_STRIDE * 4); ENS(att_raw, GC * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GC * 4); ENS(last_attack, GC * 4);
+    ENS(peaks, GP * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GP * EBL_STRIDE * 4); ENS(mask_idx, GP * EBL_STRIDE * 4);
+    ENS(eb_s, GP * EBS_STRIDE * 4); ENS(ecb_s, GP * EBS_STRIDE * 4); ENS(att_raw, GP * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GP * 4); ENS(last_attack, GP * 4);
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
-    ENS(ath_limit, (size_t)nfs * 8); ENS(E, GC * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
+    ENS(ath_limit, (size_t)nfs * 8); ENS(E, GP * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
+    ENS(fht, Cp == 4 ? (size_t)ngs * 2 * FHT_STRIDE * 4 : 64); ENS(hpf, Cp == 4 ? (size_t)ngs * 2 * 576 * 4 : 64); ENS(tot_ener, (size_t)ngs * 4 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
     ENS(seed_flag, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
     ENS(prof, 512);
@@ -734,6 +755,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.last_attack = (int32_t*)ctx->last_attack.p; W.tent = (int32_t*)ctx->tent.p; W.prev_short = (int32_t*)ctx->prev_short.p;
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
+    W.fht = (float*)ctx->fht.p; W.hpf = (float*)ctx->hpf.p; W.tot_ener = (float*)ctx->tot_ener.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
     W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 16; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
@@ -801,11 +823,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int s = 0; s < S; s++) WAVE_RUN(kb_load(T, W, dSD, dIO, s, lane_));
         if (T.rs_ratio != 1) kb_prep(T, W, dSD, dIO, S, 0, 1);
         for (int b = 0; b < ngs * C; b++) WAVE_RUN(kb_psyA(T, W, dSD, dIO, b / C, b % C, lane_, LA));
+        if (T.psy_channels == 4) for (int b = 0; b < ngs * 2; b++) WAVE_RUN(kb_psyA(T, W, dSD, dIO, b / 2, 2 + b % 2, lane_, LA));
         for (int b = 0; b < ngs; b++) kb_scan_raw(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
-        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB(T, W, dSD, b, lane_, LB));
+        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB(T, ts.pb10, W, dSD, b, lane_, LB));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
 #ifdef LHIP_WAVESIM
@@ -842,7 +865,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (nb < 1) nb = 1;
         LAUNCHB(KT_PREP, g_prep, (int)nb, 256, st, T, W, dSD, dIO, S);
     }
-    LAUNCH(KT_PSYA, g_psyA, XCD_GRID(ngs * C), st, T, W, dSD, dIO);
+    LAUNCH(KT_PSYA, g_psyA, XCD_GRID(ngs * C), st, T, W, dSD, dIO, 0, C);
+    if (T.psy_channels == 4) LAUNCH(KT_PSYA, g_psyA, XCD_GRID(ngs * 2), st, T, W, dSD, dIO, 2, 2);
     LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
@@ -872,7 +896,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_POLY, g_poly, XCD_GRID((ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE), st, T, W, dSD, dIO, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, XCD_GRID(ngs), st, T, W, dSD);
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
-    LAUNCH(KT_PSYB, g_psyB, XCD_GRID(ngs), st, T, W, dSD);
+    LAUNCH(KT_PSYB, g_psyB, XCD_GRID(ngs), st, T, ts.pb10, W, dSD);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
@@ -955,7 +979,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     } else if (nfr > 0) g_stat_pending = ctx;
 #endif
     g_stat_frames = nfr; g_stat_repaired = repaired; g_stat_iters = iters;
-    ctx->lastW = W; ctx->lastC = C; ctx->have_last = true;
+    ctx->lastW = W; ctx->lastC = C; ctx->lastCp = T.psy_channels; ctx->have_last = true;
     return true;
 }
 
@@ -1027,11 +1051,14 @@ int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes,
     // initial carried state (PsyModel.js:2566-2596 psymodel_init, Lame.js:168-171 lame_init_old)
     std::unique_ptr<StreamState> h(new StreamState());
     memset(h.get(), 0, sizeof(StreamState));
-    for (int ch = 0; ch < 2; ch++) {
+    for (int ch = 0; ch < 4; ch++) {                      // psy state exists for L, R, mid, side (PsyModel.js:2566-2596)
         for (int i = 0; i < E_STRIDE; i++) h->E[ch][i] = 1e20f;
         for (int i = 0; i < EBS_STRIDE; i++) h->ecb_s[ch][i] = 1.0f;
         for (int i = 0; i < 9; i++) h->peaks[ch][i] = 10.f;
+    }
+    for (int ch = 0; ch < 2; ch++) {
         h->tent[ch] = NORM_TYPE;
+        h->last_bt[ch] = -1;
         h->seed[ch][0] = 180; h->seed[ch][1] = 4;
     }
     h->ath_adjust = 0.01; h->ath_limit = 1.0;
@@ -1203,7 +1230,7 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
     switch (what) {
         case 0: src = W.xr; n = GC * 576 * 4; break;
         case 1: src = W.blocktype; n = GC * 4; break;
-        case 2: src = W.E; n = GC * E_STRIDE * 4; break;
+        case 2: src = W.E; n = (size_t)W.ngslots * ctx->lastCp * E_STRIDE * 4; break;
         case 3: src = W.ath_adjust; n = (size_t)W.nfslots * 8; break;
         case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ctx->lastC * sizeof(GrSide); break;
         case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;

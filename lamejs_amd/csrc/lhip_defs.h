@@ -78,15 +78,17 @@ struct Tables {
         short_blocks_coupled, useTemporal, ATH_useAdjust, athaa_loudapprox, copyright, original, emphasis,
         extension, error_protection, npart_l, npart_s, n_version_bytes,
         in_samplerate, rs_filter_l, rs_bpc,
-        rs_ratio;                           // integer decimation factor (1 = no resampling), derived at create time
+        rs_ratio,                           // integer decimation factor (1 = no resampling), derived at create time
+        psy_channels;                       // channels the psychoacoustic model analyses: channels_out, or 4 (L, R, mid, side) in joint stereo (mode == 1)
     // scalars (doubles)
     double scale, attackthre, attackthre_s, interChRatio, masking_lower_long, masking_lower_short,
-        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE, resample_ratio;
+        ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE, resample_ratio,
+        msfix, ATHlower;                    // joint stereo only (PsyModel.js:1336-1341)
     // arrays
     const float *rs_blackfilt;              // [2*bpc+1][filter_l+1]; row bpc (= 1) is the only one an integer ratio uses
     const float *amp_filter, *ATH_l, *ATH_s, *ATH_psfb21, *ATH_psfb12, *ATH_cb_l, *ATH_cb_s, *eql_w,
         *pow43, *adj43, *ipow20, *pow20, *longfact, *shortfact, *rnumlines_l, *bo_l_weight, *bo_s_weight,
-        *s3_ll, *s3_ss, *window, *window_s;
+        *s3_ll, *s3_ss, *window, *window_s, *mld_l, *mld_s;
     const int32_t *sfb_l, *sfb_s, *psfb21, *psfb12, *bv_scf, *numlines_l, *numlines_s, *bo_l, *bm_l, *bo_s,
         *bm_s, *s3ind, *s3ind_s, *fft_rv_tbl, *mdct_order, *pretab, *scfsi_band, *slen1_n, *slen2_n,
         *slen1_tab, *slen2_tab, *scale_short, *scale_long, *huf_tbl_noESC, *version_bytes, *ht_xlen,
@@ -117,6 +119,7 @@ struct GrSide {
     // what each memoised evaluation assigned (table_select / region counts are only written for non-empty regions, so
     // their final values depend on the search path) and the resulting state at the end of the bin search
     int32_t bs_asg[BS_TAB_MAX], bs_state;
+    int32_t mode_ext;                        // joint stereo: the frame's M/S decision (0 = L/R, 2 = M/S; Encoder.js:520-561), same in all records of a frame
 };
 
 }  // namespace lhip

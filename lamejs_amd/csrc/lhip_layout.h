@@ -16,7 +16,8 @@ enum {
     EBL_STRIDE = 64, EBS_STRIDE = 3 * 64,
     E_STRIDE = 2 * (SBMAX_l + 3 * SBMAX_s),   // en.l en.s thm.l thm.s = 122 floats
     E_EN_L = 0, E_EN_S = SBMAX_l, E_THM_L = SBMAX_l + 3 * SBMAX_s, E_THM_S = 2 * SBMAX_l + 3 * SBMAX_s,
-    SB_STRIDE = 18 * 32
+    SB_STRIDE = 18 * 32,
+    FHT_STRIDE = 1024 + 3 * 256
 };
 
 // Per-stream descriptor for one launch (device resident array, one entry per stream).
@@ -36,14 +37,17 @@ struct StreamDesc {
 
 enum { RS_TAPS = 33 };                       // BLACKSIZE of the reference for an integer ratio (filter_l = 32)
 
-struct StreamState {
+struct StreamState {                // psy arrays hold 4 channels: L, R and -- joint stereo only -- mid, side
     float pcm_tail[2][MF_NEEDED];
     float sb[2][SB_STRIDE];
-    float E[2][E_STRIDE];
-    float ecb_s[2][EBS_STRIDE];
-    float peaks[2][PK_STRIDE];
+    float E[4][E_STRIDE];
+    float ecb_s[4][EBS_STRIDE];
+    float peaks[4][PK_STRIDE];
     float loud[2];
-    int32_t last_attack[2], tent[2];
+    float tot_ener[4];              // joint stereo: total FFT energy of the last psy call (LameInternalFlags.js:271)
+    int32_t last_attack[4], tent[2];
+    int32_t last_bt[2];             // block type of the last granule encoded (-1: none yet); joint stereo: selects the masking_lower the next
+                                    // frame's perceptual entropy is computed with (gfc.masking_lower is left by the previous frame's last channel)
     double ath_adjust, ath_limit;
     int32_t seed[2][2];
     float rs_old[2][RS_TAPS - 1];   // resampling streams: the last 32 (scaled) input samples
@@ -85,25 +89,29 @@ struct Workspace {
     float* pcm;                 // [C][pcm_plane] scaled f32 samples, per stream segment = tail + new
     const int32_t* fslot_stream;   // [nfslots]  frame slot -> stream index
     const int32_t* gslot_stream;   // [ngslots]  granule slot -> stream index
-    // psy phase A outputs, per (gslot, ch)
-    float* peaks;               // [ngslots][C][PK_STRIDE]
-    float* loud;                // [ngslots][C]   loudness computed by that psy call
-    float* eb_l;                // [ngslots][C][64]
-    int32_t* mask_idx;          // [ngslots][C][64]
-    float* eb_s;                // [ngslots][C][3][64]
-    float* ecb_s;               // [ngslots][C][3][64]   (carry slot: sblock 1 = nb_s2, sblock 2 = nb_s1)
+    // psy phase A outputs, per (gslot, psy channel); Cp = Tables::psy_channels (C, or 4 in joint stereo: L, R, mid, side)
+    float* peaks;               // [ngslots][Cp][PK_STRIDE]
+    float* loud;                // [ngslots][C]   loudness computed by that psy call (L / R only)
+    float* eb_l;                // [ngslots][Cp][64]
+    int32_t* mask_idx;          // [ngslots][Cp][64]
+    float* eb_s;                // [ngslots][Cp][3][64]
+    float* ecb_s;               // [ngslots][Cp][3][64]   (carry slot: sblock 1 = nb_s2, sblock 2 = nb_s1)
+    // joint stereo only: what the mid / side analysis needs of the L / R one (PsyModel.js:258-273, 1113-1121)
+    float* fht;                 // [ngslots][2][FHT_STRIDE]  FHT outputs: 1024 long + 3 x 256 short
+    float* hpf;                 // [ngslots][2][576]         high-passed samples
+    float* tot_ener;            // [ngslots][4]              total FFT energy of that psy call
     // scan outputs
-    int32_t* att_raw;           // [ngslots][C]  bit j = raw ns_attacks[j]
+    int32_t* att_raw;           // [ngslots][Cp] bit j = raw ns_attacks[j]
     int32_t* uselong;           // [ngslots][C]  coupled uselongblock flag of that call
-    int32_t* ul_tmp;            // [ngslots][C]  scratch: lastAttacks before publication
-    int32_t* last_attack;       // [ngslots][C]  lastAttacks after that call
+    int32_t* ul_tmp;            // [ngslots][Cp] scratch: lastAttacks before publication
+    int32_t* last_attack;       // [ngslots][Cp] lastAttacks after that call
     int32_t* tent;              // [ngslots][C]  blocktype_old after that call (tentative type)
     int32_t* prev_short;        // [ngslots][C]  blocktype_old == SHORT as seen by that call's thresholds
     int32_t* blocktype;         // [ngslots][C]  final block type of the MDCT granule in that slot
     double* ath_adjust;         // [nfslots]     ATH.adjust after the frame in that slot (slot 0: carried in)
     double* ath_limit;          // [nfslots]
     // psy phase B output
-    float* E;                   // [ngslots][C][E_STRIDE]  thresholds computed by that psy call
+    float* E;                   // [ngslots][Cp][E_STRIDE] thresholds computed by that psy call
     // filterbank
     float* sb;                  // [ngslots][C][18][32]
     float* xr;                  // [ngslots][C][576]

@@ -24,10 +24,10 @@ _GRSIDE_FIELDS = (["part2_3_length", "part2_length", "big_values", "count1", "gl
                   ["region0_count", "region1_count", "preflag", "scalefac_scale", "count1table_select", "sfbmax", "sfbdivide", "active",
                    "bs_start", "bs_step_in", "bs_gain", "targ_bits", "scfsi"])
 GRSIDE = np.dtype([(f, "<i4") for f in _GRSIDE_FIELDS] + [("scalefac", "<i4", (SFBMAX,)), ("bs_ntab", "<i4"), ("bs_tab", "<i4", (24,)),
-                                                         ("bs_asg", "<i4", (24,)), ("bs_state", "<i4")])
+                                                         ("bs_asg", "<i4", (24,)), ("bs_state", "<i4"), ("mode_ext", "<i4")])
 
 
-def oracle_stages(channels, samplerate, kbps, L, R):
+def oracle_stages(channels, samplerate, kbps, L, R, joint=False):
     """Per-frame taps of the oracle: list of TAP records (one per emitted frame, flush excluded)."""
     import lamejs_amd
     lib = _load_oracle()
@@ -36,7 +36,7 @@ def oracle_stages(channels, samplerate, kbps, L, R):
     lib.lo_get_tap.argtypes = [ctypes.c_void_p]
     lib.lo_tap_size.restype = ctypes.c_size_t
     assert lib.lo_tap_size() == TAP.itemsize, (lib.lo_tap_size(), TAP.itemsize)
-    blob = lamejs_amd.tables_blob(channels, samplerate, kbps)
+    blob = lamejs_amd.tables_blob(channels, samplerate, kbps, joint)
     buf = ctypes.create_string_buffer(blob, len(blob))
     h = lib.lo_create(buf, len(blob))
     assert h
@@ -57,14 +57,15 @@ def oracle_stages(channels, samplerate, kbps, L, R):
     return taps
 
 
-def device_stages(lib, channels, samplerate, kbps, L, R):
+def device_stages(lib, channels, samplerate, kbps, L, R, joint=False):
     """One batch through the library under test, then its intermediate arrays (lhip_debug_read taps 0-4)."""
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(channels, samplerate, kbps, lib=lib)
+    enc = lamejs_amd.Mp3Encoder(channels, samplerate, kbps, lib=lib, joint=joint)
     lib = enc._lib
     mp3 = enc.encodeBuffer(L, R)
     nfr = enc.last_batch_stats()["frames"]
     C = channels
+    Cp = 4 if (joint and channels == 2) else C          # psy channels: L, R (+ mid, side in joint stereo)
     GR = 2 if samplerate >= 32000 else 1
     ngs, nfs = GR * nfr + 1, nfr + 1
 
@@ -77,17 +78,17 @@ def device_stages(lib, channels, samplerate, kbps, L, R):
     st = {"nframes": nfr, "GR": GR,
           "xr": read(0, "<f4", ngs * C * 576).reshape(ngs, C, 576),
           "blocktype": read(1, "<i4", ngs * C).reshape(ngs, C),
-          "E": read(2, "<f4", ngs * C * 122).reshape(ngs, C, 122),
+          "E": read(2, "<f4", ngs * Cp * 122).reshape(ngs, Cp, 122),
           "ath": read(3, "<f8", nfs),
           "side": read(4, GRSIDE, nfr * 2 * C).reshape(nfr, 2, C)}
     enc.close()
     return st, mp3
 
 
-def compare_stages(lib, channels, samplerate, kbps, L, R, psfb21_start=None):
+def compare_stages(lib, channels, samplerate, kbps, L, R, psfb21_start=None, joint=False):
     """Returns a list of human-readable mismatches (empty = every stage of every granule agrees)."""
-    taps = oracle_stages(channels, samplerate, kbps, L, R)
-    st, _ = device_stages(lib, channels, samplerate, kbps, L, R)
+    taps = oracle_stages(channels, samplerate, kbps, L, R, joint)
+    st, _ = device_stages(lib, channels, samplerate, kbps, L, R, joint)
     bad = []
     assert st["nframes"] == len(taps), (st["nframes"], len(taps))
     GR, C = st["GR"], channels
@@ -95,15 +96,20 @@ def compare_stages(lib, channels, samplerate, kbps, L, R, psfb21_start=None):
     for k, t in enumerate(taps):
         if np.float64(t["ath_adjust"]).view(np.uint64) != st["ath"][1 + k].view(np.uint64):
             bad.append(f"frame {k}: ATH.adjust {st['ath'][1 + k]!r} != {t['ath_adjust']!r}")
+        ms = 0
+        if joint:                                    # the frame's M/S decision (mode_ext 0 / 2); the maskings handed on are then mid / side
+            ms = int(t["mode_ext"])
+            if int(st["side"][k, 0, 0]["mode_ext"]) != ms:
+                bad.append(f"frame {k}: mode_ext {int(st['side'][k, 0, 0]['mode_ext'])} != {ms} (oracle pe {t['pe'].tolist()} pe_MS {t['pe_MS'].tolist()})")
         for gr in range(GR):
             gs = 1 + GR * k + gr
             for ch in range(C):
                 if st["blocktype"][gs, ch] != t["block_type"][gr, ch]:
                     bad.append(f"frame {k} gr {gr} ch {ch}: block type {st['blocktype'][gs, ch]} != {t['block_type'][gr, ch]}")
                 # masking handed to the quantizer for this granule = thresholds of the previous psy call (slot gs - 1)
-                if not np.array_equal(u32(st["E"][gs - 1, ch]), u32(t["ratio"][gr, ch])):
-                    i = int(np.nonzero(u32(st["E"][gs - 1, ch]) != u32(t["ratio"][gr, ch]))[0][0])
-                    bad.append(f"frame {k} gr {gr} ch {ch}: masking en/thm differs at index {i}: {st['E'][gs - 1, ch, i]!r} != {t['ratio'][gr, ch, i]!r}")
+                if not np.array_equal(u32(st["E"][gs - 1, ch + ms]), u32(t["ratio"][gr, ch])):
+                    i = int(np.nonzero(u32(st["E"][gs - 1, ch + ms]) != u32(t["ratio"][gr, ch]))[0][0])
+                    bad.append(f"frame {k} gr {gr} ch {ch}{' (M/S)' if ms else ''}: masking en/thm differs at index {i}: {st['E'][gs - 1, ch + ms, i]!r} != {t['ratio'][gr, ch, i]!r}")
                 # MDCT output.  The quantization kernel writes the zeros of the analog-silence rule back into xr (lines of the
                 # pseudo bands above sfb21 / sfb12 below the adjusted ATH, Quantize.js:147-202), the oracle taps xr before it
                 d, o = st["xr"][gs, ch], t["xr"][gr, ch]

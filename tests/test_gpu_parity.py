@@ -21,9 +21,9 @@ def lib():
     return l
 
 
-def _encode(ch, kbps, L, R, chunk, sr=44100):
+def _encode(ch, kbps, L, R, chunk, sr=44100, joint=False):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, joint=joint)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -115,6 +115,60 @@ def test_gpu_matches_reference_goldens(lib, golden):
         assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
         n += 1
     assert n >= 65
+
+
+def test_gpu_joint_stereo_matches_reference_goldens(lib, golden_joint):
+    """SURVEY.md 8f #3 (extension flag `joint`): every joint-stereo golden -- the reference's own encoder core asked for
+    MPEGMode.JOINT_STEREO (tests/tools/gen_golden_joint.js) -- byte for byte on the GPU: 29 streams, 10 284 frames, 7 817 of them coded
+    mid/side, incl. frame-by-frame mixtures, MPEG-2 / 2.5 and resampling configurations, one-call and many-call chunking."""
+    n = ms = 0
+    for case in golden_joint:
+        L, R = load_case_pcm(case)
+        mp3 = _encode(2, case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100), joint=True)
+        assert len(mp3) == case["mp3_len"], case
+        assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
+        n += 1
+        ms += case["ms_frames"]
+    assert n >= 29 and ms >= 7000
+
+
+def test_gpu_joint_stereo_both_quant_paths_and_streams(lib):
+    """Joint stereo through the persistent kernel (one 1500-frame call), through the two-waves-per-frame kernel (150-frame calls) and
+    as a multi-stream batch, against the oracle (pinned to the reference: tests/test_oracle_golden.py, profiles/r02_fuzz_oracle_vs_reference_joint_stereo.txt)."""
+    import lamejs_amd
+    import pcm
+    from oracle_py import oracle_encode
+    n = 1152 * 1500
+    A, B = pcm.bursts(n, 2)
+    L2, R2 = pcm.sine(n, 2, seed=777)
+    L = np.clip(A.astype(np.int32) // 2 + L2 // 2 + (B.astype(np.int32) >> 4), -32768, 32767).astype(np.int16)
+    R = np.clip(A.astype(np.int32) // 2 + R2 // 2 - (B.astype(np.int32) >> 4), -32768, 32767).astype(np.int16)
+    want = oracle_encode(2, 44100, 128, L, R, joint=True)
+    big = _encode(2, 128, L, R, n, joint=True)
+    small = _encode(2, 128, L, R, 1152 * 150, joint=True)
+    assert big == want, "persistent kernel differs from the oracle: " + _first_diff(big, want)
+    assert small == want, "pair kernel differs from the oracle: " + _first_diff(small, want)
+    # both decisions occur in this material
+    exts, pos = set(), 0
+    while pos + 4 <= len(want):
+        h = int.from_bytes(want[pos:pos + 4], "big")
+        exts.add((h >> 4) & 3)
+        pos += 144000 * 128 // 44100 + ((h >> 9) & 1)
+    assert exts == {0, 2}, exts
+    streams = [pcm.CORPORA["centre_bursts" if i % 2 else "bursts"](1152 * (20 + 7 * i), 2) for i in range(5)]
+    encs = [lamejs_amd.Mp3Encoder(2, 44100, 128, joint=True) for _ in streams]
+    got = lamejs_amd.encode_streams(encs, [s[0] for s in streams], [s[1] for s in streams])
+    for (l, r), g in zip(streams, got):
+        assert g == oracle_encode(2, 44100, 128, l, r, joint=True)
+
+
+@pytest.mark.parametrize("corpus,sr,kbps,nfr", [("bursts", 44100, 128, 400), ("centre_bursts", 22050, 64, 300)])
+def test_gpu_stage_taps_joint_stereo(lib, corpus, sr, kbps, nfr):
+    """Stage-level differential check in joint-stereo mode: the frame's M/S decision, the maskings handed to the quantizer (mid / side
+    in M/S frames), MDCT output, block types, ATH.adjust, gain / lengths per granule against the oracle's taps."""
+    import pcm, stage_taps
+    L, R = pcm.CORPORA[corpus](1152 * nfr, 2)
+    assert stage_taps.compare_stages(None, 2, sr, kbps, L, R, joint=True) == []
 
 
 def test_gpu_reference_fixture_md5s(lib, golden):

@@ -20,9 +20,9 @@ def sim():
     return lib
 
 
-def _encode(lib, ch, kbps, L, R, chunk, sr=44100):
+def _encode(lib, ch, kbps, L, R, chunk, sr=44100, joint=False):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -44,6 +44,21 @@ def test_hostsim_matches_goldens(sim, golden):
         assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
         n += 1
     assert n >= 53
+
+
+def test_hostsim_matches_joint_stereo_goldens(sim, golden_joint):
+    """SURVEY.md 8f #3 (extension): the kernel logic in joint-stereo mode -- four psy channels, the per-frame M/S decision, mid/side
+    quantization -- against the reference's own joint-stereo output (L/R-only, M/S-only and mixed streams; MPEG-1, LSF, resampling)."""
+    n = ms = 0
+    for case in golden_joint:
+        if case["nsamples"] > 1152 * 300:
+            continue
+        L, R = load_case_pcm(case)
+        mp3 = _encode(sim, 2, case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100), joint=True)
+        assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
+        n += 1
+        ms += case["ms_frames"]
+    assert n >= 18 and ms >= 2000
 
 
 def test_hostsim_batch_streams_match_single(sim):
@@ -110,3 +125,12 @@ def test_hostsim_stage_taps(sim, ch, sr, kbps, nfr):
     import pcm, stage_taps
     L, R = pcm.bursts(1152 * nfr, ch, seed=91)
     assert stage_taps.compare_stages(sim, ch, sr, kbps, L, R) == []
+
+
+@pytest.mark.parametrize("corpus,sr,kbps,nfr", [("bursts", 44100, 128, 40), ("centre_bursts", 22050, 64, 40)])
+def test_hostsim_stage_taps_joint_stereo(sim, corpus, sr, kbps, nfr):
+    """The same per-stage comparison in joint-stereo mode: additionally the frame's M/S decision, and the maskings handed to the
+    quantizer are the mid / side ones in M/S frames (`bursts` mixes M/S and L/R frames)."""
+    import pcm, stage_taps
+    L, R = pcm.CORPORA[corpus](1152 * nfr, 2)
+    assert stage_taps.compare_stages(sim, 2, sr, kbps, L, R, joint=True) == []

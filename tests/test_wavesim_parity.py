@@ -25,9 +25,9 @@ def wsim():
     return lib
 
 
-def _encode(lib, ch, kbps, L, R, chunk, sr=44100):
+def _encode(lib, ch, kbps, L, R, chunk, sr=44100, joint=False):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -66,6 +66,20 @@ def test_wavesim_matches_oracle(wsim, corpus, ch, sr, kbps, nfr, chunk):
     L, R = pcm.CORPORA[corpus](1152 * nfr + 313, ch, seed=4000 + nfr + kbps)
     got = _encode(wsim, ch, kbps, L, R, chunk, sr)
     assert got == oracle_encode(ch, sr, kbps, L, R)
+
+
+@pytest.mark.parametrize("corpus,sr,kbps,nfr,chunk", [
+    ("centre_bursts", 44100, 128, 14, 1152 * 14),  # M/S frames, one call (the one-wave-per-frame kernel)
+    ("bursts", 44100, 128, 24, 1152 * 5),          # M/S and L/R frames mixed; calls of 5 frames: the two-waves-per-frame kernel
+    ("centre_sine", 22050, 64, 10, 777),           # MPEG-2
+])
+def test_wavesim_joint_stereo_matches_oracle(wsim, corpus, sr, kbps, nfr, chunk):
+    """SURVEY.md 8f #3 (extension): the 64-lane wave programs in joint-stereo mode against the oracle (itself pinned to the
+    reference's joint-stereo output, tests/test_oracle_golden.py)."""
+    import pcm
+    L, R = pcm.CORPORA[corpus](1152 * nfr, 2)
+    got = _encode(wsim, 2, kbps, L, R, chunk, sr, joint=True)
+    assert got == oracle_encode(2, sr, kbps, L, R, joint=True)
 
 
 def test_wavesim_quiet_and_edge_material(wsim):
