@@ -11,6 +11,8 @@
  * kernels on an MI355X behind the C ABI of include/lamejs_hip.h, reached through a thin N-API addon.
  * GPU efficiency comes from batching: pass many frames per encodeBuffer() call (the reference API
  * already allows any length).  There is no CPU fallback.
+ * Extension: new Mp3Encoder(2, sampleRate, kbps, { jointStereo: true }) encodes in the reference core's joint-stereo mode (per frame
+ * mid/side or left/right), which the reference's own wrapper never selects (index.js:105 hard-codes MPEGMode.STEREO).
  */
 'use strict';
 const path = require('path');
@@ -23,13 +25,14 @@ function loadAddon() {
     return addon;
 }
 
-function Mp3Encoder(channels, samplerate, kbps) {
-    if (arguments.length != 3) {
+function Mp3Encoder(channels, samplerate, kbps, opts) {
+    if (arguments.length != 3 && !(arguments.length == 4 && opts !== null && typeof opts == 'object')) {
+        opts = undefined;
         console.error('WARN: Mp3Encoder(channels, samplerate, kbps) not specified');
         channels = 1; samplerate = 44100; kbps = 128;
     }
     const native = loadAddon();
-    const blob = tables.buildBlob(channels, samplerate, kbps).blob;
+    const blob = tables.buildBlob(channels, samplerate, kbps, opts).blob;
     const handle = native.create(blob, channels, samplerate, kbps, defaultDevice);
     Object.defineProperty(this, '_lhip', { value: { handle: handle, channels: channels }, enumerable: false });
 

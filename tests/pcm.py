@@ -59,8 +59,8 @@ def bursts(nsamples: int, channels: int, seed: int = 777):
 
 def _centre(gen):
     """Strongly correlated channels (so that joint stereo codes M/S): L = A + (B >> 3), R = A - (B >> 3); tests/tools/gen_golden_joint.js."""
-    def f(nsamples: int, channels: int):
-        a, b = gen(nsamples, 2)
+    def f(nsamples: int, channels: int, seed=None):
+        a, b = gen(nsamples, 2) if seed is None else gen(nsamples, 2, seed=seed)
         d = b.astype(np.int32) >> 3
         L = np.clip(a.astype(np.int32) + d, -32768, 32767).astype(np.int16)
         R = np.clip(a.astype(np.int32) - d, -32768, 32767).astype(np.int16)

@@ -14,14 +14,22 @@ NODE = shutil.which("node")
 ADDON = ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node"
 
 
-def _run(env_lib, corpus, ch, kbps, nfr, chunk, sr=44100):
+def _run(env_lib, corpus, ch, kbps, nfr, chunk, sr=44100, joint=False):
     env = dict(os.environ)
     if env_lib:
         env["LAMEJS_HIP_LIB"] = str(env_lib)
-    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk), str(sr)],
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk), str(sr)] + (["joint"] if joint else []),
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _joint_cases(golden_joint):
+    """Joint-stereo extension of the drop-in: an all-M/S stream, a mixed one, and an MPEG-2 one."""
+    pick = [c for c in golden_joint if (c["corpus"], c["kbps"], c["nsamples"] // 1152, c.get("samplerate", 44100)) in
+            (("centre_sine", 128, 300, 44100), ("bursts", 128, 400, 44100), ("centre_bursts", 64, 150, 22050))]
+    assert len(pick) == 3
+    return pick
 
 
 def _cases(golden):
@@ -47,6 +55,23 @@ def test_js_dropin_hostsim(golden):
 def test_js_dropin_gpu(golden):
     for c in _cases(golden):
         got = _run(None, c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100))
+        assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_joint_stereo_extension_hostsim(golden_joint):
+    """new Mp3Encoder(2, sr, kbps, { jointStereo: true }) == the reference core asked for MPEGMode.JOINT_STEREO (golden_joint.json)."""
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    for c in _joint_cases(golden_joint):
+        got = _run(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", c["corpus"], 2, c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100), joint=True)
+        assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_joint_stereo_extension_gpu(golden_joint):
+    for c in _joint_cases(golden_joint):
+        got = _run(None, c["corpus"], 2, c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100), joint=True)
         assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
 
 

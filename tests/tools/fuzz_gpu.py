@@ -51,24 +51,31 @@ RESAMPLE_CFGS = [(1, 44100, 32), (2, 44100, 48), (1, 48000, 24), (2, 48000, 64),
                  (1, 48000, 40), (1, 48000, 8), (2, 48000, 40), (2, 32000, 40), (1, 32000, 24), (2, 16000, 24)]
 
 
-def run(ncases, seed, lib=None, verbose=True, cfgs=None):
-    """Returns the list of mismatching case descriptions (empty = parity)."""
+def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False):
+    """Returns the list of mismatching case descriptions (empty = parity).  joint: the joint-stereo extension on the two-channel
+    configurations; the material (same draws as tests/tools/fuzz_ref.py joint) has strongly correlated channels in half of the cases."""
     rng = np.random.default_rng(seed)
     cfgs = cfgs or MPEG1_CFGS
+    if joint:
+        cfgs = [c for c in cfgs if c[0] == 2]
     bad = []
     t0 = time.time()
     for c in range(ncases):
         ch, sr, kbps = cfgs[c % len(cfgs)]
         nfr = int(rng.integers(20, 260))
         L, R = material(rng, 1152 * nfr + int(rng.integers(0, 1152)), ch)
+        if joint and rng.integers(0, 2):       # correlated channels: L = A + B / 2^k, R = A - B / 2^k
+            k = int(rng.integers(1, 6))
+            d = R.astype(np.int32) >> k
+            L, R = (np.clip(L.astype(np.int32) + d, -32768, 32767).astype(np.int16), np.clip(L.astype(np.int32) - d, -32768, 32767).astype(np.int16))
         try:
-            enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib)
+            enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
         except lamejs_amd.LhipError as e:
             print("skip", ch, sr, kbps, str(e)[:60]); continue
         chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
         got = b"".join(enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk]) for p in range(0, len(L), chunk)) + enc.flush()
         enc.close()
-        want = oracle_encode(ch, sr, kbps, L, R)
+        want = oracle_encode(ch, sr, kbps, L, R, joint=joint)
         ok = got == want
         if not ok:
             d = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
@@ -81,12 +88,12 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None):
 
 
 def main():
-    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample] [hostsim]"""
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample] [hostsim] [joint]"""
     cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else MPEG1_CFGS
     lib = None
     if "hostsim" in sys.argv[3:]:
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))
-    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs)
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs, joint="joint" in sys.argv[3:])
     sys.exit(1 if bad else 0)
 
 

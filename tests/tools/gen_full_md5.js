@@ -6,16 +6,19 @@
  * Every job prints one JSON line; tests/tools/gen_full_md5.sh runs the job list in parallel and merges the lines into
  * tests/golden/full_md5.json.
  *
- *   node tests/tools/gen_full_md5.js <corpus> <channels> <kbps> <frames> <seed0> [nseeds]
+ *   node tests/tools/gen_full_md5.js <corpus> <channels> <kbps> <frames> <seed0> [nseeds] [joint]
+ * corpus centre_<x>: L = A + (B >> 3), R = A - (B >> 3) of corpus x; joint: the reference's modules driven with gfp.mode = JOINT_STEREO
+ * (ref_harness.js refEncoder) -- the joint-stereo extension, SURVEY.md 8f #3.
  */
 'use strict';
 const crypto = require('crypto');
-const { refPublic } = require('./ref_harness.js');
+const { refPublic, refEncoder } = require('./ref_harness.js');
 const gen = require('./pcm_gen.js');
 const lamejs = refPublic();
 
 const corpus = process.argv[2], ch = parseInt(process.argv[3]), kbps = parseInt(process.argv[4]), frames = parseInt(process.argv[5]);
-const seed0 = parseInt(process.argv[6]), nseeds = parseInt(process.argv[7] || '1');
+const seed0 = parseInt(process.argv[6]), nseeds = parseInt(process.argv[7] || '1'), joint = process.argv[8] === 'joint';
+const base = corpus.replace('centre_', ''), centre = corpus.startsWith('centre_');
 const CHUNK = 1152 * 500;
 
 /* chunked twins of pcm_gen.sine / pcm_gen.bursts: same expressions, the sample index runs over the whole stream */
@@ -25,7 +28,7 @@ function makeSource(corpus, ch, seed) {
     return function next(n) {
         const L = new Int16Array(n), R = ch == 2 ? new Int16Array(n) : null;
         for (let k = 0; k < n; k++, i++) {
-            if (corpus == 'sine') {
+            if (base == 'sine') {
                 L[k] = Math.round(8000 * Math.sin(2 * Math.PI * 440 * i / 44100) + 2000 * (2 * u() - 1));
                 if (R) R[k] = Math.round(6000 * Math.sin(2 * Math.PI * 660 * i / 44100) + 2000 * (2 * u() - 1));
             } else {
@@ -34,12 +37,13 @@ function makeSource(corpus, ch, seed) {
                 if (R) { const inBurstR = ((i + 5000) % 22050) >= 11000 && ((i + 5000) % 22050) < 13000; R[k] = Math.round((inBurstR ? 20000 : 30) * (2 * u() - 1)); }
             }
         }
+        if (centre) for (let k = 0; k < n; k++) { const a = L[k], d = R[k] >> 3; L[k] = Math.max(-32768, Math.min(32767, a + d)); R[k] = Math.max(-32768, Math.min(32767, a - d)); }
         return [L, R];
     };
 }
 
 for (let s = seed0; s < seed0 + nseeds; s++) {
-    const src = makeSource(corpus, ch, s), enc = new lamejs.Mp3Encoder(ch, 44100, kbps), h = crypto.createHash('md5');
+    const src = makeSource(corpus, ch, s), enc = joint ? refEncoder(ch, 44100, kbps, { jointStereo: true }) : new lamejs.Mp3Encoder(ch, 44100, kbps), h = crypto.createHash('md5');
     let bytes = 0;
     for (let left = 1152 * frames; left > 0;) {
         const n = Math.min(left, CHUNK);
@@ -48,5 +52,7 @@ for (let s = seed0; s < seed0 + nseeds; s++) {
         h.update(Buffer.from(out.buffer, out.byteOffset, out.length));
         bytes += out.length; left -= n;
     }
-    console.log(JSON.stringify({ corpus, channels: ch, samplerate: 44100, kbps, frames, seed: s, flush: false, bytes, md5: h.digest('hex') }));
+    const row = { corpus, channels: ch, samplerate: 44100, kbps, frames, seed: s, flush: false, bytes, md5: h.digest('hex') };
+    if (joint) row.joint = 1;
+    console.log(JSON.stringify(row));
 }
