@@ -17,6 +17,11 @@
  *   lhip_flush    <- Mp3Encoder.flush() -> Lame.lame_encode_flush    src/js/index.js:132-135, Lame.js:1381-1488
  *   lhip_destroy  <- (garbage collection of the encoder object)
  *
+ * Channel mode.  The reference's Mp3Encoder hard-codes MPEGMode.STEREO for two channels (index.js:105).  As an extension the
+ * blob may carry mode = 1 (tables.js buildBlob(..., { jointStereo: true })): the stream is then encoded in the reference core's
+ * joint-stereo mode -- per frame mid/side or left/right (Encoder.js:520-561) -- byte for byte what the reference's own modules
+ * produce when asked for MPEGMode.JOINT_STEREO.  Nothing in the signatures below changes.
+ *
  * Semantics preserved: any chunking of the same sample stream yields the same bytes; a call
  * returns the bytes of all whole frames completed by that call (possibly 0); errors are negative
  * return codes mirroring the reference (-1 output buffer too small, -3 bad handle, -4 internal/device
@@ -106,7 +111,7 @@ int lhip_set_hip_stream(int device, void* hip_stream);
 void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations);
 
 /* Debug/test taps (tests only): copy intermediate results of the most recent batch to the host.
- * what: 0 xr [granule][ch][576] f32, 1 blocktype [granule][ch] i32, 2 E [granule][ch][122] f32 (thresholds
+ * what: 0 xr [granule][ch][576] f32, 1 blocktype [granule][ch] i32, 2 E [granule][psy ch][122] f32 (psy ch = ch, or L R mid side in joint stereo; thresholds
  * handed to the quantizer for that granule), 3 ath_adjust [frame] f64, 4 side records (struct GrSide).
  * Returns bytes copied or <0. */
 int64_t lhip_debug_read(int what, void* dst, size_t cap);
