@@ -2144,12 +2144,14 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
 // Memo-only replay, one THREAD per frame: the whole check is a few scalar look-ups in the side records, so it runs
 // as a plain grid over the frames without LDS tables.  Outcome per frame in W.seed_flag: 0 consistent, 1 re-quantize
 // with the chain-implied seed, 2 undecided (a gain the speculative pass never evaluated) -> kb_validate decides.
-LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot) {
+// only_pass > 0: just the frames stamped for that pass (successors of frames the previous repair pass re-quantized)
+LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int only_pass = 0) {
     const int C = T.channels_out;
     const StreamDesc sd = SD[W.fslot_stream[fslot]];
     const int k = fslot - sd.fslot0 - 1;
     if (k < 0) return;
     const int fidx = sd.out_slot0 + k;
+    if (only_pass > 0 && W.reval[fidx] != only_pass) return;
     int verdict = 0;
     for (int gr = 0; gr < T.mode_gr && verdict == 0; gr++)
         for (int ch = 0; ch < C && verdict == 0; ch++) {

@@ -349,8 +349,11 @@ __global__ __launch_bounds__(64 * QWAVES, 2) void g_fixup(QArgs a_unused) {
         // V: memo-only replay, one thread per frame slot.  The first pass has been made by g_validate_fast, a plain launch in front
         // of this kernel (it needs no LDS, so it runs at full occupancy; the kernel boundary orders it): in the usual case -- nothing
         // flagged -- this kernel reads two counters and ends without a single grid barrier.
+        // Later passes only look at the successors of the frames the last repair phase re-quantized (stamped in W.reval): a frame's
+        // verdict depends on its own records and on its predecessor's, and nothing else has changed.  (On material where most
+        // replays miss the memo -- `bursts`: 98 % -- a second pass over everything cost another 4 ms.)
         if (it > 0) {
-            for (int f = blockIdx.x * nthr + threadIdx.x; f < nfs; f += nblocks * nthr) kb_validate_fast(A->T, W, A->SD, f);
+            for (int f = blockIdx.x * nthr + threadIdx.x; f < nfs; f += nblocks * nthr) kb_validate_fast(A->T, W, A->SD, f, it);
             grid_barrier(base + FX_BAR, nblocks);
         }
         // (the counters are read by every lane and asserted wave-uniform: every decision below must be scalar control flow)
@@ -369,11 +372,14 @@ __global__ __launch_bounds__(64 * QWAVES, 2) void g_fixup(QArgs a_unused) {
         if (nflag == 0) break;
         repaired += nflag; iters++;
         if (iters > nfs + 2) { failed = 1; break; }                           // cannot happen: every pass finalises at least the first flagged frame
-        // R: re-quantize the flagged frames with the chain-implied seeds; 64 frame slots per step, lane = slot
+        // R: re-quantize the flagged frames with the chain-implied seeds.  Wave gw owns the frame slots congruent to gw modulo the
+        // number of waves (lane = every nw-th slot): flagged frames come in runs (a burst upsets the seeds of the frames after it),
+        // and a frame is one wave's serial search of 1-2 ms, so a run must land on different waves -- owning 64 CONSECUTIVE slots
+        // made one wave re-quantize a whole run back to back (8.7 ms for 49 frames on the `bursts` material).
         if (!tabs) { q_load_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
-        for (int b0 = 64 * gw; b0 < nfs; b0 += 64 * nw) {
+        for (int b0 = gw; b0 < nfs; b0 += 64 * nw) {
             int flagged = 0;
-            const int f = b0 + lane;
+            const int f = b0 + nw * lane;
             if (f < nfs) {
                 const StreamDesc* sd = A->SD + W.fslot_stream[f];
                 const int k = f - sd->fslot0 - 1;
@@ -383,7 +389,13 @@ __global__ __launch_bounds__(64 * QWAVES, 2) void g_fixup(QArgs a_unused) {
             while (m) {
                 const int l = (int)__builtin_ctzll(m);
                 m &= m - 1;
-                kb_quant(A->T, A->pb, W, A->SD, b0 + l, 1, lane, L[wv], Q);
+                const int fr = b0 + nw * l;
+                kb_quant(A->T, A->pb, W, A->SD, fr, 1, lane, L[wv], Q);
+                if (lane == 0) {                                              // its successor (same stream) is what the next pass re-checks
+                    const StreamDesc* sd = A->SD + W.fslot_stream[fr];
+                    const int k = fr - sd->fslot0 - 1;
+                    if (k + 1 < sd->nframes) W.reval[sd->out_slot0 + k + 1] = it + 1;
+                }
             }
         }
         grid_barrier(base + FX_BAR, nblocks);
@@ -633,7 +645,7 @@ struct Context {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
     int num_cus = 256;
@@ -745,7 +757,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GP * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
     ENS(fht, Cp == 4 ? (size_t)ngs * 2 * FHT_STRIDE * 4 : 64); ENS(hpf, Cp == 4 ? (size_t)ngs * 2 * 576 * 4 : 64); ENS(tot_ener, (size_t)ngs * 4 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
-    ENS(seed_flag, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
+    ENS(seed_flag, FR * 4); ENS(reval, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
     ENS(prof, 512);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
@@ -756,7 +768,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
     W.fht = (float*)ctx->fht.p; W.hpf = (float*)ctx->hpf.p; W.tot_ener = (float*)ctx->tot_ener.p;
-    W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p;
+    W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p; W.reval = (int32_t*)ctx->reval.p;
     W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 16; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
     // ---- descriptors / inputs ----
@@ -803,6 +815,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
     W.fslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_gm);
     if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
+    if (!rt::dzero(ctx->reval.p, FR * 4, st)) return false;
     if (!rt::dzero(ctx->nflagged.p, 256, st)) return false;
     if (!rt::dzero(ctx->prof.p, 512, st)) return false;
     const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ctx->desc.p + o_sd);

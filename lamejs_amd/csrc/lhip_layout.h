@@ -120,6 +120,7 @@ struct Workspace {
     int16_t* l3;                // [nframes_total][2][C][576]  signed quantized spectrum
     int32_t* seed;              // [nfslots][C][2]  OldValue, CurrentStep after the frame in that slot
     int32_t* seed_flag;         // [nframes_total] 1 = frame must be (re)quantized with the chain-implied seed
+    int32_t* reval;             // [nframes_total] i > 0: repair pass i - 1 re-quantized the frame's predecessor -- validation pass i re-checks it
     int32_t* nflagged;          // [0] frames to re-quantize, [1] frames the memo-only validation could not decide
     int32_t* slow_list;         // [nfslots] frame slots of the latter
     int32_t* work_ctr;          // [8] frame-slot dispensers of the persistent quantization kernels (zeroed per launch)
