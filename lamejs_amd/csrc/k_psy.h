@@ -653,14 +653,18 @@ LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc*
 // ---------------------------------------------------------------------------------------------
 // kb_psyB: one wave per psy call (all channels).
 // ---------------------------------------------------------------------------------------------
-struct PsyBLds {
-    double mt1[25], mt2[10], mt3[14], mtab[9];     // mask_add tables: looked up inside a serially dependent chain
-    float thr_l[4][CBANDS + 2];                    // psy channels: L, R and -- joint stereo -- mid, side
-    float thr_s[4][3][CBANDS + 2];
-    float E[4][E_STRIDE];
+// NCH = psy channels the instantiation can hold: 2 (mono / stereo), or 4 for joint stereo (L, R, mid, side) -- a separate kernel so that
+// the usual configurations keep their 3.5 KB of LDS per wave
+struct PsyBTabs { double mt1[25], mt2[10], mt3[14], mtab[9]; };     // mask_add tables: looked up inside a serially dependent chain
+template <int NCH> struct PsyBLdsT : PsyBTabs {
+    float thr_l[NCH][CBANDS + 2];
+    float thr_s[NCH][3][CBANDS + 2];
+    float E[NCH][E_STRIDE];
 };
+typedef PsyBLdsT<2> PsyBLds;
+typedef PsyBLdsT<4> PsyBLds4;
 
-LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, double m1, double m2, int b) {
+LHIP_DEV double mask_add_l(const Tables& T, const PsyBTabs& L, double ath_cb, double m1, double m2, int b) {
     // PsyModel.js:403-473 (long blocks).  Every logarithm here has a positive, finite, normal operand -- `ratio` lies in
     // [1, ma_max_i2) and m1 / m2 in (1, ma_max_m) on the paths that take it -- so the branch-free v8_log10_pos applies (lhip_math.h)
     double ratio;
@@ -693,8 +697,8 @@ LHIP_DEV double mask_add_l(const Tables& T, const PsyBLds& L, double ath_cb, dou
 }
 
 
-LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLds& L) {
-    const int C = T.channels_out, Cp = T.psy_channels;
+template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLdsT<NCH>& L) {
+    const int C = T.channels_out, Cp = T.psy_channels;      // Cp <= NCH: the launch picks the instantiation by Tables::psy_channels
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
     const int q = gslot - sd.gslot0 - 1;
@@ -837,7 +841,7 @@ LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, 
         }
         wave_sync();
     }
-    if (Cp == 4) {
+    if constexpr (NCH == 4) if (Cp == 4) {
         // joint stereo (PsyModel.js:1336-1342): msfix1 (548-582), then ns_msfix (591-636) with the ATH.adjust the previous frame left.
         // One lane per band (thm.l then thm.s are contiguous in E, and so are en.l / en.s); both steps only touch the band's own
         // four thresholds, so they run back to back in the lane.

@@ -233,10 +233,10 @@ __global__ __launch_bounds__(64) void g_scan_raw(Tables T, Workspace W, const St
 __global__ __launch_bounds__(64) void g_scan_attack(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_attack(T, W, SD, g); }
 __global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_blocktype(T, W, SD, g); }
 __global__ __launch_bounds__(ATH_NT) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
-__global__ __launch_bounds__(64) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD) {
-    __shared__ PsyBLds L;
+template <int NCH> __global__ __launch_bounds__(64) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD) {
+    __shared__ PsyBLdsT<NCH> L;
     const int it = xcd_item(blockIdx.x, W.ngslots);
-    if (it >= 0) kb_psyB(T, pb, W, SD, it, threadIdx.x, L);
+    if (it >= 0) kb_psyB<NCH>(T, pb, W, SD, it, threadIdx.x, L);
 }
 __global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nitems) {
     __shared__ PolyLds L;
@@ -831,7 +831,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
 #define WAVE_RUN(...) do { const int lane_ = 0; __VA_ARGS__; } while (0)
 #endif
-        static PsyALds LA; static PsyBLds LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
+        static PsyALds LA; static PsyBLds4 LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
         q_load_tabs(T, QT, 0, 1);
         for (int s = 0; s < S; s++) WAVE_RUN(kb_load(T, W, dSD, dIO, s, lane_));
         if (T.rs_ratio != 1) kb_prep(T, W, dSD, dIO, S, 0, 1);
@@ -841,7 +841,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
-        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB(T, ts.pb10, W, dSD, b, lane_, LB));
+        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
 #ifdef LHIP_WAVESIM
@@ -909,7 +909,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_POLY, g_poly, XCD_GRID((ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE), st, T, W, dSD, dIO, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, XCD_GRID(ngs), st, T, W, dSD);
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
-    LAUNCH(KT_PSYB, g_psyB, XCD_GRID(ngs), st, T, ts.pb10, W, dSD);
+    if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD);
+    else LAUNCH(KT_PSYB, g_psyB<2>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
