@@ -73,7 +73,7 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     return lib
 
 
-def tables_blob(channels: int, samplerate: int, kbps: int, joint: bool = False) -> bytes:
+def tables_blob(channels: int, samplerate: int, kbps: int, joint: bool = False, reservoir: bool = False) -> bytes:
     """The LHTB table blob for a configuration.
 
     Built by the host-side JavaScript ``lamejs_amd/js/tables.js`` (so every transcendental comes
@@ -83,12 +83,12 @@ def tables_blob(channels: int, samplerate: int, kbps: int, joint: bool = False) 
     ``Mp3Encoder`` never selects it, index.js:105); only meaningful for two channels.
     """
     joint = bool(joint) and channels == 2
-    f = _TABLE_DIR / f"t_{channels}_{samplerate}_{kbps}{'_joint' if joint else ''}.bin"
+    f = _TABLE_DIR / f"t_{channels}_{samplerate}_{kbps}{'_joint' if joint else ''}{'_resv' if reservoir else ''}.bin"
     gen = _PKG / "js" / "tables.js"
     if not f.exists() or f.stat().st_mtime < gen.stat().st_mtime:      # a cached blob older than its generator is stale
         _TABLE_DIR.mkdir(exist_ok=True)
         try:
-            subprocess.run(["node", str(_PKG / "js" / "tables.js"), str(channels), str(samplerate), str(kbps), str(f)] + (["joint"] if joint else []),
+            subprocess.run(["node", str(_PKG / "js" / "tables.js"), str(channels), str(samplerate), str(kbps), str(f)] + (["joint"] if joint else []) + (["reservoir"] if reservoir else []),
                            check=True, capture_output=True, text=True)
         except (OSError, subprocess.CalledProcessError) as e:  # pragma: no cover
             msg = getattr(e, "stderr", "") or str(e)

@@ -75,6 +75,8 @@ function resolveParams(channels, samplerate, kbps, opts) {
     p.mode = (channels == 1) ? MODE_MONO : MODE_STEREO;      /* index.js:105, Lame.js:759-761 */
     /* extension (SURVEY.md 8f #3): the reference's joint-stereo path, which its Mp3Encoder never selects (index.js:105) */
     if (opts && opts.jointStereo && channels == 2) p.mode = MODE_JOINT_STEREO;
+    /* extension (SURVEY.md 8f #4): the bit reservoir, which index.js:108 switches off */
+    p.disable_reservoir = (opts && opts.reservoir) ? 0 : 1;
     p.channels_out = (p.mode == MODE_MONO) ? 1 : 2;
     p.in_samplerate = samplerate;
     let brate = kbps;
@@ -605,7 +607,8 @@ function buildBlob(channels, samplerate, kbps, opts) {
         ATH_useAdjust: p.ATH_useAdjust, athaa_loudapprox: p.athaa_loudapprox,
         copyright: p.copyright, original: p.original, emphasis: p.emphasis, extension: p.extension,
         error_protection: p.error_protection, npart_l: T.npart_l, npart_s: T.npart_s,
-        in_samplerate: p.in_samplerate, rs_filter_l: p.rs_filter_l, rs_bpc: p.rs_bpc
+        in_samplerate: p.in_samplerate, rs_filter_l: p.rs_filter_l, rs_bpc: p.rs_bpc,
+        disable_reservoir: p.disable_reservoir
     };
     const cfg_d = {
         scale: p.scale, attackthre: p.attackthre, attackthre_s: p.attackthre_s,
@@ -654,9 +657,9 @@ function buildBlob(channels, samplerate, kbps, opts) {
 module.exports = { buildBlob, resolveParams, buildTables, packBlob };
 
 if (require.main === module) {
-    /* CLI: node tables.js <channels> <samplerate> <kbps> <out.bin> [joint] */
-    const [ch, sr, kb, out, joint] = process.argv.slice(2);
-    const r = buildBlob(+ch, +sr, +kb, { jointStereo: joint === 'joint' });
+    /* CLI: node tables.js <channels> <samplerate> <kbps> <out.bin> [joint] [reservoir] */
+    const [ch, sr, kb, out] = process.argv.slice(2), flags = process.argv.slice(6);
+    const r = buildBlob(+ch, +sr, +kb, { jointStereo: flags.includes('joint'), reservoir: flags.includes('reservoir') });
     require('fs').writeFileSync(out, r.blob);
     console.log('wrote', out, r.blob.length, 'bytes');
 }

@@ -79,6 +79,7 @@ static int lo_load_cfg(lo_cfg* c, const void* blob_in, size_t nbytes) {
     CI(sfb21_extra); CI(quant_comp); CI(quant_comp_short); CI(short_blocks_coupled); CI(useTemporal);
     CI(ATH_useAdjust); CI(athaa_loudapprox); CI(copyright); CI(original); CI(emphasis); CI(extension);
     CI(error_protection); CI(npart_l); CI(npart_s); CI(in_samplerate); CI(rs_filter_l); CI(rs_bpc);
+    CI(disable_reservoir);
     CD(resample_ratio);
     CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
     CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
@@ -175,13 +176,16 @@ static void lo_drain(const lo_cfg* c, lo_bw* w, int remaining) {
     for (; remaining >= 1; remaining -= 1) lo_put(w, 0, 1);   /* ancillary_flag stays 0 with the reservoir disabled */
 }
 
-/* returns frame size in bytes */
-static int lo_format_frame(lo_enc* e, uint8_t* out) {
+/* returns frame size in bytes.  main_bits != NULL (bit reservoir): header + side info (with main_data_begin) and the main data are
+ * written back to back into `out` (zeroed by the caller, large enough for a frame plus the reservoir), nothing is drained, and
+ * *main_bits receives the length of the main data: the caller feeds both parts to the stream writer */
+static int lo_format_frame(lo_enc* e, uint8_t* out, int* main_bits) {
     const lo_cfg* c = &e->c;
     const int frame_bits = lo_frame_bits(e);
+    const uint32_t mdb = main_bits ? (uint32_t)js_toint32(e->main_data_begin) : 0;       /* writeheader shifts the number: ToInt32 */
     lo_bw w;
     int gr, ch, sfb, band;
-    memset(out, 0, (size_t)frame_bits / 8);
+    if (!main_bits) memset(out, 0, (size_t)frame_bits / 8);
     w.p = out; w.bitpos = 0;
     /* header (BitStream.js:267-270: MPEG-2.5 rates carry the 0xffe sync) */
     lo_put(&w, c->out_samplerate < 16000 ? 0xffe : 0xfff, 12);
@@ -199,7 +203,7 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
     lo_put(&w, (uint32_t)c->emphasis, 2);
     if (c->version == 1) {
     /* side info (MPEG-1) */
-        lo_put(&w, 0, 9);                                   /* main_data_begin */
+        lo_put(&w, mdb, 9);                                 /* main_data_begin */
         lo_put(&w, 0, c->channels_out == 2 ? 3 : 5);        /* private bits */
         for (ch = 0; ch < c->channels_out; ch++)
             for (band = 0; band < 4; band++) lo_put(&w, (uint32_t)e->scfsi[ch][band], 1);
@@ -271,7 +275,7 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
         /* MPEG-2 / 2.5 LSF: one granule, 8-bit main_data_begin, 9-bit scalefac_compress, no scfsi/preflag
          * (BitStream.js:352-405), scalefactors by partition with slen[] (BitStream.js:645-686) */
         extern const int lo_nr_of_sfb_block[6][3][4];
-        lo_put(&w, 0, 8);                                   /* main_data_begin */
+        lo_put(&w, mdb, 8);                                 /* main_data_begin */
         lo_put(&w, 0, c->channels_out);                     /* private bits */
         for (ch = 0; ch < c->channels_out; ch++) {
             lo_gr* gi = &e->tt[0][ch];
@@ -347,12 +351,116 @@ static int lo_format_frame(lo_enc* e, uint8_t* out) {
                 fprintf(stderr, "frame %ld ch %d: wrote %d, part2 %d part2_3 %d bt %d slen %d %d %d %d tab %d row %d sfc %d\n", e->frame_num, ch, w.bitpos - dbg_p0, gi->part2_length, gi->part2_3_length, gi->block_type, gi->slen[0], gi->slen[1], gi->slen[2], gi->slen[3], gi->sfb_part_tab, gi->sfb_part_row, gi->scalefac_compress);
         }
     }
+    if (main_bits) { *main_bits = w.bitpos - 8 * c->sideinfo_len; return 0; }
     lo_drain(c, &w, e->resvDrain_post);
     if (w.bitpos != frame_bits) {
         fprintf(stderr, "lame_oracle: frame %ld wrote %d bits, expected %d\n", e->frame_num, w.bitpos, frame_bits);
         abort();
     }
     return frame_bits / 8;
+}
+
+/* ------------------------------------------------------------------ */
+/* bit reservoir: the continuous stream writer (BitStream.js:100-215)   */
+/* ------------------------------------------------------------------ */
+/* Main data is written where the previous frame's ended; a frame's header + side info is inserted when the stream reaches the
+ * frame's nominal start (write_timing), which may be in the middle of -- or after -- its own main data. */
+#define LO_MAX_HEADER_BUF 256
+typedef struct lo_stream {
+    uint8_t buf[16384];                         /* bytes since the last copy-out */
+    long idx, totbit; int bit_idx;              /* bufByteIdx (-1: empty), totbit, bufBitIdx */
+    struct { long write_timing; uint8_t b[40]; } header[LO_MAX_HEADER_BUF];
+    int h_ptr, w_ptr;
+} lo_stream;
+
+static void lo_putbits2(lo_enc* e, uint32_t val, int j) {
+    lo_stream* s = e->bs;
+    while (j > 0) {
+        int k;
+        if (s->bit_idx == 0) {
+            s->bit_idx = 8;
+            s->idx++;
+            if (s->header[s->w_ptr].write_timing == s->totbit) {
+                memcpy(s->buf + s->idx, s->header[s->w_ptr].b, (size_t)e->c.sideinfo_len);
+                s->idx += e->c.sideinfo_len;
+                s->totbit += e->c.sideinfo_len * 8;
+                s->w_ptr = (s->w_ptr + 1) & (LO_MAX_HEADER_BUF - 1);
+            }
+            if ((size_t)s->idx >= sizeof s->buf) { fprintf(stderr, "lame_oracle: stream buffer overflow\n"); abort(); }
+            s->buf[s->idx] = 0;
+        }
+        k = j < s->bit_idx ? j : s->bit_idx;
+        j -= k;
+        s->bit_idx -= k;
+        s->buf[s->idx] |= (uint8_t)((val >> j) << s->bit_idx);
+        s->totbit += k;
+    }
+}
+static void lo_drain_into_ancillary(lo_enc* e, int remaining) {       /* BitStream.js:175-211 */
+    static const uint32_t lame[4] = {0x4c, 0x41, 0x4d, 0x45};
+    const lo_cfg* c = &e->c;
+    int i;
+    for (i = 0; i < 4; i++) if (remaining >= 8) { lo_putbits2(e, lame[i], 8); remaining -= 8; }
+    if (remaining >= 32)
+        for (i = 0; i < c->n_version_bytes && remaining >= 8; ++i) { remaining -= 8; lo_putbits2(e, (uint32_t)c->version_bytes[i], 8); }
+    for (; remaining >= 1; remaining -= 1) {
+        lo_putbits2(e, (uint32_t)e->ancillary_flag, 1);
+        e->ancillary_flag ^= (!c->disable_reservoir ? 1 : 0);
+    }
+}
+static long lo_copy_out(lo_enc* e, uint8_t* out, size_t cap) {         /* BitStream.copy_buffer: everything written so far */
+    lo_stream* s = e->bs;
+    const long n = s->idx + 1;
+    if (n <= 0) return 0;
+    if ((size_t)n > cap) return -1;
+    memcpy(out, s->buf, (size_t)n);
+    s->idx = -1; s->bit_idx = 0;
+    return n;
+}
+/* format_bitstream (BitStream.js:836-900) */
+static void lo_format_bitstream_resv(lo_enc* e) {
+    const lo_cfg* c = &e->c;
+    lo_stream* s = e->bs;
+    static uint8_t tmp[4096];
+    const int bitsPerFrame = lo_frame_bits(e);
+    int main_bits = 0, i, old, bits;
+    lo_drain_into_ancillary(e, e->resvDrain_pre);
+    memset(tmp, 0, sizeof tmp);
+    lo_format_frame(e, tmp, &main_bits);
+    /* encodeSideInfo2: the header joins the queue, the next one is due one frame later */
+    old = s->h_ptr;
+    memcpy(s->header[old].b, tmp, (size_t)c->sideinfo_len);
+    s->h_ptr = (old + 1) & (LO_MAX_HEADER_BUF - 1);
+    s->header[s->h_ptr].write_timing = s->header[old].write_timing + bitsPerFrame;
+    /* writeMainData */
+    for (i = 0; i + 8 <= main_bits; i += 8) lo_putbits2(e, tmp[c->sideinfo_len + (i >> 3)], 8);
+    if (i < main_bits) lo_putbits2(e, (uint32_t)(tmp[c->sideinfo_len + (i >> 3)] >> (8 - (main_bits - i))), main_bits - i);
+    lo_drain_into_ancillary(e, e->resvDrain_post);
+    bits = 8 * c->sideinfo_len + main_bits + e->resvDrain_post;
+    e->main_data_begin += D(bitsPerFrame - bits) / 8;
+    if (e->main_data_begin * 8 != D(e->ResvSize)) {
+        fprintf(stderr, "lame_oracle: bit reservoir error (main_data_begin %g, ResvSize %d) -- the reference prints its 'fatal error' text here\n", e->main_data_begin, e->ResvSize);
+        abort();
+    }
+    if (s->totbit % 8 != 0) { fprintf(stderr, "lame_oracle: stream not byte aligned after a frame\n"); abort(); }
+}
+/* flush_bitstream (BitStream.js:710-780): pad the stream with ancillary data up to the end of the last frame */
+static void lo_flush_bitstream(lo_enc* e) {
+    lo_stream* s = e->bs;
+    int last_ptr = s->h_ptr - 1, first_ptr = s->w_ptr, remaining_headers;
+    long flushbits;
+    if (last_ptr == -1) last_ptr = LO_MAX_HEADER_BUF - 1;
+    flushbits = s->header[last_ptr].write_timing - s->totbit;
+    if (flushbits >= 0) {
+        remaining_headers = 1 + last_ptr - first_ptr;
+        if (last_ptr < first_ptr) remaining_headers = 1 + last_ptr - first_ptr + LO_MAX_HEADER_BUF;
+        flushbits -= (long)remaining_headers * 8 * e->c.sideinfo_len;
+    }
+    flushbits += lo_frame_bits(e);
+    if (flushbits < 0) return;
+    lo_drain_into_ancillary(e, (int)flushbits);
+    e->ResvSize = 0;
+    e->main_data_begin = 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -425,8 +533,30 @@ static int lo_encode_frame(lo_enc* e, uint8_t* out) {
         e->tap->mode_ext = e->mode_ext;
         e->tap->ms_ener_ratio[0] = ms_ener_ratio[0]; e->tap->ms_ener_ratio[1] = ms_ener_ratio[1];
     }
+    if (!c->disable_reservoir) {
+        /* Encoder.js:600-626: the frame's perceptual entropies are scaled by a 19-frame FIR of their sums (dead with the reservoir off) */
+        static const double fircoef[9] = {-0.0207887 * 5, -0.0378413 * 5, -0.0432472 * 5, -0.031183 * 5, 7.79609e-18 * 5, 0.0467745 * 5,
+                                          0.10091 * 5, 0.151365 * 5, 0.187098 * 5};
+        double (*pe_use)[2] = (e->mode_ext == 2) ? pe_MS : pe;
+        double f = 0.0;
+        int i;
+        for (i = 0; i < 18; i++) e->pefirbuf[i] = e->pefirbuf[i + 1];
+        for (gr = 0; gr < c->mode_gr; gr++)
+            for (ch = 0; ch < c->channels_out; ch++) f += pe_use[gr][ch];
+        e->pefirbuf[18] = (float)f;
+        f = e->pefirbuf[9];
+        for (i = 0; i < 9; i++) f += (D(e->pefirbuf[i]) + D(e->pefirbuf[18 - i])) * fircoef[i];
+        f = (670 * 5 * c->mode_gr * c->channels_out) / f;
+        for (gr = 0; gr < c->mode_gr; gr++)
+            for (ch = 0; ch < c->channels_out; ch++) pe_use[gr][ch] *= f;
+        lo_iteration_loop_resv(e, pe_use, (e->mode_ext == 2) ? masking_MS : masking, ms_ener_ratio);
+        lo_format_bitstream_resv(e);
+        n = (int)lo_copy_out(e, out, 1 << 20);
+        e->frame_num++;
+        return n;
+    }
     lo_iteration_loop(e, (e->mode_ext == 2) ? masking_MS : masking, ms_ener_ratio);
-    n = lo_format_frame(e, out);
+    n = lo_format_frame(e, out, NULL);
     e->frame_num++;
     return n;
 }
@@ -439,6 +569,9 @@ lo_enc* lo_create(const void* blob, size_t nbytes) {
     e->mf_size = 576 - 48;                 /* ENCDELAY - MDCTDELAY zeros in front */
     e->mf_samples_to_encode = 576 + 1152;  /* ENCDELAY + POSTDELAY */
     e->masking_lower = 1;                  /* Lame.js:175 */
+    e->bs = (lo_stream*)calloc(1, sizeof(lo_stream));
+    e->bs->idx = -1;
+    for (i = 0; i < 19; i++) e->pefirbuf[i] = (float)(700 * e->c.mode_gr * e->c.channels_out);     /* Lame.js:1120 */
     e->OldValue[0] = e->OldValue[1] = 180;
     e->CurrentStep[0] = e->CurrentStep[1] = 4;
     e->slot_lag = e->c.frac_SpF;
@@ -451,6 +584,7 @@ lo_enc* lo_create(const void* blob, size_t nbytes) {
         for (j = 0; j < 3; ++j)
             for (sb = 0; sb < SBMAX_s; sb++) { e->en[i].s[sb][j] = 1e20f; e->thm[i].s[sb][j] = 1e20f; }
         e->lastAttacks[i] = 0;
+        for (j = 0; j < CBANDS; ++j) e->nb_1[i][j] = e->nb_2[i][j] = 1e20f;
         for (j = 0; j < 9; j++) e->last_en_subshort[i][j] = 10.f;
     }
     return e;
@@ -460,6 +594,7 @@ void lo_destroy(lo_enc* e) {
     if (!e) return;
     free(e->c.blob_copy);
     free(e->tap);
+    free(e->bs);
     free(e);
 }
 
@@ -593,6 +728,13 @@ long lo_flush(lo_enc* e, uint8_t* out, size_t cap) {                 /* Lame.js:
         frames_left -= (fn != e->frame_num) ? 1 : 0;
     }
     e->mf_samples_to_encode = 0;
+    if (!e->c.disable_reservoir) {                           /* Lame.js:1445-1456: flush_bitstream + copy_buffer */
+        long n;
+        lo_flush_bitstream(e);
+        n = lo_copy_out(e, out + written, cap - (size_t)written);
+        if (n < 0) return n;
+        written += n;
+    }
     return written;
 }
 

@@ -53,7 +53,8 @@ typedef struct {
         sideinfo_len, frac_SpF, noise_shaping, noise_shaping_amp, noise_shaping_stop, subblock_gain,
         use_best_huffman, full_outer_loop, substep_shaping, sfb21_extra, quant_comp, quant_comp_short,
         short_blocks_coupled, useTemporal, ATH_useAdjust, athaa_loudapprox, copyright, original, emphasis,
-        extension, error_protection, npart_l, npart_s;
+        extension, error_protection, npart_l, npart_s,
+        disable_reservoir;                      /* 1 on the Mp3Encoder path (index.js:108); 0: the reservoir extension */
     /* doubles */
     int in_samplerate, rs_filter_l, rs_bpc;      /* resampler (Lame.js:1719-1763); rs_filter_l == 0: no resampling */
     double resample_ratio;
@@ -127,6 +128,12 @@ typedef struct lo_enc {
     lo_gr tt[2][2];
     int scfsi[2][4];
     int ResvSize, resvDrain_post;
+    /* bit reservoir (disable_reservoir == 0): Reservoir.js, BitStream.js:100-215, 300-330, 710-780, 836-900 */
+    int ResvMax, resvDrain_pre, ancillary_flag;
+    double main_data_begin;                     /* a double: the reference's arithmetic leaves fractions in it (Reservoir.js:281-286) */
+    float pefirbuf[19];                         /* NsPsy.js:30, Encoder.js:600-626 */
+    float nb_1[4][CBANDS], nb_2[4][CBANDS];     /* long-block pre-echo control (PsyModel.js:1300-1318): live once pcfact != 0 */
+    struct lo_stream* bs;                       /* the continuous bitstream writer (headers are inserted where their frame starts) */
     int slot_lag, padding;
     /* optional per-frame taps for differential debugging (tests only) */
     struct lo_tap* tap;

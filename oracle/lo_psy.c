@@ -310,6 +310,14 @@ static double lo_pecalc_l(const lo_ratio* mr, double masking_lower) {
     return pe_l;
 }
 
+/* PsyModel.js:828-842 */
+static double lo_ns_interp(double x, double y, double r) {
+    if (r >= 1.0) return x;
+    if (r <= 0.0) return y;
+    if (y > 0.0) return v8_pow(x / y, r) * y;
+    return 0.0;
+}
+
 #define LO_MAX(a, b) ((a) > (b) ? (a) : (b))      /* Math.max / Math.min on non-NaN operands */
 #define LO_MIN(a, b) ((a) < (b) ? (a) : (b))
 /* M/S thresholds after Johnston & Ferreira (PsyModel.js:548-582) */
@@ -386,6 +394,8 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
     int32_t mask_idx_l[CBANDS + 2];
     int chn, i, j, b, sb, sblock, k;
     const int numchn = (c->mode == 1) ? 4 : c->channels_out;        /* chn 2, 3 = mid, side (PsyModel.js:1031-1034) */
+    /* PsyModel.js:1036-1038: 0 with the reservoir disabled (ResvMax == 0), which makes every NS_INTERP below return its second operand */
+    const double pcfact = (e->ResvMax == 0) ? 0 : D(e->ResvSize) / e->ResvMax * 0.5;
 
     /* fs/4 high-pass for attack detection */
     for (chn = 0; chn < c->channels_out; chn++) {
@@ -570,7 +580,18 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
             for (sb = 0; sb < SBMAX_s; sb++) {
                 double thmm = e->thm[chn].s[sb][sblock], enn;
                 thmm *= 0.8;                                  /* NS_PREECHO_ATT0 */
-                /* the NS_INTERP pre-echo branches are no-ops here (pcfact == 0 -> returns thmm) */
+                /* short-block pre-echo control (PsyModel.js:1235-1253); ns_attacks only ever holds 0 / 1 (see above), so the
+                 * `>= 2` and `== 3` alternatives of the reference never fire; with pcfact == 0 both interpolations return thmm */
+                if (ns_attacks[sblock + 1] == 1) {
+                    const int idx = (sblock != 0) ? sblock - 1 : 2;
+                    const double p = lo_ns_interp(e->thm[chn].s[sb][idx], thmm, 0.6 * pcfact);      /* NS_PREECHO_ATT1 */
+                    thmm = LO_MIN(thmm, p);
+                }
+                if (ns_attacks[sblock] == 1) {
+                    const int idx = (sblock != 0) ? sblock - 1 : 2;
+                    const double p = lo_ns_interp(e->thm[chn].s[sb][idx], thmm, 0.3 * pcfact);      /* NS_PREECHO_ATT2 */
+                    thmm = LO_MIN(thmm, p);
+                }
                 enn = D(en_subshort[sblock * 3 + 3]) + D(en_subshort[sblock * 3 + 4]) + D(en_subshort[sblock * 3 + 5]);
                 if (D(en_subshort[sblock * 3 + 5]) * 6 < enn) {
                     thmm *= 0.5;
@@ -592,7 +613,15 @@ static void lo_psycho_anal(lo_enc* e, const float* const buf[2], int gr_out, lo_
                 ecb = lo_mask_add(e, ecb, D(c->s3_ll[k++]) * eb2, kk, kk - b);
             }
             ecb *= 0.158489319246111;
-            thr[b] = (float)ecb;      /* both branches of the pre-echo control reduce to ecb (pcfact == 0) */
+            /* long-block pre-echo control (PsyModel.js:1300-1318); pcfact == 0 reduces it to ecb */
+            if (e->blocktype_old[chn & 1] == SHORT_TYPE) thr[b] = (float)ecb;
+            else {
+                const double a = 2 * D(e->nb_1[chn][b]), b2 = 16 * D(e->nb_2[chn][b]);      /* rpelev, rpelev2 */
+                const double m = LO_MIN(a, b2);
+                thr[b] = (float)lo_ns_interp(LO_MIN(ecb, m), ecb, pcfact);
+            }
+            e->nb_2[chn][b] = e->nb_1[chn][b];
+            e->nb_1[chn][b] = (float)ecb;
         }
         for (; b <= CBANDS; ++b) { eb_l[b] = 0; thr[b] = 0; }
         lo_convert_p2s_l(e, eb_l, thr, chn);

@@ -980,6 +980,142 @@ static int lo_frame_bits(const lo_enc* e) {
     return 8 * bytes;
 }
 
+/* reduce_side (QuantizePVT.js:486-534): M/S granules move bits from the side to the mid channel; targ_bits is an Int32Array there */
+static void lo_reduce_side(int32_t targ_bits[2], double ms_ener_ratio, double mean_bits, double max_bits) {
+    double fac = .33 * (.5 - ms_ener_ratio) / .5;
+    int move_bits;
+    if (fac < 0) fac = 0;
+    if (fac > .5) fac = .5;
+    move_bits = js_toint32(fac * .5 * (targ_bits[0] + targ_bits[1]));
+    if (move_bits > MAX_BITS_PER_CHANNEL - targ_bits[0]) move_bits = MAX_BITS_PER_CHANNEL - targ_bits[0];
+    if (move_bits < 0) move_bits = 0;
+    if (targ_bits[1] >= 125) {
+        if (targ_bits[1] - move_bits > 125) {
+            if (targ_bits[0] < mean_bits) targ_bits[0] += move_bits;
+            targ_bits[1] -= move_bits;
+        } else {
+            targ_bits[0] += targ_bits[1] - 125;
+            targ_bits[1] = 125;
+        }
+    }
+    move_bits = targ_bits[0] + targ_bits[1];
+    if (move_bits > max_bits) {
+        targ_bits[0] = js_toint32((max_bits * targ_bits[0]) / move_bits);
+        targ_bits[1] = js_toint32((max_bits * targ_bits[1]) / move_bits);
+    }
+}
+
+/* on_pe (QuantizePVT.js:421-484) with ResvMaxBits (Reservoir.js:190-229), the reservoir in use.  The reference computes in JS
+ * numbers (doubles) except where it stores into Int32Arrays (targ_bits, add_bits): those stores truncate. */
+static double lo_on_pe_resv(lo_enc* e, double pe[2][2], int32_t targ_bits[2], double mean_bits, int gr, int cbr) {
+    const lo_cfg* c = &e->c;
+    double ResvSize = e->ResvSize, ResvMax = e->ResvMax, tbits, add_b, extra_bits, max_bits, bits;
+    int32_t add_bits[2] = {0, 0};
+    int ch;
+    if (cbr != 0) ResvSize += mean_bits;
+    tbits = mean_bits;
+    if (ResvSize * 10 > ResvMax * 9) {
+        add_b = ResvSize - (ResvMax * 9) / 10;
+        tbits += add_b;
+    } else {
+        add_b = 0;
+        if (!c->disable_reservoir) tbits -= .1 * mean_bits;
+    }
+    extra_bits = (ResvSize < (D(e->ResvMax) * 6) / 10 ? ResvSize : (D(e->ResvMax) * 6) / 10);
+    extra_bits -= add_b;
+    if (extra_bits < 0) extra_bits = 0;
+    max_bits = tbits + extra_bits;
+    if (max_bits > MAX_BITS_PER_GRANULE) max_bits = MAX_BITS_PER_GRANULE;
+    for (bits = 0, ch = 0; ch < c->channels_out; ++ch) {
+        const double t = tbits / c->channels_out;
+        targ_bits[ch] = js_toint32(t < MAX_BITS_PER_CHANNEL ? t : MAX_BITS_PER_CHANNEL);
+        add_bits[ch] = js_toint32(D(targ_bits[ch]) * pe[gr][ch] / 700.0 - targ_bits[ch]);
+        if (add_bits[ch] > mean_bits * 3 / 4) add_bits[ch] = js_toint32(mean_bits * 3 / 4);
+        if (add_bits[ch] < 0) add_bits[ch] = 0;
+        if (add_bits[ch] + targ_bits[ch] > MAX_BITS_PER_CHANNEL) add_bits[ch] = (MAX_BITS_PER_CHANNEL - targ_bits[ch]) > 0 ? MAX_BITS_PER_CHANNEL - targ_bits[ch] : 0;
+        bits += add_bits[ch];
+    }
+    if (bits > extra_bits)
+        for (ch = 0; ch < c->channels_out; ++ch) add_bits[ch] = js_toint32(extra_bits * add_bits[ch] / bits);
+    for (ch = 0; ch < c->channels_out; ++ch) {
+        targ_bits[ch] += add_bits[ch];
+        extra_bits -= add_bits[ch];
+    }
+    for (bits = 0, ch = 0; ch < c->channels_out; ++ch) bits += targ_bits[ch];
+    if (bits > MAX_BITS_PER_GRANULE)
+        for (ch = 0; ch < c->channels_out; ++ch) {
+            targ_bits[ch] = js_toint32(D(targ_bits[ch]) * MAX_BITS_PER_GRANULE);
+            targ_bits[ch] = js_toint32(D(targ_bits[ch]) / bits);
+        }
+    return max_bits;
+}
+
+/* CBRNewIterationLoop.js:25-90 with the reservoir in use: ResvFrameBegin (Reservoir.js:130-180), on_pe per granule, ResvAdjust per
+ * granule-channel, ResvFrameEnd (Reservoir.js:243-293).  The frame's bits then go through the continuous stream writer. */
+static void lo_iteration_loop_resv(lo_enc* e, double pe[2][2], lo_ratio ratio[2][2], const double ms_ener_ratio[2]) {
+    const lo_cfg* c = &e->c;
+    float l3_xmin[SFBMAX];
+    float xrpow[576];
+    int32_t targ_bits[2];
+    int gr, ch;
+    const int frameLength = lo_frame_bits(e);
+    const double mean_bits = D(frameLength - c->sideinfo_len * 8) / c->mode_gr;
+    {   /* ResvFrameBegin */
+        const int resvLimit = (8 * 256) * c->mode_gr - 8, maxmp3buf = 8 * 1440;       /* brate <= 320, not strict_ISO */
+        e->ResvMax = maxmp3buf - frameLength;
+        if (e->ResvMax > resvLimit) e->ResvMax = resvLimit;
+        if (e->ResvMax < 0 || c->disable_reservoir) e->ResvMax = 0;
+        e->resvDrain_pre = 0;
+    }
+    for (gr = 0; gr < c->mode_gr; gr++) {
+        const double max_bits = lo_on_pe_resv(e, pe, targ_bits, mean_bits, gr, gr);
+        if (e->mode_ext == 2) {
+            int i;
+            for (i = 0; i < 576; ++i) {
+                const double l = e->tt[gr][0].xr[i], r = e->tt[gr][1].xr[i];
+                e->tt[gr][0].xr[i] = (float)((l + r) * (SQRT2 * 0.5));
+                e->tt[gr][1].xr[i] = (float)((l - r) * (SQRT2 * 0.5));
+            }
+            lo_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
+        }
+        for (ch = 0; ch < c->channels_out; ch++) {
+            lo_gr* gi = &e->tt[gr][ch];
+            e->masking_lower = (gi->block_type != SHORT_TYPE) ? c->masking_lower_long : c->masking_lower_short;
+            lo_init_outer_loop(e, gi);
+            if (lo_init_xrpow(gi, xrpow)) {
+                lo_calc_xmin(e, &ratio[gr][ch], gi, l3_xmin);
+                if (e->tap) memcpy(e->tap->l3_xmin[gr][ch], l3_xmin, sizeof l3_xmin);
+                lo_outer_loop(e, gi, l3_xmin, xrpow, ch, targ_bits[ch]);
+            }
+            lo_best_scalefac_store(e, gr, ch);
+            if (c->use_best_huffman == 1) lo_best_huffman_divide(c, gi);
+            e->ResvSize -= gi->part2_3_length + gi->part2_length;                       /* ResvAdjust */
+            if (e->tap) {
+                e->tap->global_gain[gr][ch] = gi->global_gain;
+                e->tap->part2_3_length[gr][ch] = gi->part2_3_length;
+                e->tap->part2_length[gr][ch] = gi->part2_length;
+            }
+        }
+    }
+    {   /* ResvFrameEnd */
+        int over_bits, stuffingBits = 0;
+        double mdb_bytes;
+        e->ResvSize += js_toint32(mean_bits * c->mode_gr);
+        e->resvDrain_post = 0;
+        e->resvDrain_pre = 0;
+        if ((over_bits = e->ResvSize % 8) != 0) stuffingBits += over_bits;
+        over_bits = (e->ResvSize - stuffingBits) - e->ResvMax;
+        if (over_bits > 0) stuffingBits += over_bits;
+        mdb_bytes = (e->main_data_begin * 8 < stuffingBits ? e->main_data_begin * 8 : D(stuffingBits)) / 8;
+        e->resvDrain_pre += js_toint32(8 * mdb_bytes);
+        stuffingBits -= js_toint32(8 * mdb_bytes);
+        e->ResvSize -= js_toint32(8 * mdb_bytes);
+        e->main_data_begin -= mdb_bytes;
+        e->resvDrain_post += stuffingBits;
+        e->ResvSize -= stuffingBits;
+    }
+}
+
 static void lo_iteration_loop(lo_enc* e, lo_ratio ratio[2][2], const double ms_ener_ratio[2]) {
     const lo_cfg* c = &e->c;
     float l3_xmin[SFBMAX];
@@ -1014,31 +1150,8 @@ static void lo_iteration_loop(lo_enc* e, lo_ratio ratio[2][2], const double ms_e
                 e->tt[gr][0].xr[i] = (float)((l + r) * (SQRT2 * 0.5));
                 e->tt[gr][1].xr[i] = (float)((l - r) * (SQRT2 * 0.5));
             }
-            /* reduce_side (QuantizePVT.js:486-534): bits move from the side to the mid channel; targ_bits is an Int32Array there */
-            {
-                double fac = .33 * (.5 - ms_ener_ratio[gr]) / .5;
-                int move_bits;
-                max_bits = tbits < MAX_BITS_PER_GRANULE ? tbits : MAX_BITS_PER_GRANULE;      /* on_pe: tbits + extra_bits (= 0), capped */
-                if (fac < 0) fac = 0;
-                if (fac > .5) fac = .5;
-                move_bits = js_toint32(fac * .5 * (targ_bits[0] + targ_bits[1]));
-                if (move_bits > MAX_BITS_PER_CHANNEL - targ_bits[0]) move_bits = MAX_BITS_PER_CHANNEL - targ_bits[0];
-                if (move_bits < 0) move_bits = 0;
-                if (targ_bits[1] >= 125) {
-                    if (targ_bits[1] - move_bits > 125) {
-                        if (targ_bits[0] < mean_bits) targ_bits[0] += move_bits;
-                        targ_bits[1] -= move_bits;
-                    } else {
-                        targ_bits[0] += targ_bits[1] - 125;
-                        targ_bits[1] = 125;
-                    }
-                }
-                move_bits = targ_bits[0] + targ_bits[1];
-                if (move_bits > max_bits) {
-                    targ_bits[0] = js_toint32(D(max_bits * targ_bits[0]) / move_bits);
-                    targ_bits[1] = js_toint32(D(max_bits * targ_bits[1]) / move_bits);
-                }
-            }
+            max_bits = tbits < MAX_BITS_PER_GRANULE ? tbits : MAX_BITS_PER_GRANULE;      /* on_pe: tbits + extra_bits (= 0), capped */
+            lo_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         }
         for (ch = 0; ch < c->channels_out; ch++) {
             lo_gr* gi = &e->tt[gr][ch];

@@ -25,6 +25,12 @@ def golden_joint():
     return json.loads((ROOT / "tests" / "golden" / "golden_joint.json").read_text())["cases"]
 
 
+@pytest.fixture(scope="session")
+def golden_resv():
+    """Bit-reservoir goldens (SURVEY.md 8f #4): the reference's modules driven with gfp.disable_reservoir = false (tests/tools/gen_golden_resv.js)."""
+    return json.loads((ROOT / "tests" / "golden" / "golden_resv.json").read_text())["cases"]
+
+
 def load_case_pcm(case):
     """PCM of a golden case: committed excerpt for the reference's fixtures, regenerated for synthetic corpora."""
     import hashlib

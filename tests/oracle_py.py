@@ -28,12 +28,12 @@ def _load():
     return _lib
 
 
-def oracle_encode(channels, samplerate, kbps, left, right=None, chunk=None, flush=True, joint=False) -> bytes:
+def oracle_encode(channels, samplerate, kbps, left, right=None, chunk=None, flush=True, joint=False, reservoir=False) -> bytes:
     sys.path.insert(0, str(ROOT))
     from lamejs_amd import tables_blob
 
     lib = _load()
-    blob = tables_blob(channels, samplerate, kbps, joint)
+    blob = tables_blob(channels, samplerate, kbps, joint, reservoir)
     buf = ctypes.create_string_buffer(blob, len(blob))
     h = lib.lo_create(buf, len(blob))
     if not h:

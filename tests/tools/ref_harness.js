@@ -50,7 +50,7 @@ function refEncoder(channels, samplerate, kbps, opts) {
     gfp.mode = (opts && opts.jointStereo && channels == 2) ? MPEGMode.JOINT_STEREO : MPEGMode.STEREO;
     gfp.quality = 3;
     gfp.bWriteVbrTag = false;
-    gfp.disable_reservoir = true;
+    gfp.disable_reservoir = !(opts && opts.reservoir);      /* opts.reservoir: the bit reservoir index.js:108 switches off (SURVEY.md 8f #4) */
     gfp.write_id3tag_automatic = false;
     const rc = lame.lame_init_params(gfp);
     if (rc != 0) throw new Error('lame_init_params rc=' + rc);
