@@ -108,12 +108,14 @@ def _as_i16(a) -> np.ndarray:
 class Mp3Encoder:
     """Mirror of the reference's ``Mp3Encoder`` (index.js:66-136)."""
 
-    def __init__(self, channels: int = 1, samplerate: int = 44100, kbps: int = 128, device: int = -1, lib=None, joint: bool = False):
+    def __init__(self, channels: int = 1, samplerate: int = 44100, kbps: int = 128, device: int = -1, lib=None, joint: bool = False, reservoir: bool = False):
         """``joint`` (extension, not in the reference's wrapper): encode two channels in the reference's joint-stereo mode --
-        per frame mid/side or left/right, as its encoder core decides when asked for MPEGMode.JOINT_STEREO."""
+        per frame mid/side or left/right, as its encoder core decides when asked for MPEGMode.JOINT_STEREO.
+        ``reservoir`` (extension): encode with the bit reservoir in use (the reference's wrapper disables it, index.js:108); the frames
+        of a stream then form a serial chain, so only batches of many streams use the GPU well."""
         self._lib = lib or load_library()
         self.channels, self.samplerate, self.kbps = int(channels), int(samplerate), int(kbps)
-        blob = tables_blob(self.channels, self.samplerate, self.kbps, joint)
+        blob = tables_blob(self.channels, self.samplerate, self.kbps, joint, reservoir)
         cfg = _Config(self.channels, self.samplerate, self.kbps, device)
         h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(blob, len(blob))

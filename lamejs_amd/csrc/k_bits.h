@@ -133,6 +133,59 @@ LHIP_DEV void side_field(const GrSide& gi, int f, int GR, uint32_t* v, int* n) {
 // the header part is written by lane 0 only; everybody continues from where it stopped
 LHIP_DEV int uni_bits_pos(int pos) { return wave_bcast(pos, 0); }
 
+// ---- bit reservoir (extension): the continuous stream (BitStream.js:100-215, 710-780, 836-900) ----
+// ancillary stuffing at bit position pos (drain_into_ancillary): "LAME", the coerced version characters, then single bits that
+// alternate while the reservoir is in use (gfc.ancillary_flag); one lane
+LHIP_DEV int put_ancillary(const Tables& T, uint32_t* w, int pos, int remaining, int* flag) {
+    const uint32_t lame[4] = {0x4c, 0x41, 0x4d, 0x45};
+    for (int i = 0; i < 4; i++) if (remaining >= 8) { put_bits(w, pos, lame[i], 8); pos += 8; remaining -= 8; }
+    if (remaining >= 32)
+        for (int i = 0; i < T.n_version_bytes && remaining >= 8; ++i) { remaining -= 8; put_bits(w, pos, (uint32_t)T.version_bytes[i], 8); pos += 8; }
+    for (; remaining >= 1; remaining -= 1) { put_bits(w, pos, (uint32_t)*flag, 1); pos += 1; *flag ^= (!T.disable_reservoir ? 1 : 0); }
+    return pos;
+}
+// append `nbytes` bytes of the LDS image (from byte `from`) to the stream: before every byte, a header whose frame starts at the
+// current stream position is inserted (putbits2's check); returns the bytes written to `out`.  One lane.
+LHIP_DEV int resv_emit(const uint32_t* w, int from, int nbytes, int sideinfo_len, ResvState& rv, uint8_t* out, int n) {
+    int64_t totbit = rv.totbit;
+    int wp = rv.w_ptr;
+    for (int i = 0; i < nbytes; i++) {
+        if (rv.timing[wp] == totbit) {
+            for (int b = 0; b < sideinfo_len; b++) out[n++] = rv.header[wp][b];
+            totbit += 8 * sideinfo_len;
+            wp = (wp + 1) & (RESV_HQ - 1);
+        }
+        const int bi = from + i;
+        out[n++] = (uint8_t)(w[bi >> 2] >> (24 - 8 * (bi & 3)));
+        totbit += 8;
+    }
+    rv.totbit = totbit; rv.w_ptr = wp;
+    return n;
+}
+// flush_bitstream (BitStream.js:710-780): pad the stream with ancillary data up to the end of the last frame; one wave per stream
+LHIP_DEV void kb_resv_flush(const Tables& T, const Workspace& W, int st, int lane, BitsLds& L) {
+    ResvState& rv = W.io[st].state->rv;
+    for (int i = lane; i < BITS_LDS_WORDS; i += LHIP_NL) L.w[i] = 0;
+    wave_sync();
+    if (lane == 0) {
+        const int last_ptr = (rv.h_ptr - 1) & (RESV_HQ - 1), first_ptr = rv.w_ptr;
+        int64_t flushbits = rv.timing[last_ptr] - rv.totbit;
+        if (flushbits >= 0) {
+            const int remaining_headers = ((last_ptr - first_ptr) & (RESV_HQ - 1)) + 1;
+            flushbits -= (int64_t)remaining_headers * 8 * T.sideinfo_len;
+        }
+        flushbits += rv.last_frame_bits;                         // getframebits: with the last frame's padding
+        if (flushbits >= 0) {
+            int flag = rv.ancillary_flag;
+            put_ancillary(T, L.w, 0, (int)flushbits, &flag);
+            rv.ancillary_flag = flag;
+            W.out_bytes[st] = resv_emit(L.w, 0, (int)(flushbits >> 3), T.sideinfo_len, rv, W.io[st].out, W.out_bytes[st]);
+            rv.ResvSize = 0;
+            rv.main_data_begin = 0;
+        }
+    }
+}
+
 LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
@@ -142,7 +195,8 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const int fidx = sd.out_slot0 + k;
     const int padding = frame_padding(T, sd, k);
     const int frame_bits = frame_bits_of(T, padding);
-    const int nwords = (frame_bits + 31) >> 5;
+    const bool resv = !T.disable_reservoir;
+    const int nwords = resv ? BITS_LDS_WORDS - 1 : (frame_bits + 31) >> 5;      // reservoir: a frame's data may exceed its nominal size
     for (int i = lane; i < nwords + 1; i += LHIP_NL) L.w[i] = 0;
     wave_sync();
     const GrSide* side = W.side + (int64_t)fidx * 2 * C;
@@ -156,15 +210,16 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
         PUT(T.bitrate_index, 4) PUT(T.samplerate_index, 2) PUT(padding, 1) PUT(T.extension, 1)
         PUT(T.mode, 2) PUT(T.mode == 1 ? side[0].mode_ext : 0, 2)                  // mode_ext: the frame's M/S decision in joint stereo (BitStream.js:279)
         PUT(T.copyright, 1) PUT(T.original, 1) PUT(T.emphasis, 2)
+        const int mdb = resv ? js_toint32(W.fr[fidx].main_data_begin) : 0;         // writeheader shifts the number: ToInt32 of a possibly fractional value
         if (GR == 2) {
-            PUT(0, 9)
+            PUT(mdb, 9)
             PUT(0, C == 2 ? 3 : 5)
             for (int ch = 0; ch < C; ch++) {
                 const int sc = side[(1 * C) + ch].scfsi;
                 for (int band = 0; band < 4; band++) PUT((sc >> band) & 1, 1)
             }
         } else {                                             // MPEG-2/2.5 (BitStream.js:352-405)
-            PUT(0, 8)
+            PUT(mdb, 8)
             PUT(0, C)
         }
 #undef PUT
@@ -185,6 +240,14 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     pos = 8 * T.sideinfo_len;
     wave_sync();
+    int anc_flag = 0;
+    if (resv) {                                                  // drain_into_ancillary(resvDrain_pre) precedes the frame's main data
+        anc_flag = W.io[st].state->rv.ancillary_flag;
+        if (lane == 0) put_ancillary(T, L.w, pos, W.fr[fidx].drain_pre, &anc_flag);
+        anc_flag = wave_bcast(anc_flag, 0);
+        pos += W.fr[fidx].drain_pre;
+        wave_sync();
+    }
     for (int gr = 0; gr < GR; gr++)
         for (int ch = 0; ch < C; ch++) {
             const GrSide& gi = side[gr * C + ch];
@@ -247,6 +310,32 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
             }
             pos += count1_region(T, L.w, pos, gi, q, lane);
         }
+    if (resv) {
+        // bit reservoir: [drain_pre | main data | drain_post] joins the continuous stream, this frame's header + side info joins the
+        // queue of headers waiting for the stream to reach their frame start; the reservoir state is committed (format_bitstream,
+        // BitStream.js:836-900).  Sequential, one lane: a frame is ~0.4-1.4 KB.
+        const FrameResv fr = W.fr[fidx];
+        const int main_end = pos;
+        if (lane == 0) put_ancillary(T, L.w, pos, fr.drain_post, &anc_flag);
+        wave_sync();
+        if (lane == 0) {
+            ResvState& rv = W.io[st].state->rv;
+            const int sl = T.sideinfo_len;
+            const int old = rv.h_ptr;
+            for (int b = 0; b < sl; b++) rv.header[old][b] = (uint8_t)(L.w[b >> 2] >> (24 - 8 * (b & 3)));
+            rv.h_ptr = (old + 1) & (RESV_HQ - 1);
+            rv.timing[rv.h_ptr] = rv.timing[old] + frame_bits;
+            const int chunk_bits = main_end + fr.drain_post - 8 * sl;            // a whole number of bytes (ResvFrameEnd's stuffing)
+            W.out_bytes[st] = resv_emit(L.w, sl, chunk_bits >> 3, sl, rv, W.io[st].out, 0);
+            const int bits = main_end - fr.drain_pre + fr.drain_post;          // header + side info + main data + drain_post
+            rv.main_data_begin = fr.main_data_begin + (double)(frame_bits - bits) / 8;
+            rv.ResvSize = fr.ResvSize; rv.ResvMax = fr.ResvMax; rv.ancillary_flag = anc_flag; rv.last_frame_bits = frame_bits;
+            for (int i = 0; i < 18; i++) rv.pefirbuf[i] = rv.pefirbuf[i + 1];
+            rv.pefirbuf[18] = fr.pefir_new;
+            W.frame_bytes[fidx] = W.out_bytes[st];
+        }
+        return;
+    }
     // ancillary stuffing (drain_into_ancillary): "LAME", coerced version chars, then zero bits
     if (lane == 0) {
         int remaining = frame_bits - pos;

@@ -492,7 +492,9 @@ LHIP_DEV void kb_scan_attack(const Tables& T, const Workspace& W, const StreamDe
             else ul[0] = ul[1] = 0;                 // an attack in mid or side switches both channels (PsyModel.js:1198-1204)
             if (a1 != 0 && a0 != 0) a1 = 0;
             if (a2 != 0 && a1 != 0) a2 = 0;
+            if (a3 != 0 && a2 != 0) a3 = 0;
         }
+        W.att_clean[(int64_t)gslot * Cp + ch] = a0 | (a1 << 1) | (a2 << 2) | (a3 << 3);
         W.ul_tmp[(int64_t)gslot * Cp + ch] = a2;   // lastAttacks after this call (published below)
     }
     if (T.short_blocks_coupled && !(ul[0] != 0 && ul[1] != 0)) ul[0] = ul[1] = 0;
@@ -697,12 +699,26 @@ LHIP_DEV double mask_add_l(const Tables& T, const PsyBTabs& L, double ath_cb, do
 }
 
 
-template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLdsT<NCH>& L) {
+// NS_INTERP (PsyModel.js:828-842).  r = constant * pcfact; pcfact is 0 with the reservoir disabled, where this returns y unchanged
+LHIP_DEV double ns_interp(double x, double y, double r) {
+    if (r >= 1.0) return x;
+    if (r <= 0.0) return y;
+    if (y > 0.0) return v8_pow(x / y, r) * y;
+    return 0.0;
+}
+
+// par >= 0 (bit reservoir): only the psy calls with q % mode_gr == par -- the second granule's short-block pre-echo control looks at
+// the first one's finished thresholds, so the two are launched one after the other
+template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLdsT<NCH>& L, int par = -1) {
     const int C = T.channels_out, Cp = T.psy_channels;      // Cp <= NCH: the launch picks the instantiation by Tables::psy_channels
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
     const int q = gslot - sd.gslot0 - 1;
     if (q < 0) return;
+    if (par >= 0 && q % T.mode_gr != par) return;
+    // PsyModel.js:1036-1038: share of the reservoir in use, as the previous frame left it (0 with the reservoir disabled)
+    double pcfact = 0.0;
+    if (!T.disable_reservoir) { const ResvState& rv = W.io[st].state->rv; pcfact = rv.ResvMax == 0 ? 0.0 : (double)rv.ResvSize / rv.ResvMax * 0.5; }
     const int fs = sd.fslot0 + q / T.mode_gr;            // ATH.adjust as left by the previous frame
     const double ath_adjust = W.ath_adjust[fs];
     for (int i = lane; i < 25; i += LHIP_NL) {
@@ -731,7 +747,17 @@ template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, c
                 ecb = mask_add_l(T, L, acur, ecb, tc, kk - b);
             }
             ecb *= 0.158489319246111;
-            L.thr_l[ch][b] = (float)ecb;
+            float thr = (float)ecb;
+            if (!T.disable_reservoir) {   // long-block pre-echo control (PsyModel.js:1300-1318): dead with the reservoir disabled (pcfact == 0)
+                const float n1 = W.nb1[(o - Cp) * EBL_STRIDE + b], n2 = W.nb2[(o - Cp) * EBL_STRIDE + b];
+                if (pcfact > 0.0 && !W.prev_short[(int64_t)gslot * C + (ch & 1)]) {
+                    const double a = 2 * (double)n1, b2 = 16 * (double)n2, m = a < b2 ? a : b2;
+                    thr = (float)ns_interp(ecb < m ? ecb : m, ecb, pcfact);
+                }
+                W.nb2[o * EBL_STRIDE + b] = n1;
+                W.nb1[o * EBL_STRIDE + b] = (float)ecb;
+            }
+            L.thr_l[ch][b] = thr;
         }
         // short-block limiting by the two previous sub-blocks (compute_masking_s, 762-775)
         const int pshort = W.prev_short[(int64_t)gslot * C + (ch & 1)];      // blocktype_old[chn & 1] (PsyModel.js:767)
@@ -786,8 +812,7 @@ template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, c
             Eo[E_EN_L + sb] = en_f;
             Eo[E_THM_L + sb] = thm_f;
         }
-        // convert_partition2scalefac_s (644-687) + x0.8 and pulse halving (1226-1267)
-        const float* pk = W.peaks + o * PK_STRIDE;            // en_subshort[3..11]
+        // convert_partition2scalefac_s (644-687)
         for (int it = lane; it < 3 * SBMAX_s; it += LHIP_NL) {
             const int sblock = it / SBMAX_s, sb = it - sblock * SBMAX_s;
             const float* ebs = W.eb_s + o * EBS_STRIDE + sblock * CBANDS;
@@ -814,16 +839,36 @@ template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, c
                     thm_f = (float)((double)thm_f + w_curr * (double)thr[b]);
                 }
             }
-            double thmm = thm_f;
-            thmm *= 0.8;
-            const double e3 = pk[sblock * 3 + 0], e4 = pk[sblock * 3 + 1], e5 = pk[sblock * 3 + 2];
-            const double enn = e3 + e4 + e5;
-            if (e5 * 6 < enn) {
-                thmm *= 0.5;
-                if (e4 * 6 < enn) thmm *= 0.5;
-            }
             Eo[E_EN_S + sb * 3 + sblock] = en_f;
-            Eo[E_THM_S + sb * 3 + sblock] = (float)thmm;
+            Eo[E_THM_S + sb * 3 + sblock] = thm_f;                 // as converted; the pre-echo control follows
+        }
+    }
+    wave_sync();
+    for (int ch = 0; ch < Cp; ch++) {
+        // short-block pre-echo control (PsyModel.js:1226-1267), one lane per band, the three sub-blocks in order: x0.8, the two
+        // attack-driven interpolations towards the previous sub-block's finished threshold (sub-block 0: the previous CALL's
+        // sub-block 2) -- identities when pcfact == 0 -- and the pulse halving.  ns_attacks holds only 0 / 1, so
+        // the reference's `>= 2` and `== 3` alternatives never fire.
+        const int64_t o = (int64_t)gslot * Cp + ch;
+        const float* pk = W.peaks + o * PK_STRIDE;            // en_subshort[3..11]
+        const int att = W.att_clean[o];
+        float* Eo = L.E[ch];
+        LHIP_LANE_ONCE(sb, 0, SBMAX_s) {
+            float prev = pcfact > 0.0 ? W.E[(o - Cp) * E_STRIDE + E_THM_S + sb * 3 + 2] : 0.f;      // (only read where the previous call is complete)
+            for (int sblock = 0; sblock < 3; sblock++) {
+                double thmm = Eo[E_THM_S + sb * 3 + sblock];
+                thmm *= 0.8;
+                if ((att >> (sblock + 1)) & 1) { const double p = ns_interp(prev, thmm, 0.6 * pcfact); thmm = thmm < p ? thmm : p; }
+                if ((att >> sblock) & 1) { const double p = ns_interp(prev, thmm, 0.3 * pcfact); thmm = thmm < p ? thmm : p; }
+                const double e3 = pk[sblock * 3 + 0], e4 = pk[sblock * 3 + 1], e5 = pk[sblock * 3 + 2];
+                const double enn = e3 + e4 + e5;
+                if (e5 * 6 < enn) {
+                    thmm *= 0.5;
+                    if (e4 * 6 < enn) thmm *= 0.5;
+                }
+                prev = (float)thmm;
+                Eo[E_THM_S + sb * 3 + sblock] = prev;
+            }
         }
     }
     wave_sync();

@@ -1843,23 +1843,35 @@ LHIP_DEV double q_pecalc(const float* E, int is_short, double masking_lower) {
 // first and in the last granule.  The entropies belong to the psy calls of this frame: maskings of the call before (slot - 1),
 // block types of the granule, and the masking_lower the previous frame's last channel left behind (gfc.masking_lower; 1 before
 // the first frame -- Lame.js:175).  Returns mode_ext: 0 or 2 (wave-uniform).
-LHIP_DEV int q_ms_decision(const Tables& T, const Workspace& W, const StreamDesc& sd, int k, int lane, QuantLds& L) {
-    const int GR = T.mode_gr;
-    const int bt_prev = W.blocktype[(int64_t)(sd.gslot0 + GR * k) * 2 + 1];         // carry slot for k == 0: -1 on a fresh stream
+// The frame's perceptual entropies into L.nsum[granule * 4 + psy channel] (PsyModel.js:1352-1380): maskings of the psy call before
+// (slot - 1), block types of the granule, and the masking_lower the previous frame's last channel left behind (gfc.masking_lower;
+// 1 before the first frame -- Lame.js:175).
+LHIP_DEV void q_frame_pe(const Tables& T, const Workspace& W, const StreamDesc& sd, int k, int lane, QuantLds& L) {
+    const int GR = T.mode_gr, C = T.channels_out, Cp = T.psy_channels;
+    const int bt_prev = W.blocktype[(int64_t)(sd.gslot0 + GR * k) * C + (C - 1)];    // carry slot for k == 0: -1 on a fresh stream
     const double ml = bt_prev < 0 ? 1.0 : (bt_prev != SHORT_TYPE ? T.masking_lower_long : T.masking_lower_short);
     wave_sync();
     LHIP_LANE_ONCE(it, 0, 4 * GR) {                                                  // lane = granule * 4 + psy channel
         const int gr = it >> 2, chn = it & 3;
-        const int gs = sd.gslot0 + 1 + GR * k + gr;
-        const int bt0 = W.blocktype[(int64_t)gs * 2], bt1 = W.blocktype[(int64_t)gs * 2 + 1];
-        const int type = chn < 2 ? (chn ? bt1 : bt0) : ((bt0 == SHORT_TYPE || bt1 == SHORT_TYPE) ? SHORT_TYPE : NORM_TYPE);
-        L.nsum[it] = q_pecalc(W.E + ((int64_t)(gs - 1) * 4 + chn) * E_STRIDE, type == SHORT_TYPE, ml);
+        if (chn < Cp) {
+            const int gs = sd.gslot0 + 1 + GR * k + gr;
+            const int bt0 = W.blocktype[(int64_t)gs * C], bt1 = W.blocktype[(int64_t)gs * C + (C - 1)];
+            const int type = chn < 2 ? (chn ? bt1 : bt0) : ((bt0 == SHORT_TYPE || bt1 == SHORT_TYPE) ? SHORT_TYPE : NORM_TYPE);
+            L.nsum[it] = q_pecalc(W.E + ((int64_t)(gs - 1) * Cp + chn) * E_STRIDE, type == SHORT_TYPE, ml);
+        }
     }
     wave_sync();
+}
+
+// Joint stereo: M/S or L/R for frame k of the stream (Encoder.js:520-561).  M/S when the perceptual entropy of the mid / side pair,
+// summed over the frame's granules, is not larger than that of left / right, and both channels have the same block type in the
+// first and in the last granule.  Returns mode_ext: 0 or 2 (wave-uniform); the entropies stay in L.nsum.
+LHIP_DEV int q_ms_decision(const Tables& T, const Workspace& W, const StreamDesc& sd, int k, int lane, QuantLds& L) {
+    const int GR = T.mode_gr;
+    q_frame_pe(T, W, sd, k, lane, L);
     double sum_ms = 0., sum_lr = 0.;
     for (int gr = 0; gr < GR; gr++)
         for (int ch = 0; ch < 2; ch++) { sum_ms += L.nsum[4 * gr + 2 + ch]; sum_lr += L.nsum[4 * gr + ch]; }
-    wave_sync();
     int ms = 0;
     if (sum_ms <= 1.00 * sum_lr) {
         const int g0 = sd.gslot0 + 1 + GR * k, g1 = g0 + GR - 1;
@@ -1868,9 +1880,47 @@ LHIP_DEV int q_ms_decision(const Tables& T, const Workspace& W, const StreamDesc
     return uni(ms);
 }
 
+// on_pe (QuantizePVT.js:421-484) with ResvMaxBits (Reservoir.js:190-229), the bit reservoir in use.  The reference computes in JS
+// numbers (doubles) except where it stores into Int32Arrays (targ_bits, add_bits): those stores truncate.  Returns max_bits.
+LHIP_DEV double q_on_pe_resv(const Tables& T, const double* pe, int* targ, int mean_bits, int cbr, int ResvSize_i, int ResvMax_i) {
+    const int C = T.channels_out;
+    double ResvSize = ResvSize_i, ResvMax = ResvMax_i, tbits, add_b, extra_bits, max_bits, bits;
+    int add_bits[2] = {0, 0};
+    if (cbr != 0) ResvSize += mean_bits;
+    tbits = mean_bits;
+    if (ResvSize * 10 > ResvMax * 9) { add_b = ResvSize - (ResvMax * 9) / 10; tbits += add_b; }
+    else { add_b = 0; tbits -= .1 * mean_bits; }
+    extra_bits = (ResvSize < (ResvMax * 6) / 10 ? ResvSize : (ResvMax * 6) / 10);
+    extra_bits -= add_b;
+    if (extra_bits < 0) extra_bits = 0;
+    max_bits = tbits + extra_bits;
+    if (max_bits > MAX_BITS_PER_GRANULE) max_bits = MAX_BITS_PER_GRANULE;
+    bits = 0;
+    for (int ch = 0; ch < C; ++ch) {
+        const double t = tbits / C;
+        targ[ch] = js_toint32(t < MAX_BITS_PER_CHANNEL ? t : (double)MAX_BITS_PER_CHANNEL);
+        add_bits[ch] = js_toint32((double)targ[ch] * pe[ch] / 700.0 - targ[ch]);
+        if (add_bits[ch] > mean_bits * 3 / 4) add_bits[ch] = mean_bits * 3 / 4;
+        if (add_bits[ch] < 0) add_bits[ch] = 0;
+        if (add_bits[ch] + targ[ch] > MAX_BITS_PER_CHANNEL) add_bits[ch] = (MAX_BITS_PER_CHANNEL - targ[ch]) > 0 ? MAX_BITS_PER_CHANNEL - targ[ch] : 0;
+        bits += add_bits[ch];
+    }
+    if (bits > extra_bits)
+        for (int ch = 0; ch < C; ++ch) add_bits[ch] = js_toint32(extra_bits * add_bits[ch] / bits);
+    for (int ch = 0; ch < C; ++ch) { targ[ch] += add_bits[ch]; extra_bits -= add_bits[ch]; }
+    bits = 0;
+    for (int ch = 0; ch < C; ++ch) bits += targ[ch];
+    if (bits > MAX_BITS_PER_GRANULE)
+        for (int ch = 0; ch < C; ++ch) {
+            targ[ch] = js_toint32((double)targ[ch] * MAX_BITS_PER_GRANULE);
+            targ[ch] = js_toint32((double)targ[ch] / bits);
+        }
+    return max_bits;
+}
+
 // reduce_side (QuantizePVT.js:486-534): M/S granules move bits from the side to the mid channel by the energy ratio; the
 // reference's targ_bits is an Int32Array, so every store truncates
-LHIP_DEV void q_reduce_side(int* targ, double ms_ener_ratio, int mean_bits, int max_bits) {
+LHIP_DEV void q_reduce_side(int* targ, double ms_ener_ratio, int mean_bits, double max_bits) {
     double fac = .33 * (.5 - ms_ener_ratio) / .5;
     if (fac < 0) fac = 0;
     if (fac > .5) fac = .5;
@@ -1888,8 +1938,8 @@ LHIP_DEV void q_reduce_side(int* targ, double ms_ener_ratio, int mean_bits, int 
     }
     move_bits = targ[0] + targ[1];
     if (move_bits > max_bits) {
-        targ[0] = js_toint32((double)(max_bits * targ[0]) / move_bits);
-        targ[1] = js_toint32((double)(max_bits * targ[1]) / move_bits);
+        targ[0] = js_toint32((max_bits * targ[0]) / move_bits);
+        targ[1] = js_toint32((max_bits * targ[1]) / move_bits);
     }
 }
 
@@ -1943,14 +1993,45 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         seed0 = seed_before(W, sd, C, k, 0, 0);
         if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
     }
-    int ResvSize = 0;
     int gr0_bt0 = 0, gr0_bt1 = 0;
     const int Cp = T.psy_channels;
     const int mode_ext = (T.mode == 1) ? q_ms_decision(T, W, sd, k, lane, L) : 0;      // joint stereo: this frame M/S (2) or L/R (0)
+    // Bit reservoir (extension): the frame starts from the reservoir the previous frame left (one frame per stream and launch), its
+    // budget follows the perceptual entropies (on_pe), and ResvFrameEnd's verdict goes to the bit packer, which commits it.
+    const bool resv = !T.disable_reservoir;
+    const ResvState* rv = resv ? &W.io[st].state->rv : nullptr;
+    int ResvSize = resv ? uni(rv->ResvSize) : 0;
+    int ResvMax = 0;
+    double pe_use[2][2] = {{0., 0.}, {0., 0.}};
+    float pefir_new = 0.f;
+    if (resv) {
+        // ResvFrameBegin (Reservoir.js:130-180; brate <= 320, not strict_ISO)
+        const int frameLength = frame_bits_of(T, padding), resvLimit = (8 * 256) * T.mode_gr - 8, maxmp3buf = 8 * 1440;
+        ResvMax = maxmp3buf - frameLength;
+        if (ResvMax > resvLimit) ResvMax = resvLimit;
+        if (ResvMax < 0) ResvMax = 0;
+        // the entropies of the maskings in use, scaled by the 19-frame FIR of their sums (Encoder.js:600-626; pefirbuf is a Float32Array)
+        if (T.mode != 1) q_frame_pe(T, W, sd, k, lane, L);
+        double f = 0.0;
+        for (int gr = 0; gr < T.mode_gr; gr++)
+            for (int ch = 0; ch < C; ch++) { pe_use[gr][ch] = L.nsum[4 * gr + ch + mode_ext]; f += pe_use[gr][ch]; }
+        pefir_new = (float)f;
+        {
+            const double fircoef[9] = {-0.0207887 * 5, -0.0378413 * 5, -0.0432472 * 5, -0.031183 * 5, 7.79609e-18 * 5, 0.0467745 * 5,
+                                       0.10091 * 5, 0.151365 * 5, 0.187098 * 5};
+            // buffer after the shift: b[i] = old[i + 1] for i < 18, b[18] = the new sum
+            f = rv->pefirbuf[10];
+            for (int i = 0; i < 9; i++) f += ((double)rv->pefirbuf[i + 1] + (double)(i == 0 ? pefir_new : rv->pefirbuf[19 - i])) * fircoef[i];
+        }
+        f = (670 * 5 * T.mode_gr * C) / f;
+        for (int gr = 0; gr < T.mode_gr; gr++)
+            for (int ch = 0; ch < C; ch++) pe_use[gr][ch] *= f;
+        wave_sync();
+    }
     for (int gr = 0; gr < T.mode_gr; gr++) {
         const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
         int targ[2] = {0, 0};
-        const int max_bits = targ_bits_for(T, mean_bits, gr, ResvSize, targ);
+        const double max_bits = resv ? q_on_pe_resv(T, pe_use[gr], targ, mean_bits, gr, ResvSize, ResvMax) : (double)targ_bits_for(T, mean_bits, gr, ResvSize, targ);
         if (mode_ext == 2) {
             // Encoder.js:482-486: side / (mid + side) of the total energies the psy call of this granule handed back (one call of delay)
             const float* te = W.tot_ener + (int64_t)(gslot - 1) * 4;
@@ -2023,6 +2104,24 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             wg_barrier();
             ResvSize = uni(ResvSize - (mbox[2 * gr] + mbox[2 * gr + 1]));
         }
+    }
+    if (resv && lane == 0 && (!PAIR || my_ch == 0)) {
+        // ResvFrameEnd (Reservoir.js:243-293); main_data_begin is a double there (fractions of a byte survive in it)
+        const double mdb0 = rv->main_data_begin;
+        int rs = ResvSize + mean_bits * T.mode_gr, over_bits, stuffingBits = 0;
+        if ((over_bits = rs % 8) != 0) stuffingBits += over_bits;
+        over_bits = (rs - stuffingBits) - ResvMax;
+        if (over_bits > 0) stuffingBits += over_bits;
+        const double mdb_bytes = (mdb0 * 8 < stuffingBits ? mdb0 * 8 : (double)stuffingBits) / 8;
+        FrameResv fr;
+        fr.drain_pre = js_toint32(8 * mdb_bytes);
+        stuffingBits -= fr.drain_pre;
+        rs -= fr.drain_pre;
+        fr.main_data_begin = mdb0 - mdb_bytes;
+        fr.drain_post = stuffingBits;
+        rs -= stuffingBits;
+        fr.ResvSize = rs; fr.ResvMax = ResvMax; fr.pefir_new = pefir_new; fr.pad_ = 0;
+        W.fr[fidx] = fr;
     }
     if (chain && lane == 0) W.seed_flag[fidx] = 0;
 #ifdef LHIP_PHASE_PROF

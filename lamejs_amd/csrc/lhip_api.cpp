@@ -93,6 +93,7 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
         for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[chn][i];
         for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[chn][i];
         for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[chn][i];
+        for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { W.nb1[o * EBL_STRIDE + i] = S->nb1[chn][i]; W.nb2[o * EBL_STRIDE + i] = S->nb2[chn][i]; }
         if (lane == 0) W.last_attack[o] = S->last_attack[chn];
     }
     if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) W.tot_ener[(int64_t)sd.gslot0 * 4 + i] = S->tot_ener[i];
@@ -172,6 +173,7 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
             for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[chn][i] = W.E[o * E_STRIDE + i];
             for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[chn][i] = W.ecb_s[o * EBS_STRIDE + i];
             for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = W.peaks[o * PK_STRIDE + i];
+            for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { S->nb1[chn][i] = W.nb1[o * EBL_STRIDE + i]; S->nb2[chn][i] = W.nb2[o * EBL_STRIDE + i]; }
             if (lane == 0) S->last_attack[chn] = W.last_attack[o];
         }
         if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) S->tot_ener[i] = W.tot_ener[(int64_t)(sd.gslot0 + T.mode_gr * F) * 4 + i];
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(64) void g_scan_raw(Tables T, Workspace W, const St
 __global__ __launch_bounds__(64) void g_scan_attack(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_attack(T, W, SD, g); }
 __global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_blocktype(T, W, SD, g); }
 __global__ __launch_bounds__(ATH_NT) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
-template <int NCH> __global__ __launch_bounds__(64) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD) {
+template <int NCH> __global__ __launch_bounds__(64) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int par) {
     __shared__ PsyBLdsT<NCH> L;
     const int it = xcd_item(blockIdx.x, W.ngslots);
-    if (it >= 0) kb_psyB<NCH>(T, pb, W, SD, it, threadIdx.x, L);
+    if (it >= 0) kb_psyB<NCH>(T, pb, W, SD, it, threadIdx.x, L, par);
 }
 __global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nitems) {
     __shared__ PolyLds L;
@@ -406,6 +408,10 @@ __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const Stream
     __shared__ BitsLds L;
     kb_bits(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
+__global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W) {
+    __shared__ BitsLds L;
+    kb_resv_flush(T, W, blockIdx.x, threadIdx.x, L);
+}
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
 enum { KT_LOAD, KT_PREP, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
 static const char* const g_kt_names[KT_N] = {"load", "prep", "psyA", "scan", "psyB", "polyphase", "mdct", "quant", "validate", "repair", "bits", "save"};
@@ -534,6 +540,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     CI(sfb21_extra); CI(quant_comp); CI(quant_comp_short); CI(short_blocks_coupled); CI(useTemporal);
     CI(ATH_useAdjust); CI(athaa_loudapprox); CI(copyright); CI(original); CI(emphasis); CI(extension);
     CI(error_protection); CI(npart_l); CI(npart_s); CI(in_samplerate); CI(rs_filter_l); CI(rs_bpc);
+    CI(disable_reservoir);
     CD(resample_ratio);
     CD(scale); CD(attackthre); CD(attackthre_s); CD(interChRatio); CD(masking_lower_long); CD(masking_lower_short);
     CD(ATH_aaSensitivityP); CD(ATH_floor); CD(decay); CD(ma_max_i1); CD(ma_max_i2); CD(ma_max_m); CD(VO_SCALE);
@@ -645,7 +652,7 @@ struct Context {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
     int num_cus = 256;
@@ -708,7 +715,7 @@ static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
     return (int64_t)F * ts.base_frame_bytes + npad;
 }
 
-static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
+static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync, bool flush_stream = false) {
     if (jobs.empty()) return true;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(ctx->device)) return false;
@@ -718,6 +725,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     const int C = T.channels_out;
     const int GR = T.mode_gr, frame = 576 * GR, mf_needed = 1024 + frame - 272;   // calcNeeded (Lame.js:1517-1530)
     const int S = (int)jobs.size();
+    const bool resv = !T.disable_reservoir;       // bit reservoir (extension): one frame per stream and launch, output sizes known to the device only
     // ---- plan ----
     std::vector<StreamDesc> sd(S);
     std::vector<StreamIO> io(S);
@@ -732,6 +740,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (total > 0x7fffffff || (int64_t)j.n > 0x7fffffff) { set_err("too many samples in one call"); return false; }
         j.F = total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
         j.bytes = batch_bytes(ts, s->slot_lag, j.F);
+        if (resv) {
+            if (j.F > 1) { set_err("internal: more than one frame per launch with the bit reservoir"); return false; }
+            j.bytes = (int64_t)j.F * (ts.base_frame_bytes + 1 + 512 + 4 * RESV_HDR) + (flush_stream ? 1440 + 8 * RESV_HDR : 0);      // upper bound; the real count comes back from the device
+        }
         if ((size_t)j.bytes > j.cap) { j.written = LHIP_ERR_BUFFER_TOO_SMALL; set_err("output buffer too small"); return false; }
         StreamDesc& d = sd[i];
         memset(&d, 0, sizeof d);
@@ -755,6 +767,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(eb_s, GP * EBS_STRIDE * 4); ENS(ecb_s, GP * EBS_STRIDE * 4); ENS(att_raw, GP * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GP * 4); ENS(last_attack, GP * 4);
     ENS(tent, GC * 4); ENS(prev_short, GC * 4); ENS(blocktype, GC * 4); ENS(ath_adjust, (size_t)nfs * 8);
     ENS(ath_limit, (size_t)nfs * 8); ENS(E, GP * E_STRIDE * 4); ENS(sb, GC * SB_STRIDE * 4); ENS(xr, GC * 576 * 4);
+    ENS(att_clean, GP * 4); ENS(nb1, GP * EBL_STRIDE * 4); ENS(nb2, GP * EBL_STRIDE * 4); ENS(fr, FR * sizeof(FrameResv)); ENS(out_bytes, (size_t)S * 4 + 64);
     ENS(fht, Cp == 4 ? (size_t)ngs * 2 * FHT_STRIDE * 4 : 64); ENS(hpf, Cp == 4 ? (size_t)ngs * 2 * 576 * 4 : 64); ENS(tot_ener, (size_t)ngs * 4 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
     ENS(seed_flag, FR * 4); ENS(reval, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
@@ -768,6 +781,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
     W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
     W.fht = (float*)ctx->fht.p; W.hpf = (float*)ctx->hpf.p; W.tot_ener = (float*)ctx->tot_ener.p;
+    W.att_clean = (int32_t*)ctx->att_clean.p; W.nb1 = (float*)ctx->nb1.p; W.nb2 = (float*)ctx->nb2.p; W.fr = (FrameResv*)ctx->fr.p; W.out_bytes = (int32_t*)ctx->out_bytes.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p; W.reval = (int32_t*)ctx->reval.p;
     W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 16; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
@@ -816,10 +830,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.fslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_gm);
     if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
     if (!rt::dzero(ctx->reval.p, FR * 4, st)) return false;
+    if (resv && !rt::dzero(ctx->out_bytes.p, (size_t)S * 4, st)) return false;
     if (!rt::dzero(ctx->nflagged.p, 256, st)) return false;
     if (!rt::dzero(ctx->prof.p, 512, st)) return false;
     const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ctx->desc.p + o_sd);
     const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ctx->desc.p + o_io);
+    W.io = dIO;
 
     int64_t repaired = 0, iters = 0;
 #ifdef LHIP_HOSTSIM
@@ -841,7 +857,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
-        for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB));
+        for (int par = resv ? 0 : -1; par < (resv ? GR : 0); par++)
+            for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB, par));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
 #ifdef LHIP_WAVESIM
@@ -866,6 +883,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
         for (int b = 0; b < nfs; b++) WAVE_RUN(kb_bits(T, W, dSD, b, lane_, LBi));
+        if (resv && flush_stream) for (int s = 0; s < S; s++) WAVE_RUN(kb_resv_flush(T, W, s, lane_, LBi));
         for (int s = 0; s < S; s++) WAVE_RUN(kb_save(T, W, dSD, dIO, s, lane_));
 #undef QUANT_RUN
 #undef WAVE_RUN
@@ -909,8 +927,11 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_POLY, g_poly, XCD_GRID((ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE), st, T, W, dSD, dIO, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, XCD_GRID(ngs), st, T, W, dSD);
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
-    if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD);
-    else LAUNCH(KT_PSYB, g_psyB<2>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD);
+    // bit reservoir: the granules of a frame one after the other (the second one's short-block pre-echo control reads the first one's thresholds)
+    for (int par = resv ? 0 : -1; par < (resv ? GR : 0); par++) {
+        if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, par);
+        else LAUNCH(KT_PSYB, g_psyB<2>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, par);
+    }
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
@@ -945,6 +966,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         }
     }
     LAUNCH(KT_BITS, g_bits, nfs, st, T, W, dSD);
+    if (resv && flush_stream) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W);
     LAUNCH(KT_SAVE, g_save, S, st, T, W, dSD, dIO);
 #endif
 #ifndef LHIP_HOSTSIM
@@ -955,6 +977,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (fetch_fx && !rt::d2h(fx, (const int32_t*)ctx->nflagged.p + FX_STATS, sizeof fx, st)) return false;
 #endif
     // ---- outputs ----
+    std::vector<int32_t> ob;
+    if (resv) {                                   // how much each stream really wrote
+        ob.assign((size_t)S, 0);
+        if (!rt::d2h(ob.data(), ctx->out_bytes.p, (size_t)S * 4, st) || !rt::sync(st)) return false;
+        for (int i = 0; i < S; i++) jobs[i].bytes = ob[i];
+    }
     if (!dev_io) {
         for (int i = 0; i < S; i++)
             if (jobs[i].bytes > 0 && !rt::d2h(jobs[i].out, io[i].out, (size_t)jobs[i].bytes, st)) return false;
@@ -1069,7 +1097,9 @@ int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes,
         for (int i = 0; i < E_STRIDE; i++) h->E[ch][i] = 1e20f;
         for (int i = 0; i < EBS_STRIDE; i++) h->ecb_s[ch][i] = 1.0f;
         for (int i = 0; i < 9; i++) h->peaks[ch][i] = 10.f;
+        for (int i = 0; i < EBL_STRIDE; i++) h->nb1[ch][i] = h->nb2[ch][i] = 1e20f;
     }
+    for (int i = 0; i < 19; i++) h->rv.pefirbuf[i] = (float)(700 * ts->T.mode_gr * ts->T.channels_out);      // Lame.js:1120
     for (int ch = 0; ch < 2; ch++) {
         h->tent[ch] = NORM_TYPE;
         h->last_bt[ch] = -1;
@@ -1098,11 +1128,11 @@ void lhip_destroy(lhip_stream* s) {
 size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples) {
     if (!s || s->magic != 0x4c484950) return 0;
     const size_t frame = 576 * (size_t)s->ts->T.mode_gr;
-    return (nsamples / frame + 3 + (FRAME / frame)) * (size_t)(s->ts->base_frame_bytes + 1);
+    return (nsamples / frame + 3 + (FRAME / frame)) * (size_t)(s->ts->base_frame_bytes + 1) + (s->ts->T.disable_reservoir ? 0 : 4096);      // reservoir: slack for the per-launch bound
 }
 
 static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,
-                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync) {
+                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync, bool flush_stream = false) {
     if (n == 0) return 0;
     std::vector<Job> jobs(n);
     for (size_t i = 0; i < n; i++) {
@@ -1110,7 +1140,40 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
         if (streams[i]->ctx != streams[0]->ctx) { set_err("batch: streams on different devices"); return LHIP_ERR_INTERNAL; }
         jobs[i] = Job{streams[i], l[i], r ? r[i] : nullptr, ns[i], out[i], cap[i], 0, 0, 0, 0};
     }
-    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync);
+    bool ok = true;
+    const Tables& T0 = streams[0]->ts->T;
+    if (!T0.disable_reservoir) {
+        // Bit reservoir (extension): a frame's budget -- and through `pcfact` its masking -- depends on the bits every earlier frame of
+        // the stream spent, so the frames of a stream are a serial chain: every launch encodes at most one frame per stream (the
+        // streams of a batch still run side by side), and the host learns from each launch how many bytes the streams produced.
+        const size_t step = (size_t)576 * T0.mode_gr * T0.rs_ratio;
+        std::vector<size_t> pos(n, 0);
+        std::vector<int64_t> done(n, 0);
+        for (;;) {
+            std::vector<Job> sub; std::vector<size_t> idx;
+            for (size_t i = 0; i < n; i++) {
+                if (pos[i] >= ns[i] && !(flush_stream && pos[i] == ns[i])) continue;
+                const size_t m = ns[i] - pos[i] < step ? ns[i] - pos[i] : step;
+                sub.push_back(Job{streams[i], l[i] ? l[i] + pos[i] : nullptr, (r && r[i]) ? r[i] + pos[i] : nullptr, m, out[i] + done[i], cap[i] - (size_t)done[i], 0, 0, 0, 0});
+                idx.push_back(i);
+            }
+            if (sub.empty()) break;
+            bool last = true;                      // the stream flush rides on the launch that takes every stream's last samples
+            for (size_t q = 0; q < idx.size(); q++) if (pos[idx[q]] + sub[q].n < ns[idx[q]]) last = false;
+            ok = run_batch(streams[0]->ctx, sub, dev_io, true, flush_stream && last && idx.size() == n);
+            for (size_t q = 0; q < idx.size(); q++) {
+                const size_t i = idx[q];
+                if (!ok) { jobs[i].written = sub[q].written < 0 ? sub[q].written : LHIP_ERR_INTERNAL; continue; }
+                done[i] += sub[q].written; pos[i] += sub[q].n;
+                if (sub[q].n == 0) pos[i] = ns[i] + 1;      // flush-only pass done
+                jobs[i].written = done[i];
+            }
+            if (!ok) break;
+            if (flush_stream && last && idx.size() == n) break;
+        }
+        (void)sync;
+    } else
+        ok = run_batch(streams[0]->ctx, jobs, dev_io, sync);
     for (size_t i = 0; i < n; i++) if (written) written[i] = ok ? jobs[i].written : (jobs[i].written < 0 ? jobs[i].written : LHIP_ERR_INTERNAL);
     if (!ok) { for (auto& j : jobs) if (j.written < 0) return (int)j.written; return LHIP_ERR_INTERNAL; }
     return 0;
@@ -1172,7 +1235,7 @@ int64_t lhip_flush(lhip_stream* s, uint8_t* out, size_t out_cap) {
     const int16_t* l = zeros.data();
     const int16_t* r = zeros.data();
     int64_t w = 0;
-    const int rc = encode_many(&s, 1, &l, &r, &z, &out, &out_cap, &w, false, true);
+    const int rc = encode_many(&s, 1, &l, &r, &z, &out, &out_cap, &w, false, true, true);
     s->mf_samples_to_encode = 0;
     return rc < 0 ? rc : w;
 }
@@ -1192,7 +1255,7 @@ int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* cons
         zs[i].assign(ns[i] ? ns[i] : 1, 0);
         l[i] = zs[i].data();
     }
-    const int rc = encode_many(streams, nstreams, l.data(), l.data(), ns.data(), out, out_cap, written, false, true);
+    const int rc = encode_many(streams, nstreams, l.data(), l.data(), ns.data(), out, out_cap, written, false, true, true);
     for (size_t i = 0; i < nstreams; i++) streams[i]->mf_samples_to_encode = 0;
     return rc;
 }

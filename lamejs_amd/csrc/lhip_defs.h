@@ -79,7 +79,8 @@ struct Tables {
         extension, error_protection, npart_l, npart_s, n_version_bytes,
         in_samplerate, rs_filter_l, rs_bpc,
         rs_ratio,                           // integer decimation factor (1 = no resampling), derived at create time
-        psy_channels;                       // channels the psychoacoustic model analyses: channels_out, or 4 (L, R, mid, side) in joint stereo (mode == 1)
+        psy_channels,                       // channels the psychoacoustic model analyses: channels_out, or 4 (L, R, mid, side) in joint stereo (mode == 1)
+        disable_reservoir;                  // 1 on the Mp3Encoder path (index.js:108); 0 = the bit-reservoir extension: one frame per stream and launch
     // scalars (doubles)
     double scale, attackthre, attackthre_s, interChRatio, masking_lower_long, masking_lower_short,
         ATH_aaSensitivityP, ATH_floor, decay, ma_max_i1, ma_max_i2, ma_max_m, VO_SCALE, resample_ratio,

@@ -35,7 +35,26 @@ struct StreamDesc {
     int64_t frame_num0;     // absolute index of the first frame of this batch
 };
 
-enum { RS_TAPS = 33 };                       // BLACKSIZE of the reference for an integer ratio (filter_l = 32)
+enum { RS_TAPS = 33 };
+
+// Bit reservoir (extension: Tables::disable_reservoir == 0).  What the reference carries from frame to frame once the reservoir is
+// in use (Reservoir.js, BitStream.js:100-215, Encoder.js:600-626, PsyModel.js:1036-1038, 1300-1318).  A frame's bit budget, and through
+// `pcfact` even its masking thresholds, depend on the bits all earlier frames spent: a stream is then a serial chain of frames, so
+// a launch encodes ONE frame per stream and reads / updates this record directly (parallelism is across streams only).
+enum { RESV_HQ = 8, RESV_HDR = 40 };             // pending headers: at most ceil(ResvMax / smallest frame) + 1 = 5 wait at any time
+struct ResvState {
+    int32_t ResvSize, ResvMax;                   // after the last frame's ResvFrameEnd / ResvFrameBegin
+    int32_t ancillary_flag, h_ptr, w_ptr, last_frame_bits;      // last_frame_bits: getframebits of the last frame (its padding), for the flush
+    double main_data_begin;                      // a double: the reference's arithmetic leaves fractions in it (Reservoir.js:281-286)
+    int64_t totbit;                              // stream position
+    int64_t timing[RESV_HQ];                     // stream position at which header[i] is due (the nominal start of its frame)
+    uint8_t header[RESV_HQ][RESV_HDR];
+    float pefirbuf[19];                          // NsPsy.js:30
+    int32_t pad2_;
+};
+// what the quantization of a frame decides about the reservoir; committed to ResvState by the bit packer (which runs once per frame,
+// whereas a frame may be quantized again by the seed-chain repair)
+struct FrameResv { int32_t ResvSize, ResvMax, drain_pre, drain_post; double main_data_begin; float pefir_new; int32_t pad_; };                       // BLACKSIZE of the reference for an integer ratio (filter_l = 32)
 
 struct StreamState {                // psy arrays hold 4 channels: L, R and -- joint stereo only -- mid, side
     float pcm_tail[2][MF_NEEDED];
@@ -51,6 +70,8 @@ struct StreamState {                // psy arrays hold 4 channels: L, R and -- j
     double ath_adjust, ath_limit;
     int32_t seed[2][2];
     float rs_old[2][RS_TAPS - 1];   // resampling streams: the last 32 (scaled) input samples
+    float nb1[4][EBL_STRIDE], nb2[4][EBL_STRIDE];   // long-block spreading results of the last two psy calls (pre-echo control; live with the reservoir)
+    ResvState rv;
 };
 
 struct StreamIO {          // per stream, per launch (device array parallel to StreamDesc)
@@ -102,6 +123,9 @@ struct Workspace {
     float* tot_ener;            // [ngslots][4]              total FFT energy of that psy call
     // scan outputs
     int32_t* att_raw;           // [ngslots][Cp] bit j = raw ns_attacks[j]
+    int32_t* att_clean;         // [ngslots][Cp] bit j = ns_attacks[j] after the clean-up (PsyModel.js:1183-1196): short-block pre-echo control
+    float* nb1;                 // [ngslots][Cp][64] long-block spreading result (ecb) of that psy call, and
+    float* nb2;                 // [ngslots][Cp][64] of the call before it (nb_1 / nb_2 of PsyModel.js:1300-1318)
     int32_t* uselong;           // [ngslots][C]  coupled uselongblock flag of that call
     int32_t* ul_tmp;            // [ngslots][Cp] scratch: lastAttacks before publication
     int32_t* last_attack;       // [ngslots][Cp] lastAttacks after that call
@@ -126,6 +150,9 @@ struct Workspace {
     int32_t* work_ctr;          // [8] frame-slot dispensers of the persistent quantization kernels (zeroed per launch)
     uint8_t* out;               // output MP3 bytes
     int32_t* frame_bytes;       // [nframes_total]
+    FrameResv* fr;              // [nframes_total] bit reservoir: the frame's reservoir decisions (quant -> bits)
+    int32_t* out_bytes;         // [nstreams] bit reservoir: bytes this launch appended to the stream's output
+    const StreamIO* io;         // [nstreams] (device copy): the reservoir kernels read and update StreamState::rv through it
     unsigned long long* prof;   // [32] phase-profiling accumulators (profiling builds only)
     int32_t mode_gr;            // granules per frame (2: MPEG-1, 1: MPEG-2/2.5 LSF)
     int32_t spec_start, spec_step;   // seed assumed by the speculative pass (Quantize.js reset values 180 / 4)

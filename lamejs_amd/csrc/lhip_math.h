@@ -224,8 +224,13 @@ LHIP_DEV double v8_log10_pos(double x) {
 // ---- pow(x, y), x > 0 finite normal (x == 10 on this path), |y| < 2^31 ----
 struct PowBase { double t1, t2, x; };   // log2(x) = t1 + t2, t1 with a zeroed low word; the base itself (x > 1, finite) for the special cases of y
 
-// x-dependent half (host side, once per table set).  Valid for positive normal x, any y with |y| <= 2^31.
-static inline PowBase pow_log2_parts(double x) {
+// x-dependent half (on the host once per table set for base 10; on the device for v8_pow below).  Valid for positive normal x, any y with |y| <= 2^31.
+#ifdef LHIP_HOSTSIM
+static inline
+#else
+static __host__ __device__ __forceinline__
+#endif
+PowBase pow_log2_parts(double x) {
     const double bp[2] = {1.0, 1.5}, dp_h[2] = {0.0, 5.84962487220764160156e-01},
                  dp_l[2] = {0.0, 1.35003920212974897128e-08};
     const double L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01, L3 = 3.33333329818377432918e-01,
@@ -290,6 +295,17 @@ LHIP_DEV double v8_pow_base(const PowBase& pb, double y) {
         if (hy == 0x3fe00000) return d_sqrt(pb.x);
     }
     if (iy > 0x41e00000) return hy > 0 ? 1.0e300 * 1.0e300 : 1.0e-300 * 1.0e-300;          // |y| > 2^31 with x > 1: overflow / underflow
+    return v8_pow_from_parts(y, pb.t1, pb.t2);
+}
+
+// Math.pow(x, y) for x >= 0 finite and 0 < y < 1 (NS_INTERP of the psychoacoustic model, PsyModel.js:828-842: x a ratio of thresholds,
+// y a share of the bit reservoir): the engine's shortcuts that can occur there (x = 0, x = 1, y = 0.5 -> sqrt), else its general algorithm.
+LHIP_DEV double v8_pow_from_parts(double y, double t1, double t2);
+LHIP_DEV double v8_pow(double x, double y) {
+    if (x == 0.0) return 0.0;
+    if (x == 1.0) return 1.0;
+    if (y == 0.5) return d_sqrt(x);
+    const PowBase pb = pow_log2_parts(x);
     return v8_pow_from_parts(y, pb.t1, pb.t2);
 }
 

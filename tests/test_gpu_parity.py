@@ -21,9 +21,9 @@ def lib():
     return l
 
 
-def _encode(ch, kbps, L, R, chunk, sr=44100, joint=False):
+def _encode(ch, kbps, L, R, chunk, sr=44100, joint=False, reservoir=False):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, joint=joint)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, joint=joint, reservoir=reservoir)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -169,6 +169,34 @@ def test_gpu_stage_taps_joint_stereo(lib, corpus, sr, kbps, nfr):
     import pcm, stage_taps
     L, R = pcm.CORPORA[corpus](1152 * nfr, 2)
     assert stage_taps.compare_stages(None, 2, sr, kbps, L, R, joint=True) == []
+
+
+def test_gpu_bit_reservoir_matches_reference_goldens(lib, golden_resv):
+    """SURVEY.md 8f #4 (extension flag `reservoir`): every bit-reservoir golden -- the reference's own encoder core with
+    gfp.disable_reservoir = false (tests/tools/gen_golden_resv.js) -- byte for byte on the GPU: 41 streams, mono / stereo / joint
+    stereo, MPEG-1 / 2 / 2.5, resampling, main_data_begin up to 511, one-call and many-call chunking, flush."""
+    n = 0
+    for case in golden_resv:
+        L, R = load_case_pcm(case)
+        mp3 = _encode(case["channels"], case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100), joint=bool(case.get("joint")), reservoir=True)
+        assert len(mp3) == case["mp3_len"], case
+        assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
+        n += 1
+    assert n >= 41
+
+
+def test_gpu_bit_reservoir_stream_batch(lib):
+    """128 streams side by side with the reservoir in use (the parallelism that mode has) == every stream through the oracle."""
+    import lamejs_amd
+    import pcm
+    from oracle_py import oracle_encode
+    streams = [pcm.bursts(1152 * (20 + i % 7) + 37 * i, 1, seed=5000 + i)[0] for i in range(128)]
+    encs = [lamejs_amd.Mp3Encoder(1, 44100, 128, reservoir=True) for _ in streams]
+    got = lamejs_amd.encode_streams(encs, streams)
+    for i, (s_, g) in enumerate(zip(streams, got)):
+        if i % 8 == 0:
+            assert g == oracle_encode(1, 44100, 128, s_, reservoir=True), i
+    assert all(len(g) > 0 for g in got)
 
 
 def test_gpu_reference_fixture_md5s(lib, golden):

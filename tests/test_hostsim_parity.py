@@ -20,9 +20,9 @@ def sim():
     return lib
 
 
-def _encode(lib, ch, kbps, L, R, chunk, sr=44100, joint=False):
+def _encode(lib, ch, kbps, L, R, chunk, sr=44100, joint=False, reservoir=False):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint, reservoir=reservoir)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -59,6 +59,31 @@ def test_hostsim_matches_joint_stereo_goldens(sim, golden_joint):
         n += 1
         ms += case["ms_frames"]
     assert n >= 18 and ms >= 2000
+
+
+def test_hostsim_matches_bit_reservoir_goldens(sim, golden_resv):
+    """SURVEY.md 8f #4 (extension): the kernel logic with the bit reservoir in use -- frame-at-a-time launches, the reservoir-dependent
+    pre-echo control, on_pe, ResvFrameEnd, main_data_begin and the continuous stream with lazily inserted headers, the stream flush --
+    against the reference's own reservoir output (mono / stereo / joint stereo, MPEG-1 / 2 / 2.5, resampling, many-call chunking)."""
+    n = 0
+    for case in golden_resv:
+        if case["nsamples"] > 1152 * 300:
+            continue
+        L, R = load_case_pcm(case)
+        mp3 = _encode(sim, case["channels"], case["kbps"], L, R, case["chunk"], case.get("samplerate", 44100), joint=bool(case.get("joint")), reservoir=True)
+        assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
+        n += 1
+    assert n >= 25
+
+
+def test_hostsim_bit_reservoir_stream_batch(sim):
+    """Many streams side by side with the reservoir in use (the only parallelism that mode has) == every stream on its own."""
+    import lamejs_amd, pcm
+    streams = [pcm.bursts(1152 * (5 + 2 * i) + 100 * i, 1, seed=3000 + i)[0] for i in range(5)]
+    encs = [lamejs_amd.Mp3Encoder(1, 44100, 128, lib=sim, reservoir=True) for _ in streams]
+    got = lamejs_amd.encode_streams(encs, streams)
+    for s_, g in zip(streams, got):
+        assert g == oracle_encode(1, 44100, 128, s_, reservoir=True)
 
 
 def test_hostsim_batch_streams_match_single(sim):

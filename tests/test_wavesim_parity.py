@@ -25,9 +25,9 @@ def wsim():
     return lib
 
 
-def _encode(lib, ch, kbps, L, R, chunk, sr=44100, joint=False):
+def _encode(lib, ch, kbps, L, R, chunk, sr=44100, joint=False, reservoir=False):
     import lamejs_amd
-    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
+    enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint, reservoir=reservoir)
     out = b""
     for p in range(0, len(L), chunk):
         out += enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk])
@@ -80,6 +80,20 @@ def test_wavesim_joint_stereo_matches_oracle(wsim, corpus, sr, kbps, nfr, chunk)
     L, R = pcm.CORPORA[corpus](1152 * nfr, 2)
     got = _encode(wsim, 2, kbps, L, R, chunk, sr, joint=True)
     assert got == oracle_encode(2, sr, kbps, L, R, joint=True)
+
+
+@pytest.mark.parametrize("corpus,ch,sr,kbps,nfr,chunk,joint", [
+    ("bursts", 2, 44100, 128, 16, 1152 * 4, False),
+    ("bursts", 1, 22050, 64, 12, 777, False),
+    ("centre_bursts", 2, 44100, 128, 10, 1152 * 10, True),      # joint stereo + reservoir: LAME's own default combination
+])
+def test_wavesim_bit_reservoir_matches_oracle(wsim, corpus, ch, sr, kbps, nfr, chunk, joint):
+    """SURVEY.md 8f #4 (extension): the 64-lane wave programs with the bit reservoir in use against the oracle (pinned to the
+    reference's reservoir output, tests/test_oracle_golden.py)."""
+    import pcm
+    L, R = pcm.CORPORA[corpus](1152 * nfr, ch)
+    got = _encode(wsim, ch, kbps, L, R, chunk, sr, joint=joint, reservoir=True)
+    assert got == oracle_encode(ch, sr, kbps, L, R, joint=joint, reservoir=True)
 
 
 def test_wavesim_quiet_and_edge_material(wsim):
