@@ -49,6 +49,9 @@ PRESETS = {
     # (a frame-by-frame mixture of mid/side and left/right frames)
     "joint": dict(label="joint-stereo extension, correlated channels", ch=2, kbps=128, streams=1, frames=100000, corpus="centre_sine", seed0=12345, joint=True),
     "joint_bursts": dict(label="joint-stereo extension, bursts material", ch=2, kbps=128, streams=1, frames=100000, corpus="bursts", seed0=777, joint=True),
+    # bit-reservoir extension: the frames of a stream are a serial chain there (one frame per stream and launch), so
+    # the shape that uses the GPU is many streams side by side -- BASELINE configs[4]'s 128 streams x 1000 frames
+    "reservoir": dict(label="bit-reservoir extension", ch=1, kbps=128, streams=128, frames=1000, corpus="sine", seed0=1000, reservoir=True),
 }
 
 
@@ -61,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint' or 'joint_bursts'")
+    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint', 'joint_bursts' or 'reservoir'")
     ap.add_argument("--frames", type=int, default=0, help="override frames per stream (parity table then only covers a prefix check)")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -110,7 +113,7 @@ def main():
     tpath = ROOT / "tests" / "golden" / "full_md5.json"
     if tpath.exists():
         for e in json.loads(tpath.read_text())["entries"]:
-            table[(e["corpus"], e["channels"], e["kbps"], e["frames"], e["seed"], bool(e.get("joint")))] = (e["md5"], e["bytes"])
+            table[(e["corpus"], e["channels"], e["kbps"], e["frames"], e["seed"], bool(e.get("joint")), bool(e.get("reservoir")))] = (e["md5"], e["bytes"])
 
     pcm_cache = {}
 
@@ -128,7 +131,7 @@ def main():
         def __init__(self, key):
             p = dict(PRESETS[key])
             self.key = key
-            self.ch, self.kbps, self.corpus, self.joint = p["ch"], p["kbps"], p["corpus"], bool(p.get("joint"))
+            self.ch, self.kbps, self.corpus, self.joint, self.resv = p["ch"], p["kbps"], p["corpus"], bool(p.get("joint")), bool(p.get("reservoir"))
             self.ns = args.streams or p["streams"]
             self.nfr = args.frames or p["frames"]
             self.full = (self.nfr == p["frames"])
@@ -138,13 +141,13 @@ def main():
             # table blob: rank 0 builds it with the host JavaScript, everyone receives it over RCCL (setup, untimed)
             if world > 1:
                 from lamejs_amd.shard import broadcast_blob
-                self.blob = broadcast_blob(dist, lamejs_amd.tables_blob(self.ch, SR, self.kbps, self.joint) if rank == 0 else None, dev, rank)
+                self.blob = broadcast_blob(dist, lamejs_amd.tables_blob(self.ch, SR, self.kbps, self.joint, self.resv) if rank == 0 else None, dev, rank)
             else:
-                self.blob = lamejs_amd.tables_blob(self.ch, SR, self.kbps, self.joint)
+                self.blob = lamejs_amd.tables_blob(self.ch, SR, self.kbps, self.joint, self.resv)
             self.bbuf = ctypes.create_string_buffer(self.blob, len(self.blob))
             self.cfg = lamejs_amd._Config(self.ch, SR, self.kbps, dev_ord)
             self.pcs = [get_pcm(self.corpus, self.nsamp, self.ch, s) for s in self.seeds]
-            self.out_cap = (self.nfr + 4) * (144000 * self.kbps // SR + 1)
+            self.out_cap = (self.nfr + 4) * (144000 * self.kbps // SR + 1) + (8192 if self.resv else 0)
             self.d_out = [torch.empty(self.out_cap, dtype=torch.uint8, device=dev) for _ in range(self.ns)]
             NS = self.ns
             self.HN = ctypes.c_void_p * NS
@@ -213,7 +216,7 @@ def main():
             md5s = [hashlib.md5(o).hexdigest() for o in outs]
             full = None
             if self.full:
-                ent = [table.get((self.corpus, self.ch, self.kbps, self.nfr, s, self.joint)) for s in self.seeds]
+                ent = [table.get((self.corpus, self.ch, self.kbps, self.nfr, s, self.joint, self.resv)) for s in self.seeds]
                 if all(e is not None for e in ent):
                     full = all(e[0] == m and e[1] == len(o) for e, m, o in zip(ent, md5s, outs))
             prefix = None
@@ -221,7 +224,7 @@ def main():
                 from oracle_py import oracle_encode
                 k = min(args.check_frames, self.nfr - 2)
                 L, R = self.pcs[0][0], self.pcs[0][1]
-                ref = oracle_encode(self.ch, SR, self.kbps, L[: 1152 * k], R[: 1152 * k] if self.ch == 2 else None, flush=False, joint=self.joint)
+                ref = oracle_encode(self.ch, SR, self.kbps, L[: 1152 * k], R[: 1152 * k] if self.ch == 2 else None, flush=False, joint=self.joint, reservoir=self.resv)
                 prefix = bool(outs[0][: len(ref)] == ref)
             return full, prefix, md5s
 
@@ -241,7 +244,7 @@ def main():
             return kern
 
         def describe(self):
-            shape = f"{'joint stereo' if self.joint else 'stereo' if self.ch == 2 else 'mono'} 44.1kHz {self.kbps}kbps CBR, {self.ns} stream(s) x {self.nfr} synthetic {self.corpus} frames per GPU"
+            shape = f"{'joint stereo' if self.joint else 'stereo' if self.ch == 2 else 'mono'} 44.1kHz {self.kbps}kbps CBR{' with the bit reservoir' if self.resv else ''}, {self.ns} stream(s) x {self.nfr} synthetic {self.corpus} frames per GPU"
             return f"{self.label}: {shape}" if self.full and not args.streams else shape
 
     key = args.config if args.config in PRESETS else int(args.config)
@@ -333,7 +336,7 @@ def main():
     # ---- the other configurations (N = 1 only): each is its own short run, md5-checked like the main one ----
     if world == 1 and not args.no_extras and not args.frames and not args.streams:
         others = {}
-        for k2 in (2, 3, 4, 5, "bursts", "joint", "joint_bursts"):
+        for k2 in (2, 3, 4, 5, "bursts", "joint", "joint_bursts", "reservoir"):
             if k2 == key:
                 continue
             w2 = Workload(k2)

@@ -144,46 +144,49 @@ LHIP_DEV int put_ancillary(const Tables& T, uint32_t* w, int pos, int remaining,
     for (; remaining >= 1; remaining -= 1) { put_bits(w, pos, (uint32_t)*flag, 1); pos += 1; *flag ^= (!T.disable_reservoir ? 1 : 0); }
     return pos;
 }
-// append `nbytes` bytes of the LDS image (from byte `from`) to the stream: before every byte, a header whose frame starts at the
-// current stream position is inserted (putbits2's check); returns the bytes written to `out`.  One lane.
-LHIP_DEV int resv_emit(const uint32_t* w, int from, int nbytes, int sideinfo_len, ResvState& rv, uint8_t* out, int n) {
+// append `nbytes` bytes of the LDS image (from byte `from`) to the stream: wherever the stream position reaches the start of a
+// frame whose header waits in the queue, that header + side info goes in first (putbits2's check before every byte).  The wave
+// copies the pieces between such points in parallel; the verdict (stream position, queue read pointer) is stored by lane 0 after
+// everybody has read the old one.  Returns the bytes written to `out` so far.
+LHIP_DEV int resv_emit(const uint32_t* w, int from, int nbytes, int sideinfo_len, ResvState& rv, uint8_t* out, int n, int lane) {
     int64_t totbit = rv.totbit;
     int wp = rv.w_ptr;
-    for (int i = 0; i < nbytes; i++) {
-        if (rv.timing[wp] == totbit) {
-            for (int b = 0; b < sideinfo_len; b++) out[n++] = rv.header[wp][b];
-            totbit += 8 * sideinfo_len;
+    wave_sync_global();
+    for (int i = 0; i < nbytes;) {
+        const int64_t gap = (rv.timing[wp] - totbit) >> 3;                // bytes until the next waiting header is due
+        if (gap == 0) {
+            for (int b = lane; b < sideinfo_len; b += LHIP_NL) out[n + b] = rv.header[wp][b];
+            n += sideinfo_len; totbit += 8 * sideinfo_len;
             wp = (wp + 1) & (RESV_HQ - 1);
+            continue;
         }
-        const int bi = from + i;
-        out[n++] = (uint8_t)(w[bi >> 2] >> (24 - 8 * (bi & 3)));
-        totbit += 8;
+        const int seg = (gap > 0 && gap < nbytes - i) ? (int)gap : nbytes - i;
+        for (int b = lane; b < seg; b += LHIP_NL) { const int bi = from + i + b; out[n + b] = (uint8_t)(w[bi >> 2] >> (24 - 8 * (bi & 3))); }
+        n += seg; i += seg; totbit += 8 * (int64_t)seg;
     }
-    rv.totbit = totbit; rv.w_ptr = wp;
+    wave_sync_global();
+    if (lane == 0) { rv.totbit = totbit; rv.w_ptr = wp; }
     return n;
 }
 // flush_bitstream (BitStream.js:710-780): pad the stream with ancillary data up to the end of the last frame; one wave per stream
 LHIP_DEV void kb_resv_flush(const Tables& T, const Workspace& W, int st, int lane, BitsLds& L) {
     ResvState& rv = W.io[st].state->rv;
     for (int i = lane; i < BITS_LDS_WORDS; i += LHIP_NL) L.w[i] = 0;
-    wave_sync();
-    if (lane == 0) {
-        const int last_ptr = (rv.h_ptr - 1) & (RESV_HQ - 1), first_ptr = rv.w_ptr;
-        int64_t flushbits = rv.timing[last_ptr] - rv.totbit;
-        if (flushbits >= 0) {
-            const int remaining_headers = ((last_ptr - first_ptr) & (RESV_HQ - 1)) + 1;
-            flushbits -= (int64_t)remaining_headers * 8 * T.sideinfo_len;
-        }
-        flushbits += rv.last_frame_bits;                         // getframebits: with the last frame's padding
-        if (flushbits >= 0) {
-            int flag = rv.ancillary_flag;
-            put_ancillary(T, L.w, 0, (int)flushbits, &flag);
-            rv.ancillary_flag = flag;
-            W.out_bytes[st] = resv_emit(L.w, 0, (int)(flushbits >> 3), T.sideinfo_len, rv, W.io[st].out, W.out_bytes[st]);
-            rv.ResvSize = 0;
-            rv.main_data_begin = 0;
-        }
+    wave_sync_global();
+    const int last_ptr = (rv.h_ptr - 1) & (RESV_HQ - 1), first_ptr = rv.w_ptr;
+    int64_t flushbits = rv.timing[last_ptr] - rv.totbit;
+    if (flushbits >= 0) {
+        const int remaining_headers = ((last_ptr - first_ptr) & (RESV_HQ - 1)) + 1;
+        flushbits -= (int64_t)remaining_headers * 8 * T.sideinfo_len;
     }
+    flushbits += rv.last_frame_bits;                             // getframebits: with the last frame's padding
+    if (flushbits < 0) return;
+    int flag = rv.ancillary_flag;
+    if (lane == 0) put_ancillary(T, L.w, 0, (int)flushbits, &flag);
+    wave_sync_global();
+    const int n = resv_emit(L.w, 0, (int)(flushbits >> 3), T.sideinfo_len, rv, W.io[st].out, W.out_bytes[st], lane);
+    wave_sync_global();
+    if (lane == 0) { rv.ancillary_flag = flag; W.out_bytes[st] = n; rv.ResvSize = 0; rv.main_data_begin = 0; }
 }
 
 LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L) {
@@ -318,21 +321,25 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
         const int main_end = pos;
         if (lane == 0) put_ancillary(T, L.w, pos, fr.drain_post, &anc_flag);
         wave_sync();
-        if (lane == 0) {
+        {
             ResvState& rv = W.io[st].state->rv;
             const int sl = T.sideinfo_len;
             const int old = rv.h_ptr;
-            for (int b = 0; b < sl; b++) rv.header[old][b] = (uint8_t)(L.w[b >> 2] >> (24 - 8 * (b & 3)));
-            rv.h_ptr = (old + 1) & (RESV_HQ - 1);
-            rv.timing[rv.h_ptr] = rv.timing[old] + frame_bits;
+            wave_sync_global();
+            for (int b = lane; b < sl; b += LHIP_NL) rv.header[old][b] = (uint8_t)(L.w[b >> 2] >> (24 - 8 * (b & 3)));
+            if (lane == 0) { rv.h_ptr = (old + 1) & (RESV_HQ - 1); rv.timing[(old + 1) & (RESV_HQ - 1)] = rv.timing[old] + frame_bits; }
+            wave_sync_global();
             const int chunk_bits = main_end + fr.drain_post - 8 * sl;            // a whole number of bytes (ResvFrameEnd's stuffing)
-            W.out_bytes[st] = resv_emit(L.w, sl, chunk_bits >> 3, sl, rv, W.io[st].out, 0);
-            const int bits = main_end - fr.drain_pre + fr.drain_post;          // header + side info + main data + drain_post
-            rv.main_data_begin = fr.main_data_begin + (double)(frame_bits - bits) / 8;
-            rv.ResvSize = fr.ResvSize; rv.ResvMax = fr.ResvMax; rv.ancillary_flag = anc_flag; rv.last_frame_bits = frame_bits;
-            for (int i = 0; i < 18; i++) rv.pefirbuf[i] = rv.pefirbuf[i + 1];
-            rv.pefirbuf[18] = fr.pefir_new;
-            W.frame_bytes[fidx] = W.out_bytes[st];
+            const int nout = resv_emit(L.w, sl, chunk_bits >> 3, sl, rv, W.io[st].out, 0, lane);
+            if (lane == 0) {
+                const int bits = main_end - fr.drain_pre + fr.drain_post;      // header + side info + main data + drain_post
+                rv.main_data_begin = fr.main_data_begin + (double)(frame_bits - bits) / 8;
+                rv.ResvSize = fr.ResvSize; rv.ResvMax = fr.ResvMax; rv.ancillary_flag = anc_flag; rv.last_frame_bits = frame_bits;
+                for (int i = 0; i < 18; i++) rv.pefirbuf[i] = rv.pefirbuf[i + 1];
+                rv.pefirbuf[18] = fr.pefir_new;
+                W.out_bytes[st] = nout;
+                W.frame_bytes[fidx] = nout;
+            }
         }
         return;
     }

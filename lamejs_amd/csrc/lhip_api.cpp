@@ -946,7 +946,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #endif
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
       if (pair) LAUNCHB(KT_QUANT, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
-    if (nfr > 0) {
+    if (nfr > 0 && !resv) {   // (bit reservoir: one frame per stream and launch, its seed is the carried one -- nothing is speculated)
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
         LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
@@ -1149,6 +1149,7 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
         const size_t step = (size_t)576 * T0.mode_gr * T0.rs_ratio;
         std::vector<size_t> pos(n, 0);
         std::vector<int64_t> done(n, 0);
+        int64_t frames_all = 0;
         for (;;) {
             std::vector<Job> sub; std::vector<size_t> idx;
             for (size_t i = 0; i < n; i++) {
@@ -1161,6 +1162,7 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
             bool last = true;                      // the stream flush rides on the launch that takes every stream's last samples
             for (size_t q = 0; q < idx.size(); q++) if (pos[idx[q]] + sub[q].n < ns[idx[q]]) last = false;
             ok = run_batch(streams[0]->ctx, sub, dev_io, true, flush_stream && last && idx.size() == n);
+            if (ok) frames_all += g_stat_frames;
             for (size_t q = 0; q < idx.size(); q++) {
                 const size_t i = idx[q];
                 if (!ok) { jobs[i].written = sub[q].written < 0 ? sub[q].written : LHIP_ERR_INTERNAL; continue; }
@@ -1171,6 +1173,7 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
             if (!ok) break;
             if (flush_stream && last && idx.size() == n) break;
         }
+        g_stat_frames = frames_all;                  // lhip_last_batch_stats speaks for the whole call
         (void)sync;
     } else
         ok = run_batch(streams[0]->ctx, jobs, dev_io, sync);

@@ -8,6 +8,7 @@ namespace lhip {
 #if defined(LHIP_HOSTSIM) && LHIP_NL == 1
 struct Wave { int lane; };
 LHIP_DEV void wave_sync() {}
+LHIP_DEV void wave_sync_global() {}
 LHIP_DEV int wave_sum(int v) { return v; }
 template <int N> LHIP_DEV void wave_sum_n(int (&v)[N]) { (void)v; }
 template <int N> LHIP_DEV void wave_max_n(int (&v)[N]) { (void)v; }
@@ -167,6 +168,7 @@ template <class T> inline T from_bits(uint64_t u) { T v; memcpy(&v, &u, sizeof v
 }  // namespace wsim
 struct Wave { int lane; };
 LHIP_DEV void wave_sync() { uint64_t a[64]; wsim::exchange(1, 0, a); }
+LHIP_DEV void wave_sync_global() { wave_sync(); }
 LHIP_DEV void wg_barrier() { wsim::block_barrier(); }                  // __syncthreads of a multi-wave workgroup
 LHIP_DEV int wave_sum(int v) { uint64_t a[64]; wsim::exchange(2, (uint64_t)(uint32_t)v, a); int s = 0; for (int l = 0; l < 64; l++) s += (int)(uint32_t)a[l]; return s; }
 template <int N> LHIP_DEV void wave_sum_n(int (&v)[N]);
@@ -225,6 +227,13 @@ LHIP_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the same hand-over point for data that lanes pass to each other through GLOBAL memory (the reservoir's header queue): the stores
+// are made visible beyond the CU's vector cache and later loads do not reuse lines cached before
+LHIP_DEV void wave_sync_global() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // Integer reductions over the 64 lanes (all lanes active: the kernels call them under wave-uniform control flow): four DPP row
 // shifts leave each row's total in its last lane, row_bcast:15 / row_bcast:31 carry the totals into the later rows, lane 63 ends

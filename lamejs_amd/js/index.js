@@ -12,7 +12,9 @@
  * GPU efficiency comes from batching: pass many frames per encodeBuffer() call (the reference API
  * already allows any length).  There is no CPU fallback.
  * Extension: new Mp3Encoder(2, sampleRate, kbps, { jointStereo: true }) encodes in the reference core's joint-stereo mode (per frame
- * mid/side or left/right), which the reference's own wrapper never selects (index.js:105 hard-codes MPEGMode.STEREO).
+ * mid/side or left/right), which the reference's own wrapper never selects (index.js:105 hard-codes MPEGMode.STEREO); { reservoir: true }
+ * uses the bit reservoir (index.js:108 switches it off).  With the reservoir the frames of a stream are a serial chain -- a launch
+ * encodes one frame per stream -- so that mode only uses the GPU well through encodeBatch() over many streams.
  */
 'use strict';
 const path = require('path');

@@ -14,11 +14,11 @@ NODE = shutil.which("node")
 ADDON = ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node"
 
 
-def _run(env_lib, corpus, ch, kbps, nfr, chunk, sr=44100, joint=False):
+def _run(env_lib, corpus, ch, kbps, nfr, chunk, sr=44100, joint=False, reservoir=False):
     env = dict(os.environ)
     if env_lib:
         env["LAMEJS_HIP_LIB"] = str(env_lib)
-    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk), str(sr)] + (["joint"] if joint else []),
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_dropin_check.js"), corpus, str(ch), str(kbps), str(nfr), str(chunk), str(sr)] + (["joint"] if joint else []) + (["reservoir"] if reservoir else []),
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -64,6 +64,31 @@ def test_js_joint_stereo_extension_hostsim(golden_joint):
     subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
     for c in _joint_cases(golden_joint):
         got = _run(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", c["corpus"], 2, c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100), joint=True)
+        assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
+
+
+def _resv_cases(golden_resv):
+    pick = [c for c in golden_resv if (c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c.get("samplerate", 44100), bool(c.get("joint"))) in
+            (("bursts", 2, 128, 400, 44100, False), ("sine", 1, 128, 300, 44100, False), ("centre_bursts", 2, 64, 150, 22050, True))]
+    assert len(pick) == 3
+    return pick
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_bit_reservoir_extension_hostsim(golden_resv):
+    """new Mp3Encoder(ch, sr, kbps, { reservoir: true }) == the reference core with gfp.disable_reservoir = false (golden_resv.json)."""
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    for c in _resv_cases(golden_resv):
+        got = _run(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100),
+                   joint=bool(c.get("joint")), reservoir=True)
+        assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_bit_reservoir_extension_gpu(golden_resv):
+    for c in _resv_cases(golden_resv):
+        got = _run(None, c["corpus"], c["channels"], c["kbps"], c["nsamples"] // 1152, c["chunk"], c.get("samplerate", 44100), joint=bool(c.get("joint")), reservoir=True)
         assert got["md5"] == c["mp3_md5"] and got["bytes"] == c["mp3_len"], c
 
 

@@ -51,7 +51,7 @@ RESAMPLE_CFGS = [(1, 44100, 32), (2, 44100, 48), (1, 48000, 24), (2, 48000, 64),
                  (1, 48000, 40), (1, 48000, 8), (2, 48000, 40), (2, 32000, 40), (1, 32000, 24), (2, 16000, 24)]
 
 
-def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False):
+def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False):
     """Returns the list of mismatching case descriptions (empty = parity).  joint: the joint-stereo extension on the two-channel
     configurations; the material (same draws as tests/tools/fuzz_ref.py joint) has strongly correlated channels in half of the cases."""
     rng = np.random.default_rng(seed)
@@ -69,13 +69,13 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False):
             d = R.astype(np.int32) >> k
             L, R = (np.clip(L.astype(np.int32) + d, -32768, 32767).astype(np.int16), np.clip(L.astype(np.int32) - d, -32768, 32767).astype(np.int16))
         try:
-            enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
+            enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint, reservoir=reservoir)
         except lamejs_amd.LhipError as e:
             print("skip", ch, sr, kbps, str(e)[:60]); continue
         chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
         got = b"".join(enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk]) for p in range(0, len(L), chunk)) + enc.flush()
         enc.close()
-        want = oracle_encode(ch, sr, kbps, L, R, joint=joint)
+        want = oracle_encode(ch, sr, kbps, L, R, joint=joint, reservoir=reservoir)
         ok = got == want
         if not ok:
             d = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
@@ -88,12 +88,12 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False):
 
 
 def main():
-    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample] [hostsim] [joint]"""
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample] [hostsim] [joint] [reservoir]"""
     cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else MPEG1_CFGS
     lib = None
     if "hostsim" in sys.argv[3:]:
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))
-    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs, joint="joint" in sys.argv[3:])
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs, joint="joint" in sys.argv[3:], reservoir="reservoir" in sys.argv[3:])
     sys.exit(1 if bad else 0)
 
 

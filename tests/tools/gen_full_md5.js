@@ -6,7 +6,7 @@
  * Every job prints one JSON line; tests/tools/gen_full_md5.sh runs the job list in parallel and merges the lines into
  * tests/golden/full_md5.json.
  *
- *   node tests/tools/gen_full_md5.js <corpus> <channels> <kbps> <frames> <seed0> [nseeds] [joint]
+ *   node tests/tools/gen_full_md5.js <corpus> <channels> <kbps> <frames> <seed0> [nseeds] [joint] [reservoir]
  * corpus centre_<x>: L = A + (B >> 3), R = A - (B >> 3) of corpus x; joint: the reference's modules driven with gfp.mode = JOINT_STEREO
  * (ref_harness.js refEncoder) -- the joint-stereo extension, SURVEY.md 8f #3.
  */
@@ -17,7 +17,8 @@ const gen = require('./pcm_gen.js');
 const lamejs = refPublic();
 
 const corpus = process.argv[2], ch = parseInt(process.argv[3]), kbps = parseInt(process.argv[4]), frames = parseInt(process.argv[5]);
-const seed0 = parseInt(process.argv[6]), nseeds = parseInt(process.argv[7] || '1'), joint = process.argv[8] === 'joint';
+const seed0 = parseInt(process.argv[6]), nseeds = parseInt(process.argv[7] || '1'), flags = process.argv.slice(8);
+const joint = flags.includes('joint'), resv = flags.includes('reservoir');      /* reservoir: gfp.disable_reservoir = false (SURVEY.md 8f #4) */
 const base = corpus.replace('centre_', ''), centre = corpus.startsWith('centre_');
 const CHUNK = 1152 * 500;
 
@@ -43,7 +44,7 @@ function makeSource(corpus, ch, seed) {
 }
 
 for (let s = seed0; s < seed0 + nseeds; s++) {
-    const src = makeSource(corpus, ch, s), enc = joint ? refEncoder(ch, 44100, kbps, { jointStereo: true }) : new lamejs.Mp3Encoder(ch, 44100, kbps), h = crypto.createHash('md5');
+    const src = makeSource(corpus, ch, s), enc = (joint || resv) ? refEncoder(ch, 44100, kbps, { jointStereo: joint, reservoir: resv }) : new lamejs.Mp3Encoder(ch, 44100, kbps), h = crypto.createHash('md5');
     let bytes = 0;
     for (let left = 1152 * frames; left > 0;) {
         const n = Math.min(left, CHUNK);
@@ -54,5 +55,6 @@ for (let s = seed0; s < seed0 + nseeds; s++) {
     }
     const row = { corpus, channels: ch, samplerate: 44100, kbps, frames, seed: s, flush: false, bytes, md5: h.digest('hex') };
     if (joint) row.joint = 1;
+    if (resv) row.reservoir = 1;
     console.log(JSON.stringify(row));
 }

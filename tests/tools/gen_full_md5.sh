@@ -14,14 +14,15 @@ TMP=$(mktemp -d)
   for b in $(seq 0 31); do echo "sine 1 128 1000 $((1000 + 32 * b)) 32"; done  # config 5 (configs[4]): 1024 streams, seed 1000 + s
   for s in $(seq 12345 12352); do echo "centre_sine 2 128 100000 $s 1 joint"; done   # joint-stereo extension: every frame mid/side
   echo "bursts 2 128 100000 777 1 joint"                                        # joint-stereo extension: mid/side and left/right frames mixed
+  for b in $(seq 0 7); do echo "sine 1 128 1000 $((1000 + 16 * b)) 16 reservoir"; done   # bit-reservoir extension: 128 mono streams x 1000 frames (config 5 shape, rank 0)
 } > $TMP/jobs
-nl -ba $TMP/jobs | xargs -P $P -L 1 sh -c 'node tests/tools/gen_full_md5.js $1 $2 $3 $4 $5 $6 $7 > '$TMP'/out.$0'
+nl -ba $TMP/jobs | xargs -P $P -L 1 sh -c 'node tests/tools/gen_full_md5.js $1 $2 $3 $4 $5 $6 $7 $8 > '$TMP'/out.$0'
 python3 - "$TMP" "$OUT" <<'PY'
 import glob, json, sys
 rows = []
 for f in sorted(glob.glob(sys.argv[1] + "/out.*")):
     rows += [json.loads(l) for l in open(f) if l.strip()]
-rows.sort(key=lambda r: (r["corpus"], r["channels"], r["kbps"], r["frames"], r["seed"], r.get("joint", 0)))
+rows.sort(key=lambda r: (r["corpus"], r["channels"], r["kbps"], r["frames"], r["seed"], r.get("joint", 0), r.get("reservoir", 0)))
 json.dump({"generator": "tests/tools/gen_full_md5.sh (unmodified reference under node, encodeBuffer of the whole stream, no flush)", "entries": rows},
           open(sys.argv[2], "w"), indent=0)
 print("wrote", len(rows), "entries")
