@@ -21,6 +21,9 @@
  * blob may carry mode = 1 (tables.js buildBlob(..., { jointStereo: true })): the stream is then encoded in the reference core's
  * joint-stereo mode -- per frame mid/side or left/right (Encoder.js:520-561) -- byte for byte what the reference's own modules
  * produce when asked for MPEGMode.JOINT_STEREO.  Nothing in the signatures below changes.
+ * Bit reservoir.  Likewise disable_reservoir = 0 in the blob ({ reservoir: true }; index.js:108 hard-codes it off): the frames of a
+ * stream then depend on each other (budget and masking), so the library encodes one frame per stream per launch -- batches of many
+ * streams are what uses the GPU -- the byte count of a call is data-dependent, and every call synchronises (sync = 0 is ignored).
  *
  * Semantics preserved: any chunking of the same sample stream yields the same bytes; a call
  * returns the bytes of all whole frames completed by that call (possibly 0); errors are negative
