@@ -32,8 +32,16 @@ for case in json.load(open(ROOT + "/tests/golden/golden_joint.json"))["cases"]: 
     for p in range(0, len(L), case["chunk"]): out += e.encodeBuffer(L[p:p + case["chunk"]], R[p:p + case["chunk"]])
     out += e.flush(); e.close()
     assert hashlib.md5(out).hexdigest() == case["mp3_md5"], case
+for case in json.load(open(ROOT + "/tests/golden/golden_resv.json"))["cases"]:     # bit-reservoir extension: the reference core with disable_reservoir = false
+    if case["nsamples"] > 1152 * 400: continue
+    L, R = load_case_pcm(case)
+    e = lamejs_amd.Mp3Encoder(case["channels"], case.get("samplerate", 44100), case["kbps"], lib=lib, joint=bool(case.get("joint")), reservoir=True); out = b""
+    for p in range(0, len(L), case["chunk"]): out += e.encodeBuffer(L[p:p + case["chunk"]], None if R is None else R[p:p + case["chunk"]])
+    out += e.flush(); e.close()
+    assert hashlib.md5(out).hexdigest() == case["mp3_md5"], case
 import fuzz_gpu, large_frames, stage_taps
 assert fuzz_gpu.run(40, 9001, lib=lib, verbose=False, joint=True) == []
+assert fuzz_gpu.run(30, 7001, lib=lib, verbose=False, reservoir=True) == []
 L, R = pcm.bursts(1152 * 40, 2); assert stage_taps.compare_stages(lib, 2, 44100, 128, L, R, joint=True) == []
 assert fuzz_gpu.run(60, 2024, lib=lib, verbose=False) == []
 assert fuzz_gpu.run(60, 31, lib=lib, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []
@@ -59,7 +67,7 @@ PY
 )
 (cd $B && gcov -b -o . liblamejs_hostsim_cov.so-lhip_api.gcda > gcov_all.txt 2>/dev/null || gcov -b -o . $(ls *.gcda | head -1) > gcov_all.txt 2>/dev/null)
 {
-  echo "# line / branch coverage of the kernel bodies under the one-lane host simulation (tools/gcov_hostsim.sh), material: every golden of the envelope and of the joint-stereo extension,"
+  echo "# line / branch coverage of the kernel bodies under the one-lane host simulation (tools/gcov_hostsim.sh), material: every golden of the envelope and of the joint-stereo and bit-reservoir extensions,"
   echo "# 150 random cases (MPEG-1, LSF, resampling), largest-frame noise, stage-tap runs, silence / square wave, forced seed repair, device-math edge classes"
   awk '/^File /{f=$2} /^Lines executed/{l=$0} /^Branches executed/{b=$0} /^Taken at least once/{t=$0; if (f ~ /k_psy|k_fb|k_quant|k_bits|lhip_math|lhip_wave|lhip_api/) print f "\n   " l "\n   " b "\n   " t}' $B/gcov_all.txt
 } > $OUT
