@@ -1969,7 +1969,9 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
 // PAIR == 1 (latency path for small stereo batches, g_quant_pair): the workgroup is two waves, wave `my_ch` does that
 // channel only -- the channels of a granule are independent given the granule's bit budget -- and the two meet once per
 // granule to exchange the bits they used (ResvSize feeds the next granule's budget) through `mbox` in LDS.
-template <int PAIR = 0>
+// RESV == 1: the bit-reservoir extension (Tables::disable_reservoir == 0) -- a separate instantiation, so that the usual path carries none
+// of its state (the entropies, the reservoir record) through the frame
+template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
                        int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr) {
     const int C = T.channels_out;
@@ -1998,13 +2000,13 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     const int mode_ext = (T.mode == 1) ? q_ms_decision(T, W, sd, k, lane, L) : 0;      // joint stereo: this frame M/S (2) or L/R (0)
     // Bit reservoir (extension): the frame starts from the reservoir the previous frame left (one frame per stream and launch), its
     // budget follows the perceptual entropies (on_pe), and ResvFrameEnd's verdict goes to the bit packer, which commits it.
-    const bool resv = !T.disable_reservoir;
+    constexpr bool resv = RESV != 0;
     const ResvState* rv = resv ? &W.io[st].state->rv : nullptr;
     int ResvSize = resv ? uni(rv->ResvSize) : 0;
     int ResvMax = 0;
     double pe_use[2][2] = {{0., 0.}, {0., 0.}};
     float pefir_new = 0.f;
-    if (resv) {
+    if constexpr (resv) {
         // ResvFrameBegin (Reservoir.js:130-180; brate <= 320, not strict_ISO)
         const int frameLength = frame_bits_of(T, padding), resvLimit = (8 * 256) * T.mode_gr - 8, maxmp3buf = 8 * 1440;
         ResvMax = maxmp3buf - frameLength;
@@ -2105,7 +2107,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             ResvSize = uni(ResvSize - (mbox[2 * gr] + mbox[2 * gr + 1]));
         }
     }
-    if (resv && lane == 0 && (!PAIR || my_ch == 0)) {
+    if constexpr (resv) if (lane == 0 && (!PAIR || my_ch == 0)) {
         // ResvFrameEnd (Reservoir.js:243-293); main_data_begin is a double there (fractions of a byte survive in it)
         const double mdb0 = rv->main_data_begin;
         int rs = ResvSize + mean_bits * T.mode_gr, over_bits, stuffingBits = 0;

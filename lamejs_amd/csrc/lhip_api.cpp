@@ -272,7 +272,7 @@ LHIP_DEV int next_frame_slot(int32_t* ctr) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 struct QArgs { Tables T; PowBase pb; Workspace W; const StreamDesc* SD; int chain, nfs, ctr; };
-__global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused) {
+template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused
     for (;;) {
         const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
         if (fslot >= A->nfs) break;
-        kb_quant(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q);
+        kb_quant<0, RESV>(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q);
     }
 #ifdef LHIP_PHASE_PROF
     atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused
 // Latency path for small stereo batches: one workgroup of two waves per frame, one wave per channel (kb_quant<1>).  A single
 // frame is one wave's serially dependent search; with fewer frames than SIMDs the chip is idle anyway, so the two channels
 // of a granule -- independent given the granule's bit budget -- run side by side.
-__global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pair(QArgs a_unused) {
+template <int RESV> __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pair(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[2];
     __shared__ int mbox[4];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pair(QArgs a_unused) {
     q_load_tabs(A->T, Q, threadIdx.x, 128);
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    kb_quant<1>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
+    kb_quant<1, RESV>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
 }
 __global__ __launch_bounds__(256) void g_validate_fast(Tables T, Workspace W, const StreamDesc* SD, int nfs) {
     const int fslot = blockIdx.x * 256 + threadIdx.x;
@@ -866,10 +866,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         static QuantLds LQ2[2]; static int mbox[4];
         static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : 12; }();
         const bool pair = (C == 2 && nfs <= pair_max);
-#define QUANT_RUN(chain_) do { if (pair) wsim::run_block(2, [&](int wave_, int lane_) { kb_quant<1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); }); \
-                               else WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT)); } while (0)
+#define QUANT_RUN(chain_) do { if (pair) wsim::run_block(2, [&](int wave_, int lane_) { if (resv) kb_quant<1, 1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); else kb_quant<1, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); }); \
+                               else WAVE_RUN(resv ? kb_quant<0, 1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT) : kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT)); } while (0)
 #else
-#define QUANT_RUN(chain_) WAVE_RUN(kb_quant(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
+#define QUANT_RUN(chain_) WAVE_RUN(resv ? kb_quant<0, 1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT) : kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
 #endif
         for (int b = 0; b < nfs; b++) QUANT_RUN(0);
         for (;;) {
@@ -945,7 +945,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     const bool pair = (C == 2 && nfs <= (pair_max >= 0 ? pair_max : 6 * ctx->num_cus));
 #endif
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
-      if (pair) LAUNCHB(KT_QUANT, g_quant_pair, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant, qgrid, 64 * QWAVES, st, qa); }
+      if (resv) { if (pair) LAUNCHB(KT_QUANT, g_quant_pair<1>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<1>, qgrid, 64 * QWAVES, st, qa); }
+      else { if (pair) LAUNCHB(KT_QUANT, g_quant_pair<0>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<0>, qgrid, 64 * QWAVES, st, qa); } }
     if (nfr > 0 && !resv) {   // (bit reservoir: one frame per stream and launch, its seed is the carried one -- nothing is speculated)
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;

@@ -24,6 +24,9 @@ def counters(d):
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
         k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]                      # templated kernels are printed with their return type
+        k = k.split("<")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     return {k: {c: v / max(len(disp[k]), 1) for c, v in cs.items()} for k, cs in acc.items()}, {k: len(v) for k, v in disp.items()}
