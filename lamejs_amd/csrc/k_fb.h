@@ -162,8 +162,57 @@ template <int ROW> LHIP_DEV void poly_slot(const Tables& T, const float* xt, flo
     }
     for (int i = 0; i < 32; i++) out[i] = a[i];
 }
+// `cnt` (<= POLY_PER_WAVE) consecutive granule slots gs, gs + 1, ... of ONE stream, channel ch: one transposed staging serves them all
+LHIP_DEV void kb_poly_run(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int gs, int ch, int cnt, int lane, PolyLds& L) {
+    const int C = T.channels_out;
+    const int lo = POLY_BIAS - 286;                           // samples before the stream segment are never used
+    const int stg = W.gslot_stream[gs];
+    const StreamDesc sd = SD[stg];
+    const int q = gs - sd.gslot0 - 1;
+    if (q < 0) return;                                        // carry slot: nothing to compute
+    const PcmSrc P = pcm_source(T, W, sd, IO[stg], ch);
+    const int s0 = 576 * q + 286 - POLY_BIAS;                 // segment index of staging slot 0 (slots below `lo` lie before the segment)
+    const int n_need = POLY_N1 + 576 * (cnt - 1);
+    wave_sync();
+    if (!P.plane && s0 + lo >= P.mf) {                        // wave-uniform usual case: everything staged is new Int16 input
+        const int16_t* src = P.src + (s0 - P.mf);
+        for (int n = lane; n < n_need; n += LHIP_NL) {
+            float v = 0.f;
+            if (n >= lo) { v = (float)src[n]; if (P.do_scale) v = (float)((double)v * P.scale); }
+            L.xs[(n & 31) * POLY_ROW + (n >> 5)] = v;
+        }
+    } else {
+        for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? pcm_at(P, s0 + n) : 0.f;
+    }
+    wave_sync();
+#if LHIP_NL == 1
+    for (int u = lane; u < 18 * cnt; u += LHIP_NL) {
+        const int it = u / 18, j = u - 18 * it;
+        float a[32];
+        poly_slot<POLY_ROW>(T, L.xs + u, a, j);
+        float* out = W.sb + ((int64_t)(gs + it) * C + ch) * SB_STRIDE + j * 32;
+        for (int i = 0; i < 32; i++) out[i] = a[i];
+    }
+#else
+    // every lane holds one slot (32 values); stored from the registers, a lane would write 128 bytes at a 128-byte stride from
+    // its neighbours'.  Through LDS (the PCM window is no longer needed; rows padded to 33 against bank conflicts) the wave
+    // writes each item's 2304 bytes as consecutive 256-byte rows instead.
+    {
+        const int u = lane, it = u / 18, j = u - 18 * it;      // 18 * cnt <= 54 < 64: one slot per lane
+        float a[32];
+        if (u < 18 * cnt) poly_slot<POLY_ROW>(T, L.xs + u, a, j);
+        wave_sync();
+        if (u < 18 * cnt) for (int i = 0; i < 32; i++) L.xs[u * 33 + i] = a[i];
+        wave_sync();
+        for (int k = 0; k < cnt; k++) {
+            float* out = W.sb + ((int64_t)(gs + k) * C + ch) * SB_STRIDE;
+            for (int i = lane; i < SB_STRIDE; i += LHIP_NL) out[i] = L.xs[(18 * k + (i >> 5)) * 33 + (i & 31)];
+        }
+    }
+#endif
+}
 LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int wave_idx, int nitems, int lane, PolyLds& L) {
-    const int C = T.channels_out, ngs = W.ngslots;
+    const int ngs = W.ngslots;
     const int item0 = wave_idx * POLY_PER_WAVE;
     const int nit = (nitems - item0) < POLY_PER_WAVE ? (nitems - item0) : POLY_PER_WAVE;
     // item -> (channel, granule slot), channel-major
@@ -176,56 +225,12 @@ LHIP_DEV void kb_polyphase(const Tables& T, const Workspace& W, const StreamDesc
         const int item = item0 + it, ch = item / ngs, gs = item - ch * ngs;
         if (ch != ch0 || gs != g0 + it || W.gslot_stream[gs] != st0) together = 0;
     }
-    const int lo = POLY_BIAS - 286;                           // samples before the stream segment are never used
     // one pass over all items when they share a staging, else one pass per item (single instance of the slot code)
     const int npass = together ? 1 : nit;
     for (int ps = 0; ps < npass; ps++) {
         const int itA = together ? 0 : ps, cnt = together ? nit : 1;
         const int item = item0 + itA, ch = item / ngs, gs = item - ch * ngs;
-        const int stg = W.gslot_stream[gs];
-        const StreamDesc sd = SD[stg];
-        const int q = gs - sd.gslot0 - 1;
-        if (q < 0) continue;                                   // carry slot: nothing to compute
-        const PcmSrc P = pcm_source(T, W, sd, IO[stg], ch);
-        const int s0 = 576 * q + 286 - POLY_BIAS;              // segment index of staging slot 0 (slots below `lo` lie before the segment)
-        const int n_need = POLY_N1 + 576 * (cnt - 1);
-        wave_sync();
-        if (!P.plane && s0 + lo >= P.mf) {                     // wave-uniform usual case: everything staged is new Int16 input
-            const int16_t* src = P.src + (s0 - P.mf);
-            for (int n = lane; n < n_need; n += LHIP_NL) {
-                float v = 0.f;
-                if (n >= lo) { v = (float)src[n]; if (P.do_scale) v = (float)((double)v * P.scale); }
-                L.xs[(n & 31) * POLY_ROW + (n >> 5)] = v;
-            }
-        } else {
-            for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? pcm_at(P, s0 + n) : 0.f;
-        }
-        wave_sync();
-#if LHIP_NL == 1
-        for (int u = lane; u < 18 * cnt; u += LHIP_NL) {
-            const int it = u / 18, j = u - 18 * it;
-            float a[32];
-            poly_slot<POLY_ROW>(T, L.xs + u, a, j);
-            float* out = W.sb + ((int64_t)(gs + it) * C + ch) * SB_STRIDE + j * 32;
-            for (int i = 0; i < 32; i++) out[i] = a[i];
-        }
-#else
-        // every lane holds one slot (32 values); stored from the registers, a lane would write 128 bytes at a 128-byte stride from
-        // its neighbours'.  Through LDS (the PCM window is no longer needed; rows padded to 33 against bank conflicts) the wave
-        // writes each item's 2304 bytes as consecutive 256-byte rows instead.
-        {
-            const int u = lane, it = u / 18, j = u - 18 * it;      // 18 * cnt <= 54 < 64: one slot per lane
-            float a[32];
-            if (u < 18 * cnt) poly_slot<POLY_ROW>(T, L.xs + u, a, j);
-            wave_sync();
-            if (u < 18 * cnt) for (int i = 0; i < 32; i++) L.xs[u * 33 + i] = a[i];
-            wave_sync();
-            for (int k = 0; k < cnt; k++) {
-                float* out = W.sb + ((int64_t)(gs + k) * C + ch) * SB_STRIDE;
-                for (int i = lane; i < SB_STRIDE; i += LHIP_NL) out[i] = L.xs[(18 * k + (i >> 5)) * 33 + (i & 31)];
-            }
-        }
-#endif
+        kb_poly_run(T, W, SD, IO, gs, ch, cnt, lane, L);
     }
 }
 

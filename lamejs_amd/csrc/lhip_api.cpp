@@ -123,16 +123,17 @@ LHIP_DEV void kb_resample_elem(const Tables& T, float* dst, const int16_t* src, 
 
 // Resampling configurations only: the new output-rate samples of every stream, grid-stride over (stream, channel, sample).
 // (Without resampling nothing is materialised: the consumers convert the caller's Int16 where they stage it, PcmSrc.)
-LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int nstreams, int64_t tid, int64_t nthreads) {
+LHIP_DEV void kb_prep_stream(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int64_t tid, int64_t nthreads) {
     const int C = T.channels_out;
-    for (int st = 0; st < nstreams; st++) {
-        const StreamIO io = IO[st];
-        const int64_t off = SD[st].pcm_off + io.mf_size;
-        for (int ch = 0; ch < C; ch++) {
-            float* dst = W.pcm + (int64_t)ch * W.pcm_plane + off;
-            for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, io.src[ch], io.state->rs_old[ch], io.rs_p0, i);
-        }
+    const StreamIO io = IO[st];
+    const int64_t off = SD[st].pcm_off + io.mf_size;
+    for (int ch = 0; ch < C; ch++) {
+        float* dst = W.pcm + (int64_t)ch * W.pcm_plane + off;
+        for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, io.src[ch], io.state->rs_old[ch], io.rs_p0, i);
     }
+}
+LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int nstreams, int64_t tid, int64_t nthreads) {
+    for (int st = 0; st < nstreams; st++) kb_prep_stream(T, W, SD, IO, st, tid, nthreads);
 }
 
 LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
@@ -207,6 +208,61 @@ LHIP_DEV void math_op8(const double* in, double* out) {
     q_floor_fma(xa, xb, istep, ja, jb, va, vb);
     out[0] = 0;
     for (int k = 0; k < 5; k++) { out[1 + k] = ra[k]; out[6 + k] = rb[k]; out[11 + k] = va[k]; out[16 + k] = vb[k]; }
+}
+
+// ===========================================================================================
+// One frame per stream in ONE launch (small batches: the drop-in's own 1152-sample call pattern, and every launch of the bit-reservoir
+// mode).  A batch of one frame per stream is a chain of thirteen tiny kernels otherwise, each waiting for the one before it: the
+// gaps between dependent launches cost as much as the frame's quantization.  Here a workgroup of FR_WAVES waves takes a stream
+// through all stages, a workgroup barrier between them; every stage is the same kb_* body the separate kernels run, so the bytes
+// cannot differ.  The LDS of a wave is a union of the stages' structures.
+// ===========================================================================================
+enum { FS_LOAD, FS_PREP, FS_PSYA, FS_PSYA_MS, FS_SCAN_RAW, FS_SCAN_ATTACK, FS_SCAN_BT, FS_PSYB0, FS_PSYB1, FS_POLY, FS_MDCT, FS_QUANT, FS_BITS, FS_SAVE,
+       FR_STAGES, FR_LDS_PER_WAVE = (sizeof(PolyLds) + 15) & ~15 };
+static_assert(sizeof(PsyALds) <= FR_LDS_PER_WAVE && sizeof(PsyBLds4) <= FR_LDS_PER_WAVE && sizeof(MdctLds) <= FR_LDS_PER_WAVE &&
+              sizeof(QuantLds) <= FR_LDS_PER_WAVE && sizeof(BitsLds) <= FR_LDS_PER_WAVE, "frame kernel: the per-wave LDS union is sized by PolyLds");
+// stage `stage` of the frame program for wave `wv` (of `nw`) of the workgroup that owns stream `st`.  PAIRQ: stereo quantization by
+// two waves (kb_quant<1>, which meets once per granule at a workgroup barrier: the other waves keep the barrier count).
+template <int RESV, int PAIRQ>
+LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO,
+                             int st, int wv, int nw, int lane, unsigned char* lds, QuantTabs& Q, int* mbox) {
+    const int C = T.channels_out, Cp = T.psy_channels, GR = T.mode_gr;
+    const StreamDesc sd = SD[st];
+    const bool has = sd.nframes > 0;                          // this launch completes a frame of the stream (else only the state moves)
+    const int g1 = sd.gslot0 + 1, fslot = sd.fslot0 + 1;
+    switch (stage) {
+        case FS_LOAD: if (wv == 0) kb_load(T, W, SD, IO, st, lane); break;
+        case FS_PREP: if (T.rs_ratio != 1) kb_prep_stream(T, W, SD, IO, st, (int64_t)wv * LHIP_NL + lane, (int64_t)nw * LHIP_NL); break;
+        case FS_PSYA: if (has && wv < GR * C) kb_psyA(T, W, SD, IO, g1 + wv / C, wv % C, lane, *(PsyALds*)lds); break;
+        case FS_PSYA_MS: if (has && Cp == 4 && wv < GR * 2) kb_psyA(T, W, SD, IO, g1 + wv / 2, 2 + wv % 2, lane, *(PsyALds*)lds); break;
+        case FS_SCAN_RAW: if (has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_raw(T, W, SD, g1 + g); break;
+        case FS_SCAN_ATTACK: if (has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_attack(T, W, SD, g1 + g); break;
+        case FS_SCAN_BT:
+            if (has && wv == 0) {
+                for (int g = lane; g < GR; g += LHIP_NL) kb_scan_blocktype(T, W, SD, g1 + g);
+                if (lane == 0) {                              // adjust_ATH of the one frame (Encoder.js:166-243)
+                    double a = W.ath_adjust[sd.fslot0], l = W.ath_limit[sd.fslot0];
+                    ath_step(T, ath_max_pow(T, W, sd, C, 0), a, l);
+                    W.ath_adjust[fslot] = a; W.ath_limit[fslot] = l;
+                }
+            }
+            break;
+        case FS_PSYB0:   // bit reservoir: the frame's granules one after the other (FS_PSYB1 takes the second)
+            if (has && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds);
+            break;
+        case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds); break;
+        case FS_POLY: if (has && wv < C) kb_poly_run(T, W, SD, IO, g1, wv, GR, lane, *(PolyLds*)lds); break;
+        case FS_MDCT: if (has && wv < GR) kb_mdct(T, W, SD, g1 + wv, lane, *(MdctLds*)lds); break;
+        case FS_QUANT:
+            if (PAIRQ && C == 2) {
+                if (has && wv < 2) kb_quant<1, RESV>(T, pb, W, SD, fslot, 0, lane, *(QuantLds*)lds, Q, wv, mbox);
+                else for (int gr = 0; gr < GR; gr++) wg_barrier();
+            } else if (has && wv == 0) kb_quant<0, RESV>(T, pb, W, SD, fslot, 0, lane, *(QuantLds*)lds, Q);
+            break;
+        case FS_BITS: if (has && wv == 0) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds); break;
+        case FS_SAVE: if (wv == 0) kb_save(T, W, SD, IO, st, lane); break;
+        default: break;
+    }
 }
 
 // ===========================================================================================
@@ -411,6 +467,20 @@ __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const Stream
 __global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W) {
     __shared__ BitsLds L;
     kb_resv_flush(T, W, blockIdx.x, threadIdx.x, L);
+}
+// one workgroup per stream, one frame per stream (see kb_frame_stage); NW = 4 waves, 8 in joint stereo (two granules x four psy channels)
+template <int RESV, int NW> __global__ __launch_bounds__(64 * NW) void g_frame(QArgs a_unused, const StreamIO* IO) {
+    __shared__ QuantTabs Q;
+    __shared__ __attribute__((aligned(16))) unsigned char U[NW][FR_LDS_PER_WAVE];
+    __shared__ int mbox[4];
+    const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    q_load_tabs(A->T, Q, threadIdx.x, 64 * NW);
+    __syncthreads();
+    for (int stage = 0; stage < FR_STAGES; stage++) {
+        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, NW, lane, U[wv], Q, mbox);
+        __syncthreads();
+    }
 }
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
 enum { KT_LOAD, KT_PREP, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
@@ -729,7 +799,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // ---- plan ----
     std::vector<StreamDesc> sd(S);
     std::vector<StreamIO> io(S);
-    int nfs = 0, ngs = 0, nfr = 0;
+    int nfs = 0, ngs = 0, nfr = 0, maxF = 0;
     int64_t pcm_plane = 0, in_total = 0, out_total = 0;
     for (int i = 0; i < S; i++) {
         Job& j = jobs[i];
@@ -751,6 +821,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         d.pcm_off = pcm_plane; d.out_off = out_total; d.seg_len = (int)total; d.first_call = s->frame_num == 0;
         d.slot_lag = s->slot_lag; d.frame_num0 = s->frame_num;
         nfs += j.F + 1; ngs += GR * j.F + 1; nfr += j.F;
+        if (j.F > maxF) maxF = j.F;
         pcm_plane += (total + 63) & ~(int64_t)63;
         in_total += (int64_t)j.n; out_total += (j.bytes + 15) & ~(int64_t)15;
     }
@@ -838,6 +909,9 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.io = dIO;
 
     int64_t repaired = 0, iters = 0;
+    // at most one frame per stream: the whole frame program in one launch (kb_frame_stage); LAMEJS_HIP_NO_FRAME_KERNEL=1 keeps the separate kernels
+    static const bool no_frame = []() { const char* e = getenv("LAMEJS_HIP_NO_FRAME_KERNEL"); return e && e[0] == '1'; }();
+    const bool use_frame = maxF <= 1 && !no_frame;
 #ifdef LHIP_HOSTSIM
     {
         // WAVE_RUN: one wave of a kernel body.  Scalar simulation: the body runs once with lane 0 (NL = 1); wave simulation
@@ -849,6 +923,29 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #endif
         static PsyALds LA; static PsyBLds4 LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
         q_load_tabs(T, QT, 0, 1);
+        if (use_frame) {
+            // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
+            const int NW = T.psy_channels == 4 ? 8 : 4;
+            static unsigned char UL[8][FR_LDS_PER_WAVE]; static int fmbox[4];
+            for (int s = 0; s < S; s++) {
+#ifdef LHIP_WAVESIM
+                wsim::run_block(NW, [&](int wave_, int lane_) {
+                    for (int stage = 0; stage < FR_STAGES; stage++) {
+                        if (resv) kb_frame_stage<1, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox);
+                        else kb_frame_stage<0, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox);
+                        wg_barrier();
+                    }
+                });
+#else
+                for (int stage = 0; stage < FR_STAGES; stage++)
+                    for (int wv = 0; wv < NW; wv++) {
+                        if (resv) kb_frame_stage<1, 0>(stage, T, ts.pb10, W, dSD, dIO, s, wv, 1, 0, UL[wv], QT, fmbox);
+                        else kb_frame_stage<0, 0>(stage, T, ts.pb10, W, dSD, dIO, s, wv, 1, 0, UL[wv], QT, fmbox);
+                    }
+#endif
+            }
+            if (resv && flush_stream) for (int s = 0; s < S; s++) WAVE_RUN(kb_resv_flush(T, W, s, lane_, LBi));
+        } else {
         for (int s = 0; s < S; s++) WAVE_RUN(kb_load(T, W, dSD, dIO, s, lane_));
         if (T.rs_ratio != 1) kb_prep(T, W, dSD, dIO, S, 0, 1);
         for (int b = 0; b < ngs * C; b++) WAVE_RUN(kb_psyA(T, W, dSD, dIO, b / C, b % C, lane_, LA));
@@ -885,10 +982,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < nfs; b++) WAVE_RUN(kb_bits(T, W, dSD, b, lane_, LBi));
         if (resv && flush_stream) for (int s = 0; s < S; s++) WAVE_RUN(kb_resv_flush(T, W, s, lane_, LBi));
         for (int s = 0; s < S; s++) WAVE_RUN(kb_save(T, W, dSD, dIO, s, lane_));
+        }
 #undef QUANT_RUN
 #undef WAVE_RUN
     }
 #else
+    if (use_frame) {
+        QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
+        if (T.psy_channels == 4) { if (resv) LAUNCHB(KT_QUANT, (g_frame<1, 8>), S, 512, st, qa, dIO); else LAUNCHB(KT_QUANT, (g_frame<0, 8>), S, 512, st, qa, dIO); }
+        else { if (resv) LAUNCHB(KT_QUANT, (g_frame<1, 4>), S, 256, st, qa, dIO); else LAUNCHB(KT_QUANT, (g_frame<0, 4>), S, 256, st, qa, dIO); }
+        if (resv && flush_stream) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W);
+    } else {
     LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);
     if (T.rs_ratio != 1) {          // only the resampler materialises samples; otherwise the consumers convert the caller's Int16 themselves
         int64_t nb = (in_total / C + 255) / 256;
@@ -969,6 +1073,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_BITS, g_bits, nfs, st, T, W, dSD);
     if (resv && flush_stream) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W);
     LAUNCH(KT_SAVE, g_save, S, st, T, W, dSD, dIO);
+    }
 #endif
 #ifndef LHIP_HOSTSIM
     // repair statistics live on the device; they travel with the final synchronisation when there is one, else they are fetched

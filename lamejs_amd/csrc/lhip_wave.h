@@ -52,7 +52,7 @@ template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) { double s =
 #include <functional>
 namespace lhip {
 namespace wsim {
-enum { NLANES = 64, MAXWAVES = 2, NFIB = NLANES * MAXWAVES, STACK = 1 << 20 };   // a workgroup of up to two waves
+enum { NLANES = 64, MAXWAVES = 8, NFIB = NLANES * MAXWAVES, STACK = 1 << 20 };   // a workgroup of up to eight waves (the frame kernel in joint stereo)
 // Context switch between the scheduler and a lane fiber.  x86-64: six callee-saved registers and the stack pointer (glibc's
 // swapcontext also saves the signal mask -- a system call per switch, and a wave program switches ~10^4 times per frame);
 // elsewhere ucontext.
