@@ -911,7 +911,9 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     int64_t repaired = 0, iters = 0;
     // at most one frame per stream: the whole frame program in one launch (kb_frame_stage); LAMEJS_HIP_NO_FRAME_KERNEL=1 keeps the separate kernels
     static const bool no_frame = []() { const char* e = getenv("LAMEJS_HIP_NO_FRAME_KERNEL"); return e && e[0] == '1'; }();
-    const bool use_frame = maxF <= 1 && !no_frame;
+    // (one workgroup per stream at one wave per SIMD: beyond one stream per CU the separate kernels, each at full occupancy, are faster --
+    //  bit-reservoir mode over 2048 streams: 0.7 M frames/s with this kernel, measured; the launch set of the separate kernels costs ~0.5 ms whatever S)
+    const bool use_frame = maxF <= 1 && !no_frame && S <= ctx->num_cus;
 #ifdef LHIP_HOSTSIM
     {
         // WAVE_RUN: one wave of a kernel body.  Scalar simulation: the body runs once with lane 0 (NL = 1); wave simulation
