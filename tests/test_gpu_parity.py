@@ -197,6 +197,15 @@ def test_gpu_bit_reservoir_stream_batch(lib):
         if i % 8 == 0:
             assert g == oracle_encode(1, 44100, 128, s_, reservoir=True), i
     assert all(len(g) > 0 for g in got)
+    # more streams than CUs: the launches take the separate kernels instead of the one-launch frame program (both orders of magnitude
+    # of batch are then covered); and the same without the reservoir, where such a batch is one frame per stream as well
+    streams = [pcm.bursts(1152 * 3 + 11 * (i % 13), 1, seed=6000 + i)[0] for i in range(300)]
+    for resv in (True, False):
+        encs = [lamejs_amd.Mp3Encoder(1, 44100, 128, reservoir=resv) for _ in streams]
+        got = lamejs_amd.encode_streams(encs, [s_[:1152 + 700] for s_ in streams], flush=False)       # first call: one frame per stream
+        got2 = lamejs_amd.encode_streams(encs, [s_[1152 + 700:] for s_ in streams])
+        for i in range(0, 300, 23):
+            assert got[i] + got2[i] == oracle_encode(1, 44100, 128, streams[i], reservoir=resv), (resv, i)
 
 
 def test_gpu_reference_fixture_md5s(lib, golden):
