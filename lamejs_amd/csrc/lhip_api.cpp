@@ -812,7 +812,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         j.bytes = batch_bytes(ts, s->slot_lag, j.F);
         if (resv) {
             if (j.F > 1) { set_err("internal: more than one frame per launch with the bit reservoir"); return false; }
-            j.bytes = (int64_t)j.F * (ts.base_frame_bytes + 1 + 512 + 4 * RESV_HDR) + (flush_stream ? 1440 + 8 * RESV_HDR : 0);      // upper bound; the real count comes back from the device
+            j.bytes = (int64_t)j.F * (ts.base_frame_bytes + 1 + 512 + RESV_HQ * RESV_HDR) + (flush_stream ? 1440 + RESV_HQ * RESV_HDR : 0);      // upper bound; the real count comes back from the device
         }
         if ((size_t)j.bytes > j.cap) { j.written = LHIP_ERR_BUFFER_TOO_SMALL; set_err("output buffer too small"); return false; }
         StreamDesc& d = sd[i];

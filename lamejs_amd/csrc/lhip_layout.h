@@ -41,7 +41,8 @@ enum { RS_TAPS = 33 };
 // in use (Reservoir.js, BitStream.js:100-215, Encoder.js:600-626, PsyModel.js:1036-1038, 1300-1318).  A frame's bit budget, and through
 // `pcfact` even its masking thresholds, depend on the bits all earlier frames spent: a stream is then a serial chain of frames, so
 // a launch encodes ONE frame per stream and reads / updates this record directly (parallelism is across streams only).
-enum { RESV_HQ = 8, RESV_HDR = 40 };             // pending headers: at most ceil(ResvMax / smallest frame) + 1 = 5 wait at any time
+enum { RESV_HQ = 16, RESV_HDR = 40 };            // pending headers: at most ceil(ResvMax / smallest frame) + 1 wait at any time -- 7 for the
+                                                 // smallest frames of the envelope (48 bytes: 12 kHz, 8 kbps); the reference's ring holds 256
 struct ResvState {
     int32_t ResvSize, ResvMax;                   // after the last frame's ResvFrameEnd / ResvFrameBegin
     int32_t ancillary_flag, h_ptr, w_ptr, last_frame_bits;      // last_frame_bits: getframebits of the last frame (its padding), for the flush
