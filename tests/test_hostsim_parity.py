@@ -140,6 +140,10 @@ def test_hostsim_asan_largest_frames():
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "large_frames.py"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim_asan.so")],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    # the extension modes (joint stereo, bit reservoir) and the one-frame-per-stream frame program under the same sanitizer build
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "asan_modes.py"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim_asan.so")],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("ch,sr,kbps,nfr", [(2, 44100, 128, 40), (1, 22050, 64, 40)])
