@@ -55,6 +55,157 @@ PRESETS = {
 }
 
 
+def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank, sim, dsync, table):
+    """--config shard3: ONE stream (stereo 44.1 kHz 128 kbps, 1e5 frames, seed 12345) cut into `world` frame
+    ranges that the ranks encode side by side (second mode; strong scaling).  The encoder state at a cut is speculated
+    (lhip_seek + H warm-up frames), verified (the state blob after the warm-up must equal the blob of the rank that encoded up to
+    the cut) and, on a miss, transplanted from that rank and the range encoded again -- so the concatenation is always byte for
+    byte what one stream produces; it is checked against the reference's md5 of the whole stream."""
+    import lamejs_amd
+    import pcm
+    ch, kbps, corpus, seed, H = 2, 128, args.shard_corpus, 12345, args.shard_warmup
+    nfr = args.frames or 100000
+    fs = 1152
+    L, R = pcm.CORPORA[corpus](fs * nfr, ch, seed=seed)
+    dl, dr = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+    cuts = [fs * ((r * nfr) // world) for r in range(world + 1)]
+    cuts[-1] = fs * nfr
+    a, b = cuts[rank], cuts[rank + 1]
+    if world > 1:
+        from lamejs_amd.shard import broadcast_blob
+        blob = broadcast_blob(dist, lamejs_amd.tables_blob(ch, SR, kbps) if rank == 0 else None, dev, rank)
+    else:
+        blob = lamejs_amd.tables_blob(ch, SR, kbps)
+    bbuf = ctypes.create_string_buffer(blob, len(blob))
+    cfg = lamejs_amd._Config(ch, SR, kbps, dev_ord)
+    cap = ((b - a) // fs + H + 8) * (144000 * kbps // SR + 1)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_scr = torch.empty((H + 8) * (144000 * kbps // SR + 1), dtype=torch.uint8, device=dev)
+    lib.lhip_state_bytes.restype = ctypes.c_size_t
+    lib.lhip_state_bytes.argtypes = [ctypes.c_void_p]
+    lib.lhip_state_get.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.lhip_state_set.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.lhip_seek.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.lhip_seek_tail_samples.restype = ctypes.c_size_t
+    lib.lhip_seek_tail_samples.argtypes = [ctypes.c_void_p]
+
+    def new_stream():
+        h = ctypes.c_void_p()
+        assert lib.lhip_create(ctypes.byref(cfg), bbuf, len(blob), ctypes.byref(h)) == 0, lib.lhip_last_error()
+        return h
+
+    def encode(h, p0, p1, out):
+        wr = (ctypes.c_int64 * 1)()
+        HN, SN = ctypes.c_void_p * 1, ctypes.c_size_t * 1
+        rc = lib.lhip_encode_batch_device(HN(h), 1, HN(dl.data_ptr() + 2 * p0), HN(dr.data_ptr() + 2 * p0), SN(p1 - p0), HN(out.data_ptr()), SN(out.numel()), wr, 1)
+        assert rc == 0, lib.lhip_last_error()
+        return int(wr[0])
+
+    def state(h):
+        n = int(lib.lhip_state_bytes(h))
+        buf = ctypes.create_string_buffer(n)
+        assert lib.lhip_state_get(h, buf, n) == 0, lib.lhip_last_error()
+        return buf.raw
+
+    stats = {"state_mismatches": 0, "ranges_encoded_again": 0}
+
+    def one_pass():
+        h = new_stream()
+        s_start = None
+        if rank > 0:
+            p0 = a - H * fs
+            nt = int(lib.lhip_seek_tail_samples(h))
+            if p0 - nt < 0:
+                p0 = 0                                           # a cut this close to the start: the warm-up is the true beginning
+            else:
+                tl, tr = np.ascontiguousarray(L[p0 - nt:p0]), np.ascontiguousarray(R[p0 - nt:p0])
+                assert lib.lhip_seek(h, p0, tl.ctypes.data, tr.ctypes.data) == 0, lib.lhip_last_error()
+            encode(h, p0, a, d_scr)                              # warm-up frames, output discarded
+            s_start = state(h)
+        nb = encode(h, a, b, d_out)
+        s_end = state(h)
+        if world > 1:
+            dig = lambda x: hashlib.md5(x).hexdigest() if x is not None else None
+            allv = [None] * world
+            dist.all_gather_object(allv, (dig(s_start), dig(s_end)))
+            ends = [v[1] for v in allv]
+            starts = [v[0] for v in allv]
+            r = 1
+            while r < world:
+                if starts[r] == ends[r - 1]:
+                    r += 1
+                    continue
+                # rank r guessed wrong: it receives the true state of the cut from rank r - 1 and encodes its range again
+                stats["state_mismatches"] += 1
+                t = torch.frombuffer(bytearray(s_end), dtype=torch.uint8).to(dev) if rank == r - 1 else torch.empty(len(s_end), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, src=r - 1)
+                if rank == r:
+                    lib.lhip_destroy(h)
+                    h = new_stream()
+                    raw = t.cpu().numpy().tobytes()
+                    assert lib.lhip_state_set(h, ctypes.create_string_buffer(raw, len(raw)), len(raw)) == 0, lib.lhip_last_error()
+                    nb = encode(h, a, b, d_out)
+                    s_end = state(h)
+                    stats["ranges_encoded_again"] += 1
+                newv = [None] * world
+                dist.all_gather_object(newv, dig(s_end))
+                ends = newv
+                starts[r] = ends[r - 1]
+                r += 1
+        lib.lhip_destroy(h)
+        return nb
+
+    for _ in range(args.warmup):
+        one_pass()
+    dsync()
+    if world > 1:
+        dist.barrier()
+    dsync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nb = one_pass()
+    dsync()
+    if world > 1:
+        dist.barrier()
+    dsync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # the pieces travel to rank 0 (RCCL gather, untimed) and are hashed as one stream
+    mine = d_out[:nb]
+    whole = None
+    if world > 1:
+        sizes = [None] * world
+        dist.all_gather_object(sizes, nb)
+        nmax = max(sizes)
+        pad = torch.zeros(nmax, dtype=torch.uint8, device=dev)
+        pad[:nb] = mine
+        parts = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, parts, dst=0)
+        if rank == 0:
+            whole = b"".join(parts[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world))
+    else:
+        whole = mine.cpu().numpy().tobytes()
+    allstats = [stats]
+    if world > 1:
+        allstats = [None] * world
+        dist.all_gather_object(allstats, stats)
+    if rank == 0:
+        ent = table.get((corpus, ch, kbps, nfr, seed, False, False))
+        md5 = hashlib.md5(whole).hexdigest()
+        line = {"metric": f"1152-sample frames/s encoded (44.1kHz {kbps}kbps CBR); bit-exact", "value": round((nfr - 1) * args.steps / dt, 1), "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"ONE stream (BASELINE configs[2] material: stereo 44.1kHz 128kbps CBR, {nfr} synthetic {corpus} frames) cut into {world} frame range(s), "
+                                       f"{H} warm-up frames per cut, state verified at every cut",
+                           "bit_exact_full": (None if ent is None else bool(ent[0] == md5 and ent[1] == len(whole))), "output_md5": md5,
+                           "cut_state_mismatches": sum(s_["state_mismatches"] for s_ in allstats) // max(world, 1),
+                           "ranges_encoded_again": sum(s_["ranges_encoded_again"] for s_ in allstats)}}
+        print(json.dumps(line))
+
+
 def alg_bytes_per_frame(ch, kbps):
     return 1152 * ch * 2 + 144000.0 * kbps / SR     # Int16 PCM in + MP3 bytes out (SURVEY.md 8d): 5026 B stereo 128k
 
@@ -64,7 +215,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint', 'joint_bursts' or 'reservoir'")
+    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint', 'joint_bursts', 'reservoir', or 'shard3' (ONE config-3 stream cut into frame ranges over the GPUs: strong scaling)")
+    ap.add_argument("--shard-corpus", default="sine", help="shard3 only: the material (tests/pcm.py); 'bursts' has cuts whose speculated state misses")
+    ap.add_argument("--shard-warmup", type=int, default=8, help="shard3 only: warm-up frames in front of a cut")
     ap.add_argument("--frames", type=int, default=0, help="override frames per stream (parity table then only covers a prefix check)")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -247,6 +400,11 @@ def main():
             shape = f"{'joint stereo' if self.joint else 'stereo' if self.ch == 2 else 'mono'} 44.1kHz {self.kbps}kbps CBR{' with the bit reservoir' if self.resv else ''}, {self.ns} stream(s) x {self.nfr} synthetic {self.corpus} frames per GPU"
             return f"{self.label}: {shape}" if self.full and not args.streams else shape
 
+    if args.config == "shard3":
+        run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank, sim, dsync, table)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     key = args.config if args.config in PRESETS else int(args.config)
     wl = Workload(key)
     dt = wl.timed(args.steps, args.warmup)

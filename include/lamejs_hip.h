@@ -65,6 +65,22 @@ int lhip_device_count(void);
  * device; device -1 = the calling thread's current HIP device).  Returns the number of allowed devices or <0. */
 int lhip_set_devices(uint64_t mask);
 
+/* Frame-range sharding of ONE stream (extension; SURVEY.md 8e, second mode).  A long stream can be cut at frame boundaries and the
+ * pieces encoded side by side (other GPUs, other processes): the state at a cut is SPECULATED -- lhip_seek puts a fresh stream at an
+ * input position with the samples in front of it, a few warm-up frames (output discarded) let the masking history, the
+ * filterbank overlap, the attack / block-type chains, the ATH adjustment and the bin-search seeds converge -- and then VERIFIED:
+ * lhip_state_get of that stream at the cut must equal, byte for byte, lhip_state_get of the stream that encoded up to the cut; if it
+ * does, everything after the cut is what one stream would have produced.  On a miss the true state is transplanted (lhip_state_set)
+ * and the piece is encoded again.  bench.py --config shard3 does exactly that over torch.distributed
+ * (one range per rank; tests/test_shard_gloo.py runs it with two and three ranks, tests/test_hostsim_parity.py the API itself).
+ *   lhip_seek(s, sample_pos, tail_l, tail_r): s fresh; sample_pos a whole number (>= 2) of frames; tail_*: the lhip_seek_tail_samples(s)
+ *   input samples in front of sample_pos (host memory).  Not for resampling or bit-reservoir streams. */
+size_t lhip_state_bytes(const lhip_stream* s);
+int lhip_state_get(lhip_stream* s, void* buf, size_t cap);
+int lhip_state_set(lhip_stream* s, const void* buf, size_t n);
+size_t lhip_seek_tail_samples(const lhip_stream* s);
+int lhip_seek(lhip_stream* s, int64_t sample_pos, const int16_t* tail_left, const int16_t* tail_right);
+
 /* Create an encoder stream.  `tables` is the LHTB blob produced by lamejs_amd/js/tables.js for
  * (channels, samplerate, kbps); it is validated against cfg, uploaded to HBM (shared between
  * streams with identical blobs) and may be freed by the caller on return.  Returns 0 or <0. */

@@ -124,6 +124,42 @@ class Mp3Encoder:
             raise LhipError(f"lhip_create failed ({rc}): {self._lib.lhip_last_error().decode()}")
         self._h = h
 
+    # ---- frame-range sharding of one stream (extension; include/lamejs_hip.h: lhip_seek / lhip_state_get / lhip_state_set) ----
+    def seek_tail_samples(self) -> int:
+        self._lib.lhip_seek_tail_samples.restype = ctypes.c_size_t
+        self._lib.lhip_seek_tail_samples.argtypes = [ctypes.c_void_p]
+        return int(self._lib.lhip_seek_tail_samples(self._h))
+
+    def seek(self, sample_pos: int, tail_left, tail_right=None) -> None:
+        """Put this FRESH encoder at input position ``sample_pos`` (a whole number >= 2 of frames); ``tail_*``: the
+        ``seek_tail_samples()`` input samples in front of that position."""
+        l = _as_i16(tail_left)
+        r = l if (self.channels == 1 or tail_right is None) else _as_i16(tail_right)
+        assert len(l) == self.seek_tail_samples() == len(r)
+        self._lib.lhip_seek.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        rc = self._lib.lhip_seek(self._h, int(sample_pos), l.ctypes.data, r.ctypes.data)
+        if rc != 0:
+            raise LhipError(f"lhip_seek failed ({rc}): {self._lib.lhip_last_error().decode()}")
+
+    def state_get(self) -> bytes:
+        """The complete carried state of the stream (host counters + device record): equal blobs = equal futures."""
+        self._lib.lhip_state_bytes.restype = ctypes.c_size_t
+        self._lib.lhip_state_bytes.argtypes = [ctypes.c_void_p]
+        n = int(self._lib.lhip_state_bytes(self._h))
+        buf = ctypes.create_string_buffer(n)
+        self._lib.lhip_state_get.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        rc = self._lib.lhip_state_get(self._h, buf, n)
+        if rc != 0:
+            raise LhipError(f"lhip_state_get failed ({rc}): {self._lib.lhip_last_error().decode()}")
+        return buf.raw
+
+    def state_set(self, blob: bytes) -> None:
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        self._lib.lhip_state_set.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        rc = self._lib.lhip_state_set(self._h, buf, len(blob))
+        if rc != 0:
+            raise LhipError(f"lhip_state_set failed ({rc}): {self._lib.lhip_last_error().decode()}")
+
     def encodeBuffer(self, left, right=None) -> bytes:
         l = _as_i16(left)
         r = l if (self.channels == 1 or right is None) else _as_i16(right)

@@ -93,7 +93,7 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
         for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[chn][i];
         for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[chn][i];
         for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[chn][i];
-        for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { W.nb1[o * EBL_STRIDE + i] = S->nb1[chn][i]; W.nb2[o * EBL_STRIDE + i] = S->nb2[chn][i]; }
+        if (!T.disable_reservoir) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { W.nb1[o * EBL_STRIDE + i] = S->nb1[chn][i]; W.nb2[o * EBL_STRIDE + i] = S->nb2[chn][i]; }
         if (lane == 0) W.last_attack[o] = S->last_attack[chn];
     }
     if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) W.tot_ener[(int64_t)sd.gslot0 * 4 + i] = S->tot_ener[i];
@@ -174,7 +174,7 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
             for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[chn][i] = W.E[o * E_STRIDE + i];
             for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[chn][i] = W.ecb_s[o * EBS_STRIDE + i];
             for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = W.peaks[o * PK_STRIDE + i];
-            for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { S->nb1[chn][i] = W.nb1[o * EBL_STRIDE + i]; S->nb2[chn][i] = W.nb2[o * EBL_STRIDE + i]; }
+            if (!T.disable_reservoir) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { S->nb1[chn][i] = W.nb1[o * EBL_STRIDE + i]; S->nb2[chn][i] = W.nb2[o * EBL_STRIDE + i]; }
             if (lane == 0) S->last_attack[chn] = W.last_attack[o];
         }
         if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) S->tot_ener[i] = W.tot_ener[(int64_t)(sd.gslot0 + T.mode_gr * F) * 4 + i];
@@ -1374,6 +1374,73 @@ int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* cons
 int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const int16_t* const* d_left, const int16_t* const* d_right,
                              const size_t* nsamples, uint8_t* const* d_out, const size_t* out_cap, int64_t* written, int sync) {
     return encode_many(streams, nstreams, d_left, d_right, nsamples, d_out, out_cap, written, true, sync != 0);
+}
+
+// ---- frame-range sharding of ONE stream (second mode): speculate the state at a cut, verify it, transplant on a miss ----
+struct StateHdr { uint32_t magic, bytes; int32_t mf_size, mf_samples_to_encode, slot_lag, pad_; int64_t frame_num, rs_n_in; };
+size_t lhip_state_bytes(const lhip_stream* s) {
+    if (!s || s->magic != 0x4c484950) return 0;
+    return sizeof(StateHdr) + sizeof(StreamState);
+}
+int lhip_state_get(lhip_stream* s, void* buf, size_t cap) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    if (!buf || cap < lhip_state_bytes(s)) { set_err("state buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
+    Context* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    StateHdr h; memset(&h, 0, sizeof h);
+    h.magic = 0x5453484cu; h.bytes = (uint32_t)lhip_state_bytes(s);
+    h.mf_size = s->mf_size; h.mf_samples_to_encode = s->mf_samples_to_encode; h.slot_lag = s->slot_lag; h.frame_num = s->frame_num; h.rs_n_in = s->rs_n_in;
+    memcpy(buf, &h, sizeof h);
+    if (!rt::set_device(ctx->device) || !rt::d2h((uint8_t*)buf + sizeof h, s->d_state, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    return 0;
+}
+int lhip_state_set(lhip_stream* s, const void* buf, size_t n) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    StateHdr h;
+    if (!buf || n < sizeof h) { set_err("state blob too small"); return LHIP_ERR_INTERNAL; }
+    memcpy(&h, buf, sizeof h);
+    if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
+    Context* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!rt::set_device(ctx->device) || !rt::h2d(s->d_state, (const uint8_t*)buf + sizeof h, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    s->mf_size = h.mf_size; s->mf_samples_to_encode = h.mf_samples_to_encode; s->slot_lag = h.slot_lag; s->frame_num = h.frame_num; s->rs_n_in = h.rs_n_in;
+    return 0;
+}
+size_t lhip_seek_tail_samples(const lhip_stream* s) {
+    if (!s || s->magic != 0x4c484950) return 0;
+    return (size_t)(MF_INIT + 576 * s->ts->T.mode_gr);
+}
+// Put a FRESH stream where a stream that has consumed `sample_pos` input samples stands, as far as that is known without encoding:
+// the buffered samples (the lhip_seek_tail_samples() samples in front of sample_pos), the frame counter and the padding
+// accumulator.  Everything the encoder derives from earlier audio (masking history, filterbank overlap, attack / block-type
+// chains, ATH adjustment, bin-search seeds) starts from its initial value and converges while a few warm-up frames are encoded.
+int lhip_seek(lhip_stream* s, int64_t sample_pos, const int16_t* tail_left, const int16_t* tail_right) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    const Tables& T = s->ts->T;
+    const int frame = 576 * T.mode_gr, ntail = MF_INIT + frame;
+    if (T.rs_ratio != 1 || !T.disable_reservoir) { set_err("lhip_seek: not for resampling or bit-reservoir streams"); return LHIP_ERR_INTERNAL; }
+    if (s->frame_num != 0 || s->mf_size != MF_INIT) { set_err("lhip_seek: the stream has been used"); return LHIP_ERR_INTERNAL; }
+    if (sample_pos < 2 * frame || sample_pos % frame != 0 || !tail_left) { set_err("lhip_seek: position must be a whole number (>= 2) of frames"); return LHIP_ERR_INTERNAL; }
+    Context* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const bool do_scale = !(T.scale == 0.0) && !(T.scale == 1.0);
+    std::vector<float> t((size_t)2 * MF_NEEDED, 0.f);
+    for (int ch = 0; ch < T.channels_out; ch++) {
+        const int16_t* src = (ch == 1 && tail_right) ? tail_right : tail_left;
+        for (int i = 0; i < ntail; i++) { float v = (float)src[i]; if (do_scale) v = (float)((double)v * T.scale); t[(size_t)ch * MF_NEEDED + i] = v; }
+    }
+    if (!rt::set_device(ctx->device) || !rt::h2d((uint8_t*)s->d_state + offsetof(StreamState, pcm_tail), t.data(), sizeof(float) * 2 * MF_NEEDED, ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    const int64_t k = sample_pos / frame;                     // the stream has emitted k - 1 frames
+    s->frame_num = k - 1;
+    s->rs_n_in = sample_pos;
+    s->mf_size = ntail;
+    s->mf_samples_to_encode = 576 + 1152 + frame;
+    if (T.frac_SpF != 0) {
+        int64_t m = ((int64_t)T.frac_SpF - (k - 1) * (int64_t)T.frac_SpF) % T.out_samplerate;     // slot_lag starts at frac_SpF, one decrement per frame
+        if (m < 0) m += T.out_samplerate;
+        s->slot_lag = (int)m;
+    }
+    return 0;
 }
 
 int lhip_set_hip_stream(int device, void* hip_stream) {

@@ -495,3 +495,60 @@ def test_gpu_async_batch_and_device_mask(lib):
         lib.lhip_set_devices(0)
         for p in bufs:
             hip.hipFree(p)
+
+
+def _gpu_encode_in_ranges(ch, sr, kbps, L, R, cuts, H, joint=False):
+    """ONE stream as frame ranges on separate encoders (second mode): seek + H warm-up frames at every cut, the
+    state verified against the state the previous range ended in, transplanted on a miss."""
+    import lamejs_amd
+    fs = 1152 if sr >= 32000 else 576
+    bounds = [0] + [c * fs for c in cuts] + [len(L)]
+    outs, prev, missed = [], None, []
+    for r in range(len(bounds) - 1):
+        a, b = bounds[r], bounds[r + 1]
+        enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, joint=joint)
+        if r > 0:
+            p0, nt = a - H * fs, enc.seek_tail_samples()
+            enc.seek(p0, L[p0 - nt:p0], None if R is None else R[p0 - nt:p0])
+            enc.encodeBuffer(L[p0:a], None if R is None else R[p0:a])
+            if enc.state_get() != prev:
+                missed.append(r)
+                enc.state_set(prev)
+        out = enc.encodeBuffer(L[a:b], None if R is None else R[a:b])
+        prev = enc.state_get()
+        if r == len(bounds) - 2:
+            out += enc.flush()
+        outs.append(out)
+        enc.close()
+    return b"".join(outs), missed
+
+
+@pytest.mark.parametrize("corpus,ch,sr,kbps,nfr,cuts,H,joint", [
+    ("sine", 2, 44100, 128, 400, [100, 200, 300], 8, False),
+    ("bursts", 2, 44100, 128, 400, [131, 262], 8, False),
+    ("bursts", 1, 22050, 64, 400, [133, 290], 10, False),
+    ("bursts", 2, 44100, 128, 300, [100, 200], 2, False),
+    ("centre_bursts", 2, 44100, 128, 300, [150], 8, True),
+])
+def test_gpu_frame_range_shards(lib, corpus, ch, sr, kbps, nfr, cuts, H, joint):
+    """The frame-range pieces of one stream, concatenated, are the oracle's bytes of the whole stream -- whether the speculated
+    state at a cut verified (steady material) or had to be transplanted (silence gaps; a warm-up far too short)."""
+    import pcm
+    from oracle_py import oracle_encode
+    L, R = pcm.CORPORA[corpus](1152 * nfr, ch)
+    got, missed = _gpu_encode_in_ranges(ch, sr, kbps, L, R, cuts, H, joint)
+    assert got == oracle_encode(ch, sr, kbps, L, R, joint=joint)
+    if corpus == "sine":
+        assert missed == []
+
+
+def test_gpu_frame_range_shards_full_size(lib):
+    """BASELINE configs[2] material at full size (stereo 128 kbps, 1e5 frames) cut into 8 ranges: every cut verifies and the
+    concatenation is the stream encoded in one piece."""
+    import pcm
+    nfr = 100000
+    L, R = pcm.sine(1152 * nfr, 2, seed=12345)
+    whole = _encode(2, 128, L, R, 1152 * nfr)
+    got, missed = _gpu_encode_in_ranges(2, 44100, 128, L, R, [nfr * i // 8 for i in range(1, 8)], 8)
+    assert missed == []
+    assert hashlib.md5(got).hexdigest() == hashlib.md5(whole).hexdigest()

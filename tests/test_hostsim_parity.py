@@ -163,3 +163,78 @@ def test_hostsim_stage_taps_joint_stereo(sim, corpus, sr, kbps, nfr):
     import pcm, stage_taps
     L, R = pcm.CORPORA[corpus](1152 * nfr, 2)
     assert stage_taps.compare_stages(sim, 2, sr, kbps, L, R, joint=True) == []
+
+
+def _encode_in_ranges(lib, ch, sr, kbps, L, R, cuts, H, joint=False):
+    """One stream cut at the frame numbers `cuts`; every piece on its own encoder: seek + H warm-up frames, state verified against
+    the state the previous piece ended in, transplanted on a miss.  Returns (bytes, cuts whose speculated state missed)."""
+    import lamejs_amd
+    fs = 1152 if sr >= 32000 else 576
+    bounds = [0] + [c * fs for c in cuts] + [len(L)]
+    outs, prev, missed = [], None, []
+    for r in range(len(bounds) - 1):
+        a, b = bounds[r], bounds[r + 1]
+        enc = lamejs_amd.Mp3Encoder(ch, sr, kbps, lib=lib, joint=joint)
+        if r > 0:
+            p0, nt = a - H * fs, enc.seek_tail_samples()
+            enc.seek(p0, L[p0 - nt:p0], None if R is None else R[p0 - nt:p0])
+            enc.encodeBuffer(L[p0:a], None if R is None else R[p0:a])          # warm-up frames, output discarded
+            if enc.state_get() != prev:
+                missed.append(r)
+                enc.state_set(prev)
+                assert enc.state_get() == prev
+        out = enc.encodeBuffer(L[a:b], None if R is None else R[a:b])
+        prev = enc.state_get()
+        if r == len(bounds) - 2:
+            out += enc.flush()
+        outs.append(out)
+        enc.close()
+    return b"".join(outs), missed
+
+
+@pytest.mark.parametrize("corpus,ch,sr,kbps,nfr,cuts,H,joint", [
+    ("sine", 2, 44100, 128, 60, [20, 40], 8, False),        # loud steady material: every speculated cut verifies
+    ("bursts", 2, 44100, 128, 90, [30, 61], 8, False),      # silence gaps: the ATH adjustment has not converged at one cut -> transplant
+    ("bursts", 1, 22050, 64, 80, [25, 50], 10, False),      # MPEG-2 (576-sample frames), no padding accumulator
+    ("bursts", 2, 44100, 128, 90, [30, 61], 2, False),      # a warm-up far too short: both cuts miss, the transplant still gives the bytes
+    ("centre_bursts", 2, 44100, 128, 70, [33], 8, True),    # joint stereo (four psy channels in the state)
+])
+def test_hostsim_frame_range_shards(sim, corpus, ch, sr, kbps, nfr, cuts, H, joint):
+    """SURVEY.md 8e, second mode (extension): ONE stream encoded as frame ranges on separate encoders == the stream encoded in one
+    piece (the oracle's bytes), whether the speculated state at a cut verifies or has to be transplanted."""
+    import pcm
+    L, R = pcm.CORPORA[corpus](1152 * nfr, ch)
+    got, missed = _encode_in_ranges(sim, ch, sr, kbps, L, R, cuts, H, joint)
+    assert got == oracle_encode(ch, sr, kbps, L, R, joint=joint)
+    if corpus == "sine":
+        assert missed == []
+    if H == 2:
+        assert missed == [1, 2]
+
+
+def test_hostsim_seek_and_state_errors(sim):
+    import lamejs_amd, pcm
+    L, R = pcm.sine(1152 * 6, 2)
+    enc = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim)
+    nt = enc.seek_tail_samples()
+    assert nt == 528 + 1152                               # the samples the encoder holds back + one frame
+    with pytest.raises(lamejs_amd.LhipError):
+        enc.seek(1152 * 2 + 1, L[:nt], R[:nt])             # not a frame boundary
+    with pytest.raises(lamejs_amd.LhipError):
+        enc.seek(1152, L[:nt], R[:nt])                     # too close to the start
+    enc.encodeBuffer(L, R)
+    with pytest.raises(lamejs_amd.LhipError):
+        enc.seek(1152 * 3, L[:nt], R[:nt])                 # only a fresh stream can be moved
+    st = enc.state_get()
+    with pytest.raises(lamejs_amd.LhipError):
+        enc.state_set(st[:100])
+    with pytest.raises(lamejs_amd.LhipError):
+        enc.state_set(b"\0" * len(st))
+    other = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim)
+    other.state_set(st)                                     # a clone continues exactly like the original
+    assert other.encodeBuffer(L, R) + other.flush() == enc.encodeBuffer(L, R) + enc.flush()
+    for e in (lamejs_amd.Mp3Encoder(1, 44100, 32, lib=sim), lamejs_amd.Mp3Encoder(1, 44100, 128, lib=sim, reservoir=True)):
+        with pytest.raises(lamejs_amd.LhipError):           # resampling in front / bit reservoir: no seek
+            e.seek(1152 * 4, L[:e.seek_tail_samples()])
+        e.close()
+    enc.close(); other.close()

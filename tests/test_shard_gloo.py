@@ -78,3 +78,26 @@ def test_bench_py_two_ranks_gloo(cfg, extra, ch, kbps):
             md5s.append(hashlib.md5(oracle_encode(ch, 44100, kbps, L, R, flush=False)).hexdigest())
         want = md5s[0] if ns == 1 else hashlib.md5("".join(md5s).encode()).hexdigest()
         assert c["output_md5_per_rank"][rank] == want, (rank, c)
+
+
+@pytest.mark.parametrize("world,corpus,nfr", [(2, "sine", 30), (3, "bursts", 90)])
+def test_bench_py_frame_range_shards_gloo(world, corpus, nfr):
+    """bench.py --config shard3 (second mode): ONE stream cut into one frame range per rank, the state at every cut
+    speculated, verified across ranks and -- `bursts` has such a cut -- transplanted from the neighbour; the concatenation that
+    rank 0 gathers must be the bytes of the stream encoded in one piece."""
+    if not HOSTSIM.exists():
+        pytest.skip("host simulation not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, LAMEJS_HIP_LIB=str(HOSTSIM), LAMEJS_BENCH_HOSTSIM="1", MASTER_ADDR="127.0.0.1")
+    port = 33500 + (os.getpid() % 2000) + world
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--config", "shard3",
+                        "--cpu-seconds", "0", "--frames", str(nfr), "--shard-corpus", corpus], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["value"] > 0
+    L, R = pcm.CORPORA[corpus](1152 * nfr, 2, seed=12345)
+    assert line["config"]["output_md5"] == hashlib.md5(oracle_encode(2, 44100, 128, L, R, flush=False)).hexdigest()
+    if corpus == "bursts":
+        assert line["config"]["ranges_encoded_again"] >= 1
+    else:
+        assert line["config"]["cut_state_mismatches"] == 0
