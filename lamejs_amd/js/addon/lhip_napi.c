@@ -10,6 +10,8 @@
  *              flush(handle) -> Int8Array ;  deviceCount() -> number
  *              encodeBatch(handles[], lefts: Int16Array[], rights: Int16Array[]|null) -> Int8Array[]   (lhip_encode_batch:
  *              flushBatch(handles[]) -> Int8Array[]                                 many independent streams, one launch)
+ *              seekTailSamples(handle) -> number ; seek(handle, samplePos, tailLeft, tailRight|null)       (frame-range sharding of
+ *              stateGet(handle) -> Uint8Array ; stateSet(handle, Uint8Array)                                one stream: lhip_seek ...)
  */
 #define _GNU_SOURCE
 #define NAPI_VERSION 6
@@ -31,6 +33,11 @@ static int (*p_encode_batch)(lhip_stream* const*, size_t, const int16_t* const*,
 static int (*p_flush_batch)(lhip_stream* const*, size_t, uint8_t* const*, const size_t*, int64_t*);
 static const char* (*p_last_error)(void);
 static int (*p_set_devices)(uint64_t);
+static size_t (*p_state_bytes)(const lhip_stream*);
+static int (*p_state_get)(lhip_stream*, void*, size_t);
+static int (*p_state_set)(lhip_stream*, const void*, size_t);
+static size_t (*p_seek_tail)(const lhip_stream*);
+static int (*p_seek)(lhip_stream*, int64_t, const int16_t*, const int16_t*);
 
 static int load_lib(napi_env env) {
     if (g_lib) return 1;
@@ -50,6 +57,8 @@ static int load_lib(napi_env env) {
     SYM(p_device_count, "lhip_device_count") SYM(p_create, "lhip_create") SYM(p_encode, "lhip_encode") SYM(p_flush, "lhip_flush")
     SYM(p_destroy, "lhip_destroy") SYM(p_max_out, "lhip_max_output_bytes") SYM(p_last_error, "lhip_last_error")
     SYM(p_encode_batch, "lhip_encode_batch") SYM(p_flush_batch, "lhip_flush_batch") SYM(p_set_devices, "lhip_set_devices")
+    SYM(p_state_bytes, "lhip_state_bytes") SYM(p_state_get, "lhip_state_get") SYM(p_state_set, "lhip_state_set")
+    SYM(p_seek_tail, "lhip_seek_tail_samples") SYM(p_seek, "lhip_seek")
 #undef SYM
     return 1;
 }
@@ -190,6 +199,60 @@ static napi_value batch_common(napi_env env, napi_callback_info info, int is_flu
     if (err) { napi_throw_error(env, NULL, err); return NULL; }
     return result;
 }
+/* Frame-range sharding of one stream (include/lamejs_hip.h: lhip_seek / lhip_state_get / lhip_state_set).  Unlike encode(), these
+ * throw on failure: there is no reference behaviour to mirror. */
+static lhip_stream* handle_arg(napi_env env, napi_value v) {
+    lhip_stream* s = NULL;
+    if (napi_get_value_external(env, v, (void**)&s) != napi_ok || !s) { napi_throw_type_error(env, NULL, "first argument must be a stream handle"); return NULL; }
+    return s;
+}
+static napi_value js_seek_tail(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], r;
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    lhip_stream* s = argc >= 1 ? handle_arg(env, argv[0]) : NULL;
+    if (!s) return NULL;
+    napi_create_uint32(env, (uint32_t)p_seek_tail(s), &r);
+    return r;
+}
+static napi_value js_seek(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    lhip_stream* s = argc >= 3 ? handle_arg(env, argv[0]) : NULL;
+    if (!s) return NULL;
+    int64_t pos = 0;
+    if (napi_get_value_int64(env, argv[1], &pos) != napi_ok) { napi_throw_type_error(env, NULL, "samplePos must be a number"); return NULL; }
+    napi_typedarray_type tt; size_t nl = 0, nr = 0; void *dl = NULL, *dr = NULL;
+    if (napi_get_typedarray_info(env, argv[2], &tt, &nl, &dl, NULL, NULL) != napi_ok || tt != napi_int16_array || nl != p_seek_tail(s)) { napi_throw_type_error(env, NULL, "tailLeft must be an Int16Array of seekTailSamples() samples"); return NULL; }
+    napi_valuetype vt = napi_undefined;
+    if (argc > 3) napi_typeof(env, argv[3], &vt);
+    if (vt != napi_null && vt != napi_undefined) {
+        if (napi_get_typedarray_info(env, argv[3], &tt, &nr, &dr, NULL, NULL) != napi_ok || tt != napi_int16_array || nr != nl) { napi_throw_type_error(env, NULL, "tailRight must be an Int16Array of the same length"); return NULL; }
+    }
+    if (p_seek(s, pos, (const int16_t*)dl, (const int16_t*)dr) != 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
+    return NULL;
+}
+static napi_value js_state_get(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], ab, ta; void* data = NULL;
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    lhip_stream* s = argc >= 1 ? handle_arg(env, argv[0]) : NULL;
+    if (!s) return NULL;
+    const size_t n = p_state_bytes(s);
+    napi_create_arraybuffer(env, n, &data, &ab);
+    if (p_state_get(s, data, n) != 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
+    napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta);
+    return ta;
+}
+static napi_value js_state_set(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    lhip_stream* s = argc >= 2 ? handle_arg(env, argv[0]) : NULL;
+    if (!s) return NULL;
+    napi_typedarray_type tt; size_t n = 0; void* d = NULL;
+    if (napi_get_typedarray_info(env, argv[1], &tt, &n, &d, NULL, NULL) != napi_ok || tt != napi_uint8_array) { napi_throw_type_error(env, NULL, "state must be a Uint8Array"); return NULL; }
+    if (p_state_set(s, d, n) != 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
+    return NULL;
+}
+
 static napi_value js_encode_batch(napi_env env, napi_callback_info info) { return batch_common(env, info, 0); }
 static napi_value js_flush_batch(napi_env env, napi_callback_info info) { return batch_common(env, info, 1); }
 
@@ -198,8 +261,10 @@ static napi_value init(napi_env env, napi_value exports) {
         {"deviceCount", 0, js_device_count, 0, 0, 0, napi_default, 0}, {"create", 0, js_create, 0, 0, 0, napi_default, 0},
         {"encode", 0, js_encode, 0, 0, 0, napi_default, 0}, {"flush", 0, js_flush, 0, 0, 0, napi_default, 0},
         {"encodeBatch", 0, js_encode_batch, 0, 0, 0, napi_default, 0}, {"flushBatch", 0, js_flush_batch, 0, 0, 0, napi_default, 0},
-        {"setDevices", 0, js_set_devices, 0, 0, 0, napi_default, 0}};
-    napi_define_properties(env, exports, 6, d);
+        {"setDevices", 0, js_set_devices, 0, 0, 0, napi_default, 0},
+        {"seekTailSamples", 0, js_seek_tail, 0, 0, 0, napi_default, 0}, {"seek", 0, js_seek, 0, 0, 0, napi_default, 0},
+        {"stateGet", 0, js_state_get, 0, 0, 0, napi_default, 0}, {"stateSet", 0, js_state_set, 0, 0, 0, napi_default, 0}};
+    napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;
 }
 NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -45,6 +45,14 @@ function Mp3Encoder(channels, samplerate, kbps, opts) {
         return native.encode(handle, left, right || null);
     };
     this.flush = function () { return native.flush(handle); };
+    /* Extension -- frame-range sharding of ONE stream (include/lamejs_hip.h, lhip_seek ...; DESIGN.md 7): a fresh encoder is put
+     * at input sample `samplePos` (a whole number >= 2 of frames) with the seekTailSamples() samples in front of it, encodes a few
+     * warm-up frames whose bytes are thrown away, and its getState() at the cut is compared with the getState() of the encoder that
+     * came from the left; equal states = equal futures, otherwise setState() transplants the true one. */
+    this.seekTailSamples = function () { return native.seekTailSamples(handle); };
+    this.seek = function (samplePos, tailLeft, tailRight) { native.seek(handle, samplePos, tailLeft, channels == 1 ? null : (tailRight || null)); };
+    this.getState = function () { return native.stateGet(handle); };
+    this.setState = function (state) { native.stateSet(handle, state); };
 }
 
 /* RIFF/WAVE header reader with the reference's field names (index.js:138-193) */

@@ -126,3 +126,35 @@ def test_js_batch_extension_gpu():
     for ch, kbps, ns, nfr, chunk in ((1, 128, 16, 60, 5000), (2, 320, 5, 40, 1152 * 7)):
         got = _run_batch(None, ch, kbps, ns, nfr, chunk)
         assert got["single"] == got["batch"] and len(got["batch"]) == ns
+
+
+def _shard(env_lib, corpus, ch, kbps, nfr, H, cuts):
+    env = dict(os.environ)
+    if env_lib:
+        env["LAMEJS_HIP_LIB"] = str(env_lib)
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_shard_check.js"), corpus, str(ch), str(kbps), str(nfr), str(H)] + [str(c) for c in cuts], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_frame_range_shards_hostsim():
+    """The sharding extension through the JavaScript surface (seek / getState / setState; setDevices): pieces == whole == oracle."""
+    import hashlib
+    import pcm
+    from oracle_py import oracle_encode
+    sim = ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"
+    for corpus, ch, nfr, H, cuts in (("sine", 2, 40, 8, [14, 27]), ("bursts", 1, 60, 2, [20, 41])):
+        got = _shard(sim, corpus, ch, 128, nfr, H, cuts)
+        L, R = pcm.CORPORA[corpus](1152 * nfr, ch)
+        want = oracle_encode(ch, 44100, 128, L, R)
+        assert got["whole"] == got["pieces"] == hashlib.md5(want).hexdigest() and got["bytes"] == len(want), got
+        assert got["devices_allowed"] >= 1
+        assert (got["missed"] == 0) if corpus == "sine" else (got["missed"] >= 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_frame_range_shards_gpu():
+    got = _shard(None, "sine", 2, 128, 300, 8, [100, 200])
+    assert got["whole"] == got["pieces"] and got["missed"] == 0 and got["devices_allowed"] >= 1, got
