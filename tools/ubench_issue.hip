@@ -277,6 +277,78 @@ KERNEL_BEGIN(k_quant_mix)
 #undef M
 KERNEL_END()
 
+// ---- selects: what does v_cndmask cost depending on where its mask comes from?  (k_cndmask above, 16 cycles, reads a VCC that nobody
+// has written for thousands of instructions; compiled code mostly selects on masks that are not freshly written either) ----
+KERNEL_BEGIN(k_sel_vcc_set_per_iter)
+    asm volatile("s_mov_b64 vcc, exec" ::: "vcc");
+#define M(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(a0 | 1u) : "vcc");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_sgpr_mask)
+    asm volatile("s_mov_b64 s[40:41], exec" ::: "s40", "s41");
+#define M(i) asm volatile("v_cndmask_b32 %0, %0, %1, s[40:41]" : "+v"(a##i) : "v"(a0 | 1u) : "s40", "s41");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_cmp1_cnd4)
+#define M(i) asm volatile("v_cmp_lt_u32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc" \
+    : "+v"(a##i), "+v"(s##i##x), "+v"(s##i##y), "+v"(s##i##z) : "v"(a0 | 1u) : "vcc");
+    unsigned s0x = a0, s0y = a0, s0z = a0, s1x = a1, s1y = a1, s1z = a1, s2x = a2, s2y = a2, s2z = a2, s3x = a3, s3y = a3, s3z = a3,
+             s4x = a4, s4y = a4, s4z = a4, s5x = a5, s5y = a5, s5z = a5, s6x = a6, s6y = a6, s6z = a6, s7x = a7, s7y = a7, s7z = a7;
+    REP8(M)
+    a0 ^= s0x ^ s0y ^ s0z ^ s1x ^ s1y ^ s1z ^ s2x ^ s2y ^ s2z ^ s3x ^ s3y ^ s3z ^ s4x ^ s4y ^ s4z ^ s5x ^ s5y ^ s5z ^ s6x ^ s6y ^ s6z ^ s7x ^ s7y ^ s7z;
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_cmp_add_cnd)
+#define M(i) asm volatile("v_cmp_lt_u32 vcc, %0, %2\n v_add_u32 %1, %1, %2\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a##i), "+v"(f##i) : "v"(a0 | 1u) : "vcc");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_salu_mask_cnd)
+#define M(i) asm volatile("s_and_b64 vcc, exec, exec\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(a0 | 1u) : "vcc", "scc");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_cmp_sgpr_cnd)
+#define M(i) asm volatile("v_cmp_lt_u32 s[40:41], %0, %1\n v_cndmask_b32 %0, %0, %1, s[40:41]" : "+v"(a##i) : "v"(a0 | 1u) : "s40", "s41");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_cmp_vcc_only)
+#define M(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_add_u32 %0, %0, %1" : "+v"(a##i) : "v"(a0 | 1u) : "vcc");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_cmp_sgpr_only)
+#define M(i) asm volatile("v_cmp_lt_u32 s[40:41], %0, %1\n v_add_u32 %0, %0, %1" : "+v"(a##i) : "v"(a0 | 1u) : "s40", "s41");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_add_sgpr_operand)
+    asm volatile("s_mov_b32 s40, 3" ::: "s40");
+#define M(i) asm volatile("v_add_u32 %0, s40, %0" : "+v"(a##i) :: "s40");
+    REP32(M)
+#undef M
+KERNEL_END()
+KERNEL_BEGIN(k_sel_cmp_far_cnd)
+    // the mask is written eight instructions before it is used (the compiler's usual distance when it hoists compares)
+#define M(i) asm volatile("v_cmp_lt_u32 s[40:41], %0, %1" :: "v"(a##i), "v"(a0 | 1u) : "s40", "s41");
+#define N(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##i) : "v"(a0 | 1u));
+#define P(i) asm volatile("v_cndmask_b32 %0, %0, %1, s[40:41]" : "+v"(a##i) : "v"(a0 | 1u) : "s40", "s41");
+    M(0) N(1) N(2) N(3) N(4) N(5) N(6) N(7) N(1) P(0)  M(1) N(2) N(3) N(4) N(5) N(6) N(7) N(0) N(2) P(1)
+    M(2) N(3) N(4) N(5) N(6) N(7) N(0) N(1) N(3) P(2)  M(3) N(4) N(5) N(6) N(7) N(0) N(1) N(2) N(4) P(3)
+#undef M
+#undef N
+#undef P
+KERNEL_END()
+KERNEL_BEGIN(k_sel_bfi)
+    // arithmetic select: (a & m) | (b & ~m) with a lane mask value kept in a VGPR
+#define M(i) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a##i) : "v"(a0 | 1u));
+    REP32(M)
+#undef M
+KERNEL_END()
+
 struct Case { const char* name; void (*fn)(unsigned*, unsigned long long*, int); int ops_per_iter; const char* cls; };
 #define C(name, ops, cls) {#name, name, ops, cls}
 static const Case cases[] = {
@@ -290,6 +362,9 @@ static const Case cases[] = {
     C(k_salu_add, 32, "salu"), C(k_valu_salu_1to1, 64, "mix"), C(k_f64_int_1to1, 64, "mix"),
     C(k_ds_read_b32, 32, "lds"), C(k_ds_read_u8, 32, "lds"), C(k_ds_read_b64, 32, "lds"), C(k_ds_write_b32, 32, "lds"), C(k_ds_u8_valu_1to3, 32, "mix"),
     C(k_quant_mix, 8 * 16, "quantmix(VALU only counted: 16 VALU + 10 SALU + 1 LDS per group)"),
+    C(k_sel_vcc_set_per_iter, 32, "select"), C(k_sel_sgpr_mask, 32, "select"), C(k_sel_cmp1_cnd4, 40, "select"), C(k_sel_cmp_add_cnd, 96, "select"),
+    C(k_sel_salu_mask_cnd, 32, "select(VALU only counted)"), C(k_sel_cmp_sgpr_cnd, 64, "select"), C(k_sel_cmp_vcc_only, 64, "select"), C(k_sel_cmp_sgpr_only, 64, "select"),
+    C(k_sel_add_sgpr_operand, 32, "select"), C(k_sel_cmp_far_cnd, 40, "select"), C(k_sel_bfi, 32, "select"),
 };
 
 int main(int argc, char** argv) {
@@ -303,7 +378,9 @@ int main(int argc, char** argv) {
     const int wps[6] = {1, 2, 4, 5, 6, 8};
     printf("%-22s %-9s  G wave-inst/s at 1, 2, 4, 5, 6, 8 waves/SIMD | cycles/inst/SIMD at 4 and 8 | shader MHz at 4\n", "instruction", "class");
     bool first = true;
+    const char* only = argc > 2 ? argv[2] : nullptr;          // run only the cases whose name contains this
     for (const Case& c : cases) {
+        if (only && !strstr(c.name, only)) continue;
         double rate[6], nsi[6], tick_mhz[6], ev[6], inker[6];
         for (int k = 0; k < 6; k++) {
             const int w = wps[k];
