@@ -1377,7 +1377,12 @@ int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const
 }
 
 // ---- frame-range sharding of ONE stream (second mode): speculate the state at a cut, verify it, transplant on a miss ----
-struct StateHdr { uint32_t magic, bytes; int32_t mf_size, mf_samples_to_encode, slot_lag, pad_; int64_t frame_num, rs_n_in; };
+struct StateHdr { uint32_t magic, bytes; int32_t mf_size, mf_samples_to_encode, slot_lag, config; int64_t frame_num, rs_n_in; };
+// what must agree between the stream a state blob came from and the stream it is put into
+static int32_t state_config_tag(const Tables& T) {
+    return (int32_t)((uint32_t)T.channels_out | ((uint32_t)T.mode << 2) | ((uint32_t)(T.disable_reservoir != 0) << 4) | ((uint32_t)T.samplerate_index << 5) |
+                     ((uint32_t)T.version << 8) | ((uint32_t)T.bitrate_index << 10) | ((uint32_t)T.rs_ratio << 16));
+}
 size_t lhip_state_bytes(const lhip_stream* s) {
     if (!s || s->magic != 0x4c484950) return 0;
     return sizeof(StateHdr) + sizeof(StreamState);
@@ -1390,6 +1395,7 @@ int lhip_state_get(lhip_stream* s, void* buf, size_t cap) {
     StateHdr h; memset(&h, 0, sizeof h);
     h.magic = 0x5453484cu; h.bytes = (uint32_t)lhip_state_bytes(s);
     h.mf_size = s->mf_size; h.mf_samples_to_encode = s->mf_samples_to_encode; h.slot_lag = s->slot_lag; h.frame_num = s->frame_num; h.rs_n_in = s->rs_n_in;
+    h.config = state_config_tag(s->ts->T);
     memcpy(buf, &h, sizeof h);
     if (!rt::set_device(ctx->device) || !rt::d2h((uint8_t*)buf + sizeof h, s->d_state, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
     return 0;
@@ -1399,7 +1405,7 @@ int lhip_state_set(lhip_stream* s, const void* buf, size_t n) {
     StateHdr h;
     if (!buf || n < sizeof h) { set_err("state blob too small"); return LHIP_ERR_INTERNAL; }
     memcpy(&h, buf, sizeof h);
-    if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
+    if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes || h.config != state_config_tag(s->ts->T)) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(ctx->device) || !rt::h2d(s->d_state, (const uint8_t*)buf + sizeof h, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;

@@ -230,6 +230,10 @@ def test_hostsim_seek_and_state_errors(sim):
         enc.state_set(st[:100])
     with pytest.raises(lamejs_amd.LhipError):
         enc.state_set(b"\0" * len(st))
+    wrong = lamejs_amd.Mp3Encoder(2, 44100, 160, lib=sim)   # same layout, another configuration: refused, not silently accepted
+    with pytest.raises(lamejs_amd.LhipError):
+        wrong.state_set(st)
+    wrong.close()
     other = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim)
     other.state_set(st)                                     # a clone continues exactly like the original
     assert other.encodeBuffer(L, R) + other.flush() == enc.encodeBuffer(L, R) + enc.flush()
