@@ -18,7 +18,22 @@ namespace lhip {
 // 361 words, and kb_bits also touches word nwords (a straddling put_bits); lhip_create checks the configuration's
 // frame size against BITS_LDS_WORDS.
 enum { BITS_LDS_WORDS = 368 };
-struct BitsLds { uint32_t w[BITS_LDS_WORDS]; };
+// w: the frame being assembled; side / q: the frame's side records and quantized spectra, fetched once with many loads in flight
+// (read field by field from global memory, every dependent look-up of the packer used to wait out a full memory latency)
+struct BitsLds { uint32_t w[BITS_LDS_WORDS]; GrSide side[4]; uint32_t q[288]; };      // q: one granule-channel at a time (4.4 KB: LDS does not limit the occupancy)
+
+// n 32-bit words global -> LDS, eight loads in flight per lane (the trip count is not a compile-time constant, so a plain
+// lane-strided loop would issue one load per trip and wait for it)
+LHIP_DEV void stage_words(uint32_t* dst, const uint32_t* src, int n, int lane) {
+    enum { K = 8 };
+    for (int i0 = 0; i0 < n; i0 += LHIP_NL * K) {
+        uint32_t v[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int i = i0 + lane + LHIP_NL * k; v[k] = src[i < n ? i : n - 1]; }   // clamped, not predicated: a predicated load is waited for inside its branch
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int i = i0 + lane + LHIP_NL * k; if (i < n) dst[i] = v[k]; }
+    }
+}
 
 // write the low n bits of val at bit position pos (MSB-first stream); n <= 32
 LHIP_DEV void put_bits(uint32_t* w, int pos, uint32_t val, int n) {
@@ -201,9 +216,11 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const bool resv = !T.disable_reservoir;
     const int nwords = resv ? BITS_LDS_WORDS - 1 : (frame_bits + 31) >> 5;      // reservoir: a frame's data may exceed its nominal size
     for (int i = lane; i < nwords + 1; i += LHIP_NL) L.w[i] = 0;
-    wave_sync();
-    const GrSide* side = W.side + (int64_t)fidx * 2 * C;
     const int GR = T.mode_gr;
+    static_assert(sizeof(GrSide) % 4 == 0, "side records are staged as words");
+    stage_words((uint32_t*)L.side, (const uint32_t*)(W.side + (int64_t)fidx * 2 * C), GR * C * (int)(sizeof(GrSide) / 4), lane);
+    wave_sync();
+    const GrSide* side = L.side;
     int pos = 0;
     if (lane == 0) {
         uint32_t* w = L.w;
@@ -254,7 +271,10 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     for (int gr = 0; gr < GR; gr++)
         for (int ch = 0; ch < C; ch++) {
             const GrSide& gi = side[gr * C + ch];
-            const int16_t* q = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+            wave_sync();                                                 // the previous granule-channel's spectrum is no longer read
+            stage_words(L.q, (const uint32_t*)(W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576), 288, lane);
+            wave_sync();
+            const int16_t* q = (const int16_t*)L.q;
             if (GR == 2) {
                 // scalefactors: at most 36 short fields
                 const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];

@@ -153,12 +153,14 @@ template <int ROW> LHIP_DEV void poly_slot(const Tables& T, const float* xt, flo
     window_subband<ROW>(LHIP_CTAB(T.enwindow), xt, a);
     if (j & 1)
         for (int band = 1; band < 32; band += 2) a[band] = (float)((double)a[band] * -1);
-    for (int band = 0; band < 32; band++) {
-        const double af = T.amp_filter[band];
-        if (!(af < 1e-12) && af < 1.0) {
-            const int ob = T.mdct_order[band];
-            a[ob] = (float)((double)a[ob] * af);
-        }
+    // the band filter of the lowpass (NewMDCT.js:1075-1086: `a[order[band]] *= amp_filter[band]` where 1e-12 <= amp_filter < 1): by
+    // OUTPUT index, from a table derived at create time -- indexing the register array with a loaded `order[band]` made the
+    // compiler search for the register at run time, one memory round trip per band
+    {
+        lhip_ctab amp = LHIP_CTAB(T.amp_by_out);
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            if ((T.amp_mask >> i) & 1) a[i] = (float)((double)a[i] * amp[i]);
     }
     for (int i = 0; i < 32; i++) out[i] = a[i];
 }
@@ -175,11 +177,27 @@ LHIP_DEV void kb_poly_run(const Tables& T, const Workspace& W, const StreamDesc*
     const int n_need = POLY_N1 + 576 * (cnt - 1);
     wave_sync();
     if (!P.plane && s0 + lo >= P.mf) {                        // wave-uniform usual case: everything staged is new Int16 input
+        // eight loads in flight per lane: with one load per trip (the trip count is not a compile-time constant) the wave waited
+        // out a full memory latency 36 times, which was most of this kernel's time
         const int16_t* src = P.src + (s0 - P.mf);
-        for (int n = lane; n < n_need; n += LHIP_NL) {
-            float v = 0.f;
-            if (n >= lo) { v = (float)src[n]; if (P.do_scale) v = (float)((double)v * P.scale); }
-            L.xs[(n & 31) * POLY_ROW + (n >> 5)] = v;
+        enum { STG = 8 };
+        for (int n0 = 0; n0 < n_need; n0 += LHIP_NL * STG) {
+            int raw[STG];
+#pragma unroll
+            for (int k = 0; k < STG; k++) {                  // unconditional loads from a clamped index: a predicated load is waited for inside its branch
+                const int n = n0 + lane + LHIP_NL * k;
+                raw[k] = (int)src[n < lo ? lo : (n < n_need ? n : n_need - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < STG; k++) LHIP_PIN_LOADED(raw[k]);
+#pragma unroll
+            for (int k = 0; k < STG; k++) {
+                const int n = n0 + lane + LHIP_NL * k;
+                float v = (float)raw[k];
+                if (P.do_scale) v = (float)((double)v * P.scale);
+                if (n < lo) v = 0.f;                            // (0 * scale could be -0 or NaN for an odd scale; the slot is defined as +0)
+                if (n < n_need) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = v;
+            }
         }
     } else {
         for (int n = lane; n < n_need; n += LHIP_NL) L.xs[(n & 31) * POLY_ROW + (n >> 5)] = (n >= lo) ? pcm_at(P, s0 + n) : 0.f;

@@ -685,12 +685,30 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     extra.resize(4 * CBANDS + SBMAX_l + SBMAX_s);
     walk(h_bo_l, SBMAX_l, T.npart_l, extra.data() + 4 * CBANDS);
     walk(h_bo_s, SBMAX_s, T.npart_s, extra.data() + 4 * CBANDS + SBMAX_l);
+    // the polyphase band filter by output index (k_fb.h poly_slot): amp_by_out[order[band]] = amp_filter[band] where it scales at all
+    const size_t amp_at = (extra.size() + 1) & ~(size_t)1;                   // 8-byte aligned
+    extra.resize(amp_at + 64);
+    {
+        const float* h_af = (const float*)host_arr("amp_filter");
+        const int32_t* h_order = (const int32_t*)host_arr("mdct_order");
+        double amp[32];
+        for (int i = 0; i < 32; i++) amp[i] = 1.0;
+        T.amp_mask = 0;
+        for (int band = 0; band < 32; band++) {
+            const double af = (double)h_af[band];
+            const int ob = h_order[band];
+            if (ob < 0 || ob > 31) { set_err("mdct_order is not a permutation of 0..31"); return false; }
+            if (!(af < 1e-12) && af < 1.0) { amp[ob] = af; T.amp_mask |= 1 << ob; }
+        }
+        memcpy(extra.data() + amp_at, amp, sizeof amp);
+    }
     ts.d_extra = rt::dmalloc(extra.size() * 4);
     if (!ts.d_extra) { set_err("hipMalloc failed"); return false; }
     if (!rt::h2d(ts.d_extra, extra.data(), extra.size() * 4, stream)) return false;
     if (!rt::sync(stream)) return false;
     T.s3off_l = (const int32_t*)ts.d_extra; T.s3off_s = T.s3off_l + CBANDS; T.lineoff_l = T.s3off_l + 2 * CBANDS; T.lineoff_s = T.s3off_l + 3 * CBANDS;
     T.bo_l = T.s3off_l + 4 * CBANDS; T.bo_s = T.bo_l + SBMAX_l;
+    T.amp_by_out = (const double*)(T.s3off_l + amp_at);
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
     // kb_bits assembles a frame in BitsLds (and zeroes one word past its last one): the largest frame of this configuration must fit

@@ -38,7 +38,11 @@
 typedef const double* lhip_ctab;
 #define LHIP_CTAB(p) (p)
 #define LHIP_SCHED_FENCE() ((void)0)
+#define LHIP_PIN_LOADED(x) ((void)0)
 #else
+// the value of a load is needed HERE: keeps the compiler from sinking a batch of independent loads into the (conditional) code
+// that uses them one by one, where each would be waited for on its own
+#define LHIP_PIN_LOADED(x) asm volatile("" : "+v"(x))
 #define LHIP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)     /* the instruction scheduler moves nothing across this point */
 typedef const double __attribute__((address_space(4)))* lhip_ctab;
 #define LHIP_CTAB(p) ((lhip_ctab)(uintptr_t)(p))
@@ -99,6 +103,8 @@ struct Tables {
     // derived on the host at create time (device pointers)
     const int32_t *s3off_l, *s3off_s;       // start offset of partition b inside s3_ll / s3_ss
     const int32_t *lineoff_l, *lineoff_s;   // first FFT line of partition b
+    const double *amp_by_out;               // [32] polyphase output i is scaled by this (1.0: not at all): amp_filter through mdct_order
+    int amp_mask;                           // bit i: amp_by_out[i] != 1.0
 };
 
 // Per-granule-channel side information produced by the quantization kernel and consumed by the
