@@ -1265,7 +1265,7 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
                 if (s >= 0) { if (lane == 0) scalefac[sfb] = s; }
                 else {
                     if (lane == 0) scalefac[sfb] = 0;
-                    amp = ipow20(Q, 210 + (s << (g.scalefac_scale + 1)));
+                    amp = ipow20(Q, 210 + s * (1 << (g.scalefac_scale + 1)));      // s < 0 here: a multiplication, not a shift of a negative value
                     doamp = 1;
                 }
             } else { amp = ipow20(Q, 202); doamp = 1; }

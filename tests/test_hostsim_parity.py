@@ -146,6 +146,21 @@ def test_hostsim_asan_largest_frames():
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_hostsim_ubsan_modes():
+    """The kernel bodies under UndefinedBehaviorSanitizer (any report aborts the run): the extension modes, the frame program and
+    the sharding calls of tests/tools/asan_modes.py.  (It found a left shift of a negative scalefactor in inc_subblock_gain.)"""
+    import os, shutil, sys
+    gcc = shutil.which("gcc")
+    ub = subprocess.run([gcc, "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip() if gcc else ""
+    if not ub or not os.path.isabs(ub):
+        pytest.skip("libubsan not available")
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "ubsan"], check=True, capture_output=True)
+    env = dict(os.environ, LD_PRELOAD=ub, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "asan_modes.py"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim_ubsan.so")],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout and "runtime error" not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("ch,sr,kbps,nfr", [(2, 44100, 128, 40), (1, 22050, 64, 40)])
 def test_hostsim_stage_taps(sim, ch, sr, kbps, nfr):
     """Stage-level differential check of the kernel logic (host simulation) against the oracle's taps: MDCT output, block types,

@@ -1,4 +1,5 @@
-"""TEST TOOL: the extension modes (joint stereo, bit reservoir, both) and the one-frame-per-stream frame program through a library
+"""TEST TOOL: the extension modes (joint stereo, bit reservoir, both), the one-frame-per-stream frame program and the frame-range
+sharding calls through a library
 given on the command line -- run by tests/test_hostsim_parity.py against the AddressSanitizer build of the host simulation.
 usage: python tests/tools/asan_modes.py <liblamejs_hostsim_asan.so>   (prints OK, exit code 0, if every output equals the oracle's)"""
 import sys
@@ -23,5 +24,9 @@ for corpus, ch, sr, kbps, nfr, chunk, joint, resv in [("bursts", 2, 44100, 128, 
     if out != oracle_encode(ch, sr, kbps, L, R, joint=joint, reservoir=resv):
         print("MISMATCH", corpus, ch, sr, kbps, joint, resv)
         bad += 1
+# frame-range sharding of one stream (lhip_seek / lhip_state_get / lhip_state_set) under the same sanitizer build
+sys.path.insert(0, str(ROOT / "tests" / "tools"))
+import fuzz_shard
+bad += len(fuzz_shard.run(6, 3, lib=lib, verbose=False))
 print("OK" if not bad else "FAILED")
 sys.exit(1 if bad else 0)
