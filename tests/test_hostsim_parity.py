@@ -213,6 +213,8 @@ def _encode_in_ranges(lib, ch, sr, kbps, L, R, cuts, H, joint=False):
     ("bursts", 1, 22050, 64, 80, [25, 50], 10, False),      # MPEG-2 (576-sample frames), no padding accumulator
     ("bursts", 2, 44100, 128, 90, [30, 61], 2, False),      # a warm-up far too short: both cuts miss, the transplant still gives the bytes
     ("centre_bursts", 2, 44100, 128, 70, [33], 8, True),    # joint stereo (four psy channels in the state)
+    ("sine", 1, 44100, 128, 30, [3, 29], 1, False),         # the earliest position a stream can be put at (2 frames) and a cut one frame before the end
+    ("sine", 2, 48000, 192, 40, [11, 12, 13], 4, False),    # ranges of a single frame
 ])
 def test_hostsim_frame_range_shards(sim, corpus, ch, sr, kbps, nfr, cuts, H, joint):
     """SURVEY.md 8e, second mode (extension): ONE stream encoded as frame ranges on separate encoders == the stream encoded in one
@@ -221,7 +223,7 @@ def test_hostsim_frame_range_shards(sim, corpus, ch, sr, kbps, nfr, cuts, H, joi
     L, R = pcm.CORPORA[corpus](1152 * nfr, ch)
     got, missed = _encode_in_ranges(sim, ch, sr, kbps, L, R, cuts, H, joint)
     assert got == oracle_encode(ch, sr, kbps, L, R, joint=joint)
-    if corpus == "sine":
+    if corpus == "sine" and H >= 8:
         assert missed == []
     if H == 2:
         assert missed == [1, 2]
@@ -252,6 +254,14 @@ def test_hostsim_seek_and_state_errors(sim):
     other = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim)
     other.state_set(st)                                     # a clone continues exactly like the original
     assert other.encodeBuffer(L, R) + other.flush() == enc.encodeBuffer(L, R) + enc.flush()
+    # a clone taken in the middle of a bit-reservoir stream (the reservoir fill, the header queue and the entropy history travel too)
+    M = pcm.bursts(1152 * 9, 1)[0]
+    ra = lamejs_amd.Mp3Encoder(1, 44100, 128, lib=sim, reservoir=True)
+    head = ra.encodeBuffer(M[:1152 * 5])
+    rb = lamejs_amd.Mp3Encoder(1, 44100, 128, lib=sim, reservoir=True)
+    rb.state_set(ra.state_get())
+    assert head + rb.encodeBuffer(M[1152 * 5:]) + rb.flush() == oracle_encode(1, 44100, 128, M, reservoir=True)
+    ra.close(); rb.close()
     for e in (lamejs_amd.Mp3Encoder(1, 44100, 32, lib=sim), lamejs_amd.Mp3Encoder(1, 44100, 128, lib=sim, reservoir=True)):
         with pytest.raises(lamejs_amd.LhipError):           # resampling in front / bit reservoir: no seek
             e.seek(1152 * 4, L[:e.seek_tail_samples()])
