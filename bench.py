@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint', 'joint_bursts', 'reservoir', or 'shard3' (ONE config-3 stream cut into frame ranges over the GPUs: strong scaling)")
     ap.add_argument("--shard-corpus", default="sine", help="shard3 only: the material (tests/pcm.py); 'bursts' has cuts whose speculated state misses")
-    ap.add_argument("--shard-warmup", type=int, default=8, help="shard3 only: warm-up frames in front of a cut")
+    ap.add_argument("--shard-warmup", type=int, default=64, help="shard3 only: warm-up frames in front of a cut (64: the ATH adjustment has forgotten its past, DESIGN.md 7)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per stream (parity table then only covers a prefix check)")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")

@@ -70,7 +70,8 @@ int lhip_set_devices(uint64_t mask);
  * input position with the samples in front of it, a few warm-up frames (output discarded) let the masking history, the
  * filterbank overlap, the attack / block-type chains, the ATH adjustment and the bin-search seeds converge -- and then VERIFIED:
  * lhip_state_get of that stream at the cut must equal, byte for byte, lhip_state_get of the stream that encoded up to the cut; if it
- * does, everything after the cut is what one stream would have produced.  On a miss the true state is transplanted (lhip_state_set)
+ * does, everything after the cut is what one stream would have produced (64 warm-up frames verified at every cut of every stream tried,
+ * material with long silences included; 8 are enough on steady material).  On a miss the true state is transplanted (lhip_state_set)
  * and the piece is encoded again.  bench.py --config shard3 does exactly that over torch.distributed
  * (one range per rank; tests/test_shard_gloo.py runs it with two and three ranks, tests/test_hostsim_parity.py the API itself).
  *   lhip_seek(s, sample_pos, tail_l, tail_r): s fresh; sample_pos a whole number (>= 2) of frames; tail_*: the lhip_seek_tail_samples(s)

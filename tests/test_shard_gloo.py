@@ -83,7 +83,7 @@ def test_bench_py_two_ranks_gloo(cfg, extra, ch, kbps):
 @pytest.mark.parametrize("world,corpus,nfr", [(2, "sine", 30), (3, "bursts", 90)])
 def test_bench_py_frame_range_shards_gloo(world, corpus, nfr):
     """bench.py --config shard3 (second mode): ONE stream cut into one frame range per rank, the state at every cut
-    speculated, verified across ranks and -- `bursts` has such a cut -- transplanted from the neighbour; the concatenation that
+    speculated, verified across ranks and -- `bursts` with a warm-up of two frames -- transplanted from the neighbour; the concatenation that
     rank 0 gathers must be the bytes of the stream encoded in one piece."""
     if not HOSTSIM.exists():
         pytest.skip("host simulation not built (python -c 'import __graft_entry__ as g; g.build()')")
@@ -91,7 +91,7 @@ def test_bench_py_frame_range_shards_gloo(world, corpus, nfr):
     port = 33500 + (os.getpid() % 2000) + world
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--config", "shard3",
-                        "--cpu-seconds", "0", "--frames", str(nfr), "--shard-corpus", corpus], env=env, capture_output=True, text=True, timeout=900)
+                        "--cpu-seconds", "0", "--frames", str(nfr), "--shard-corpus", corpus, "--shard-warmup", "8" if corpus == "sine" else "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == world and line["scaling"] == "strong" and line["value"] > 0
