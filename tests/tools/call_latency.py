@@ -1,3 +1,5 @@
+"""DEV TOOL (GPU): frames per second as a function of the call size -- the reference's own call pattern (1152 samples per
+encodeBuffer call), 8 and 64 frames per call, mono and stereo; the record is profiles/r02_call_latency.txt."""
 import sys,time
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import lamejs_amd, pcm, numpy as np

@@ -1,7 +1,7 @@
 /*
  * TEST TOOL (needs /root/reference): encode a corpus with the unmodified reference and with the
- * CPU oracle (tests/hostsim/_build/abi_cli_hostsim) and byte-compare.
- * usage: node tests/tools/compare_oracle.js <corpus> <channels> <kbps> [nframes] [chunk]
+ * host simulation of the kernel bodies behind the C ABI (tests/hostsim/_build/abi_cli_hostsim) and byte-compare.
+ * usage: node tests/tools/compare_abi.js <corpus> <channels> <kbps> [nframes] [chunk]
  *   corpus: wav | sine | bursts
  */
 'use strict';
