@@ -124,6 +124,11 @@ def test_hostsim_random_material(sim):
     assert fuzz_gpu.run(42, 2024, lib=sim, verbose=False) == []
     assert fuzz_gpu.run(48, 31, lib=sim, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []      # MPEG-2 / 2.5
     assert fuzz_gpu.run(42, 5, lib=sim, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []  # integer-ratio resampling in front
+    # the lowest bit budgets (8-32 kbps, MPEG-2 / 2.5): joint stereo's reduce_side takes its "side keeps 125 bits" branch only here
+    # (found with tools/gcov_hostsim.sh; the oracle is pinned on this family by tests/tools/fuzz_ref.py ... lowrate)
+    assert fuzz_gpu.run(16, 9301, lib=sim, verbose=False, cfgs=fuzz_gpu.LOWRATE_CFGS, joint=True) == []
+    assert fuzz_gpu.run(16, 9302, lib=sim, verbose=False, cfgs=fuzz_gpu.LOWRATE_CFGS, joint=True, reservoir=True) == []
+    assert fuzz_gpu.run(16, 9303, lib=sim, verbose=False, cfgs=fuzz_gpu.LOWRATE_CFGS) == []
 
 
 def test_hostsim_asan_largest_frames():

@@ -46,6 +46,10 @@ MPEG1_CFGS = [(1, 44100, 128), (2, 44100, 128), (2, 44100, 320), (1, 44100, 64),
 LSF_CFGS = [(1, 22050, 64), (2, 22050, 64), (2, 24000, 128), (1, 16000, 32), (2, 16000, 64), (1, 8000, 8), (2, 8000, 24), (1, 11025, 24),
             (2, 11025, 64), (1, 12000, 40), (2, 12000, 48), (2, 22050, 160), (1, 24000, 80), (1, 8000, 64), (2, 16000, 48), (1, 22050, 32)]
 
+# the lowest bit budgets (MPEG-2.5 / MPEG-2 at 8-24 kbps, two channels): joint stereo's reduce_side reaches its "side channel keeps 125
+# bits" branch here and nowhere else (QuantizePVT.js:486-534), and the granule targets sit at their floors
+LOWRATE_CFGS = [(2, 8000, 8), (2, 8000, 16), (2, 16000, 16), (2, 16000, 24), (2, 8000, 24), (1, 8000, 8), (1, 16000, 8), (2, 12000, 32)]
+
 # resampling by an integer ratio in front of the encoder (fill_buffer_resample)
 RESAMPLE_CFGS = [(1, 44100, 32), (2, 44100, 48), (1, 48000, 24), (2, 48000, 64), (1, 32000, 16), (2, 32000, 8), (1, 16000, 8), (2, 24000, 16),
                  (1, 48000, 40), (1, 48000, 8), (2, 48000, 40), (2, 32000, 40), (1, 32000, 24), (2, 16000, 24)]

@@ -1,6 +1,6 @@
 """DEV/TEST TOOL (authoring container only: needs /root/reference + node): pins the CPU oracle against the unmodified
 reference on the same seeded random material tests/tools/fuzz_gpu.py feeds the GPU path, so that "GPU == oracle" on that
-material means "GPU == reference".  usage: python tests/tools/fuzz_ref.py [ncases] [seed] [mpeg1|lsf|resample] [joint] [reservoir]
+material means "GPU == reference".  usage: python tests/tools/fuzz_ref.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [joint] [reservoir]
 `joint`: the joint-stereo extension (two-channel configurations only; the channels of half of the cases are made strongly
 correlated so that M/S frames, L/R frames and mixtures all occur).  `reservoir`: the bit-reservoir extension (gfp.disable_reservoir = false)."""
 import subprocess, sys, tempfile, time
@@ -45,5 +45,5 @@ def run(ncases, seed, cfgs, verbose=True, joint=False, reservoir=False):
 
 
 if __name__ == "__main__":
-    cfgs = fuzz_gpu.LSF_CFGS if "lsf" in sys.argv[3:] else fuzz_gpu.RESAMPLE_CFGS if "resample" in sys.argv[3:] else fuzz_gpu.MPEG1_CFGS
+    cfgs = fuzz_gpu.LSF_CFGS if "lsf" in sys.argv[3:] else fuzz_gpu.RESAMPLE_CFGS if "resample" in sys.argv[3:] else fuzz_gpu.LOWRATE_CFGS if "lowrate" in sys.argv[3:] else fuzz_gpu.MPEG1_CFGS
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, cfgs, joint="joint" in sys.argv[3:], reservoir="reservoir" in sys.argv[3:]) else 0)

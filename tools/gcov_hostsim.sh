@@ -46,6 +46,8 @@ L, R = pcm.bursts(1152 * 40, 2); assert stage_taps.compare_stages(lib, 2, 44100,
 assert fuzz_gpu.run(60, 2024, lib=lib, verbose=False) == []
 assert fuzz_gpu.run(60, 31, lib=lib, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []
 assert fuzz_gpu.run(30, 5, lib=lib, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []
+assert fuzz_gpu.run(24, 9301, lib=lib, verbose=False, cfgs=fuzz_gpu.LOWRATE_CFGS, joint=True) == []
+assert fuzz_gpu.run(24, 9302, lib=lib, verbose=False, cfgs=fuzz_gpu.LOWRATE_CFGS, joint=True, reservoir=True) == []
 assert large_frames.run(lib) == []
 for ch, sr, kb in ((2, 44100, 128), (1, 22050, 64)):
     L, R = pcm.bursts(1152 * 60, ch, seed=92); assert stage_taps.compare_stages(lib, ch, sr, kb, L, R) == []
@@ -68,7 +70,7 @@ PY
 (cd $B && gcov -b -o . liblamejs_hostsim_cov.so-lhip_api.gcda > gcov_all.txt 2>/dev/null || gcov -b -o . $(ls *.gcda | head -1) > gcov_all.txt 2>/dev/null)
 {
   echo "# line / branch coverage of the kernel bodies under the one-lane host simulation (tools/gcov_hostsim.sh), material: every golden of the envelope and of the joint-stereo and bit-reservoir extensions,"
-  echo "# 150 random cases (MPEG-1, LSF, resampling), largest-frame noise, stage-tap runs, silence / square wave, forced seed repair, device-math edge classes"
+  echo "# 200 random cases (MPEG-1, LSF, resampling, lowest bitrates in joint stereo), largest-frame noise, stage-tap runs, silence / square wave, forced seed repair, device-math edge classes"
   awk '/^File /{f=$2} /^Lines executed/{l=$0} /^Branches executed/{b=$0} /^Taken at least once/{t=$0; if (f ~ /k_psy|k_fb|k_quant|k_bits|lhip_math|lhip_wave|lhip_api/) print f "\n   " l "\n   " b "\n   " t}' $B/gcov_all.txt
 } > $OUT
 cat $OUT
