@@ -92,8 +92,8 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
 
 
 def main():
-    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample] [hostsim] [joint] [reservoir]"""
-    cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else MPEG1_CFGS
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim] [joint] [reservoir]"""
+    cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else LOWRATE_CFGS if "lowrate" in sys.argv[3:] else MPEG1_CFGS
     lib = None
     if "hostsim" in sys.argv[3:]:
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))
