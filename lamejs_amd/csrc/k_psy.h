@@ -543,7 +543,13 @@ LHIP_DEV void kb_scan_blocktype(const Tables& T, const Workspace& W, const Strea
 // first such reset point onwards (no dependence on other threads), then the segment prefixes are filled in
 // as soon as the state at the end of the previous segment is known (at most ATH_NT rounds, 1 in the common case).
 // Nothing but the segment end states is staged: max_pow is recomputed from the per-granule loudness (L2-resident).
-#ifdef LHIP_HOSTSIM
+#if defined(LHIP_HOSTSIM) && defined(LHIP_WAVESIM)
+// TEST-ONLY: the wave simulator runs the scan as a workgroup of two waves with two-frame segments, so that a few hundred frames walk
+// through several chunks, multi-frame segments, reset points, prefix rounds and the chunk carry (the device: 1024 threads x 16)
+enum { ATH_NT = 128, ATH_SEG = 2 };
+LHIP_DEV void block_sync() { wg_barrier(); }
+LHIP_DEV int block_any(int p) { static int any_ = 0; wg_barrier(); if (p) any_ = 1; wg_barrier(); const int r = any_; wg_barrier(); any_ = 0; return r; }
+#elif defined(LHIP_HOSTSIM)
 enum { ATH_NT = 1, ATH_SEG = 1 << 20 };
 LHIP_DEV void block_sync() {}
 LHIP_DEV int block_any(int p) { return p != 0; }

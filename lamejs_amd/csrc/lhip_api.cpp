@@ -973,7 +973,11 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_scan_raw(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
+#ifdef LHIP_WAVESIM
+        { static AthLds LAth; for (int s = 0; s < S; s++) wsim::run_block(ATH_NT / 64, [&](int wave_, int lane_) { kb_scan_ath(T, W, dSD, s, 64 * wave_ + lane_, LAth); }); }
+#else
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
+#endif
         for (int par = resv ? 0 : -1; par < (resv ? GR : 0); par++)
             for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB, par));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));

@@ -148,3 +148,14 @@ def test_wavesim_random_material(wsim):
     assert fuzz_gpu.run(n1, 2024, lib=wsim, verbose=False) == []
     assert fuzz_gpu.run(n2, 31, lib=wsim, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []
     assert fuzz_gpu.run(n3, 5, lib=wsim, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []
+
+
+def test_wavesim_ath_scan_segments(wsim):
+    """The ATH recurrence as the device runs it -- a workgroup whose threads own segments of frames, evaluate them from their first
+    reset point and fill in the prefixes round by round once the previous segment's end state is known (k_psy.h kb_scan_ath).  The
+    one-lane simulation runs it with one thread; here it is a two-wave workgroup (128 threads, two-frame segments, 256-frame chunks),
+    so 600 frames of quiet noise with bursts walk through three chunks, multi-frame segments, resets, prefix rounds and the chunk
+    carry.  ATH.adjust of every frame (and every other stage tap) against the oracle."""
+    import pcm, stage_taps
+    L, _ = pcm.bursts(1152 * 600, 1, seed=5)
+    assert stage_taps.compare_stages(wsim, 1, 44100, 128, L, None) == []
