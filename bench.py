@@ -55,7 +55,7 @@ PRESETS = {
 }
 
 
-def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank, sim, dsync, table):
+def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank, sim, dsync, table, use_dist):
     """--config shard3: ONE stream (stereo 44.1 kHz 128 kbps, 1e5 frames, seed 12345) cut into `world` frame
     ranges that the ranks encode side by side (second mode; strong scaling).  The encoder state at a cut is speculated
     (lhip_seek + H warm-up frames), verified (the state blob after the warm-up must equal the blob of the rank that encoded up to
@@ -71,7 +71,7 @@ def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank
     cuts = [fs * ((r * nfr) // world) for r in range(world + 1)]
     cuts[-1] = fs * nfr
     a, b = cuts[rank], cuts[rank + 1]
-    if world > 1:
+    if use_dist:
         from lamejs_amd.shard import broadcast_blob
         blob = broadcast_blob(dist, lamejs_amd.tables_blob(ch, SR, kbps) if rank == 0 else None, dev, rank)
     else:
@@ -124,7 +124,7 @@ def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank
             s_start = state(h)
         nb = encode(h, a, b, d_out)
         s_end = state(h)
-        if world > 1:
+        if use_dist:
             dig = lambda x: hashlib.md5(x).hexdigest() if x is not None else None
             allv = [None] * world
             dist.all_gather_object(allv, (dig(s_start), dig(s_end)))
@@ -158,25 +158,25 @@ def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank
     for _ in range(args.warmup):
         one_pass()
     dsync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dsync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nb = one_pass()
     dsync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dsync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # the pieces travel to rank 0 (RCCL gather, untimed) and are hashed as one stream
     mine = d_out[:nb]
     whole = None
-    if world > 1:
+    if use_dist:
         sizes = [None] * world
         dist.all_gather_object(sizes, nb)
         nmax = max(sizes)
@@ -189,7 +189,7 @@ def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank
     else:
         whole = mine.cpu().numpy().tobytes()
     allstats = [stats]
-    if world > 1:
+    if use_dist:
         allstats = [None] * world
         dist.all_gather_object(allstats, stats)
     if rank == 0:
@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--check-frames", type=int, default=2000, help="prefix byte-compared with the CPU oracle (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs (they are only run at N = 1)")
+    ap.add_argument("--no-cpu-aggregate", action="store_true", help="skip the all-cores leg of the CPU baseline")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the MP3 bytes to rank 0 (N > 1)")
     args = ap.parse_args()
 
@@ -234,7 +235,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # The collectives run whenever a process group is asked for: N > 1 ranks, a `torch.distributed.run --nproc-per-node 1` launch
+    # (RANK / MASTER_ADDR in the environment), or LAMEJS_BENCH_FORCE_DIST=1 -- so that the real RCCL path (init, blob broadcast,
+    # all_reduce(MAX), all_gather_object, gather of the MP3 bytes) can be executed on a one-GPU box too.
+    force_dist = os.environ.get("LAMEJS_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist or ("RANK" in os.environ and "MASTER_ADDR" in os.environ and os.environ.get("LAMEJS_BENCH_NO_DIST") != "1")
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if sim:
             dist.init_process_group("gloo")
         else:
@@ -292,7 +302,7 @@ def main():
             self.seeds = [p["seed0"] + rank * self.ns + i for i in range(self.ns)]     # one stream: seed0 + rank; config 5: 1000 + global stream index
             self.nsamp = 1152 * self.nfr
             # table blob: rank 0 builds it with the host JavaScript, everyone receives it over RCCL (setup, untimed)
-            if world > 1:
+            if use_dist:
                 from lamejs_amd.shard import broadcast_blob
                 self.blob = broadcast_blob(dist, lamejs_amd.tables_blob(self.ch, SR, self.kbps, self.joint, self.resv) if rank == 0 else None, dev, rank)
             else:
@@ -339,18 +349,18 @@ def main():
             for w in range(warmup):
                 self.step(sets[w])
             dsync()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             dsync()
             t0 = time.perf_counter()
             for s in range(steps):
                 self.step(sets[warmup + s])
             dsync()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             dsync()
             dt = time.perf_counter() - t0
-            if world > 1:
+            if use_dist:
                 tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dt = float(tmax.item())
@@ -401,8 +411,8 @@ def main():
             return f"{self.label}: {shape}" if self.full and not args.streams else shape
 
     if args.config == "shard3":
-        run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank, sim, dsync, table)
-        if world > 1:
+        run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank, sim, dsync, table, use_dist)
+        if use_dist:
             dist.destroy_process_group()
         return
     key = args.config if args.config in PRESETS else int(args.config)
@@ -415,7 +425,7 @@ def main():
     # ---- N > 1: verdicts of all ranks; RCCL gather of the MP3 bytes to rank 0 (untimed), re-hashed there ----
     verdicts = [(rank, md5s, full, prefix, wl.nbytes)]
     gathered_ok = None
-    if world > 1:
+    if use_dist:
         allv = [None] * world
         dist.all_gather_object(allv, verdicts[0])
         verdicts = allv
@@ -521,24 +531,48 @@ def main():
         t1 = time.perf_counter()
         oracle_encode(wl.ch, SR, wl.kbps, L[: 1152 * k], R[: 1152 * k] if wl.ch == 2 else None)
         cdt = time.perf_counter() - t1
-        line["cpu_baseline"] = {"value": round(k / cdt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+        line["cpu_baseline"] = {"value": round(k / cdt, 1), "unit": "frames/s", "cores": 1, "kind": "port", "same_box": True,
                                 "sample": f"first {k} frames of the same stream, plain-C oracle (oracle/), 1 thread, on this host"}
+        # N-process aggregate over all host cores: one worker per logical core, each encoding the same bounded sample
+        # of the stream with the C port; the clocks start together, the aggregate is the frames all workers encoded / the slowest one
+        ncores = os.cpu_count() or 1
+        if not args.no_cpu_aggregate and ncores > 1:
+            import subprocess
+            ka = int(min(wl.nfr, max(500, rate * min(args.cpu_seconds, 8.0))))
+            start = time.time() + 6.0 + 0.02 * ncores
+            cmd = [sys.executable, str(ROOT / "tests" / "tools" / "cpu_port_worker.py"), wl.corpus, str(wl.ch), str(wl.kbps), str(ka), str(wl.seeds[0]), repr(start)]
+            procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(ncores)]
+            secs = []
+            for p_ in procs:
+                try:
+                    o_, _ = p_.communicate(timeout=120 + 20 * args.cpu_seconds)
+                    secs.append(float(o_.split()[1]))
+                except Exception:
+                    p_.kill()
+            if secs:
+                line["cpu_baseline"]["aggregate"] = {"value": round(len(secs) * ka / max(secs), 1), "unit": "frames/s", "cores": len(secs), "processes": len(secs),
+                                                     "logical_cores_of_host": ncores, "kind": "port", "same_box": True,
+                                                     "sample": f"{len(secs)} processes x the first {ka} frames of the same stream, plain-C oracle, clocks started together; "
+                                                               f"slowest {max(secs):.2f} s, fastest {min(secs):.2f} s"}
         rn = ROOT / "profiles" / "r02_reference_node_cpu.jsonl"
         if rn.exists():
+            shapes = {}
             for l_ in rn.read_text().splitlines():
                 try:
                     e = json.loads(l_)
                 except ValueError:
                     continue
+                ent = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": False, "channels": e.get("channels"), "kbps": e.get("kbps"),
+                       "what": e.get("what"), "frames": e.get("frames"), "host": e.get("host")}
+                shapes[f"{'mono' if e.get('channels') == 1 else 'stereo'}{e.get('kbps')}"] = ent
                 if e.get("channels") == wl.ch and e.get("kbps") == wl.kbps:
-                    line["cpu_baseline"]["reference_node"] = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1,
-                                                              "what": e.get("what"), "frames": e.get("frames"), "host": e.get("host"),
-                                                              "note": "unmodified lamejs under Node.js (tests/tools/time_reference.js); measured in the build container "
-                                                                      "(/root/reference does not exist on the GPU box), NOT on this host"}
+                    line["cpu_baseline"]["reference_node"] = dict(ent, note="unmodified lamejs under Node.js (tests/tools/time_reference.js); measured in the build container "
+                                                                       "(/root/reference does not exist on the GPU box), NOT on this host: same_box = false")
+            line["cpu_baseline"]["reference_node_all_shapes"] = shapes
     if rank == 0:
         print(json.dumps(line))
     wl.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -76,6 +76,10 @@ int lhip_set_devices(uint64_t mask);
  * (one range per rank; tests/test_shard_gloo.py runs it with two and three ranks, tests/test_hostsim_parity.py the API itself).
  *   lhip_seek(s, sample_pos, tail_l, tail_r): s fresh; sample_pos a whole number (>= 2) of frames; tail_*: the lhip_seek_tail_samples(s)
  *   input samples in front of sample_pos (host memory).  Not for resampling or bit-reservoir streams. */
+/* lhip_state_get returns the blob in canonical form (fields no later launch can read are zeroed), so two streams that stand at the
+ * same point compare equal whatever call sizes took them there.  lhip_state_set may be applied to a fresh or to a used stream of the
+ * same configuration (it replaces everything the stream carries); like every call on a handle it must not run concurrently with
+ * another call on the same handle.  A two-channel lhip_seek needs both tails. */
 size_t lhip_state_bytes(const lhip_stream* s);
 int lhip_state_get(lhip_stream* s, void* buf, size_t cap);
 int lhip_state_set(lhip_stream* s, const void* buf, size_t n);

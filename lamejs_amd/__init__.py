@@ -134,7 +134,9 @@ class Mp3Encoder:
         """Put this FRESH encoder at input position ``sample_pos`` (a whole number >= 2 of frames); ``tail_*``: the
         ``seek_tail_samples()`` input samples in front of that position."""
         l = _as_i16(tail_left)
-        r = l if (self.channels == 1 or tail_right is None) else _as_i16(tail_right)
+        if self.channels == 2 and tail_right is None:
+            raise ValueError("seek: a two-channel stream needs both tails")
+        r = l if self.channels == 1 else _as_i16(tail_right)
         assert len(l) == self.seek_tail_samples() == len(r)
         self._lib.lhip_seek.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         rc = self._lib.lhip_seek(self._h, int(sample_pos), l.ctypes.data, r.ctypes.data)

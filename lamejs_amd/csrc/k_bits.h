@@ -184,8 +184,9 @@ LHIP_DEV int resv_emit(const uint32_t* w, int from, int nbytes, int sideinfo_len
     return n;
 }
 // flush_bitstream (BitStream.js:710-780): pad the stream with ancillary data up to the end of the last frame; one wave per stream
-LHIP_DEV void kb_resv_flush(const Tables& T, const Workspace& W, int st, int lane, BitsLds& L) {
-    ResvState& rv = W.io[st].state->rv;
+// rv: the stream's reservoir record (global memory or the per-stream kernel's LDS copy); *nout: bytes this launch has appended to the
+// stream's output so far
+LHIP_DEV void kb_resv_flush(const Tables& T, const Workspace& W, int st, int lane, BitsLds& L, ResvState& rv, int32_t* nout) {
     for (int i = lane; i < BITS_LDS_WORDS; i += LHIP_NL) L.w[i] = 0;
     wave_sync_global();
     const int last_ptr = (rv.h_ptr - 1) & (RESV_HQ - 1), first_ptr = rv.w_ptr;
@@ -199,12 +200,12 @@ LHIP_DEV void kb_resv_flush(const Tables& T, const Workspace& W, int st, int lan
     int flag = rv.ancillary_flag;
     if (lane == 0) put_ancillary(T, L.w, 0, (int)flushbits, &flag);
     wave_sync_global();
-    const int n = resv_emit(L.w, 0, (int)(flushbits >> 3), T.sideinfo_len, rv, W.io[st].out, W.out_bytes[st], lane);
+    const int n = resv_emit(L.w, 0, (int)(flushbits >> 3), T.sideinfo_len, rv, W.io[st].out, *nout, lane);
     wave_sync_global();
-    if (lane == 0) { rv.ancillary_flag = flag; W.out_bytes[st] = n; rv.ResvSize = 0; rv.main_data_begin = 0; }
+    if (lane == 0) { rv.ancillary_flag = flag; *nout = n; rv.ResvSize = 0; rv.main_data_begin = 0; }
 }
 
-LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L) {
+LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L, ResvState* rvp = nullptr, int32_t* nout = nullptr) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -262,7 +263,7 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     wave_sync();
     int anc_flag = 0;
     if (resv) {                                                  // drain_into_ancillary(resvDrain_pre) precedes the frame's main data
-        anc_flag = W.io[st].state->rv.ancillary_flag;
+        anc_flag = rvp->ancillary_flag;
         if (lane == 0) put_ancillary(T, L.w, pos, W.fr[fidx].drain_pre, &anc_flag);
         anc_flag = wave_bcast(anc_flag, 0);
         pos += W.fr[fidx].drain_pre;
@@ -342,7 +343,7 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
         if (lane == 0) put_ancillary(T, L.w, pos, fr.drain_post, &anc_flag);
         wave_sync();
         {
-            ResvState& rv = W.io[st].state->rv;
+            ResvState& rv = *rvp;
             const int sl = T.sideinfo_len;
             const int old = rv.h_ptr;
             wave_sync_global();
@@ -350,15 +351,17 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
             if (lane == 0) { rv.h_ptr = (old + 1) & (RESV_HQ - 1); rv.timing[(old + 1) & (RESV_HQ - 1)] = rv.timing[old] + frame_bits; }
             wave_sync_global();
             const int chunk_bits = main_end + fr.drain_post - 8 * sl;            // a whole number of bytes (ResvFrameEnd's stuffing)
-            const int nout = resv_emit(L.w, sl, chunk_bits >> 3, sl, rv, W.io[st].out, 0, lane);
+            const int n0 = *nout;                                                // bytes of this launch's earlier frames
+            wave_sync_global();
+            const int n1 = resv_emit(L.w, sl, chunk_bits >> 3, sl, rv, W.io[st].out, n0, lane);
             if (lane == 0) {
                 const int bits = main_end - fr.drain_pre + fr.drain_post;      // header + side info + main data + drain_post
                 rv.main_data_begin = fr.main_data_begin + (double)(frame_bits - bits) / 8;
                 rv.ResvSize = fr.ResvSize; rv.ResvMax = fr.ResvMax; rv.ancillary_flag = anc_flag; rv.last_frame_bits = frame_bits;
                 for (int i = 0; i < 18; i++) rv.pefirbuf[i] = rv.pefirbuf[i + 1];
                 rv.pefirbuf[18] = fr.pefir_new;
-                W.out_bytes[st] = nout;
-                W.frame_bytes[fidx] = nout;
+                *nout = n1;
+                W.frame_bytes[fidx] = n1 - n0;
             }
         }
         return;

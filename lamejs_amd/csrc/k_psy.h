@@ -715,7 +715,11 @@ LHIP_DEV double ns_interp(double x, double y, double r) {
 
 // par >= 0 (bit reservoir): only the psy calls with q % mode_gr == par -- the second granule's short-block pre-echo control looks at
 // the first one's finished thresholds, so the two are launched one after the other
-template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLdsT<NCH>& L, int par = -1) {
+// resv_size / resv_max (bit reservoir only): ResvSize / ResvMax as the previous frame left them -- handed in by the caller, which knows
+// where the stream's reservoir record lives (the persistent per-stream kernel keeps it in LDS and pipelines the previous frame's bit
+// packing with this call, so this function must not read the record itself)
+template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int gslot, int lane, PsyBLdsT<NCH>& L, int par = -1,
+                                         int resv_size = 0, int resv_max = 0) {
     const int C = T.channels_out, Cp = T.psy_channels;      // Cp <= NCH: the launch picks the instantiation by Tables::psy_channels
     const int st = W.gslot_stream[gslot];
     const StreamDesc sd = SD[st];
@@ -724,7 +728,7 @@ template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, c
     if (par >= 0 && q % T.mode_gr != par) return;
     // PsyModel.js:1036-1038: share of the reservoir in use, as the previous frame left it (0 with the reservoir disabled)
     double pcfact = 0.0;
-    if (!T.disable_reservoir) { const ResvState& rv = W.io[st].state->rv; pcfact = rv.ResvMax == 0 ? 0.0 : (double)rv.ResvSize / rv.ResvMax * 0.5; }
+    if (!T.disable_reservoir) pcfact = resv_max == 0 ? 0.0 : (double)resv_size / resv_max * 0.5;
     const int fs = sd.fslot0 + q / T.mode_gr;            // ATH.adjust as left by the previous frame
     const double ath_adjust = W.ath_adjust[fs];
     for (int i = lane; i < 25; i += LHIP_NL) {

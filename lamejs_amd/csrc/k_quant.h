@@ -1965,7 +1965,10 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
 }
 
 // One wave per frame slot.  chain == 0: speculative reset seed (exact for the first frame of a stream
-// batch, whose seed is the carried one); chain == 1: chain-implied seed (repair pass, flagged frames only).
+// batch, whose seed is the carried one); chain == 1: chain-implied seed (repair pass, flagged frames only);
+// chain == 2: the frames of the stream are quantized in order (bit reservoir: the persistent per-stream kernel), the seed is what the
+// frame before left in W.seed[fslot - 1] and this frame leaves its own in W.seed[fslot] (no walk back through the side records).
+// rvp (RESV only): the stream's reservoir record -- in global memory (one-frame launches) or in the LDS of the per-stream kernel.
 // PAIR == 1 (latency path for small stereo batches, g_quant_pair): the workgroup is two waves, wave `my_ch` does that
 // channel only -- the channels of a granule are independent given the granule's bit budget -- and the two meet once per
 // granule to exchange the bits they used (ResvSize feeds the next granule's budget) through `mbox` in LDS.
@@ -1973,14 +1976,14 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
 // of its state (the entropies, the reservoir record) through the frame
 template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
-                       int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr) {
+                       int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
     const int k = fslot - sd.fslot0 - 1;
     if (k < 0) return;
     const int fidx = sd.out_slot0 + k;                    // dense frame index
-    if (chain && !W.seed_flag[fidx]) return;
+    if (chain == 1 && !W.seed_flag[fidx]) return;
 #ifdef LHIP_PHASE_PROF
     const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();     // L.prof is zeroed / flushed once per wave by g_quant
 #endif
@@ -1991,7 +1994,11 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     // and everything read back from scratch counts as divergent for the compiler
     Seed seed0, seed1;
     seed0.start = seed1.start = W.spec_start; seed0.step = seed1.step = W.spec_step;
-    if (chain || k == 0) {
+    if (chain == 2) {
+        const int32_t* ps = W.seed + (int64_t)(fslot - 1) * C * 2;
+        seed0.start = uni(ps[0]); seed0.step = uni(ps[1]);
+        if (C > 1) { seed1.start = uni(ps[2]); seed1.step = uni(ps[3]); }
+    } else if (chain || k == 0) {
         seed0 = seed_before(W, sd, C, k, 0, 0);
         if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
     }
@@ -2001,7 +2008,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     // Bit reservoir (extension): the frame starts from the reservoir the previous frame left (one frame per stream and launch), its
     // budget follows the perceptual entropies (on_pe), and ResvFrameEnd's verdict goes to the bit packer, which commits it.
     constexpr bool resv = RESV != 0;
-    const ResvState* rv = resv ? &W.io[st].state->rv : nullptr;
+    const ResvState* rv = resv ? rvp : nullptr;
     int ResvSize = resv ? uni(rv->ResvSize) : 0;
     int ResvMax = 0;
     double pe_use[2][2] = {{0., 0.}, {0., 0.}};
@@ -2125,7 +2132,12 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         fr.ResvSize = rs; fr.ResvMax = ResvMax; fr.pefir_new = pefir_new; fr.pad_ = 0;
         W.fr[fidx] = fr;
     }
-    if (chain && lane == 0) W.seed_flag[fidx] = 0;
+    if (chain == 1 && lane == 0) W.seed_flag[fidx] = 0;
+    if (chain == 2 && lane == 0) {                            // OldValue / CurrentStep after this frame (every wave of a pair its own channel)
+        int32_t* ps = W.seed + (int64_t)fslot * C * 2;
+        if (!PAIR || my_ch == 0) { ps[0] = seed0.start; ps[1] = seed0.step; }
+        if (C > 1 && (!PAIR || my_ch == 1)) { ps[2] = seed1.start; ps[3] = seed1.step; }
+    }
 #ifdef LHIP_PHASE_PROF
     if (lane == 0) { L.prof[PH_TOTAL] += (unsigned int)(__builtin_amdgcn_s_memtime() - ph_total0_); L.prof[32 + PH_TOTAL] += 1; }
 #endif

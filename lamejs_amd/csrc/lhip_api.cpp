@@ -163,7 +163,9 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
             S->loud[ch] = W.loud[o];
             S->tent[ch] = W.tent[o];
             S->last_bt[ch] = W.blocktype[o];
-            const Seed s = seed_before(W, sd, C, F, 0, ch);
+            Seed s;                                               // bit reservoir: the frames were quantized in order and left their seeds in W.seed
+            if (T.disable_reservoir) s = seed_before(W, sd, C, F, 0, ch);
+            else { s.start = W.seed[((int64_t)(sd.fslot0 + F) * C + ch) * 2]; s.step = W.seed[((int64_t)(sd.fslot0 + F) * C + ch) * 2 + 1]; }
             S->seed[ch][0] = s.start; S->seed[ch][1] = s.step;
         }
     }
@@ -230,6 +232,7 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
     const StreamDesc sd = SD[st];
     const bool has = sd.nframes > 0;                          // this launch completes a frame of the stream (else only the state moves)
     const int g1 = sd.gslot0 + 1, fslot = sd.fslot0 + 1;
+    ResvState* rv = RESV ? &IO[st].state->rv : nullptr;       // one-frame launches work on the record in global memory
     switch (stage) {
         case FS_LOAD: if (wv == 0) kb_load(T, W, SD, IO, st, lane); break;
         case FS_PREP: if (T.rs_ratio != 1) kb_prep_stream(T, W, SD, IO, st, (int64_t)wv * LHIP_NL + lane, (int64_t)nw * LHIP_NL); break;
@@ -248,19 +251,65 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             }
             break;
         case FS_PSYB0:   // bit reservoir: the frame's granules one after the other (FS_PSYB1 takes the second)
-            if (has && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds);
+            if (has && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
             break;
-        case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds); break;
+        case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax); break;
         case FS_POLY: if (has && wv < C) kb_poly_run(T, W, SD, IO, g1, wv, GR, lane, *(PolyLds*)lds); break;
         case FS_MDCT: if (has && wv < GR) kb_mdct(T, W, SD, g1 + wv, lane, *(MdctLds*)lds); break;
         case FS_QUANT:
             if (PAIRQ && C == 2) {
-                if (has && wv < 2) kb_quant<1, RESV>(T, pb, W, SD, fslot, 0, lane, *(QuantLds*)lds, Q, wv, mbox);
+                if (has && wv < 2) kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv);
                 else for (int gr = 0; gr < GR; gr++) wg_barrier();
-            } else if (has && wv == 0) kb_quant<0, RESV>(T, pb, W, SD, fslot, 0, lane, *(QuantLds*)lds, Q);
+            } else if (has && wv == 0) kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv);
             break;
-        case FS_BITS: if (has && wv == 0) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds); break;
+        case FS_BITS: if (has && wv == 0) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds, rv, W.out_bytes + st); break;
         case FS_SAVE: if (wv == 0) kb_save(T, W, SD, IO, st, lane); break;
+        default: break;
+    }
+}
+
+// ===========================================================================================
+// Bit reservoir: ALL frames of a stream in one launch.  With the reservoir in use a frame's bit budget and -- through pcfact -- the
+// second half of its psychoacoustics depend on the bits every earlier frame spent: the frames of a stream are a
+// serial chain.  What does NOT depend on the reservoir (load, resampling, psyA, the scans, the ATH recurrence, polyphase, MDCT) runs
+// batched over all frames of all streams like any other batch; then ONE workgroup per stream walks the stream's frames in order:
+//     psyB(granule 0) | psyB(granule 1) | quantization | bit packing        (workgroup barriers in between)
+// with the stream's reservoir record in LDS for the whole walk and the bit packing of frame k - 1 running beside psyB(granule 0) of
+// frame k on another wave (the packer commits the record; psyB takes the reservoir fill from what the quantization of frame k - 1
+// decided, W.fr, so the two do not touch the same words).  No launch and no read-back per frame: the byte counts stay on the device
+// until the call ends.  Waves: 0 (and 1: second channel, kb_quant<1>) quantize, 2 runs psyB, 3 packs bits.
+// ===========================================================================================
+enum { RS_PSYB0, RS_PSYB1, RS_QUANT, RS_STAGES, RS_WAVES = 4,
+       RS_LDS_PER_WAVE = ((sizeof(QuantLds) > sizeof(PsyBLds4) ? (sizeof(QuantLds) > sizeof(BitsLds) ? sizeof(QuantLds) : sizeof(BitsLds))
+                                                                : (sizeof(PsyBLds4) > sizeof(BitsLds) ? sizeof(PsyBLds4) : sizeof(BitsLds))) + 15) & ~15 };
+// stage `stage` of frame k (of F) of stream st for wave wv; k == F: only the tail (bit packing of the last frame)
+template <int PAIRQ>
+LHIP_DEV void kb_resv_stage(int stage, const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, int st, int k, int F,
+                            int wv, int lane, unsigned char* lds, QuantTabs& Q, int* mbox, ResvState& RV, int32_t* nout) {
+    const int C = T.channels_out, GR = T.mode_gr;
+    const StreamDesc sd = SD[st];
+    const int g1 = sd.gslot0 + 1 + GR * k, fslot = sd.fslot0 + 1 + k, fidx = sd.out_slot0 + k;
+    switch (stage) {
+        case RS_PSYB0:
+            if (wv == 2 && k < F) {       // the reservoir as frame k - 1 left it: decided by that frame's quantization (the packer may still be committing it)
+                const int rs = k == 0 ? RV.ResvSize : W.fr[fidx - 1].ResvSize, rm = k == 0 ? RV.ResvMax : W.fr[fidx - 1].ResvMax;
+                kb_psyB<4>(T, pb, W, SD, g1, lane, *(PsyBLds4*)lds, -1, rs, rm);
+            }
+            if (wv == 3 && k > 0) kb_bits(T, W, SD, fslot - 1, lane, *(BitsLds*)lds, &RV, nout);
+            break;
+        case RS_PSYB1:
+            if (wv == 2 && k < F && GR == 2) {
+                const int rs = k == 0 ? RV.ResvSize : W.fr[fidx - 1].ResvSize, rm = k == 0 ? RV.ResvMax : W.fr[fidx - 1].ResvMax;
+                kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rs, rm);
+            }
+            break;
+        case RS_QUANT:
+            if (k >= F) break;
+            if (PAIRQ && C == 2) {
+                if (wv < 2) kb_quant<1, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, wv, mbox, &RV);
+                else for (int gr = 0; gr < GR; gr++) wg_barrier();
+            } else if (wv == 0) kb_quant<0, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, -1, nullptr, &RV);
+            break;
         default: break;
     }
 }
@@ -464,9 +513,35 @@ __global__ __launch_bounds__(64) void g_bits(Tables T, Workspace W, const Stream
     __shared__ BitsLds L;
     kb_bits(T, W, SD, blockIdx.x, threadIdx.x, L);
 }
-__global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W) {
+__global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W, const StreamDesc* SD) {
     __shared__ BitsLds L;
-    kb_resv_flush(T, W, blockIdx.x, threadIdx.x, L);
+    if (SD[blockIdx.x].flush) kb_resv_flush(T, W, blockIdx.x, threadIdx.x, L, W.io[blockIdx.x].state->rv, W.out_bytes + blockIdx.x);
+}
+// the per-stream reservoir program (kb_resv_stage): one workgroup of RS_WAVES waves per stream
+__global__ __launch_bounds__(64 * RS_WAVES) void g_resv_stream(QArgs a_unused) {
+    __shared__ QuantTabs Q;
+    __shared__ __attribute__((aligned(16))) unsigned char U[RS_WAVES][RS_LDS_PER_WAVE];
+    __shared__ ResvState RV;
+    __shared__ int mbox[4];
+    __shared__ int32_t nout;
+    const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, st = blockIdx.x;
+    q_load_tabs(A->T, Q, threadIdx.x, 64 * RS_WAVES);
+    static_assert(sizeof(ResvState) % 4 == 0, "the reservoir record is copied as words");
+    ResvState* grv = &A->W.io[st].state->rv;
+    for (int i = threadIdx.x; i < (int)(sizeof(ResvState) / 4); i += 64 * RS_WAVES) ((uint32_t*)&RV)[i] = ((const uint32_t*)grv)[i];
+    if (threadIdx.x == 0) nout = 0;
+    __syncthreads();
+    const int F = __builtin_amdgcn_readfirstlane(A->SD[st].nframes);
+    for (int k = 0; k <= F; k++)
+        for (int stage = 0; stage < RS_STAGES; stage++) {
+            kb_resv_stage<1>(stage, A->T, A->pb, A->W, A->SD, st, k, F, wv, lane, U[wv], Q, mbox, RV, &nout);
+            __syncthreads();
+        }
+    if (wv == 3 && A->SD[st].flush) kb_resv_flush(A->T, A->W, st, lane, *(BitsLds*)U[3], RV, &nout);
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)(sizeof(ResvState) / 4); i += 64 * RS_WAVES) ((uint32_t*)grv)[i] = ((const uint32_t*)&RV)[i];
+    if (threadIdx.x == 0) A->W.out_bytes[st] = nout;
 }
 // one workgroup per stream, one frame per stream (see kb_frame_stage); NW = 4 waves, 8 in joint stereo (two granules x four psy channels)
 template <int RESV, int NW> __global__ __launch_bounds__(64 * NW) void g_frame(QArgs a_unused, const StreamIO* IO) {
@@ -786,6 +861,7 @@ struct Job {
     lhip_stream* s; const int16_t* l; const int16_t* r; size_t n; uint8_t* out; size_t cap; int64_t written;
     int F; int64_t bytes;
     int64_t n_out;              // samples this call appends to the encoder's buffer (== n unless resampling)
+    bool flush = false;         // bit reservoir: the stream ends with this call (its bitstream is padded to the end of the last frame)
 };
 
 // resampling by the integer ratio r: output sample m exists once m*r + 16 < (input samples received) -- see kb_resample_elem
@@ -803,7 +879,7 @@ static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
     return (int64_t)F * ts.base_frame_bytes + npad;
 }
 
-static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync, bool flush_stream = false) {
+static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
     if (jobs.empty()) return true;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(ctx->device)) return false;
@@ -813,7 +889,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     const int C = T.channels_out;
     const int GR = T.mode_gr, frame = 576 * GR, mf_needed = 1024 + frame - 272;   // calcNeeded (Lame.js:1517-1530)
     const int S = (int)jobs.size();
-    const bool resv = !T.disable_reservoir;       // bit reservoir (extension): one frame per stream and launch, output sizes known to the device only
+    const bool resv = !T.disable_reservoir;       // bit reservoir (extension): the frames of a stream are a serial chain (g_resv_stream), output sizes known to the device only
     // ---- plan ----
     std::vector<StreamDesc> sd(S);
     std::vector<StreamIO> io(S);
@@ -828,16 +904,15 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (total > 0x7fffffff || (int64_t)j.n > 0x7fffffff) { set_err("too many samples in one call"); return false; }
         j.F = total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
         j.bytes = batch_bytes(ts, s->slot_lag, j.F);
-        if (resv) {
-            if (j.F > 1) { set_err("internal: more than one frame per launch with the bit reservoir"); return false; }
-            j.bytes = (int64_t)j.F * (ts.base_frame_bytes + 1 + 512 + RESV_HQ * RESV_HDR) + (flush_stream ? 1440 + RESV_HQ * RESV_HDR : 0);      // upper bound; the real count comes back from the device
-        }
+        if (resv)     // upper bound (the real count comes back from the device): the call's own frames, what earlier frames left in the
+                      // reservoir (main data up to 511 bytes ahead of its header) and in the header queue, the flush padding
+            j.bytes = (int64_t)j.F * (ts.base_frame_bytes + 1) + (j.F > 0 || j.flush ? 512 + RESV_HQ * RESV_HDR : 0) + (j.flush ? 1440 + RESV_HQ * RESV_HDR : 0);
         if ((size_t)j.bytes > j.cap) { j.written = LHIP_ERR_BUFFER_TOO_SMALL; set_err("output buffer too small"); return false; }
         StreamDesc& d = sd[i];
         memset(&d, 0, sizeof d);
         d.nframes = j.F; d.fslot0 = nfs; d.gslot0 = ngs; d.out_slot0 = nfr;
         d.pcm_off = pcm_plane; d.out_off = out_total; d.seg_len = (int)total; d.first_call = s->frame_num == 0;
-        d.slot_lag = s->slot_lag; d.frame_num0 = s->frame_num;
+        d.slot_lag = s->slot_lag; d.frame_num0 = s->frame_num; d.flush = (resv && j.flush) ? 1 : 0;
         nfs += j.F + 1; ngs += GR * j.F + 1; nfr += j.F;
         if (j.F > maxF) maxF = j.F;
         pcm_plane += (total + 63) & ~(int64_t)63;
@@ -964,7 +1039,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
                     }
 #endif
             }
-            if (resv && flush_stream) for (int s = 0; s < S; s++) WAVE_RUN(kb_resv_flush(T, W, s, lane_, LBi));
+            if (resv) for (int s = 0; s < S; s++) if (sd[s].flush) WAVE_RUN(kb_resv_flush(T, W, s, lane_, LBi, dIO[s].state->rv, W.out_bytes + s));
         } else {
         for (int s = 0; s < S; s++) WAVE_RUN(kb_load(T, W, dSD, dIO, s, lane_));
         if (T.rs_ratio != 1) kb_prep(T, W, dSD, dIO, S, 0, 1);
@@ -978,19 +1053,41 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
         { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
 #endif
-        for (int par = resv ? 0 : -1; par < (resv ? GR : 0); par++)
-            for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB, par));
+        if (!resv) for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB, -1));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
+        if (resv) {
+            // the per-stream reservoir program (kb_resv_stage), as g_resv_stream runs it; the wave simulation as a real workgroup of four waves
+            static unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static int rmbox[4];
+            for (int s = 0; s < S; s++) {
+                ResvState RV = dIO[s].state->rv;
+                int32_t nout = 0;
+                const int F = sd[s].nframes;
+#ifdef LHIP_WAVESIM
+                wsim::run_block(RS_WAVES, [&](int wave_, int lane_) {
+                    for (int k = 0; k <= F; k++)
+                        for (int stage = 0; stage < RS_STAGES; stage++) { kb_resv_stage<1>(stage, T, ts.pb10, W, dSD, s, k, F, wave_, lane_, RU[wave_], QT, rmbox, RV, &nout); wg_barrier(); }
+                    if (wave_ == 3 && sd[s].flush) kb_resv_flush(T, W, s, lane_, *(BitsLds*)RU[3], RV, &nout);
+                });
+#else
+                for (int k = 0; k <= F; k++)
+                    for (int stage = 0; stage < RS_STAGES; stage++)
+                        for (int wv = 0; wv < RS_WAVES; wv++) kb_resv_stage<0>(stage, T, ts.pb10, W, dSD, s, k, F, wv, 0, RU[wv], QT, rmbox, RV, &nout);
+                if (sd[s].flush) kb_resv_flush(T, W, s, 0, *(BitsLds*)RU[3], RV, &nout);
+#endif
+                dIO[s].state->rv = RV;
+                W.out_bytes[s] = nout;
+            }
+        } else {
 #ifdef LHIP_WAVESIM
         // small stereo batches: the two-waves-per-frame latency kernel (kb_quant<1>), as run_batch chooses on the device
         static QuantLds LQ2[2]; static int mbox[4];
         static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : 12; }();
         const bool pair = (C == 2 && nfs <= pair_max);
-#define QUANT_RUN(chain_) do { if (pair) wsim::run_block(2, [&](int wave_, int lane_) { if (resv) kb_quant<1, 1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); else kb_quant<1, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); }); \
-                               else WAVE_RUN(resv ? kb_quant<0, 1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT) : kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT)); } while (0)
+#define QUANT_RUN(chain_) do { if (pair) wsim::run_block(2, [&](int wave_, int lane_) { kb_quant<1, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); }); \
+                               else WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT)); } while (0)
 #else
-#define QUANT_RUN(chain_) WAVE_RUN(resv ? kb_quant<0, 1>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT) : kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
+#define QUANT_RUN(chain_) WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
 #endif
         for (int b = 0; b < nfs; b++) QUANT_RUN(0);
         for (;;) {
@@ -1004,7 +1101,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             if (iters > nfr + 2) { set_err("seed-chain repair did not converge"); return false; }
         }
         for (int b = 0; b < nfs; b++) WAVE_RUN(kb_bits(T, W, dSD, b, lane_, LBi));
-        if (resv && flush_stream) for (int s = 0; s < S; s++) WAVE_RUN(kb_resv_flush(T, W, s, lane_, LBi));
+        }
         for (int s = 0; s < S; s++) WAVE_RUN(kb_save(T, W, dSD, dIO, s, lane_));
         }
 #undef QUANT_RUN
@@ -1015,7 +1112,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
         if (T.psy_channels == 4) { if (resv) LAUNCHB(KT_QUANT, (g_frame<1, 8>), S, 512, st, qa, dIO); else LAUNCHB(KT_QUANT, (g_frame<0, 8>), S, 512, st, qa, dIO); }
         else { if (resv) LAUNCHB(KT_QUANT, (g_frame<1, 4>), S, 256, st, qa, dIO); else LAUNCHB(KT_QUANT, (g_frame<0, 4>), S, 256, st, qa, dIO); }
-        if (resv && flush_stream) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W);
+        if (resv) { bool any_flush = false; for (int i = 0; i < S; i++) any_flush |= sd[i].flush != 0; if (any_flush) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W, dSD); }
     } else {
     LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);
     if (T.rs_ratio != 1) {          // only the resampler materialises samples; otherwise the consumers convert the caller's Int16 themselves
@@ -1055,11 +1152,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_POLY, g_poly, XCD_GRID((ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE), st, T, W, dSD, dIO, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, XCD_GRID(ngs), st, T, W, dSD);
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
-    // bit reservoir: the granules of a frame one after the other (the second one's short-block pre-echo control reads the first one's thresholds)
-    for (int par = resv ? 0 : -1; par < (resv ? GR : 0); par++) {
-        if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, par);
-        else LAUNCH(KT_PSYB, g_psyB<2>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, par);
-    }
+    if (resv) {
+        // bit reservoir: psyB -> quantization -> bit packing of a stream's frames are a serial chain: one workgroup per stream walks them
+        QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 2; qa.nfs = nfs; qa.ctr = 0;
+        LAUNCHB(KT_QUANT, g_resv_stream, S, 64 * RS_WAVES, st, qa);
+    } else {
+    if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, -1);
+    else LAUNCH(KT_PSYB, g_psyB<2>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, -1);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;
@@ -1073,9 +1172,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     const bool pair = (C == 2 && nfs <= (pair_max >= 0 ? pair_max : 6 * ctx->num_cus));
 #endif
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
-      if (resv) { if (pair) LAUNCHB(KT_QUANT, g_quant_pair<1>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<1>, qgrid, 64 * QWAVES, st, qa); }
-      else { if (pair) LAUNCHB(KT_QUANT, g_quant_pair<0>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<0>, qgrid, 64 * QWAVES, st, qa); } }
-    if (nfr > 0 && !resv) {   // (bit reservoir: one frame per stream and launch, its seed is the carried one -- nothing is speculated)
+      if (pair) LAUNCHB(KT_QUANT, g_quant_pair<0>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<0>, qgrid, 64 * QWAVES, st, qa); }
+    if (nfr > 0) {
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
         LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
@@ -1095,7 +1193,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         }
     }
     LAUNCH(KT_BITS, g_bits, nfs, st, T, W, dSD);
-    if (resv && flush_stream) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W);
+    }
     LAUNCH(KT_SAVE, g_save, S, st, T, W, dSD, dIO);
     }
 #endif
@@ -1270,43 +1368,14 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
         if (streams[i]->ctx != streams[0]->ctx) { set_err("batch: streams on different devices"); return LHIP_ERR_INTERNAL; }
         jobs[i] = Job{streams[i], l[i], r ? r[i] : nullptr, ns[i], out[i], cap[i], 0, 0, 0, 0};
     }
-    bool ok = true;
+    // Bit reservoir (extension): the frames of a stream are a serial chain, walked by one workgroup per stream inside the launch
+    // (g_resv_stream); a stream that ends with this call (flush) has its bitstream padded by the same launch -- decided per stream
+    // (an already flushed stream in a flush batch has nothing to encode and is not flushed again).  The byte counts are only known
+    // on the device, so these calls always synchronise.
     const Tables& T0 = streams[0]->ts->T;
-    if (!T0.disable_reservoir) {
-        // Bit reservoir (extension): a frame's budget -- and through `pcfact` its masking -- depends on the bits every earlier frame of
-        // the stream spent, so the frames of a stream are a serial chain: every launch encodes at most one frame per stream (the
-        // streams of a batch still run side by side), and the host learns from each launch how many bytes the streams produced.
-        const size_t step = (size_t)576 * T0.mode_gr * T0.rs_ratio;
-        std::vector<size_t> pos(n, 0);
-        std::vector<int64_t> done(n, 0);
-        int64_t frames_all = 0;
-        for (;;) {
-            std::vector<Job> sub; std::vector<size_t> idx;
-            for (size_t i = 0; i < n; i++) {
-                if (pos[i] >= ns[i] && !(flush_stream && pos[i] == ns[i])) continue;
-                const size_t m = ns[i] - pos[i] < step ? ns[i] - pos[i] : step;
-                sub.push_back(Job{streams[i], l[i] ? l[i] + pos[i] : nullptr, (r && r[i]) ? r[i] + pos[i] : nullptr, m, out[i] + done[i], cap[i] - (size_t)done[i], 0, 0, 0, 0});
-                idx.push_back(i);
-            }
-            if (sub.empty()) break;
-            bool last = true;                      // the stream flush rides on the launch that takes every stream's last samples
-            for (size_t q = 0; q < idx.size(); q++) if (pos[idx[q]] + sub[q].n < ns[idx[q]]) last = false;
-            ok = run_batch(streams[0]->ctx, sub, dev_io, true, flush_stream && last && idx.size() == n);
-            if (ok) frames_all += g_stat_frames;
-            for (size_t q = 0; q < idx.size(); q++) {
-                const size_t i = idx[q];
-                if (!ok) { jobs[i].written = sub[q].written < 0 ? sub[q].written : LHIP_ERR_INTERNAL; continue; }
-                done[i] += sub[q].written; pos[i] += sub[q].n;
-                if (sub[q].n == 0) pos[i] = ns[i] + 1;      // flush-only pass done
-                jobs[i].written = done[i];
-            }
-            if (!ok) break;
-            if (flush_stream && last && idx.size() == n) break;
-        }
-        g_stat_frames = frames_all;                  // lhip_last_batch_stats speaks for the whole call
-        (void)sync;
-    } else
-        ok = run_batch(streams[0]->ctx, jobs, dev_io, sync);
+    const bool resv = !T0.disable_reservoir;
+    if (resv) for (size_t i = 0; i < n; i++) jobs[i].flush = flush_stream && ns[i] > 0;
+    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync || resv);
     for (size_t i = 0; i < n; i++) if (written) written[i] = ok ? jobs[i].written : (jobs[i].written < 0 ? jobs[i].written : LHIP_ERR_INTERNAL);
     if (!ok) { for (auto& j : jobs) if (j.written < 0) return (int)j.written; return LHIP_ERR_INTERNAL; }
     return 0;
@@ -1369,8 +1438,9 @@ int64_t lhip_flush(lhip_stream* s, uint8_t* out, size_t out_cap) {
     const int16_t* r = zeros.data();
     int64_t w = 0;
     const int rc = encode_many(&s, 1, &l, &r, &z, &out, &out_cap, &w, false, true, true);
+    if (rc < 0) return rc;                 // nothing was consumed (e.g. -1: the call can be repeated with a larger buffer)
     s->mf_samples_to_encode = 0;
-    return rc < 0 ? rc : w;
+    return w;
 }
 
 int lhip_encode_batch(lhip_stream* const* streams, size_t nstreams, const int16_t* const* left, const int16_t* const* right,
@@ -1389,7 +1459,7 @@ int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* cons
         l[i] = zs[i].data();
     }
     const int rc = encode_many(streams, nstreams, l.data(), l.data(), ns.data(), out, out_cap, written, false, true, true);
-    for (size_t i = 0; i < nstreams; i++) streams[i]->mf_samples_to_encode = 0;
+    if (rc >= 0) for (size_t i = 0; i < nstreams; i++) streams[i]->mf_samples_to_encode = 0;
     return rc;
 }
 
@@ -1402,8 +1472,13 @@ int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const
 struct StateHdr { uint32_t magic, bytes; int32_t mf_size, mf_samples_to_encode, slot_lag, config; int64_t frame_num, rs_n_in; };
 // what must agree between the stream a state blob came from and the stream it is put into
 static int32_t state_config_tag(const Tables& T) {
-    return (int32_t)((uint32_t)T.channels_out | ((uint32_t)T.mode << 2) | ((uint32_t)(T.disable_reservoir != 0) << 4) | ((uint32_t)T.samplerate_index << 5) |
-                     ((uint32_t)T.version << 8) | ((uint32_t)T.bitrate_index << 10) | ((uint32_t)T.rs_ratio << 16));
+    // FNV-1a over everything that selects a different table set or state layout (MPEG-2 and MPEG-2.5 share version and
+    // samplerate_index, so the rates themselves are part of it)
+    const int32_t f[] = {T.channels_out, T.mode, T.disable_reservoir != 0, T.samplerate_index, T.version, T.bitrate_index, T.rs_ratio,
+                         T.out_samplerate, T.in_samplerate, T.brate, T.mode_gr, T.psy_channels};
+    uint32_t h = 2166136261u;
+    for (int32_t v : f) for (int b = 0; b < 4; b++) { h ^= (uint32_t)(v >> (8 * b)) & 0xffu; h *= 16777619u; }
+    return (int32_t)h;
 }
 size_t lhip_state_bytes(const lhip_stream* s) {
     if (!s || s->magic != 0x4c484950) return 0;
@@ -1420,6 +1495,19 @@ int lhip_state_get(lhip_stream* s, void* buf, size_t cap) {
     h.config = state_config_tag(s->ts->T);
     memcpy(buf, &h, sizeof h);
     if (!rt::set_device(ctx->device) || !rt::d2h((uint8_t*)buf + sizeof h, s->d_state, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    // Canonical form: fields no later launch can read are zeroed, so that "equal blobs = equal futures" also holds the other way round
+    // for streams that reached the same point through different call sizes (kb_save never clears the samples beyond mf_size, the
+    // resampler tail and the reservoir record are dead without resampler / reservoir).
+    {
+        const Tables& T = s->ts->T;
+        StreamState* S = (StreamState*)((uint8_t*)buf + sizeof h);
+        for (int ch = 0; ch < 2; ch++) {
+            const int live = ch < T.channels_out ? s->mf_size : 0;
+            for (int i = live; i < MF_NEEDED; i++) S->pcm_tail[ch][i] = 0.f;
+        }
+        if (T.rs_ratio == 1) memset(S->rs_old, 0, sizeof S->rs_old);
+        if (T.disable_reservoir) { memset(S->nb1, 0, sizeof S->nb1); memset(S->nb2, 0, sizeof S->nb2); memset(&S->rv, 0, sizeof S->rv); }
+    }
     return 0;
 }
 int lhip_state_set(lhip_stream* s, const void* buf, size_t n) {
@@ -1427,9 +1515,9 @@ int lhip_state_set(lhip_stream* s, const void* buf, size_t n) {
     StateHdr h;
     if (!buf || n < sizeof h) { set_err("state blob too small"); return LHIP_ERR_INTERNAL; }
     memcpy(&h, buf, sizeof h);
-    if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes || h.config != state_config_tag(s->ts->T)) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes || h.config != state_config_tag(s->ts->T)) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
     if (!rt::set_device(ctx->device) || !rt::h2d(s->d_state, (const uint8_t*)buf + sizeof h, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
     s->mf_size = h.mf_size; s->mf_samples_to_encode = h.mf_samples_to_encode; s->slot_lag = h.slot_lag; s->frame_num = h.frame_num; s->rs_n_in = h.rs_n_in;
     return 0;
@@ -1446,11 +1534,12 @@ int lhip_seek(lhip_stream* s, int64_t sample_pos, const int16_t* tail_left, cons
     if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
     const Tables& T = s->ts->T;
     const int frame = 576 * T.mode_gr, ntail = MF_INIT + frame;
+    Context* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     if (T.rs_ratio != 1 || !T.disable_reservoir) { set_err("lhip_seek: not for resampling or bit-reservoir streams"); return LHIP_ERR_INTERNAL; }
     if (s->frame_num != 0 || s->mf_size != MF_INIT) { set_err("lhip_seek: the stream has been used"); return LHIP_ERR_INTERNAL; }
     if (sample_pos < 2 * frame || sample_pos % frame != 0 || !tail_left) { set_err("lhip_seek: position must be a whole number (>= 2) of frames"); return LHIP_ERR_INTERNAL; }
-    Context* ctx = s->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (T.channels_out == 2 && !tail_right) { set_err("lhip_seek: a two-channel stream needs both tails"); return LHIP_ERR_INTERNAL; }
     const bool do_scale = !(T.scale == 0.0) && !(T.scale == 1.0);
     std::vector<float> t((size_t)2 * MF_NEEDED, 0.f);
     for (int ch = 0; ch < T.channels_out; ch++) {

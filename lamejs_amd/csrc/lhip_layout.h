@@ -31,7 +31,7 @@ struct StreamDesc {
     int32_t seg_len;        // valid samples in the segment (tail + new)
     int32_t first_call;     // 1 if the stream has not produced a frame yet (filterbank priming rules)
     int32_t slot_lag;       // padding accumulator before the first frame of this batch
-    int32_t pad_;
+    int32_t flush;          // bit reservoir: the stream ends with this call -- pad its bitstream to the end of the last frame (flush_bitstream)
     int64_t frame_num0;     // absolute index of the first frame of this batch
 };
 

@@ -237,9 +237,9 @@ static napi_value js_state_get(napi_env env, napi_callback_info info) {
     lhip_stream* s = argc >= 1 ? handle_arg(env, argv[0]) : NULL;
     if (!s) return NULL;
     const size_t n = p_state_bytes(s);
-    napi_create_arraybuffer(env, n, &data, &ab);
+    if (n == 0 || napi_create_arraybuffer(env, n, &data, &ab) != napi_ok || !data) { napi_throw_error(env, NULL, "stateGet: could not allocate the state buffer"); return NULL; }
     if (p_state_get(s, data, n) != 0) { napi_throw_error(env, NULL, p_last_error()); return NULL; }
-    napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta);
+    if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) { napi_throw_error(env, NULL, "stateGet: could not create the result array"); return NULL; }
     return ta;
 }
 static napi_value js_state_set(napi_env env, napi_callback_info info) {

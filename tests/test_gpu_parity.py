@@ -552,3 +552,12 @@ def test_gpu_frame_range_shards_full_size(lib):
     got, missed = _gpu_encode_in_ranges(2, 44100, 128, L, R, [nfr * i // 8 for i in range(1, 8)], 8)
     assert missed == []
     assert hashlib.md5(got).hexdigest() == hashlib.md5(whole).hexdigest()
+
+
+def test_gpu_boundary_error_paths(lib):
+    """The C ABI's error paths on the device build: -1 with a too-small out_cap on lhip_encode / lhip_flush / batch entries (and the
+    stream unchanged afterwards), -3 on destroyed / garbage handles, the flush batch with an already flushed stream."""
+    from boundary_checks import run_boundary_checks, run_state_canonical_checks
+    from oracle_py import oracle_encode
+    run_boundary_checks(lib, oracle_encode)
+    run_state_canonical_checks(lib)

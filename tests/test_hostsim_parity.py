@@ -272,3 +272,15 @@ def test_hostsim_seek_and_state_errors(sim):
             e.seek(1152 * 4, L[:e.seek_tail_samples()])
         e.close()
     enc.close(); other.close()
+
+
+def test_hostsim_boundary_error_paths(sim):
+    """-1 (output buffer too small) on lhip_encode / lhip_flush / batch entries and the stream state afterwards, -3 on destroyed and
+    garbage handles, the flush batch with an already flushed stream (tests/boundary_checks.py; the GPU tier runs the same)."""
+    from boundary_checks import run_boundary_checks
+    run_boundary_checks(sim, oracle_encode)
+
+
+def test_hostsim_state_blob_is_canonical(sim):
+    from boundary_checks import run_state_canonical_checks
+    run_state_canonical_checks(sim)
