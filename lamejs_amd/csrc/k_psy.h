@@ -96,12 +96,14 @@ struct PsyALds {
 #define PSYA_EBS(L, b) ((L).fz + 516 + (3 + (b)) * CBANDS)
 
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
-#define PSY_STAMP(i) const unsigned long long psy_t##i = __builtin_amdgcn_s_memtime()
-#define PSY_FLUSH() do { if (lane == 0 && (gslot & 63) == 0) {   /* a sample of the waves: a flush per wave congests what it measures */ const unsigned long long t_[8] = {psy_t0, psy_t1, psy_t2, psy_t3, psy_t4, psy_t5, psy_t6, psy_t7}; \
-    for (int i_ = 0; i_ < 7; i_++) atomicAdd((unsigned long long*)W.prof + 22 + i_, t_[i_ + 1] - t_[i_]); atomicAdd((unsigned long long*)W.prof + 54, 1ull); } } while (0)
+#define PSY_STAMP(i) psy_t_[i] = __builtin_amdgcn_s_memtime()      /* stamp 2 sits inside the `ch < 2` branch: the mid / side waves keep stamp 1's time there */
+#define PSY_FLUSH() do { if (lane == 0 && (gslot & 63) == 0) {   /* a sample of the waves: a flush per wave congests what it measures */ if (psy_t_[2] == 0) psy_t_[2] = psy_t_[1]; \
+    for (int i_ = 0; i_ < 7; i_++) atomicAdd((unsigned long long*)W.prof + 22 + i_, psy_t_[i_ + 1] - psy_t_[i_]); atomicAdd((unsigned long long*)W.prof + 54, 1ull); } } while (0)
+#define PSY_DECL() unsigned long long psy_t_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #else
 #define PSY_STAMP(i) do {} while (0)
 #define PSY_FLUSH() do {} while (0)
+#define PSY_DECL() do {} while (0)
 #endif
 // one wave per (granule slot >= 1 of a stream, psy channel).  ch = 0, 1: L, R.  Joint stereo adds ch = 2, 3 (mid, side) in a second
 // launch: their high-passed samples and their spectra are linear combinations of the L / R ones (PsyModel.js:1113-1121, 258-273),
@@ -133,6 +135,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
 #define buf(i) L.fz[i]
     const int64_t o = (int64_t)gslot * Cp + ch;
+    PSY_DECL();
     PSY_STAMP(0);
 
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---

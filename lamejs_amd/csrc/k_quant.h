@@ -147,10 +147,14 @@ struct QuantLds {
     };
     int16_t ixw[576];            // l3_enc of the working copy (cod_info_w)
     int32_t sfw[SFBMAX + 1], sfb[SFBMAX + 1];     // scalefac working / kept
-    int32_t width[SFBMAX + 1], window[SFBMAX + 1], start[SFBMAX + 2];
+    int16_t width[SFBMAX + 1], window[SFBMAX + 1], start[SFBMAX + 2];
     float xmin[SFBMAX + 1], distort[SFBMAX + 1];
     int32_t pn_step[SFBMAX + 1];
-    float pn_noise[SFBMAX + 1], pn_noise_log[SFBMAX + 1];
+    float pn_noise[SFBMAX + 1];
+    // the cache of the reference's Float32 noise_log, without the logarithm: pn_x = the band's noise / xmin (f64) as last evaluated,
+    // pn_cls = noise_class of the Float32 copy of its logarithm (lhip_math.h); the logarithm itself is only formed when max_noise is read
+    double pn_x[SFBMAX + 1];
+    int16_t pn_cls[SFBMAX + 1];
     int32_t qmode[SFBMAX + 1];
     struct alignas(8) BandInfo { int32_t nstart, kind, nend; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range (empty: nend <= nstart), cached flag (kind 0), step
     int8_t sf_gr0[2][SFBMAX + 1];                 // final gr0 scalefactors per channel (for scfsi): -2..15
@@ -203,7 +207,7 @@ LHIP_DEV int sbgain(const GI& g, int w) {   // subblock_gain[w] without a dynami
     return w == 0 ? g.subblock_gain[0] : w == 1 ? g.subblock_gain[1] : w == 2 ? g.subblock_gain[2] : g.subblock_gain[3];
 }
 
-LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, const int32_t* window, int sfb) {
+LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, const int16_t* window, int sfb) {
     return g.global_gain - ((scalefac[sfb] + (g.preflag != 0 ? Q.pretab[sfb] : 0)) << (g.scalefac_scale + 1))
            - sbgain(g, window[sfb]) * 8;
 }
@@ -257,7 +261,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         LHIP_LANE_ONCE(i, 0, nsfb) {
             const int sfb = i / 3, win = i - 3 * sfb;
             const int w = T.sfb_s[sfb + 1] - T.sfb_s[sfb];
-            L.width[i] = w; L.window[i] = win; L.start[i] = 3 * T.sfb_s[sfb] + win * w;
+            L.width[i] = (int16_t)w; L.window[i] = (int16_t)win; L.start[i] = (int16_t)(3 * T.sfb_s[sfb] + win * w);
         }
         if (lane == 0) L.start[nsfb] = 576;
         // re-order: within each short sfb the three windows become consecutive runs
@@ -269,7 +273,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
     } else {
         nsfb = SBMAX_l;
         LHIP_LANE_ONCE(i, 0, SBMAX_l) {
-            L.width[i] = T.sfb_l[i + 1] - T.sfb_l[i]; L.window[i] = 3; L.start[i] = T.sfb_l[i];
+            L.width[i] = (int16_t)(T.sfb_l[i + 1] - T.sfb_l[i]); L.window[i] = 3; L.start[i] = (int16_t)T.sfb_l[i];
         }
         if (lane == 0) L.start[SBMAX_l] = 576;
         for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_at(xr_g, d);
@@ -999,38 +1003,105 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         wave_sync();
         PH_MARK(L, PH_N_FOLD, tm_);
     }
-    int over = 0, ssd = 0;
-    double max_noise = -20.0;
-    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
-        double noise;
+    // Per band: distortion ratio x = noise / xmin, its class (over? tmp) -- without the logarithm wherever that is safe (noise_class,
+    // lhip_math.h) -- and the cache.  Lanes whose band sits next to a step of the class function (or outside the shortcut's range) make
+    // the whole wave take the logarithm for this call (about one call in a hundred); the logarithm is also taken when the caller will
+    // read max_noise (need_max) or the result turns out to have no distorted band.
+#if LHIP_NL == 1
+    // one-lane build: the same per band (a band next to a step takes the logarithm by itself; where the shortcut is taken it equals
+    // the logarithm's verdict, so the wave-wide fallback of the 64-lane program gives the same numbers)
+    int over = 0, ssd = 0, any_log_needed = need_max;
+    for (int sfb = 0; sfb < g.psymax; sfb++) {
         const QuantLds::BandInfo bi = L.binfo[sfb];
+        int cls;
         if (bi.kind == 0) {
-            noise = L.pn_noise[sfb];
-            L.distort[sfb] = (float)(noise / (double)L.xmin[sfb]);
-            noise = L.pn_noise_log[sfb];
+            L.distort[sfb] = (float)((double)L.pn_noise[sfb] / (double)L.xmin[sfb]);
+            cls = L.pn_cls[sfb];
         } else {
-            noise = (bi.nend > bi.nstart) ? L.nsum[sfb] : 0.0;
+            const double noise = (bi.nend > bi.nstart) ? L.nsum[sfb] : 0.0;
             if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
-            noise = noise / (double)L.xmin[sfb];
-            L.distort[sfb] = (float)noise;
-            noise = v8_log10_pos(noise > 1E-20 ? noise : 1E-20);      // operand >= 1e-20 (a NaN compares false and becomes 1e-20 too)
-            if (use_pn) L.pn_noise_log[sfb] = (float)noise;
+            const double x = noise / (double)L.xmin[sfb];
+            L.distort[sfb] = (float)x;
+            cls = need_max ? -1 : noise_class(x);          // the logarithm will be formed anyway: no shortcut
+            int cls_cache = cls;
+            if (cls < 0) {
+                const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
+                cls = noise_class_of_log(l); cls_cache = noise_class_of_log((double)(float)l);
+            }
+            if (use_pn) { L.pn_x[sfb] = x; L.pn_cls[sfb] = (int16_t)cls_cache; }
+            else L.nsum[sfb] = x;                          // (no cache in this call: the value for the max_noise pass below)
         }
-        if (noise > 0.0) {
-            int tmp = (int)(noise * 10 + .5);          // 0 < noise < ~400: truncation == ToInt32
-            if (tmp < 1) tmp = 1;
-            ssd += tmp * tmp;
-            over++;
-        }
-        if (noise > max_noise) max_noise = noise;
+        if (cls > 0) { ssd += cls * cls; over++; }
     }
     PH_MARK(L, PH_N_TERMS, tm_);
+    if (use_pn) pn.gain = g.global_gain;
+    res->over_count = over; res->over_SSD = ssd;
+    res->max_noise = 0.0;
+    if (any_log_needed || over == 0) {
+        double max_noise = -20.0;
+        for (int sfb = 0; sfb < g.psymax; sfb++) {
+            const bool fresh = L.binfo[sfb].kind != 0;
+            const double x = (fresh && !use_pn) ? L.nsum[sfb] : L.pn_x[sfb];
+            const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
+            const double nl = fresh ? l : (double)(float)l;
+            if (nl > max_noise) max_noise = nl;
+        }
+        res->max_noise = max_noise;
+    }
+#else
+    double x = 1.0;                                   // this lane's band: noise / xmin (cached bands: as last evaluated)
+    int cls = 0, fresh = 0;                           // class used by THIS call; fresh: the band was evaluated in this call
+    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
+        const QuantLds::BandInfo bi = L.binfo[sfb];
+        if (bi.kind == 0) {
+            L.distort[sfb] = (float)((double)L.pn_noise[sfb] / (double)L.xmin[sfb]);
+            x = L.pn_x[sfb];
+            cls = L.pn_cls[sfb];
+        } else {
+            const double noise = (bi.nend > bi.nstart) ? L.nsum[sfb] : 0.0;
+            if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
+            x = noise / (double)L.xmin[sfb];
+            L.distort[sfb] = (float)x;
+            cls = need_max ? -1 : noise_class(x);          // the logarithm will be formed anyway: no shortcut
+            fresh = 1;
+        }
+    }
+    PH_MARK(L, PH_N_TERMS, tm_);
+    int cls_cache = cls;                              // class the reference will derive from its Float32 copy in later calls
+    int have_log = 0;
+    double nl = -20.0;                                // noise_log as this call sees it (only valid when have_log)
+    if (wave_any(cls < 0)) {
+        LHIP_LANE_ONCE(sfb, 0, g.psymax) {
+            const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);       // operand >= 1e-20 (a NaN compares false and becomes 1e-20 too)
+            const double lf = (double)(float)l;
+            nl = fresh ? l : lf;
+            if (fresh) { cls = noise_class_of_log(l); cls_cache = noise_class_of_log(lf); }
+        }
+        have_log = 1;
+    }
+    int over = 0, ssd = 0;
+    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
+        if (use_pn && fresh) { L.pn_x[sfb] = x; L.pn_cls[sfb] = (int16_t)cls_cache; }
+        if (cls > 0) { ssd = cls * cls; over = 1; }
+    }
     if (use_pn) pn.gain = g.global_gain;
     {   // over <= 39 bands and over_SSD <= 39 * 400^2 < 2^25: one packed integer reduction
         const int os = wave_sum((ssd << 6) | over);
         res->over_count = os & 63; res->over_SSD = os >> 6;
     }
-    res->max_noise = (need_max || res->over_count == 0) ? wave_maxd(max_noise) : 0.0;
+    res->max_noise = 0.0;
+    if (need_max || res->over_count == 0) {
+        double max_noise = -20.0;
+        if (!have_log) {
+            LHIP_LANE_ONCE(sfb, 0, g.psymax) {
+                const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
+                nl = fresh ? l : (double)(float)l;
+            }
+        }
+        LHIP_LANE_ONCE(sfb, 0, g.psymax) max_noise = nl;
+        res->max_noise = wave_maxd(max_noise);
+    }
+#endif
     wave_sync();
     PH_MARK(L, PH_N_SUMS, tm_);
 }
@@ -1360,7 +1431,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
     best.max_noise = 0; best.over_count = 0; best.over_SSD = 0; best.bits = 0;
-    LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_noise_log[i] = 0.f; L.distort[i] = 0.f; }
+    LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_x[i] = 1.0; L.pn_cls[i] = 0; L.distort[i] = 0.f; }
     wave_sync();
     targ_bits = uni(targ_bits); bs_start = uni(bs_start); bs_step = uni(bs_step);
     uni_gi(g);

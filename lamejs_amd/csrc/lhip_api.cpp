@@ -610,6 +610,10 @@ __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase 
         case 5: r = (double)js_toint32(x); break;
         case 6: r = x / 3.0 + x * 0.1; break;
         case 7: r = v8_log10_pos(x); break;
+        case 9: {   // calc_noise's shortcut: noise_class(x) + 1000 * class from the f64 logarithm + 1e6 * class from its Float32 copy
+            const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
+            r = (double)noise_class(x) + 1000.0 * (double)noise_class_of_log(l) + 1e6 * (double)noise_class_of_log((double)(float)l);
+        } break;
     }
     out[i] = r;
 }
@@ -822,6 +826,11 @@ struct Context {
     // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
     // beside the filterbank kernels, which do not depend on it
     void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
+    // large host-buffer calls (the drop-in's encodeBuffer with a long Int16Array): chunks of the call are copied in on this stream
+    // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
+    void* copy_stream = nullptr; void* ev_in[2] = {nullptr, nullptr}; void* ev_done[2] = {nullptr, nullptr};
+    DevBuf chunk_in, chunk_out;
+    std::mutex chunk_mu;        // one chunked call at a time per device (they share the two staging halves); taken BEFORE mu, never inside it
 };
 
 static std::mutex g_ctx_mu;
@@ -1381,10 +1390,86 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
     return 0;
 }
 
+// Host-buffer calls with many frames (what encodeBuffer() hands over when a caller passes a long Int16Array): the call is cut into
+// chunks of whole frames' worth of samples; chunk k + 1 travels to the device (copy stream) while chunk k is encoded (launch stream)
+// and the bytes of chunk k - 1 travel back -- PCIe needs about a sixth of the encode time, so it hides behind it.  Any chunking of a
+// sample stream gives the same bytes (the library's basic contract), so the result is what one batch gives.  Not for the bit
+// reservoir (its byte counts are only known after each launch).
+#ifndef LHIP_HOSTSIM
+enum { HOST_CHUNK_FRAMES = 8192 };
+static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
+    Context* ctx = s->ctx;
+    std::lock_guard<std::mutex> chunk_lk(ctx->chunk_mu);
+    const Tables& T = s->ts->T;
+    const int C = T.channels_out;
+    const size_t chunk = (size_t)HOST_CHUNK_FRAMES * 576 * T.mode_gr * T.rs_ratio;
+    const size_t nchunks = (nsamples + chunk - 1) / chunk;
+    // the whole call must fit the caller's buffer BEFORE anything is consumed (a failed call consumes nothing)
+    {
+        const int frame = 576 * T.mode_gr, mf_needed = 1024 + frame - 272;
+        const int64_t n_out = T.rs_ratio == 1 ? (int64_t)nsamples : rs_outputs(s->rs_n_in + (int64_t)nsamples, T.rs_ratio) - rs_outputs(s->rs_n_in, T.rs_ratio);
+        const int64_t total = (int64_t)s->mf_size + n_out;
+        const int F = total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
+        if ((size_t)batch_bytes(*s->ts, s->slot_lag, F) > out_cap) { set_err("output buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!rt::set_device(ctx->device)) return LHIP_ERR_INTERNAL;
+        if (!ctx->copy_stream) {
+            hipStream_t cs; hipEvent_t e[4];
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return LHIP_ERR_INTERNAL; }
+            for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&e[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return LHIP_ERR_INTERNAL; }
+            ctx->copy_stream = cs; ctx->ev_in[0] = e[0]; ctx->ev_in[1] = e[1]; ctx->ev_done[0] = e[2]; ctx->ev_done[1] = e[3];
+        }
+        const size_t out_chunk = (size_t)(HOST_CHUNK_FRAMES + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
+        if (!ctx->chunk_in.ensure(2 * C * chunk * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk)) return LHIP_ERR_INTERNAL;
+    }
+    const size_t out_chunk = (size_t)(HOST_CHUNK_FRAMES + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
+    hipStream_t cs = (hipStream_t)ctx->copy_stream, ks = (hipStream_t)ctx->stream;
+    int64_t total = 0, pending_bytes = 0, frames_all = 0;      // pending: the chunk whose output is still on the device
+    uint8_t* pending_dst = nullptr; int pending_par = 0; bool have_pending = false;
+    auto fail = [&](const char* what) -> int64_t { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ks); if (what) set_err(what); return LHIP_ERR_INTERNAL; };
+    auto drain = [&]() -> bool {               // copy the pending chunk's bytes out (waits for its kernels)
+        if (!have_pending) return true;
+        have_pending = false;
+        if (pending_bytes == 0) return true;
+        if (hipStreamWaitEvent(cs, (hipEvent_t)ctx->ev_done[pending_par], 0) != hipSuccess) return false;
+        if (hipMemcpyAsync(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) return false;
+        return hipStreamSynchronize(cs) == hipSuccess;
+    };
+    for (size_t k = 0; k < nchunks; k++) {
+        const int par = (int)(k & 1);
+        const size_t p0 = k * chunk, m = nsamples - p0 < chunk ? nsamples - p0 : chunk;
+        int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * chunk;
+        // buffer `par` was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
+        if (hipMemcpyAsync(d_in, left + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+        if (C == 2 && hipMemcpyAsync(d_in + chunk, (right ? right : left) + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+        if (hipEventRecord((hipEvent_t)ctx->ev_in[par], cs) != hipSuccess || hipStreamWaitEvent(ks, (hipEvent_t)ctx->ev_in[par], 0) != hipSuccess) return fail("event record / wait failed");
+        std::vector<Job> jobs(1);
+        jobs[0] = Job{s, d_in, C == 2 ? d_in + chunk : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};
+        if (!run_batch(ctx, jobs, true, false)) { (void)fail(nullptr); return jobs[0].written < 0 ? jobs[0].written : LHIP_ERR_INTERNAL; }
+        if (hipEventRecord((hipEvent_t)ctx->ev_done[par], ks) != hipSuccess) return fail("event record failed");
+        if (!drain()) return fail("copying a chunk's output failed");             // chunk k - 1, while chunk k is being encoded
+        pending_bytes = jobs[0].written; pending_dst = out + total; pending_par = par; have_pending = true;
+        total += jobs[0].written; frames_all += g_stat_frames;
+    }
+    if (!drain()) return fail("copying a chunk's output failed");
+    g_stat_frames = frames_all;                    // lhip_last_batch_stats: frames of the whole call, repair counters of its last chunk
+    return total;
+}
+#endif
+
 int64_t lhip_encode(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
     if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
     if (nsamples == 0) return 0;
     if (!left) { set_err("null input"); return LHIP_ERR_INTERNAL; }
+#ifndef LHIP_HOSTSIM
+    {
+        static const bool no_chunk = []() { const char* e = getenv("LAMEJS_HIP_NO_HOST_CHUNKS"); return e && e[0] == '1'; }();
+        const Tables& T = s->ts->T;
+        if (!no_chunk && T.disable_reservoir && nsamples > (size_t)2 * HOST_CHUNK_FRAMES * 576 * T.mode_gr * T.rs_ratio) return encode_host_chunked(s, left, right, nsamples, out, out_cap);
+    }
+#endif
     int64_t w = 0;
     const int rc = encode_many(&s, 1, &left, &right, &nsamples, &out, &out_cap, &w, false, true);
     return rc < 0 ? rc : w;
@@ -1668,6 +1753,8 @@ int lhip_debug_math(int op, const double* in, double* out, size_t n) {
             case 4: out[i] = (double)(float)x; break;
             case 5: out[i] = (double)js_toint32(x); break;
             case 7: out[i] = v8_log10_pos(x); break;
+            case 9: { const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
+                      out[i] = (double)noise_class(x) + 1000.0 * (double)noise_class_of_log(l) + 1e6 * (double)noise_class_of_log((double)(float)l); } break;
             default: out[i] = x / 3.0 + x * 0.1; break;
         }
     }

@@ -221,6 +221,39 @@ LHIP_DEV double v8_log10_pos(double x) {
     return infnan ? x + x : res;
 }
 
+// ---- calc_noise without the logarithm (QuantizePVT.js:846-868) ------------------------------------------------------------------
+// Per band the reference computes noise = log10(max(x, 1e-20)), x = band noise / allowed noise, and then only asks:
+//   over:  noise > 0                      <=>  x > 1   (log10 is exact in sign around 1, and so is its Float32 copy)
+//   tmp:   max(ToInt32(noise * 10 + .5), 1)   -- the band's contribution tmp^2 to over_SSD
+// (max_noise needs the value itself; it is only read for results without distorted bands, see q_calc_noise_).  tmp is a step
+// function of x with steps at 10^((k - .5) / 10): away from the steps ANY approximation of 10 log10(x) + .5 with an error below the
+// distance to the next integer gives the reference's integer -- whether the reference derives it from the f64 logarithm (a band
+// evaluated in this call) or from the Float32 copy it cached (QuantizePVT.js:838-842; the copy moves noise * 10 by at most 2.4e-5).
+// noise_class(x): t = log2_f32((float)x) * 10 log10(2) + .5 (error < 5e-5 for x < 1e37: one ulp of the hardware's v_log_f32 at
+// |log2| <= 123, the conversion of x, the f32 multiply-add); returns tmp (0: not over), or -1 when t is within 2e-4 of an integer or x
+// is outside (1, 1e37) x-range where the shortcut is valid -- the caller then evaluates the logarithm itself, as before.
+#ifdef LHIP_HOSTSIM
+LHIP_DEV float fast_log2f(float x) { return log2f(x); }
+#else
+LHIP_DEV float fast_log2f(float x) { return __builtin_amdgcn_logf(x); }       // v_log_f32
+#endif
+LHIP_DEV int noise_class(double x) {
+    if (!(x > 1.0)) return 0;                              // not over (NaN included: the reference clamps it to 1e-20)
+    if (!(x < 1e37)) return -1;
+    const float t = fast_log2f((float)x) * 3.01029995663981195f + 0.5f;
+    const float k = __builtin_floorf(t);
+    const float fr = t - k;
+    if (fr < 2e-4f || fr > 1.0f - 2e-4f) return -1;
+    const int tmp = (int)k;
+    return tmp < 1 ? 1 : tmp;
+}
+// the same from the logarithm (what the reference computes): nl = log10(max(x, 1e-20)) or its Float32 copy
+LHIP_DEV int noise_class_of_log(double nl) {
+    if (!(nl > 0.0)) return 0;
+    int tmp = (int)(nl * 10 + .5);                         // 0 < nl < ~400: truncation == ToInt32
+    return tmp < 1 ? 1 : tmp;
+}
+
 // ---- pow(x, y), x > 0 finite normal (x == 10 on this path), |y| < 2^31 ----
 struct PowBase { double t1, t2, x; };   // log2(x) = t1 + t2, t1 with a zeroed low word; the base itself (x > 1, finite) for the special cases of y
 

@@ -73,6 +73,15 @@ def test_device_math_matches_v8(lib):
         assert bad.size == 0, f"op {op}: {bad.size} mismatches, first x={x[bad[0]]!r} ({x[bad[0]].hex()}) gpu={a[bad[0]]!r} ref={b[bad[0]]!r}"
 
 
+def test_device_noise_class_shortcut(lib):
+    """calc_noise's logarithm-free band class on the device (v_log_f32 behind it): wherever the shortcut is taken it equals the class
+    the reference derives from log10 -- f64 value and Float32 copy -- on 1.3 M operands incl. every step of the class function
+    approached from both sides down to one ulp (tests/noise_class_check.py)."""
+    from noise_class_check import check_noise_class
+    took, n = check_noise_class(lib)
+    assert took > 0.5 * n
+
+
 def test_device_quantize_truncations(lib):
     """quantize_lines_xrpow's two truncations, (int)(x istep) and (int)(x istep + adj43[.]) in f64 (Takehiro.js:125-165), are ONE f32
     instruction each under round-toward-zero on the device (lhip_math.h q_floor_prod / q_floor_fma).  2.1 M operand triples,
@@ -223,6 +232,17 @@ def test_gpu_reference_fixture_md5s(lib, golden):
             assert hashlib.md5(mp3).hexdigest() == case["mp3_md5"], (case, chunk)
         seen += 1
     assert seen == 3
+
+
+def test_gpu_reference_fixtures_48k_and_stereo(lib, golden_wavfix):
+    """The reference's remaining fixtures: testdata/Left.wav + Right.wav (48 kHz; mono / stereo, 64-320 kbps, the
+    1152-sample call pattern of Tests.js, odd chunks and one large call) and Stereo44100.wav de-interleaved -- md5 and length of the
+    unmodified reference's output (tests/tools/gen_golden_wavfix.js)."""
+    assert len(golden_wavfix) >= 13
+    for case in golden_wavfix:
+        L, R = load_case_pcm(case)
+        mp3 = _encode(case["channels"], case["kbps"], L, R, case["chunk"], case["samplerate"])
+        assert len(mp3) == case["mp3_len"] and hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
 
 
 def test_gpu_matches_oracle_seeded(lib):
@@ -386,6 +406,27 @@ def test_gpu_random_material(lib):
     assert fuzz_gpu.run(56, 7, verbose=False) == []
     assert fuzz_gpu.run(96, 31, verbose=False, cfgs=fuzz_gpu.LSF_CFGS) == []               # MPEG-2 / 2.5
     assert fuzz_gpu.run(70, 5, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []           # integer-ratio resampling in front
+
+
+def test_gpu_random_material_fresh_seed(lib):
+    """The randomised sweep of tests/tools/fuzz_gpu.py with a seed nobody has seen before (taken from the clock, printed, and part of
+    the failure message): device-only code -- DPP reductions, readfirstlane uniformity, the rounding-mode asm -- is exercised on
+    whatever HEAD the driver runs, not only by the sweeps the builder kept logs of.  540 short cases: MPEG-1, LSF, resampling,
+    joint stereo, bit reservoir (a tenth of the 5400-case sweep under profiles/)."""
+    import os
+    import sys
+    import time
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    seed = int(os.environ.get("LAMEJS_FUZZ_SEED", "0")) or int(time.time())
+    print(f"fresh-seed fuzz: seed {seed} (re-run with LAMEJS_FUZZ_SEED={seed})")
+    bad = []
+    bad += fuzz_gpu.run(240, seed, verbose=False, max_frames=100)
+    bad += fuzz_gpu.run(130, seed + 1, verbose=False, cfgs=fuzz_gpu.LSF_CFGS, max_frames=100)
+    bad += fuzz_gpu.run(70, seed + 2, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS, max_frames=100)
+    bad += fuzz_gpu.run(50, seed + 3, verbose=False, joint=True, max_frames=80)
+    bad += fuzz_gpu.run(50, seed + 4, verbose=False, cfgs=fuzz_gpu.MPEG1_CFGS + fuzz_gpu.LSF_CFGS, reservoir=True, max_frames=80)
+    assert bad == [], f"seed {seed}: {bad[:5]}"
 
 
 @pytest.mark.gpu

@@ -46,6 +46,14 @@ def test_hostsim_matches_goldens(sim, golden):
     assert n >= 53
 
 
+def test_hostsim_matches_reference_wav_fixtures_48k_and_stereo(sim, golden_wavfix):
+    """testdata/Left.wav + Right.wav (48 kHz) and Stereo44100.wav (SURVEY.md 8f #2), reference output vs the kernel logic."""
+    for case in golden_wavfix:
+        L, R = load_case_pcm(case)
+        mp3 = _encode(sim, case["channels"], case["kbps"], L, R, case["chunk"], case["samplerate"])
+        assert len(mp3) == case["mp3_len"] and hashlib.md5(mp3).hexdigest() == case["mp3_md5"], case
+
+
 def test_hostsim_matches_joint_stereo_goldens(sim, golden_joint):
     """SURVEY.md 8f #3 (extension): the kernel logic in joint-stereo mode -- four psy channels, the per-frame M/S decision, mid/side
     quantization -- against the reference's own joint-stereo output (L/R-only, M/S-only and mixed streams; MPEG-1, LSF, resampling)."""
@@ -284,3 +292,10 @@ def test_hostsim_boundary_error_paths(sim):
 def test_hostsim_state_blob_is_canonical(sim):
     from boundary_checks import run_state_canonical_checks
     run_state_canonical_checks(sim)
+
+
+def test_hostsim_noise_class_shortcut(sim):
+    """calc_noise without the logarithm (lhip_math.h noise_class): equals the class from log10 (f64 and Float32 copy) wherever taken."""
+    from noise_class_check import check_noise_class
+    took, n = check_noise_class(sim)
+    assert took > 0.5 * n

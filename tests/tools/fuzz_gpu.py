@@ -55,7 +55,7 @@ RESAMPLE_CFGS = [(1, 44100, 32), (2, 44100, 48), (1, 48000, 24), (2, 48000, 64),
                  (1, 48000, 40), (1, 48000, 8), (2, 48000, 40), (2, 32000, 40), (1, 32000, 24), (2, 16000, 24)]
 
 
-def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False):
+def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False, max_frames=260):
     """Returns the list of mismatching case descriptions (empty = parity).  joint: the joint-stereo extension on the two-channel
     configurations; the material (same draws as tests/tools/fuzz_ref.py joint) has strongly correlated channels in half of the cases."""
     rng = np.random.default_rng(seed)
@@ -66,7 +66,7 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
     t0 = time.time()
     for c in range(ncases):
         ch, sr, kbps = cfgs[c % len(cfgs)]
-        nfr = int(rng.integers(20, 260))
+        nfr = int(rng.integers(20, max_frames))
         L, R = material(rng, 1152 * nfr + int(rng.integers(0, 1152)), ch)
         if joint and rng.integers(0, 2):       # correlated channels: L = A + B / 2^k, R = A - B / 2^k
             k = int(rng.integers(1, 6))
