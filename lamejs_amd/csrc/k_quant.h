@@ -98,6 +98,10 @@ struct QuantTabs {
     struct PlanEnt { uint32_t d0, d1, pw; } plan[30];
     // scale_bitcount candidates (Takehiro.js:980-1030): row k = slen1_n | slen2_n << 8 | scale_long << 16 | scale_short << 24
     uint32_t sbc[16];
+    // calc_noise's systolic fold (lane l owns the lines 9 l .. 9 l + 8): bit k = line 9 l + k is the first of its scalefactor band,
+    // bit 16 + k = it is the last one; [0] long blocks, [1] short blocks.  wpre: widest band among bands 0 .. b (long / short).
+    uint32_t fold_marks[2][64];
+    uint16_t wpre_long[24], wpre_short[40];
 };
 
 LHIP_DEV void q_fill_plans(QuantTabs& Q, int tid, int nthr);
@@ -137,6 +141,9 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
         Q.l2s_short[d] = (uint8_t)(3 * sfb + win);
         (void)l;
     }
+    for (int e = tid; e < 2 * 64; e += nthr) Q.fold_marks[e >> 6][e & 63] = (uint32_t)T.fold_marks[e];
+    for (int e = tid; e < 24; e += nthr) Q.wpre_long[e] = (uint16_t)T.wpre[e];
+    for (int e = tid; e < 40; e += nthr) Q.wpre_short[e] = (uint16_t)T.wpre[24 + e];
 }
 
 struct QuantLds {
@@ -149,14 +156,15 @@ struct QuantLds {
     int32_t sfw[SFBMAX + 1], sfb[SFBMAX + 1];     // scalefac working / kept
     int16_t width[SFBMAX + 1], window[SFBMAX + 1], start[SFBMAX + 2];
     float xmin[SFBMAX + 1], distort[SFBMAX + 1];
+    double rxmin[SFBMAX + 1];                    // 1 / xmin, correctly rounded (0: xmin outside the range div_by_f32 is proven for): calc_noise divides by xmin in every call
     int32_t pn_step[SFBMAX + 1];
-    float pn_noise[SFBMAX + 1];
+    float pn_dist[SFBMAX + 1];                   // the cache of the reference's Float32 noise, as what every later call derives from it: (float)(noise / xmin)
     // the cache of the reference's Float32 noise_log, without the logarithm: pn_x = the band's noise / xmin (f64) as last evaluated,
     // pn_cls = noise_class of the Float32 copy of its logarithm (lhip_math.h); the logarithm itself is only formed when max_noise is read
     double pn_x[SFBMAX + 1];
     int16_t pn_cls[SFBMAX + 1];
     int32_t qmode[SFBMAX + 1];
-    struct alignas(8) BandInfo { int32_t nstart, kind, nend; float step; } binfo[SFBMAX + 1];   // calc_noise: summing range (empty: nend <= nstart), cached flag (kind 0), step
+    float bstep[SFBMAX + 1];                     // calc_noise: POW20 of the band's step (what the per-line pass reads)
     int8_t sf_gr0[2][SFBMAX + 1];                 // final gr0 scalefactors per channel (for scfsi): -2..15
     union {                      // calc_noise band sums live only inside the outer loop, the split tables only after it
         struct { int32_t r01_bits[24], r01_div[24], r0_tbl[24], r1_tbl[24], r2_bits[24], r2_tbl[24]; };
@@ -418,7 +426,8 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
                 const double x = en0 * (double)ratio[E_THM_L + gsfb] * masking_lower / en;
                 if (xmin < x) xmin = x;
             }
-            L.xmin[gsfb] = (float)(xmin * (double)T.longfact[gsfb]);
+            const float xm = (float)(xmin * (double)T.longfact[gsfb]);
+            L.xmin[gsfb] = xm; L.rxmin[gsfb] = recip_for_div((double)xm);
         }
         int t = -1;
         for (int k = lane; k < 576; k += LHIP_NL) if (!((double)L.xr[k] == 0)) t = k;
@@ -444,6 +453,7 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
                 if ((double)px[1] > (double)px[2]) px[2] = (float)((double)px[2] + ((double)px[1] - (double)px[2]) * T.decay);
             }
             L.xmin[3 * sfb] = px[0]; L.xmin[3 * sfb + 1] = px[1]; L.xmin[3 * sfb + 2] = px[2];
+            L.rxmin[3 * sfb] = recip_for_div((double)px[0]); L.rxmin[3 * sfb + 1] = recip_for_div((double)px[1]); L.rxmin[3 * sfb + 2] = recip_for_div((double)px[2]);
         }
         g.max_nonzero_coeff = 575;
     }
@@ -900,128 +910,52 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
                            int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
-    // 1) summing range and error formula per band (calc_noise_core's branches).  The reference walks a start line j
-    //    from band to band (QuantizePVT.js:806-830); j stays aligned with the band starts up to the first band that
-    //    reaches past max_nonzero_coeff (`firstcut`), that band is summed over its useful part only, and for every
-    //    later band the walk leaves no pairs at all (j + width > max_nonzero_coeff with j >= max_nonzero_coeff).
-    uint64_t m_cut = 0;
-    LHIP_LANE_ONCE(sfb, 0, g.psymax)
-        if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m_cut |= 1ull << sfb;
-    m_cut = wave_lane_bits(m_cut);
-    const int firstcut = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
-    int maxlen = 0;                                          // longest summing range of this call (cached bands have none)
-    // One error formula serves the three branches of calc_noise_core (QuantizePVT.js:725-767): a band that starts above
-    // count1 holds only zeros and one that starts above big_values only 0/1, and pow43[0] = 0, pow43[1] = 1, so
-    // |xr| - pow43[ix] * step is bit for bit `xr` (squared), `|xr| - ix01[ix]` and `|xr| - pow43[ix] * step` there.
-    // Bands past psymax and cached bands get an empty range (nend = 0 / nstart), which is all the per-line code tests.
-    LHIP_LANE_ONCE(sfb, 0, SFBMAX + 1) {
-        QuantLds::BandInfo bi;
-        bi.nstart = 0; bi.nend = 0; bi.kind = 0; bi.step = 0.f;
-        if (sfb < g.psymax) {
-            const int s = sf_step(Q, g, scalefac, L.window, sfb);
-            const int cached = (use_pn && L.pn_step[sfb] == s);
-            L.qmode[sfb] = s;                               // step of the band (stored into the cache below)
-            const int js = L.start[sfb], w = L.width[sfb];
-            int l = w >> 1;
-            if (sfb == firstcut) { const int usefullsize = g.max_nonzero_coeff - js + 1; l = usefullsize > 0 ? usefullsize >> 1 : 0; }
-            if (sfb > firstcut || cached) l = 0;
-            if (maxlen < 2 * l) maxlen = 2 * l;
-            bi.nstart = js; bi.nend = js + 2 * l;
-            bi.kind = cached ? 0 : 1;
-            bi.step = Q.pow20[s + Q_MAX2];
-        }
-        L.binfo[sfb] = bi;
-    }
-    maxlen = wave_max(maxlen);
-    wave_sync();
-    PH_MARK(L, PH_N_WALK, tm_);
-    // 2) squared errors summed per band in the reference's line order (f64 sums are order-sensitive) as a
-    //    systolic fold: lane l owns NLN consecutive lines and folds their terms, in order, onto the running sum
-    //    handed over by lane l-1 (reset at band starts).  One hand-over step extends every band's chain by one
-    //    lane, so ceil(longest band / NLN) + 1 steps reproduce the strictly sequential sums exactly, while the
-    //    terms themselves are computed once, all lanes busy.  All non-empty summing ranges start at their band's
-    //    first line (after the first band cut by max_nonzero_coeff every range is empty).
-    enum { NLN = 576 / LHIP_NL };
+    // 1) per band: its step and whether the cache answers for it.  The reference walks a start line from band to band and sums the
+    //    first band that reaches past max_nonzero_coeff over its useful part only, every later band over nothing
+    //    (QuantizePVT.js:806-830).  Summing every evaluated band over its WHOLE width gives the same sums: from
+    //    max_nonzero_coeff on xr is zero (it is the first of the spectrum's trailing zeros) and so is the quantized value
+    //    ((int)(0 * istep + adj43[0]) = 0, cached values by induction), hence every skipped line would add (|0| - pow43[0] * step)^2 = +0
+    //    to a non-negative sum -- so there is no range bookkeeping here at all.
+    // One error formula serves the three branches of calc_noise_core (QuantizePVT.js:725-767): a band that starts above count1 holds
+    // only zeros and one that starts above big_values only 0/1, and pow43[0] = 0, pow43[1] = 1, so |xr| - pow43[ix] * step is bit for
+    // bit `xr` (squared), `|xr| - ix01[ix]` and `|xr| - pow43[ix] * step` there.
+    const int is_short = g.block_type == SHORT_TYPE;
     // quantized values are <= xrpow_max * ipow20(gain) + 1 (the working copy was quantized at this gain): below QT_N - 1
     // no line can need the part of pow43 that is not staged in LDS
     const int may_big = !(g.xrpow_max * ipow20(Q, g.global_gain) < (double)(QT_N - 1));
-    {
-        double tq[NLN], keep[NLN];
-        unsigned lastm = 0;                      // bit k: line k of this lane ends a summing range
-        int lastb[NLN];
-        int prevb = (lane == 0) ? -1 : (int)line2sfb(Q, g.block_type)[NLN * lane - 1];
-        const uint8_t* l2s = line2sfb(Q, g.block_type);
-        // Terms are computed for EVERY line, inside a summing range or not: a sum is only stored at the last line of a
-        // non-empty range (lastm), every band's chain starts afresh at its first line (keep = 0), and the lines of a band
-        // that follow its range come after the stored prefix -- whatever the other lines contribute is never read.
-        // keep[k] = 0 at a band start, 1 elsewhere: fma(sum, keep, t) is `sum + t` or `t` with ONE rounding, i.e.
-        // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit
-#pragma unroll
-        for (int k = 0; k < NLN; k++) {
-            const int j = NLN * lane + k;
-            const int bnd = l2s[j];
-            const int nend = L.binfo[bnd].nend; const float bstep = L.binfo[bnd].step;   // adjacent: one 8-byte load
-            const float xa = L.xr[j]; const int iv = ix[j];
-            float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
-            if (may_big && iv >= QT_N) pw = T.pow43[iv];
-            const double x = d_abs((double)xa) - (double)pw * (double)bstep;
-            tq[k] = x * x;
-            keep[k] = (bnd != prevb) ? 0.0 : 1.0;
-            if (j == nend - 1) lastm |= 1u << (k & 31);
-            lastb[k] = bnd; prevb = bnd;
-        }
-        PH_MARK(L, PH_N_LINES, tm_);
-        // NLN <= 32 on the device; the one-lane host build folds everything in a single pass below
-        const int nsteps = (LHIP_NL == 1) ? 1 : (maxlen + NLN - 1) / NLN + 1;
 #if LHIP_NL == 1
-        {
-            double sacc = 0.0;
-            for (int k = 0; k < NLN; k++) {
-                const int bnd = lastb[k];
-                if ((k == 0) || (lastb[k - 1] != bnd)) sacc = 0.0;
-                sacc += tq[k];
-                if (k == L.binfo[bnd].nend - 1) L.nsum[bnd] = sacc;
-            }
-            (void)keep; (void)nsteps; (void)lastm;
-        }
-#else
-        double carry = 0.0;
-        for (int st = 0; st + 1 < nsteps; st++) {
-            double sacc = carry;
-#pragma unroll
-            for (int k = 0; k < NLN; k++) sacc = __builtin_fma(sacc, keep[k], tq[k]);
-            carry = wave_shr1d(sacc, 0.0);
-        }
-        {
-            double sacc = carry;
-#pragma unroll
-            for (int k = 0; k < NLN; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); tq[k] = sacc; }   // tq := running sums of the last step
-        }
-#pragma unroll
-        for (int k = 0; k < NLN; k++) if ((lastm >> k) & 1u) L.nsum[lastb[k]] = tq[k];
-#endif
-        wave_sync();
-        PH_MARK(L, PH_N_FOLD, tm_);
-    }
-    // Per band: distortion ratio x = noise / xmin, its class (over? tmp) -- without the logarithm wherever that is safe (noise_class,
-    // lhip_math.h) -- and the cache.  Lanes whose band sits next to a step of the class function (or outside the shortcut's range) make
-    // the whole wave take the logarithm for this call (about one call in a hundred); the logarithm is also taken when the caller will
-    // read max_noise (need_max) or the result turns out to have no distorted band.
-#if LHIP_NL == 1
-    // one-lane build: the same per band (a band next to a step takes the logarithm by itself; where the shortcut is taken it equals
-    // the logarithm's verdict, so the wave-wide fallback of the 64-lane program gives the same numbers)
-    int over = 0, ssd = 0, any_log_needed = need_max;
+    // one-lane build: the same band by band (a band next to a step of the class function takes the logarithm by itself; where the
+    // shortcut is taken it equals the logarithm's verdict, so the wave-wide fallback of the 64-lane program gives the same numbers)
+    const uint8_t* l2s = line2sfb(Q, g.block_type);
+    int over = 0, ssd = 0;
+    uint64_t m_fresh = 0;
+    (void)may_big; (void)is_short;
     for (int sfb = 0; sfb < g.psymax; sfb++) {
-        const QuantLds::BandInfo bi = L.binfo[sfb];
+        const int s = sf_step(Q, g, scalefac, L.window, sfb);
+        if (!(use_pn && L.pn_step[sfb] == s)) m_fresh |= 1ull << sfb;
+        L.qmode[sfb] = s;
+        L.bstep[sfb] = Q.pow20[s + Q_MAX2];
+    }
+    PH_MARK(L, PH_N_WALK, tm_);
+    {
+        double sacc = 0.0;
+        for (int j = 0; j < 576; j++) {
+            const int bnd = l2s[j];
+            if (j == 0 || l2s[j - 1] != bnd) sacc = 0.0;
+            const double x = __builtin_fma(-pow43v(T, Q, ix[j]), (double)L.bstep[bnd < SFBMAX + 1 ? bnd : SFBMAX], d_abs((double)L.xr[j]));
+            sacc += x * x;
+            if (j == 575 || l2s[j + 1] != bnd) L.nsum[bnd] = sacc;
+        }
+    }
+    PH_MARK(L, PH_N_FOLD, tm_);
+    for (int sfb = 0; sfb < g.psymax; sfb++) {
         int cls;
-        if (bi.kind == 0) {
-            L.distort[sfb] = (float)((double)L.pn_noise[sfb] / (double)L.xmin[sfb]);
-            cls = L.pn_cls[sfb];
-        } else {
-            const double noise = (bi.nend > bi.nstart) ? L.nsum[sfb] : 0.0;
-            if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
-            const double x = noise / (double)L.xmin[sfb];
+        if (!((m_fresh >> sfb) & 1)) { L.distort[sfb] = L.pn_dist[sfb]; cls = L.pn_cls[sfb]; }
+        else {
+            const double noise = L.nsum[sfb], b = (double)L.xmin[sfb], rb = L.rxmin[sfb];
+            const double x = rb != 0.0 ? div_by_f32(noise, b, rb) : noise / b;
             L.distort[sfb] = (float)x;
+            if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; const double nf = (double)(float)noise; L.pn_dist[sfb] = (float)(rb != 0.0 ? div_by_f32(nf, b, rb) : nf / b); }
             cls = need_max ? -1 : noise_class(x);          // the logarithm will be formed anyway: no shortcut
             int cls_cache = cls;
             if (cls < 0) {
@@ -1037,10 +971,10 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     if (use_pn) pn.gain = g.global_gain;
     res->over_count = over; res->over_SSD = ssd;
     res->max_noise = 0.0;
-    if (any_log_needed || over == 0) {
+    if (need_max || over == 0) {
         double max_noise = -20.0;
         for (int sfb = 0; sfb < g.psymax; sfb++) {
-            const bool fresh = L.binfo[sfb].kind != 0;
+            const bool fresh = (m_fresh >> sfb) & 1;
             const double x = (fresh && !use_pn) ? L.nsum[sfb] : L.pn_x[sfb];
             const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
             const double nl = fresh ? l : (double)(float)l;
@@ -1049,21 +983,100 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         res->max_noise = max_noise;
     }
 #else
-    double x = 1.0;                                   // this lane's band: noise / xmin (cached bands: as last evaluated)
-    int cls = 0, fresh = 0;                           // class used by THIS call; fresh: the band was evaluated in this call
+    int my_step = 0, my_fresh = 0;                        // lane = band: kept in registers for the per-band part after the fold
     LHIP_LANE_ONCE(sfb, 0, g.psymax) {
-        const QuantLds::BandInfo bi = L.binfo[sfb];
-        if (bi.kind == 0) {
-            L.distort[sfb] = (float)((double)L.pn_noise[sfb] / (double)L.xmin[sfb]);
+        my_step = sf_step(Q, g, scalefac, L.window, sfb);
+        my_fresh = !(use_pn && L.pn_step[sfb] == my_step);
+        L.bstep[sfb] = Q.pow20[my_step + Q_MAX2];
+    }
+    // the longest chain the fold must carry: the widest evaluated band (an upper bound -- the widest band up to the highest evaluated one)
+    const uint64_t m_fresh = wave_ballot(my_fresh);
+    const int hib = m_fresh ? 63 - (int)__builtin_clzll(m_fresh) : 0;
+    const int maxlen = m_fresh ? (int)(is_short ? Q.wpre_short[hib] : Q.wpre_long[hib]) : 0;
+    wave_sync();
+    PH_MARK(L, PH_N_WALK, tm_);
+    // 2) squared errors summed per band in the reference's line order (f64 sums are order-sensitive) as a
+    //    systolic fold: lane l owns NLN consecutive lines and folds their terms, in order, onto the running sum
+    //    handed over by lane l-1 (reset at band starts).  One hand-over step extends every band's chain by one
+    //    lane, so ceil(longest band / NLN) + 1 steps reproduce the strictly sequential sums exactly, while the
+    //    terms themselves are computed once, all lanes busy.
+    enum { NLN = 576 / LHIP_NL };
+    static_assert(NLN == 9, "QuantTabs::fold_marks is laid out for 9 lines per lane");
+    {
+        double tq[NLN], keep[NLN];
+        int lastb[NLN];
+        const uint32_t marks = Q.fold_marks[is_short][lane];
+        const uint8_t* l2s = line2sfb(Q, g.block_type);
+        // Terms are computed for EVERY line, evaluated band or not: a cached band's sum is never read.
+        // keep[k] = 0 at a band start, 1 elsewhere: fma(sum, keep, t) is `sum + t` or `t` with ONE rounding, i.e.
+        // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit.
+        // |xr| - pow43 * step: the product of two Float32 values is exact in f64, so the explicit fma's single rounding is the
+        // reference's (a product, then a difference).
+#pragma unroll
+        for (int k = 0; k < NLN; k++) {
+            const int j = NLN * lane + k;
+            const int bnd = l2s[j];
+            const float bstep = L.bstep[bnd];
+            const float xa = L.xr[j]; const int iv = ix[j];
+            const float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
+            const double x = __builtin_fma(-(double)pw, (double)bstep, d_abs((double)xa));
+            tq[k] = x * x;
+            keep[k] = one_unless_bit(marks, k);
+            lastb[k] = bnd;
+        }
+        if (may_big) {                                   // rare: quantized values beyond the part of pow43 staged in LDS
+#pragma unroll
+            for (int k = 0; k < NLN; k++) {
+                const int j = NLN * lane + k;
+                const int iv = ix[j];
+                if (iv >= QT_N) {
+                    const double x = __builtin_fma(-(double)T.pow43[iv], (double)L.bstep[lastb[k]], d_abs((double)L.xr[j]));
+                    tq[k] = x * x;
+                }
+            }
+        }
+        PH_MARK(L, PH_N_LINES, tm_);
+        const int nsteps = (maxlen + NLN - 1) / NLN + 1;
+        double carry = 0.0;
+        for (int st = 0; st + 1 < nsteps; st++) {
+            double sacc = carry;
+#pragma unroll
+            for (int k = 0; k < NLN; k++) sacc = __builtin_fma(sacc, keep[k], tq[k]);
+            carry = wave_shr1d(sacc, 0.0);
+        }
+        {
+            double sacc = carry;
+#pragma unroll
+            for (int k = 0; k < NLN; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); tq[k] = sacc; }   // tq := running sums of the last step
+        }
+#pragma unroll
+        for (int k = 0; k < NLN; k++) if ((marks >> (16 + k)) & 1u) L.nsum[lastb[k]] = tq[k];
+        wave_sync();
+        PH_MARK(L, PH_N_FOLD, tm_);
+    }
+    // 3) per band: distortion ratio x = noise / xmin (div_by_f32: the division's result from the reciprocal calc_xmin left), its class
+    //    (over? tmp) -- without the logarithm wherever that is safe (noise_class, lhip_math.h) -- and the cache.  The reference caches
+    //    the Float32 copy of the noise and divides it by xmin again in every later call; that quotient is formed here, once.  Lanes whose
+    //    band sits next to a step of the class function (or outside the shortcut's range) make the whole wave take the logarithm for
+    //    this call (about one call in a hundred); the logarithm is also taken when the caller will read max_noise (need_max) or the
+    //    result turns out to have no distorted band.
+    double x = 1.0;                                   // this lane's band: noise / xmin (cached bands: as last evaluated)
+    int cls = 0;                                      // class used by THIS call
+    const int fresh = my_fresh;
+    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
+        if (!fresh) {
+            L.distort[sfb] = L.pn_dist[sfb];
             x = L.pn_x[sfb];
             cls = L.pn_cls[sfb];
         } else {
-            const double noise = (bi.nend > bi.nstart) ? L.nsum[sfb] : 0.0;
-            if (use_pn) { L.pn_step[sfb] = L.qmode[sfb]; L.pn_noise[sfb] = (float)noise; }
-            x = noise / (double)L.xmin[sfb];
+            const double noise = L.nsum[sfb], b = (double)L.xmin[sfb], rb = L.rxmin[sfb];
+            const double nf = (double)(float)noise;
+            x = div_by_f32(noise, b, rb);
+            double xf = div_by_f32(nf, b, rb);
+            if (rb == 0.0) { x = noise / b; xf = nf / b; }         // never on sane material: an xmin outside div_by_f32's proof
             L.distort[sfb] = (float)x;
+            if (use_pn) { L.pn_step[sfb] = my_step; L.pn_dist[sfb] = (float)xf; }
             cls = need_max ? -1 : noise_class(x);          // the logarithm will be formed anyway: no shortcut
-            fresh = 1;
         }
     }
     PH_MARK(L, PH_N_TERMS, tm_);
@@ -1431,7 +1444,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
     best.max_noise = 0; best.over_count = 0; best.over_SSD = 0; best.bits = 0;
-    LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.pn_step[i] = 0; L.pn_noise[i] = 0.f; L.pn_x[i] = 1.0; L.pn_cls[i] = 0; L.distort[i] = 0.f; }
+    LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.pn_step[i] = 0; L.pn_dist[i] = 0.f; L.pn_x[i] = 1.0; L.pn_cls[i] = 0; L.distort[i] = 0.f; }
     wave_sync();
     targ_bits = uni(targ_bits); bs_start = uni(bs_start); bs_step = uni(bs_step);
     uni_gi(g);

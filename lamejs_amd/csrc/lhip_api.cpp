@@ -781,6 +781,38 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
         }
         memcpy(extra.data() + amp_at, amp, sizeof amp);
     }
+    // calc_noise's systolic fold (k_quant.h): lane l owns the lines 9 l .. 9 l + 8 of the (re-ordered) spectrum; per lane, bit k =
+    // line 9 l + k is the first line of its scalefactor band, bit 16 + k = it is the last one ([0..63] long, [64..127] short blocks);
+    // then the widest band among bands 0 .. b: 24 entries for long blocks, 40 for short ones (band = 3 * sfb + window)
+    const size_t fold_at = extra.size();
+    extra.resize(fold_at + 128 + 24 + 40);
+    {
+        const int32_t* h_sl = (const int32_t*)host_arr("sfb_l");
+        const int32_t* h_ss = (const int32_t*)host_arr("sfb_s");
+        std::vector<int> band_l(576), band_s(576);
+        for (int d = 0, sfb = 0; d < 576; d++) { while (sfb < SBMAX_l - 1 && h_sl[sfb + 1] <= d) sfb++; band_l[d] = sfb; }
+        for (int d = 0, sfb = 0; d < 576; d++) {
+            while (sfb < SBMAX_s - 1 && 3 * h_ss[sfb + 1] <= d) sfb++;
+            const int st = h_ss[sfb], w = h_ss[sfb + 1] - st;
+            band_s[d] = 3 * sfb + (w > 0 ? (d - 3 * st) / w : 0);
+        }
+        for (int sh = 0; sh < 2; sh++) {
+            const std::vector<int>& b = sh ? band_s : band_l;
+            for (int ln = 0; ln < 64; ln++) {
+                uint32_t m = 0;
+                for (int kk = 0; kk < 9; kk++) {
+                    const int jj = 9 * ln + kk;
+                    if (jj == 0 || b[jj - 1] != b[jj]) m |= 1u << kk;
+                    if (jj == 575 || b[jj + 1] != b[jj]) m |= 1u << (16 + kk);
+                }
+                extra[fold_at + 64 * sh + ln] = (int32_t)m;
+            }
+        }
+        int mx = 0;
+        for (int i = 0; i < 24; i++) { if (i < SBMAX_l) { const int w = h_sl[i + 1] - h_sl[i]; if (mx < w) mx = w; } extra[fold_at + 128 + i] = mx; }
+        mx = 0;
+        for (int i = 0; i < 40; i++) { if (i < 3 * SBMAX_s) { const int w = h_ss[i / 3 + 1] - h_ss[i / 3]; if (mx < w) mx = w; } extra[fold_at + 128 + 24 + i] = mx; }
+    }
     ts.d_extra = rt::dmalloc(extra.size() * 4);
     if (!ts.d_extra) { set_err("hipMalloc failed"); return false; }
     if (!rt::h2d(ts.d_extra, extra.data(), extra.size() * 4, stream)) return false;
@@ -788,6 +820,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     T.s3off_l = (const int32_t*)ts.d_extra; T.s3off_s = T.s3off_l + CBANDS; T.lineoff_l = T.s3off_l + 2 * CBANDS; T.lineoff_s = T.s3off_l + 3 * CBANDS;
     T.bo_l = T.s3off_l + 4 * CBANDS; T.bo_s = T.bo_l + SBMAX_l;
     T.amp_by_out = (const double*)(T.s3off_l + amp_at);
+    T.fold_marks = T.s3off_l + fold_at; T.wpre = T.fold_marks + 128;
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
     // kb_bits assembles a frame in BitsLds (and zeroes one word past its last one): the largest frame of this configuration must fit

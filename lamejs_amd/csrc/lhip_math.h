@@ -247,6 +247,29 @@ LHIP_DEV int noise_class(double x) {
     const int tmp = (int)k;
     return tmp < 1 ? 1 : tmp;
 }
+// ---- a / b where b is a Float32 value and rb = RN(1 / b) is at hand (calc_noise divides every band's noise by the same xmin in every
+// call of a granule).  q0 = RN(a rb) lies within 1.5 ulp of a / b, so the residual r = a - b q0 is exact in one fma (it is a multiple of
+// lsb(b) lsb(q0) below 2^26 of them), and q0 + r rb = a / b + (a / b - q0) eps with |eps| <= 2^-53: less than 2^-104 |a / b| away from
+// the quotient.  A quotient by a divisor of 24 significant bits keeps at least 2^-78 |a / b| from every midpoint of the f64 grid
+// (|a - m b| is a non-zero multiple of lsb(m) lsb(b); a = m b would need 54 bits), so the fma's single rounding is RN(a / b): the
+// result is the division's, bit for bit.  Proven for finite a >= 0 and b a positive Float32 (subnormal ones included: normal doubles)
+// whose reciprocal is finite -- recip_for_div returns 0 for any other b and the caller then divides.
+// 0.0 if bit k of m is set, else 1.0 -- as two integer operations on the high word (a compare-and-select pair per word otherwise)
+LHIP_DEV double one_unless_bit(uint32_t m, int k) {
+#ifdef LHIP_HOSTSIM
+    return ((m >> k) & 1u) ? 0.0 : 1.0;
+#else
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)~m, (unsigned)k, 1u) & 0x3ff00000u;
+    return __builtin_bit_cast(double, (uint64_t)hi << 32);
+#endif
+}
+LHIP_DEV double recip_for_div(double b) { return (b > 0.0 && b < 1e300) ? 1.0 / b : 0.0; }
+LHIP_DEV double div_by_f32(double a, double b, double rb) {
+    const double q0 = a * rb;
+    const double r = __builtin_fma(-b, q0, a);
+    return __builtin_fma(r, rb, q0);
+}
+
 // the same from the logarithm (what the reference computes): nl = log10(max(x, 1e-20)) or its Float32 copy
 LHIP_DEV int noise_class_of_log(double nl) {
     if (!(nl > 0.0)) return 0;

@@ -552,8 +552,10 @@ def _gpu_encode_in_ranges(ch, sr, kbps, L, R, cuts, H, joint=False):
             p0, nt = a - H * fs, enc.seek_tail_samples()
             enc.seek(p0, L[p0 - nt:p0], None if R is None else R[p0 - nt:p0])
             enc.encodeBuffer(L[p0:a], None if R is None else R[p0:a])
-            if enc.state_get() != prev:
-                missed.append(r)
+            got_state = enc.state_get()
+            if got_state != prev:
+                from state_fields import describe_diff
+                missed.append((r, describe_diff(got_state, prev)))
                 enc.state_set(prev)
         out = enc.encodeBuffer(L[a:b], None if R is None else R[a:b])
         prev = enc.state_get()
