@@ -102,6 +102,10 @@ struct QuantTabs {
     // bit 16 + k = it is the last one; [0] long blocks, [1] short blocks.  wpre: widest band among bands 0 .. b (long / short).
     uint32_t fold_marks[2][64];
     uint16_t wpre_long[24], wpre_short[40];
+    // analog silence (Quantize.js:147-202): pseudo-band borders above sfb21 / sfb12, their ATH values ([0..5] long, [6..11] short) and the
+    // two band factors they are scaled with
+    int16_t psfb21[PSFB21 + 1], psfb12[PSFB12 + 1];
+    float ath_psfb[PSFB21 + PSFB12], fact_psfb[2];
 };
 
 LHIP_DEV void q_fill_plans(QuantTabs& Q, int tid, int nthr);
@@ -141,6 +145,10 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
         Q.l2s_short[d] = (uint8_t)(3 * sfb + win);
         (void)l;
     }
+    for (int e = tid; e < PSFB21 + 1; e += nthr) Q.psfb21[e] = (int16_t)T.psfb21[e];
+    for (int e = tid; e < PSFB12 + 1; e += nthr) Q.psfb12[e] = (int16_t)T.psfb12[e];
+    for (int e = tid; e < PSFB21 + PSFB12; e += nthr) Q.ath_psfb[e] = e < PSFB21 ? T.ATH_psfb21[e] : T.ATH_psfb12[e - PSFB21];
+    if (tid == 0) { Q.fact_psfb[0] = T.longfact[21]; Q.fact_psfb[1] = T.shortfact[12]; }
     for (int e = tid; e < 2 * 64; e += nthr) Q.fold_marks[e >> 6][e & 63] = (uint32_t)T.fold_marks[e];
     for (int e = tid; e < 24; e += nthr) Q.wpre_long[e] = (uint16_t)T.wpre[e];
     for (int e = tid; e < 40; e += nthr) Q.wpre_short[e] = (uint16_t)T.wpre[24 + e];
@@ -161,7 +169,10 @@ struct QuantLds {
     float pn_dist[SFBMAX + 1];                   // the cache of the reference's Float32 noise, as what every later call derives from it: (float)(noise / xmin)
     // the cache of the reference's Float32 noise_log, without the logarithm: pn_x = the band's noise / xmin (f64) as last evaluated,
     // pn_cls = noise_class of the Float32 copy of its logarithm (lhip_math.h); the logarithm itself is only formed when max_noise is read
-    double pn_x[SFBMAX + 1];
+    union {                      // pn_x is dead once the outer loop has finished; the Huffman split's range-maximum tables reuse it
+        double pn_x[SFBMAX + 1];
+        int16_t hmax[5][24];     // hmax[t][b] = largest quantized value in the bands b .. b + 2^t - 1 (q_band_max_tables)
+    };
     int16_t pn_cls[SFBMAX + 1];
     int32_t qmode[SFBMAX + 1];
     float bstep[SFBMAX + 1];                     // calc_noise: POW20 of the band's step (what the per-line pass reads)
@@ -173,7 +184,7 @@ struct QuantLds {
     };
     alignas(8) uint32_t rdesc[4][2];   // per Huffman region: offsets of its candidate length tables | row stride
     int32_t gkeep[24];                 // the mutable scalars of the kept quantization (cod_info) while the outer loop runs on cod_info_w
-    double ath_pseudo[6];
+    double ath_pseudo[PSFB21 + PSFB12];   // this frame's analog-silence thresholds (q_ath_pseudo): [0..5] long blocks, [6..11] short blocks
 #ifdef LHIP_PHASE_PROF
     unsigned int prof[64];           // per-frame cycle sums fit 32 bits
 #endif
@@ -241,10 +252,72 @@ LHIP_DEV float xr_at(const XrSrc& X, int i) {
     const double l = X.a[i], r = X.b[i];
     return X.side ? (float)((l - r) * (LHIP_SQRT2 * 0.5)) : (float)((l + r) * (LHIP_SQRT2 * 0.5));
 }
+// The analog-silence thresholds of a frame (Quantize.js:147-202: athAdjust of the pseudo bands' ATH, scaled by the band factor of
+// sfb21 / sfb12): functions of the frame's ATH adjustment alone, so they are formed once per frame -- [0..5] for long blocks,
+// [6..11] for short ones -- and not once per granule and channel.
+LHIP_DEV void q_ath_pseudo(const Tables& T, const PowBase& pb10, double ath_adjust, int lane, QuantLds& L, const QuantTabs& Q) {
+    wave_sync();
+    LHIP_LANE_ONCE(e, 0, PSFB21 + PSFB12) {
+        double a = athAdjust(T, pb10, ath_adjust, Q.ath_psfb[e], T.ATH_floor);
+        const double f = (double)Q.fact_psfb[e < PSFB21 ? 0 : 1];
+        if (f > 1e-12) a *= f;
+        L.ath_pseudo[e] = a;
+    }
+    wave_sync();
+}
+
+// the lines of a granule-channel from HBM, in the order the quantizer keeps them (short blocks: the three windows of a band as
+// consecutive runs).  All loads of a lane are issued before the first one is needed (a lane-strided loop compiles to one load per
+// trip, each waited for by itself: nine round trips to memory).
+LHIP_DEV void q_load_lines(const XrSrc& X, int is_short, int lane, QuantLds& L, const QuantTabs& Q) {
+#if LHIP_NL == 1
+    for (int d = 0; d < 576; d++) {
+        int src = d;
+        if (is_short) {
+            const int sw = Q.l2s_short[d], sfb = sw / 3, win = sw - 3 * sfb;
+            const int st = Q.sfb_s[sfb], w = Q.sfb_s[sfb + 1] - st;
+            src = 3 * (st + (d - 3 * st - win * w)) + win;
+        }
+        L.xr[d] = xr_at(X, src);
+    }
+    (void)lane;
+#else
+    enum { NV = 576 / LHIP_NL };
+    int src[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int d = lane + LHIP_NL * k;
+        src[k] = d;
+        if (is_short) {
+            const int sw = Q.l2s_short[d], sfb = sw / 3, win = sw - 3 * sfb;
+            const int st = Q.sfb_s[sfb], w = Q.sfb_s[sfb + 1] - st;
+            src[k] = 3 * (st + (d - 3 * st - win * w)) + win;
+        }
+    }
+    float va[NV], vb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) { va[k] = X.a[src[k]]; vb[k] = 0.f; }
+    if (X.b) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) vb[k] = X.b[src[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) { LHIP_PIN_LOADED(va[k]); LHIP_PIN_LOADED(vb[k]); }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        float v = va[k];
+        if (X.b) { const double l = va[k], r = vb[k]; v = X.side ? (float)((l - r) * (LHIP_SQRT2 * 0.5)) : (float)((l + r) * (LHIP_SQRT2 * 0.5)); }
+        L.xr[lane + LHIP_NL * k] = v;
+    }
+#endif
+}
+
+// ath_ready: L.ath_pseudo holds this frame's thresholds (q_ath_pseudo); only read when the silence rule runs
 LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath_adjust, GI& g, int block_type,
                                 const XrSrc& xr_g, float* xr_wb, int skip_silence, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     unsigned long long tmi_ = PH_NOW(); (void)tmi_;
+    (void)pb10; (void)ath_adjust;
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
     __builtin_amdgcn_s_waitcnt(0);           // profiling build only: everything this wave still has in flight (stores of the previous granule)
     PH_MARK(L, PH_DRAIN, tmi_);
@@ -268,67 +341,51 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
         nsfb = 3 * SBMAX_s;
         LHIP_LANE_ONCE(i, 0, nsfb) {
             const int sfb = i / 3, win = i - 3 * sfb;
-            const int w = T.sfb_s[sfb + 1] - T.sfb_s[sfb];
-            L.width[i] = (int16_t)w; L.window[i] = (int16_t)win; L.start[i] = (int16_t)(3 * T.sfb_s[sfb] + win * w);
+            const int w = Q.sfb_s[sfb + 1] - Q.sfb_s[sfb];
+            L.width[i] = (int16_t)w; L.window[i] = (int16_t)win; L.start[i] = (int16_t)(3 * Q.sfb_s[sfb] + win * w);
         }
         if (lane == 0) L.start[nsfb] = 576;
-        // re-order: within each short sfb the three windows become consecutive runs
-        for (int d = lane; d < 576; d += LHIP_NL) {
-            const int sw = Q.l2s_short[d], sfb = sw / 3, win = sw - 3 * sfb;
-            const int st = Q.sfb_s[sfb], w = Q.sfb_s[sfb + 1] - st;
-            L.xr[d] = xr_at(xr_g, 3 * (st + (d - 3 * st - win * w)) + win);
-        }
+        q_load_lines(xr_g, 1, lane, L, Q);       // re-ordered: within each short sfb the three windows become consecutive runs
     } else {
         nsfb = SBMAX_l;
         LHIP_LANE_ONCE(i, 0, SBMAX_l) {
-            L.width[i] = (int16_t)(T.sfb_l[i + 1] - T.sfb_l[i]); L.window[i] = 3; L.start[i] = (int16_t)T.sfb_l[i];
+            L.width[i] = (int16_t)(Q.sfb_l[i + 1] - Q.sfb_l[i]); L.window[i] = 3; L.start[i] = (int16_t)Q.sfb_l[i];
         }
         if (lane == 0) L.start[SBMAX_l] = 576;
-        for (int d = lane; d < 576; d += LHIP_NL) L.xr[d] = xr_at(xr_g, d);
+        q_load_lines(xr_g, 0, lane, L, Q);
     }
     LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) { L.sfw[i] = 0; L.sfb[i] = 0; }
     wave_sync();
     PH_MARK(L, PH_COPY, tmi_);
 
-    // analog silence in the pseudo bands above sfb21 / sfb12: zero trailing lines below the adjusted ATH
+    // analog silence in the pseudo bands above sfb21 / sfb12: zero trailing lines below the adjusted ATH (thresholds: q_ath_pseudo)
     if (skip_silence) return;
     if (block_type != SHORT_TYPE) {
-        LHIP_LANE_ONCE(gsfb, 0, PSFB21) {
-            double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb21[gsfb], T.ATH_floor);
-            if ((double)T.longfact[21] > 1e-12) a *= (double)T.longfact[21];
-            L.ath_pseudo[gsfb] = a;
-        }
-        wave_sync();
-        PH_MARK(L, PH_XRPOW, tmi_);
-        const int lo = T.psfb21[0];
+        const int lo = Q.psfb21[0];
         int top = lo - 1;                       // highest line that is NOT below its threshold
         for (int j = lo + lane; j < 576; j += LHIP_NL) {
-            int gsfb = 0;
-            while (T.psfb21[gsfb + 1] <= j) gsfb++;
+            int gsfb = 0;                       // pseudo band of line j: the number of inner borders at or below it
+#pragma unroll
+            for (int q = 1; q < PSFB21; q++) gsfb += (Q.psfb21[q] <= j);
             if (!(d_abs((double)L.xr[j]) < L.ath_pseudo[gsfb])) top = j;   // ascending j per lane
         }
         top = wave_max(top);
         for (int j = lo + lane; j < 576; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[j] = 0; }
         PH_MARK(L, PH_PUBLISH, tmi_);
     } else {
-        LHIP_LANE_ONCE(gsfb, 0, PSFB12) {
-            double a = athAdjust(T, pb10, ath_adjust, T.ATH_psfb12[gsfb], T.ATH_floor);
-            if ((double)T.shortfact[12] > 1e-12) a *= (double)T.shortfact[12];
-            L.ath_pseudo[gsfb] = a;
-        }
-        wave_sync();
-        const int w12 = T.sfb_s[13] - T.sfb_s[12];
+        const int s12 = Q.sfb_s[12], w12 = Q.sfb_s[13] - s12;
         for (int block = 0; block < 3; block++) {
-            const int lo = T.sfb_s[12] * 3 + w12 * block;
+            const int lo = s12 * 3 + w12 * block;
             int top = lo - 1;
             for (int j = lo + lane; j < lo + w12; j += LHIP_NL) {
-                const int rel = j - lo + T.psfb12[0];
+                const int rel = j - lo + Q.psfb12[0];
                 int gsfb = 0;
-                while (T.psfb12[gsfb + 1] <= rel) gsfb++;
-                if (!(d_abs((double)L.xr[j]) < L.ath_pseudo[gsfb])) top = j;
+#pragma unroll
+                for (int q = 1; q < PSFB12; q++) gsfb += (Q.psfb12[q] <= rel);
+                if (!(d_abs((double)L.xr[j]) < L.ath_pseudo[PSFB21 + gsfb])) top = j;
             }
             top = wave_max(top);
-            for (int j = lo + lane; j < lo + w12; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[3 * (T.sfb_s[12] + (j - lo)) + block] = 0; }
+            for (int j = lo + lane; j < lo + w12; j += LHIP_NL) if (j > top) { L.xr[j] = 0; if (xr_wb) xr_wb[3 * (s12 + (j - lo)) + block] = 0; }
         }
     }
     wave_sync();
@@ -344,7 +401,7 @@ LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
         sum += tmp;
         const float v = (float)d_sqrt(tmp * d_sqrt(tmp));
         L.xrpow[i] = v;
-        if (v > m) m = v;
+        m = fmax_nonneg(m, v);
     }
     m = wave_maxf_pos(m);
     g.xrpow_max = m;
@@ -479,6 +536,14 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // per-band decision as wave-uniform bit masks: cached (keep old values) / 0-1 shortcut; the first
     // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
     unsigned long long tm_ = PH_NOW(); (void)tm_;
+    // the lines first: their LDS latency passes while the band masks are formed
+    float xa[NPL], xb[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int p = 2 * (lane + LHIP_NL * j);
+        xa[j] = 0.f; xb[j] = 0.f;
+        if (p < 576) { struct F2 { float x, y; }; const F2 xx = *(const F2*)(L.xrpow + p); xa[j] = xx.x; xb[j] = xx.y; }   // 8-byte aligned: p is even
+    }
     uint64_t m_cached = 0, m_zo = 0, m_cut = 0;       // bit sfb, produced by lane sfb (sfbmax < 64)
     if (use_prev) {                                      // bin-search rounds have no cache and no 0/1 shortcut: nothing to decide
         LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1) {
@@ -500,26 +565,19 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // shortcut.
     if (sstar <= sfbmax) m_zo &= ~(1ull << sstar);
     PH_MARK(L, PH_Q_MASK, tm_);
-    const double compareval0 = (1.0 - 0.4054) / istep;
     const uint8_t* l2s = line2sfb(Q, g.block_type);
     const int need_old = (m_cached != 0);
     const float istep_f = Q.ipow20[g.global_gain];     // the Float32Array value itself; `istep` above is its f64 image
     // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here); the two
     // truncations of every line are q_floor_prod / q_floor_fma (lhip_math.h)
-    float xa[NPL], xb[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        const int p = 2 * (lane + LHIP_NL * j);
-        xa[j] = 0.f; xb[j] = 0.f;
-        if (p < 576) { struct F2 { float x, y; }; const F2 xx = *(const F2*)(L.xrpow + p); xa[j] = xx.x; xb[j] = xx.y; }   // 8-byte aligned: p is even
-    }
     int ra[NPL], rb[NPL];
     q_floor_prod(xa, xb, istep_f, ra, rb);                                 // 0 <= x <= 8206: truncation == ToInt32
     float aa[NPL], ab[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        aa[j] = Q.adj43[ra[j] < QT_N ? ra[j] : QT_N - 1]; ab[j] = Q.adj43[rb[j] < QT_N ? rb[j] : QT_N - 1];
-        if (may_big) {                                                     // rare: large quantized values
+    for (int j = 0; j < NPL; j++) { aa[j] = Q.adj43[ra[j] < QT_N ? ra[j] : QT_N - 1]; ab[j] = Q.adj43[rb[j] < QT_N ? rb[j] : QT_N - 1]; }
+    if (may_big) {                                                         // rare: large quantized values
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
             if (ra[j] >= QT_N) aa[j] = T.adj43[ra[j]];
             if (rb[j] >= QT_N) ab[j] = T.adj43[rb[j]];
         }
@@ -533,7 +591,25 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
             const int p = 2 * (lane + LHIP_NL * j);
             if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)vx[j] | ((uint32_t)vy[j] << 16);
         }
+    } else if (m_zo == 0) {
+        // cached bands keep their values, nothing else
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int p = 2 * (lane + LHIP_NL * j);
+            int sf = 0; uint32_t oldw = 0;
+            if (p < 576) { sf = l2s[p]; oldw = *(const uint32_t*)(ix + p); }
+            const int cached = (int)((m_cached >> sf) & 1);
+            const int va = cached ? (int)(oldw & 0xffffu) : vx[j], vb = cached ? (int)(oldw >> 16) : vy[j];
+            vx[j] = va; vy[j] = vb;
+            if (p < 576) *(uint32_t*)(ix + p) = (uint32_t)va | ((uint32_t)vb << 16);
+        }
     } else {
+        // 0/1 shortcut (Takehiro.js:187-210): ix = (compareval0 > xrpow) ? 0 : 1 with compareval0 = (1 - 0.4054) / istep in f64.  xrpow is a
+        // Float32 value, so the f64 comparison is a Float32 one against zo_thr, the smallest Float32 not below compareval0:
+        // compareval0 > x  <=>  x < zo_thr
+        const double compareval0 = (1.0 - 0.4054) / istep;
+        float zo_thr = (float)compareval0;
+        if ((double)zo_thr < compareval0) zo_thr = f32_next_up(zo_thr);
         // the previous values are only fetched when some band is cached
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
@@ -542,7 +618,7 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
             if (p < 576) { sf = l2s[p]; if (need_old) oldw = *(const uint32_t*)(ix + p); }
             const int cached = (int)((m_cached >> sf) & 1), zo = (int)((m_zo >> sf) & 1);
             int va = vx[j], vb = vy[j];
-            if (zo) { va = (compareval0 > (double)xa[j]) ? 0 : 1; vb = (compareval0 > (double)xb[j]) ? 0 : 1; }
+            if (zo) { va = (xa[j] < zo_thr) ? 0 : 1; vb = (xb[j] < zo_thr) ? 0 : 1; }
             const int oa = (int)(oldw & 0xffffu), ob = (int)(oldw >> 16);
             va = cached ? oa : va;
             vb = cached ? ob : vb;
@@ -729,16 +805,14 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         const int p = (int)(((w0 & 1u) << 3) | ((w0 >> 16) << 2) | ((w1 & 1u) << 1) | (w1 >> 16));
         a12 += Q.t32l[p] + (Q.t33l[p] << 16);
     }
-    a12 = wave_sum(a12);
-    int a1 = a12 & 0xffff, a2 = a12 >> 16;
+    // the quads' two candidate lengths (packed) are reduced together with the region sums below: one reduction chain less per call
     i -= 4 * firstbig;
-    int bits = a1;
-    g.count1table_select = 0;
-    if (a1 > a2) { bits = a2; g.count1table_select = 1; }
-    g.count1bits = bits;
     g.big_values = i;
+    int a1, a2, bits;
+#define COUNT1_FINISH(A12) do { const int c1_ = (A12) & 0xffff, c2_ = (int)((unsigned)(A12) >> 16); bits = c1_; g.count1table_select = 0; \
+                                if (c1_ > c2_) { bits = c2_; g.count1table_select = 1; } g.count1bits = bits; } while (0)
     PH_MARK(L, PH_C_QUADS, tm_);
-    if (i == 0) return bits;
+    if (i == 0) { const int t = wave_sum(a12); COUNT1_FINISH(t); return bits; }
     int use2 = 0;
     if (g.block_type == SHORT_TYPE) {
         a1 = 3 * Q.sfb_s[3];
@@ -834,10 +908,12 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     }
     // unpack to (A|B<<16), (C|N<<16) per region: wave totals stay below 2^16 (<= 288 pairs x 21 bits = 6048)
 #define FLD(A, R) ((uint32_t)(((A) >> (FB * (R))) & FM))
-    int qq[6] = {(int)(FLD(accA, 0) | (FLD(accB, 0) << 16)), (int)(FLD(accC, 0) | (FLD(accN, 0) << 16)), (int)(FLD(accA, 1) | (FLD(accB, 1) << 16)),
-                 (int)(FLD(accC, 1) | (FLD(accN, 1) << 16)), (int)(FLD(accA, 2) | (FLD(accB, 2) << 16)), (int)(FLD(accC, 2) | (FLD(accN, 2) << 16))};
-    wave_sum_n(qq);                       // six packed sums reduced side by side
+    int qq[7] = {(int)(FLD(accA, 0) | (FLD(accB, 0) << 16)), (int)(FLD(accC, 0) | (FLD(accN, 0) << 16)), (int)(FLD(accA, 1) | (FLD(accB, 1) << 16)),
+                 (int)(FLD(accC, 1) | (FLD(accN, 1) << 16)), (int)(FLD(accA, 2) | (FLD(accB, 2) << 16)), (int)(FLD(accC, 2) | (FLD(accN, 2) << 16)), a12};
+    wave_sum_n(qq);                       // six packed region sums and the count1 quads' pair, reduced side by side
     const int q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3], q4 = qq[4], q5 = qq[5];
+    COUNT1_FINISH(qq[6]);
+#undef COUNT1_FINISH
 #undef FLD
     PH_MARK(L, PH_C_SUMS, tm_);
     // finish (Takehiro.js count_bit_noESC / _from2 / _from3 / count_bit_ESC tie-breaking): lane r picks the cheapest
@@ -1232,8 +1308,7 @@ LHIP_DEV void q_amplify_flagged(GI& g, double amp, uint64_t m_amp, int lane, Qua
         const double a = ((m_amp >> bnd[j]) & 1) ? amp : 1.0;
         xx[j].x = (float)((double)xx[j].x * a); xx[j].y = (float)((double)xx[j].y * a);
         if (p < 576) *(F2*)(L.xrpow + p) = xx[j];
-        if (xx[j].x > m) m = xx[j].x;
-        if (xx[j].y > m) m = xx[j].y;
+        m = fmax_nonneg(m, fmax_nonneg(xx[j].x, xx[j].y));      // xrpow values are >= +0
     }
     m = wave_maxf_pos(m);
     if ((double)m > g.xrpow_max) g.xrpow_max = m;
@@ -1360,7 +1435,7 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
                 for (int i = st + lane; i < st + w; i += LHIP_NL) {
                     const float v = (float)((double)L.xrpow[i] * amp);
                     L.xrpow[i] = v;
-                    if (v > m) m = v;
+                    m = fmax_nonneg(m, v);
                 }
                 m = wave_maxf_pos(m);
                 if ((double)m > g.xrpow_max) g.xrpow_max = m;
@@ -1648,6 +1723,7 @@ LHIP_DEV void q_best_scalefac_store(const Tables& T, GI& g, int gr, int ch, int 
 // row 0 max (kept per band), 1 t1, 2 table23 (packed), 3 table56 (packed), 4..6 t7-9, 7..9 t10-12, 10..12 t13-15,
 // 13 largetbl hi, 14 largetbl lo, 15 number of escaped values.  A row is only meaningful for regions whose
 // maximum admits the table group, which is exactly when the reference would look at it.
+LHIP_DEV void q_band_max_tables(int lane, QuantLds& L);
 LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     // One lane per run of consecutive pairs (5 on the device): every pair contributes its 17 code lengths, the
@@ -1708,14 +1784,37 @@ LHIP_DEV void q_band_stats(const Tables& T, const int16_t* ix, int limit, int la
     }
     LHIP_LANE_ONCE(k, 1, 16) L.hd.bstat[k][0] = 0;
     wave_sync();
+    q_band_max_tables(lane, L);
+}
+
+// Range maxima over whole bands in O(1): hmax[t][b] = maximum of the band maxima (row 0 of the statistics) of the bands
+// b .. b + 2^t - 1, bands past SBMAX_l counting as 0; any range is covered by two (overlapping) power-of-two windows.
+LHIP_DEV void q_band_max_tables(int lane, QuantLds& L) {
+    LHIP_LANE_ONCE(b, 0, 24) L.hmax[0][b] = (int16_t)(b < SBMAX_l ? L.hd.bstat[0][b + 1] : 0);     // quantized values are <= IXMAX_VAL
+    wave_sync();
+#pragma unroll
+    for (int t = 1; t < 5; t++) {
+        LHIP_LANE_ONCE(b, 0, 24) {
+            const int h = 1 << (t - 1);
+            const int a = L.hmax[t - 1][b], c = (b + h < 24) ? (int)L.hmax[t - 1][b + h] : 0;
+            L.hmax[t][b] = (int16_t)(a > c ? a : c);
+        }
+        wave_sync();
+    }
+}
+LHIP_DEV int q_band_range_max(const QuantLds& L, int lo, int hi) {      // bands [lo, hi); 0 for an empty range
+    const int len = hi - lo;
+    const int t = 31 - (int)__builtin_clz((unsigned)(len > 0 ? len : 1));
+    const int a = L.hmax[t][lo < 23 ? lo : 23], c = L.hmax[t][hi - (1 << t) >= 0 ? hi - (1 << t) : 0];
+    const int m = a > c ? a : c;
+    return len > 0 ? m : 0;
 }
 
 // choose_table for the union of whole bands [b0, b1) from the statistics above (bits are added to *bits).
 // Called with lane-varying ranges, so it is written branch-free (selects), like the region planning of count_bits.
 LHIP_DEV int q_choose_from_stats(const Tables& T, int b0, int b1, int* bits, const QuantLds& L, const QuantTabs& Q) {
     (void)T; (void)Q;
-    int mx = 0;
-    for (int b = b0; b < b1; b++) { const int v = L.hd.bstat[0][b + 1]; mx = mx < v ? v : mx; }
+    const int mx = q_band_range_max(L, b0, b1);
     const int kind = (mx == 0) ? 0 : (mx == 1) ? 1 : (mx <= 3) ? 2 : (mx <= 15) ? 4 : (mx <= IXMAX_VAL) ? 5 : 6;
     const int t1 = (mx <= 1) ? mx : (mx == 2) ? 2 : (mx == 3) ? 5 : (mx <= 5) ? 7 : (mx <= 7) ? 10 : 13;
     const int rowA = (kind == 1) ? 1 : (kind == 2) ? (mx == 2 ? 2 : 3) : (kind == 4) ? (mx <= 5 ? 4 : mx <= 7 ? 7 : 10) : 13;
@@ -2121,6 +2220,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
             for (int ch = 0; ch < C; ch++) pe_use[gr][ch] *= f;
         wave_sync();
     }
+    q_ath_pseudo(T, pb10, ath_adjust, lane, L, Q);          // the frame's analog-silence thresholds, both block kinds
     for (int gr = 0; gr < T.mode_gr; gr++) {
         const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
         int targ[2] = {0, 0};
@@ -2150,7 +2250,19 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
                 q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, lane, L, Q);
                 uni_gi(g); bs_gain = uni(bs_gain);
                 wave_sync();                                    // the kept spectrum was written by other lanes of this wave
+#if LHIP_NL == 1
                 for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
+#else
+                {   // all of a lane's words in flight at once (a lane-strided loop waits for every load by itself)
+                    uint32_t kw[NPL];
+#pragma unroll
+                    for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)kept)[i < 288 ? i : 287]; }
+#pragma unroll
+                    for (int j = 0; j < NPL; j++) LHIP_PIN_LOADED(kw[j]);
+#pragma unroll
+                    for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
+                }
+#endif
                 wave_sync();
                 Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
                 if (ch == 0) seed0 = nx; else seed1 = nx;
@@ -2280,6 +2392,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
                 if (nBits < 0) {
                     if (!inited) {
                         const int ms = uni(rec->mode_ext) == 2;        // M/S granules were not written back: the silence rule runs again
+                        if (ms) q_ath_pseudo(T, pb10, ath_adjust, lane, L, Q);
                         q_init_outer_loop(T, pb10, ath_adjust, g, W.blocktype[(int64_t)gslot * C + ch],
                                           xr_source(W, C, gslot, ch, ms), nullptr, ms ? 0 : 1, lane, L, Q);
                         q_init_xrpow(g, lane, L, Q);

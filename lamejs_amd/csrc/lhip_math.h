@@ -254,6 +254,15 @@ LHIP_DEV int noise_class(double x) {
 // (|a - m b| is a non-zero multiple of lsb(m) lsb(b); a = m b would need 54 bits), so the fma's single rounding is RN(a / b): the
 // result is the division's, bit for bit.  Proven for finite a >= 0 and b a positive Float32 (subnormal ones included: normal doubles)
 // whose reciprocal is finite -- recip_for_div returns 0 for any other b and the caller then divides.
+// maximum of two Float32 values that are >= +0 and not NaN: IEEE order == integer order of the bit patterns (one v_max_i32; the
+// compare-and-select the source form `if (v > m) m = v` compiles to costs three issue slots)
+LHIP_DEV float fmax_nonneg(float a, float b) {
+    int32_t ia, ib; __builtin_memcpy(&ia, &a, 4); __builtin_memcpy(&ib, &b, 4);
+    const int32_t im = ia > ib ? ia : ib;
+    float r; __builtin_memcpy(&r, &im, 4); return r;
+}
+// the next Float32 above a positive finite one
+LHIP_DEV float f32_next_up(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); u += 1; float r; __builtin_memcpy(&r, &u, 4); return r; }
 // 0.0 if bit k of m is set, else 1.0 -- as two integer operations on the high word (a compare-and-select pair per word otherwise)
 LHIP_DEV double one_unless_bit(uint32_t m, int k) {
 #ifdef LHIP_HOSTSIM

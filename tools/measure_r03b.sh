@@ -2,7 +2,8 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03b}; mkdir -p $O
 cd $R
-timeout 700 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -5 $O/pytest_gpu.txt
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -8 $O/pytest_gpu.txt
+timeout 120 python tests/tools/state_diff.py > $O/state_diff.txt 2>&1; head -12 $O/state_diff.txt
 timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.err
 timeout 120 python tests/tools/phase_prof.py 20000 > $O/quant_phase_cycles.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
