@@ -836,13 +836,17 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     *asg_mask = (g.block_type != SHORT_TYPE ? 8 : 0) | (use2 ? 4 : 0) | (0 < a1 ? 1 : 0) | (a1 < a2 ? 2 : 0);
     // region maxima: region of a pair = number of boundaries at or below it
     int m0 = 0, m1 = 0, m2 = 0;
+    int rj[NPL];                                                    // region of the lane's pairs (3: at or beyond big_values), kept for the length sums
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
+        rj[j] = 3;
         if (2 * LHIP_NL * j >= i) continue;                         // wave-uniform: every pair of this round of lanes lies beyond big_values
         const int p = 2 * (lane + LHIP_NL * j);
-        const int m = (p < i) ? (vx[j] > vy[j] ? vx[j] : vy[j]) : 0;
-        const int mr0 = (p < a1) ? m : 0, mr1 = (p >= a1 && p < a2) ? m : 0, mr2 = (p >= a2) ? m : 0;
+        const int r = (p >= a1) + (p >= a2) + (p >= i);             // a1 <= a2 <= i
+        const int m = vx[j] > vy[j] ? vx[j] : vy[j];
+        const int mr0 = (r == 0) ? m : 0, mr1 = (r == 1) ? m : 0, mr2 = (r == 2) ? m : 0;
         m0 = m0 > mr0 ? m0 : mr0; m1 = m1 > mr1 ? m1 : mr1; m2 = m2 > mr2 ? m2 : mr2;
+        rj[j] = r;
     }
     { int mm[3] = {m0, m1, m2}; wave_max_n(mm); m0 = mm[0]; m1 = mm[1]; m2 = mm[2]; }
     // Data-driven length sums: every region publishes the pool offsets of its (up to three) candidate tables and
@@ -882,6 +886,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     const acc_t FM = ((acc_t)1 << FB) - 1;
     acc_t accA = 0, accB = 0, accC = 0, accN = 0;
     const int any_esc = (m0 > 15) | (m1 > 15) | (m2 > 15);          // escaped values only cost extra bits in ESC regions
+#if LHIP_NL == 1
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const int p = 2 * (lane + LHIP_NL * j);
@@ -891,21 +896,46 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
             const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
             const int x = vx[j], y = vy[j];
             const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
-#if LHIP_NL == 1
             const int sh = FB * r;
             accA += (acc_t)Q.hlen[(d0 & 0xffffu) + idx] << sh;
             accB += (acc_t)Q.hlen[(d0 >> 16) + idx] << sh;
             accC += (acc_t)Q.hlen[(d1 & 0xffffu) + idx] << sh;
             if (any_esc) accN += (acc_t)((x > 14) + (y > 14)) << sh;
-#else
-            const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
-            accA = mul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
-            accB = mul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
-            accC = mul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
-            if (any_esc) accN = mul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
-#endif
         }
     }
+    (void)rj;
+#else
+    {
+        // in stages, every stage's loads independent of each other (a pair at a time costs two dependent LDS round trips per pair):
+        // the descriptors of all pairs, then all byte gathers, then the sums.  Pairs at or beyond big_values read region 2's
+        // descriptor (any valid address will do) and are counted with weight 0.
+        uint64_t dj[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) dj[j] = *(const uint64_t*)L.rdesc[rj[j] < 3 ? rj[j] : 2];
+        unsigned la[NPL], lb[NPL], lc[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const uint32_t d0 = (uint32_t)dj[j], d1 = (uint32_t)(dj[j] >> 32);
+            const unsigned xc = (unsigned)(vx[j] < 15 ? vx[j] : 15), yc = (unsigned)(vy[j] < 15 ? vy[j] : 15);
+            const unsigned idx = mul24(xc, d1 >> 16) + yc;
+            la[j] = Q.hlen[(d0 & 0xffffu) + idx]; lb[j] = Q.hlen[(d0 >> 16) + idx]; lc[j] = Q.hlen[(d1 & 0xffffu) + idx];
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const unsigned mult = rj[j] < 3 ? 1u << (FB * rj[j]) : 0u;     // field of the pair's region; 24-bit multiply-add accumulates in one instruction
+            accA = mul24(la[j], mult) + accA;
+            accB = mul24(lb[j], mult) + accB;
+            accC = mul24(lc[j], mult) + accC;
+        }
+        if (any_esc) {
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                const unsigned mult = rj[j] < 3 ? 1u << (FB * rj[j]) : 0u;
+                accN = mul24((unsigned)((vx[j] > 14) + (vy[j] > 14)), mult) + accN;
+            }
+        }
+    }
+#endif
     // unpack to (A|B<<16), (C|N<<16) per region: wave totals stay below 2^16 (<= 288 pairs x 21 bits = 6048)
 #define FLD(A, R) ((uint32_t)(((A) >> (FB * (R))) & FM))
     int qq[7] = {(int)(FLD(accA, 0) | (FLD(accB, 0) << 16)), (int)(FLD(accC, 0) | (FLD(accN, 0) << 16)), (int)(FLD(accA, 1) | (FLD(accB, 1) << 16)),

@@ -19,6 +19,7 @@
 #include <vector>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <atomic>
 #include <memory>
 #include <cstring>
@@ -175,7 +176,7 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
             const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * Cp + chn;
             for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[chn][i] = W.E[o * E_STRIDE + i];
             for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[chn][i] = W.ecb_s[o * EBS_STRIDE + i];
-            for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = W.peaks[o * PK_STRIDE + i];
+            for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = i < 9 ? W.peaks[o * PK_STRIDE + i] : 0.f;   // 9 peaks; the pad words are never written by anybody (stale workspace bytes must not reach the state record)
             if (!T.disable_reservoir) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { S->nb1[chn][i] = W.nb1[o * EBL_STRIDE + i]; S->nb2[chn][i] = W.nb2[o * EBL_STRIDE + i]; }
             if (lane == 0) S->last_attack[chn] = W.last_attack[o];
         }
@@ -863,6 +864,8 @@ struct Context {
     // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
     void* copy_stream = nullptr; void* ev_in[2] = {nullptr, nullptr}; void* ev_done[2] = {nullptr, nullptr};
     DevBuf chunk_in, chunk_out;
+    void* pin_in = nullptr; size_t pin_in_cap = 0;      // pinned staging, two halves each (hipHostMalloc): the caller's pageable memory reaches the
+    void* pin_out = nullptr; size_t pin_out_cap = 0;    // DMA engine through these (a pageable hipMemcpyAsync is a host-side copy at ~6 GB/s, measured)
     std::mutex chunk_mu;        // one chunked call at a time per device (they share the two staging halves); taken BEFORE mu, never inside it
 };
 
@@ -1430,6 +1433,22 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
 // reservoir (its byte counts are only known after each launch).
 #ifndef LHIP_HOSTSIM
 enum { HOST_CHUNK_FRAMES = 8192 };
+// a large host-to-host copy on a few threads (one core moves ~10 GB/s; the chunk must be staged faster than the GPU encodes it)
+static void par_memcpy(void* dst, const void* src, size_t n) {
+    static const unsigned nt = []() { unsigned h = std::thread::hardware_concurrency(); return h >= 8 ? 4u : h >= 4 ? 2u : 1u; }();
+    if (nt <= 1 || n < ((size_t)4 << 20)) { memcpy(dst, src, n); return; }
+    const size_t part = ((n / nt) + 4095) & ~(size_t)4095;
+    std::thread th[4];
+    unsigned started = 0;
+    for (unsigned i = 1; i < nt; i++) {
+        const size_t o = (size_t)i * part;
+        if (o >= n) break;
+        const size_t len = n - o < part ? n - o : part;
+        th[started++] = std::thread([=]() { memcpy((uint8_t*)dst + o, (const uint8_t*)src + o, len); });
+    }
+    memcpy(dst, src, part < n ? part : n);
+    for (unsigned i = 0; i < started; i++) th[i].join();
+}
 static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> chunk_lk(ctx->chunk_mu);
@@ -1459,6 +1478,21 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
     }
     const size_t out_chunk = (size_t)(HOST_CHUNK_FRAMES + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
     hipStream_t cs = (hipStream_t)ctx->copy_stream, ks = (hipStream_t)ctx->stream;
+    // pinned staging halves (grow-only, per context): the caller's samples are copied into them by a few host threads, the DMA engine
+    // takes them from there -- both really asynchronous, unlike a hipMemcpyAsync from pageable memory
+    static const bool no_pin = []() { const char* e = getenv("LAMEJS_HIP_NO_PINNED_STAGING"); return e && e[0] == '1'; }();
+    const size_t in_half = (size_t)C * chunk * 2;
+    bool pinned = !no_pin;
+    if (pinned) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto grow = [&](void*& ptr, size_t& cap, size_t need) -> bool {
+            if (cap >= need) return true;
+            if (ptr) { (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
+            if (hipHostMalloc(&ptr, need, hipHostMallocDefault) != hipSuccess) { ptr = nullptr; return false; }
+            cap = need; return true;
+        };
+        if (!grow(ctx->pin_in, ctx->pin_in_cap, 2 * in_half) || !grow(ctx->pin_out, ctx->pin_out_cap, 2 * out_chunk)) pinned = false;   // fall back to pageable copies
+    }
     int64_t total = 0, pending_bytes = 0, frames_all = 0;      // pending: the chunk whose output is still on the device
     uint8_t* pending_dst = nullptr; int pending_par = 0; bool have_pending = false;
     auto fail = [&](const char* what) -> int64_t { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ks); if (what) set_err(what); return LHIP_ERR_INTERNAL; };
@@ -1467,16 +1501,27 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         have_pending = false;
         if (pending_bytes == 0) return true;
         if (hipStreamWaitEvent(cs, (hipEvent_t)ctx->ev_done[pending_par], 0) != hipSuccess) return false;
-        if (hipMemcpyAsync(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) return false;
-        return hipStreamSynchronize(cs) == hipSuccess;
+        uint8_t* hdst = pinned ? (uint8_t*)ctx->pin_out + (size_t)pending_par * out_chunk : pending_dst;
+        if (hipMemcpyAsync(hdst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) return false;
+        if (hipStreamSynchronize(cs) != hipSuccess) return false;
+        if (pinned) memcpy(pending_dst, hdst, (size_t)pending_bytes);
+        return true;
     };
     for (size_t k = 0; k < nchunks; k++) {
         const int par = (int)(k & 1);
         const size_t p0 = k * chunk, m = nsamples - p0 < chunk ? nsamples - p0 : chunk;
         int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * chunk;
-        // buffer `par` was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
-        if (hipMemcpyAsync(d_in, left + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-        if (C == 2 && hipMemcpyAsync(d_in + chunk, (right ? right : left) + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+        // buffer `par` (device and pinned half alike) was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
+        if (pinned) {
+            int16_t* h_in = (int16_t*)((uint8_t*)ctx->pin_in + (size_t)par * in_half);
+            par_memcpy(h_in, left + p0, m * 2);
+            if (C == 2) par_memcpy(h_in + chunk, (right ? right : left) + p0, m * 2);
+            if (hipMemcpyAsync(d_in, h_in, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+            if (C == 2 && hipMemcpyAsync(d_in + chunk, h_in + chunk, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+        } else {
+            if (hipMemcpyAsync(d_in, left + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+            if (C == 2 && hipMemcpyAsync(d_in + chunk, (right ? right : left) + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+        }
         if (hipEventRecord((hipEvent_t)ctx->ev_in[par], cs) != hipSuccess || hipStreamWaitEvent(ks, (hipEvent_t)ctx->ev_in[par], 0) != hipSuccess) return fail("event record / wait failed");
         std::vector<Job> jobs(1);
         jobs[0] = Job{s, d_in, C == 2 ? d_in + chunk : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};

@@ -2,7 +2,7 @@
  * BENCH TOOL (GPU): the drop-in's own throughput through the JavaScript surface -- one Mp3Encoder.encodeBuffer(left, right) call with
  * host Int16Arrays of N frames (lamejs_amd/js -> N-API addon -> lhip_encode, which cuts the call into chunks and overlaps their PCIe
  * copies with the encode of the chunk before), then flush().  Prints one JSON line: frames/s of the encodeBuffer call (wall clock
- * around it: H2D + encode + D2H + the copy into the returned Int8Array), md5 and length of encodeBuffer + flush.
+ * around it: H2D + encode + D2H + the copy into the returned Int8Array), md5 and length of encodeBuffer + flush, and of the encodeBuffer output alone (what tests/golden/full_md5.json holds).
  * usage: node tests/tools/bench_dropin.js <corpus> <channels> <kbps> <frames> <seed>
  */
 'use strict';
@@ -21,7 +21,9 @@ const t0 = process.hrtime.bigint();
 const a = ch == 2 ? enc.encodeBuffer(L, R) : enc.encodeBuffer(L);
 const dt = Number(process.hrtime.bigint() - t0) / 1e9;
 const b = enc.flush();
-const h = crypto.createHash('md5');
+const h = crypto.createHash('md5'), ha = crypto.createHash('md5');
 h.update(Buffer.from(a.buffer, a.byteOffset, a.length)); h.update(Buffer.from(b.buffer, b.byteOffset, b.length));
+ha.update(Buffer.from(a.buffer, a.byteOffset, a.length));
 console.log(JSON.stringify({ what: 'Mp3Encoder.encodeBuffer, one call, host Int16Arrays (node ' + process.version + ', N-API addon)', corpus, channels: ch, kbps, frames: nfr - 1,
-    seconds: +dt.toFixed(4), frames_per_s: +((nfr - 1) / dt).toFixed(1), md5: h.digest('hex'), bytes: a.length + b.length }));
+    seconds: +dt.toFixed(4), frames_per_s: +((nfr - 1) / dt).toFixed(1), md5: h.digest('hex'), bytes: a.length + b.length,
+    md5_encode_buffer: ha.digest('hex'), bytes_encode_buffer: a.length }));
