@@ -81,6 +81,17 @@ LHIP_DEV void fht_pass(float* fz, int n, int k1, int kx, int lane, int nl, int b
     for (int t = lane - base; t < items - nz; t += nl) if (t >= 0) { const int m = t / kx1; fht_item1(fz, k1, kx, m, 1 + t - m * kx1, tw); }
 }
 
+// the same pass over `nb` equally long transforms stored back to back, as ONE work list: three 256-point transforms have 32 items
+// each per pass -- one list of 96 fills the lanes where three lists of 32 leave half of them idle
+LHIP_DEV void fht_pass_blocks(float* fz, int nb, int n, int k1, int kx, int lane, int nl, const double* tw) {
+    const int items = n / 8, nz = items / kx, kx1 = kx - 1, n1 = items - nz;
+    for (int t = lane; t < nb * nz; t += nl) { const int b = t / nz; fht_item0(fz + b * n, k1, kx, t - b * nz); }
+    for (int t = lane; t < nb * n1; t += nl) {
+        const int b = t / n1, r = t - b * n1, m = r / kx1;
+        fht_item1(fz + b * n, k1, kx, m, 1 + r - m * kx1, tw);
+    }
+}
+
 // LDS of one psy-A wave.  The energies overwrite the lower halves of the FHT buffers they are computed from
 // (fe = fz[0..512], fes[b] = fs[b][0..128]) and the partition arrays live in the then-dead upper half of fz:
 // 7.2 KB instead of 12.3 KB per wave, i.e. LDS no longer caps the kernel at 3 waves per SIMD.
@@ -105,6 +116,32 @@ struct PsyALds {
 #define PSY_FLUSH() do {} while (0)
 #define PSY_DECL() do {} while (0)
 #endif
+// (float)((sum of the LHIP_NL * K non-negative values, lane l holding [l K, (l + 1) K)) * scale + add) when that Float32 does not depend
+// on the order of the additions: *out is set and 1 returned if both ends of the error band of an any-order sum round to the same
+// Float32 (wave-uniform verdict); 0: the caller must form the sum in the reference's order.  scale > 0, add >= 0.
+template <int K> LHIP_DEV int guarded_f32_of_sum(const double (&p)[K], double scale, double add, float* out) {
+#if LHIP_NL == 1
+    (void)p; (void)scale; (void)add; (void)out;
+    return 0;                                         // the one-lane build always takes the sequential sum
+#else
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; k++) s += p[k];
+    s = wave_sumd(s);
+    // any-order sum vs the reference's sequential one: both within (n - 1) u (n = 512, u = 2^-53) of the exact sum, then one rounding
+    // each for `* scale` and `+ add` on either side: 2e-13 covers it with a margin of 1.7
+    const float lo = (float)((s * (1.0 - 2e-13)) * scale + add), hi = (float)((s * (1.0 + 2e-13)) * scale + add);
+    *out = lo;
+#ifdef LHIP_WAVESIM
+    if (lo == hi) {       // the simulation checks the claim on everything it encodes: the guarded value IS the sequential sum's
+        const float ref = (float)(wave_seq_sum<K>(p) * scale + add);
+        if (ref != lo) { fprintf(stderr, "wavesim: guarded_f32_of_sum disagrees with the sequential sum (%a vs %a)\n", (double)lo, (double)ref); abort(); }
+    }
+#endif
+    return lo == hi;
+#endif
+}
+
 // one wave per (granule slot >= 1 of a stream, psy channel).  ch = 0, 1: L, R.  Joint stereo adds ch = 2, 3 (mid, side) in a second
 // launch: their high-passed samples and their spectra are linear combinations of the L / R ones (PsyModel.js:1113-1121, 258-273),
 // which the L / R waves leave in W.hpf / W.fht; everything from the energies on is the same code for all four.
@@ -182,8 +219,14 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             pk[sbk] = m;
         }
         wave_sync();                                  // the magnitudes are dead: the short windowing refills L.fs
+        {   // nine maxima of values >= 1: IEEE order == integer order of the bit patterns; reduced side by side (one DPP step serves all nine)
+            int pb[9];
 #pragma unroll
-        for (int sbk = 0; sbk < 9; sbk++) pk[sbk] = wave_maxf(pk[sbk]);
+            for (int sbk = 0; sbk < 9; sbk++) __builtin_memcpy(&pb[sbk], &pk[sbk], 4);
+            wave_max_n(pb);
+#pragma unroll
+            for (int sbk = 0; sbk < 9; sbk++) __builtin_memcpy(&pk[sbk], &pb[sbk], 4);
+        }
         if (lane == 0) {
 #pragma unroll
             for (int sbk = 0; sbk < 9; sbk++) W.peaks[o * PK_STRIDE + sbk] = pk[sbk];
@@ -271,8 +314,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
 #pragma unroll
         for (int k1 = 4, kx = 2; k1 < BLKSIZE; k1 <<= 2, kx <<= 2) {
             fht_pass(L.fz, BLKSIZE, k1, kx, lane, LHIP_NL, 0, T.fht_twiddle + 4 * off);
-            if (k1 < BLKSIZE_s)
-                for (int b = 0; b < 3; b++) fht_pass(L.fs[b], BLKSIZE_s, k1, kx, lane, LHIP_NL, 0, T.fht_twiddle + 4 * off);
+            if (k1 < BLKSIZE_s) fht_pass_blocks(&L.fs[0][0], 3, BLKSIZE_s, k1, kx, lane, LHIP_NL, T.fht_twiddle + 4 * off);
             wave_sync();
             off += kx - 1;
         }
@@ -323,23 +365,30 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         double pr[K];
 #pragma unroll
         for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (double)PSYA_FE(L)[i] * (double)T.eql_w[i]; }
+        // The reference's sum is strictly sequential, and only its Float32 rounding is ever read.  All terms are >= 0, so a sum in ANY
+        // order lies within (n - 1) u of the exact sum, as the reference's own does: the two differ by less than 1.2e-13 (relative).
+        // A tree sum (8 adds per lane + a wave reduction instead of 64 hand-over steps) therefore rounds to the reference's Float32
+        // whenever both ends of its 2e-13 error band round to the same Float32; when they do not (about one call in 10^5) the
+        // sequential fold decides.  (T.eql_w >= 0 is checked where the table is loaded.)
         if (ch < 2) {                                 // no loudness for mid / side (PsyModel.js:319)
-            double lp = wave_seq_sum<K>(pr);
-            lp *= T.VO_SCALE;
-            if (lane == 0) W.loud[(int64_t)gslot * C + ch] = (float)lp;
+            float lf;
+            if (!guarded_f32_of_sum<K>(pr, T.VO_SCALE, 0.0, &lf)) lf = (float)(wave_seq_sum<K>(pr) * T.VO_SCALE);
+            if (lane == 0) W.loud[(int64_t)gslot * C + ch] = lf;
         }
         if (Cp == 4) {
             // total energy: lines 11 .. 512 summed in ascending order (PsyModel.js:300-307); the leading zeros change nothing
 #pragma unroll
             for (int k = 0; k < K; k++) { const int i = K * lane + k; pr[k] = (i >= 11) ? (double)PSYA_FE(L)[i] : 0.0; }
-            double tot = wave_seq_sum<K>(pr);
-            tot += (double)PSYA_FE(L)[BLKSIZE / 2];
-            if (lane == 0) W.tot_ener[(int64_t)gslot * 4 + ch] = (float)tot;
+            const double last = (double)PSYA_FE(L)[BLKSIZE / 2];
+            float tf;
+            if (!guarded_f32_of_sum<K>(pr, 1.0, last, &tf)) tf = (float)(wave_seq_sum<K>(pr) + last);
+            if (lane == 0) W.tot_ener[(int64_t)gslot * 4 + ch] = tf;
         }
     }
 
     PSY_STAMP(5);
     // --- long partitions: energy, max, average (calc_energy, PsyModel.js:906-928) ---
+#if LHIP_NL == 1
     LHIP_LANE_ONCE(b, 0, T.npart_l) {                        // npart_l < CBANDS = 64
         double ebb = 0, m = 0;
         int j = T.lineoff_l[b];
@@ -352,6 +401,65 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         PSYA_MX(L)[b] = (float)m;
         PSYA_AV(L)[b] = (float)(ebb * (double)T.rnumlines_l[b]);
     }
+#else
+    {
+        // The partitions tile the 513 lines, and a partition's energy is the f64 sum of its lines in ascending order: a systolic fold
+        // (as calc_noise's band sums, k_quant.h) -- lane l owns the lines 8 l .. 8 l + 7 and folds them, in order, onto the running sum
+        // lane l - 1 hands over, the chain restarting at every partition's first line; ceil(longest partition / 8) + 1 hand-overs give
+        // every partition's strictly sequential sum (one lane per partition walking its lines took as many trips as the longest
+        // partition has lines: 83 at 44.1 kHz).  Line 512 is added by lane 63 at the end -- it is the last line of the last partition.
+        // The maxima are order-free: every lane reduces its lines per partition and merges through an LDS integer maximum (energies
+        // are >= 0: IEEE order == integer order of the bit patterns).
+        enum { KF = 8 };
+        static_assert(BLKSIZE / 2 == KF * LHIP_NL, "psy_fold is laid out for 8 lines per lane");
+        const int32_t* pf = T.psy_fold + 3 * lane;
+        const uint32_t marks = (uint32_t)pf[0], pw0 = (uint32_t)pf[1], pw1 = (uint32_t)pf[2];
+        LHIP_LANE_ONCE(b, 0, CBANDS) PSYA_MX(L)[b] = 0.f;
+        double tq[KF], keep[KF];
+        float ev[KF];
+#pragma unroll
+        for (int k = 0; k < KF; k++) { ev[k] = PSYA_FE(L)[KF * lane + k]; tq[k] = (double)ev[k]; keep[k] = one_unless_bit(marks, k); }
+        const float e512 = PSYA_FE(L)[BLKSIZE / 2];
+        wave_sync();                                  // the maxima start from zero
+        {   // maxima: running maximum inside the lane, flushed where a partition ends (or the lane does)
+            float m = 0.f;
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                m = ((marks >> k) & 1u) ? ev[k] : fmax_nonneg(m, ev[k]);
+                const int bnd = (int)(((k < 4 ? pw0 : pw1) >> (8 * (k & 3))) & 0xffu);
+                float mm = m;
+                if (lane == LHIP_NL - 1 && k == KF - 1 && !((marks >> (8 + k)) & 1u)) mm = fmax_nonneg(mm, e512);     // line 512 belongs to the same partition
+                if (((marks >> (8 + k)) & 1u) || k == KF - 1) { int32_t bits; __builtin_memcpy(&bits, &mm, 4); lds_max((int32_t*)&PSYA_MX(L)[bnd], bits); }
+            }
+            if (lane == LHIP_NL - 1 && ((marks >> (8 + KF - 1)) & 1u)) {       // line 512 is a partition of its own (the last one)
+                int32_t bits; __builtin_memcpy(&bits, &e512, 4); lds_max((int32_t*)&PSYA_MX(L)[T.npart_l - 1], bits);
+            }
+        }
+        const int nsteps = (T.psy_maxlen_l + KF - 1) / KF + 1;
+        double carry = 0.0;
+        for (int st = 0; st + 1 < nsteps; st++) {
+            double sacc = carry;
+#pragma unroll
+            for (int k = 0; k < KF; k++) sacc = __builtin_fma(sacc, keep[k], tq[k]);
+            carry = wave_shr1d(sacc, 0.0);
+        }
+        {
+            double sacc = carry;
+#pragma unroll
+            for (int k = 0; k < KF; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); tq[k] = sacc; }   // tq := running sums of the last step
+        }
+#pragma unroll
+        for (int k = 0; k < KF; k++) {
+            const int bnd = (int)(((k < 4 ? pw0 : pw1) >> (8 * (k & 3))) & 0xffu);
+            if ((marks >> (8 + k)) & 1u) { PSYA_EB(L)[bnd] = (float)tq[k]; PSYA_AV(L)[bnd] = (float)(tq[k] * (double)T.rnumlines_l[bnd]); }
+        }
+        if (lane == LHIP_NL - 1) {                    // the partition line 512 closes
+            const int bl = T.npart_l - 1;
+            const double ebb = ((marks >> (8 + KF - 1)) & 1u) ? (double)e512 : tq[KF - 1] + (double)e512;
+            PSYA_EB(L)[bl] = (float)ebb; PSYA_AV(L)[bl] = (float)(ebb * (double)T.rnumlines_l[bl]);
+        }
+    }
+#endif
     // --- short partitions: energy per sub-block (compute_masking_s first loop, 740-750) ---
     for (int it = lane; it < 3 * T.npart_s; it += LHIP_NL) {
         const int sblock = it / T.npart_s, b = it - sblock * T.npart_s;

@@ -814,6 +814,31 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
         mx = 0;
         for (int i = 0; i < 40; i++) { if (i < 3 * SBMAX_s) { const int w = h_ss[i / 3 + 1] - h_ss[i / 3]; if (mx < w) mx = w; } extra[fold_at + 128 + 24 + i] = mx; }
     }
+    // psyA's partition energies as a systolic fold (k_psy.h): lane l owns the FFT lines 8 l .. 8 l + 7; per lane three words -- marks
+    // (bit k: line 8 l + k is the first of its partition, bit 8 + k: the last one, counting line 512 as part of the spectrum) and
+    // the partition numbers of its eight lines, a byte each
+    const size_t psyfold_at = extra.size();
+    extra.resize(psyfold_at + 3 * 64);
+    {
+        std::vector<int> part(514, 0);
+        for (int p = 0, jj = 0; p < T.npart_l; p++) for (int i = 0; i < h_nl[p] && jj < 513; i++) part[jj++] = p;
+        part[513] = -1;
+        int mx = 0;
+        for (int p = 0; p < T.npart_l; p++) if (mx < h_nl[p]) mx = h_nl[p];
+        T.psy_maxlen_l = mx;
+        for (int ln = 0; ln < 64; ln++) {
+            uint32_t m = 0, w[2] = {0, 0};
+            for (int kk = 0; kk < 8; kk++) {
+                const int jj = 8 * ln + kk;
+                if (jj == 0 || part[jj - 1] != part[jj]) m |= 1u << kk;
+                if (part[jj + 1] != part[jj]) m |= 1u << (8 + kk);
+                w[kk >> 2] |= (uint32_t)part[jj] << (8 * (kk & 3));
+            }
+            extra[psyfold_at + 3 * ln] = (int32_t)m; extra[psyfold_at + 3 * ln + 1] = (int32_t)w[0]; extra[psyfold_at + 3 * ln + 2] = (int32_t)w[1];
+        }
+        const float* h_eql = (const float*)host_arr("eql_w");
+        for (int i = 0; i < BLKSIZE / 2; i++) if (!(h_eql[i] >= 0.f)) { set_err("eql_w has a negative entry (the loudness sum's error bound needs non-negative terms)"); return false; }
+    }
     ts.d_extra = rt::dmalloc(extra.size() * 4);
     if (!ts.d_extra) { set_err("hipMalloc failed"); return false; }
     if (!rt::h2d(ts.d_extra, extra.data(), extra.size() * 4, stream)) return false;
@@ -822,6 +847,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     T.bo_l = T.s3off_l + 4 * CBANDS; T.bo_s = T.bo_l + SBMAX_l;
     T.amp_by_out = (const double*)(T.s3off_l + amp_at);
     T.fold_marks = T.s3off_l + fold_at; T.wpre = T.fold_marks + 128;
+    T.psy_fold = T.s3off_l + psyfold_at;
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
     // kb_bits assembles a frame in BitsLds (and zeroes one word past its last one): the largest frame of this configuration must fit

@@ -105,6 +105,7 @@ struct Tables {
     const int32_t *lineoff_l, *lineoff_s;   // first FFT line of partition b
     const double *amp_by_out;               // [32] polyphase output i is scaled by this (1.0: not at all): amp_filter through mdct_order
     int amp_mask;                           // bit i: amp_by_out[i] != 1.0
+    const int32_t *psy_fold; int psy_maxlen_l; // psyA's partition fold: [64][3] marks | partition numbers of the lane's 8 lines; longest long partition
     const int32_t *fold_marks, *wpre;       // calc_noise's fold: band-start / band-end marks per lane [2][64]; widest band among bands 0 .. b [24 long | 40 short]
 };
 
