@@ -64,6 +64,8 @@ int lhip_device_count(void);
  * path's multi-GPU axis); an explicit cfg.device outside the mask is refused.  mask == 0 restores the default (every
  * device; device -1 = the calling thread's current HIP device).  Returns the number of allowed devices or <0. */
 int lhip_set_devices(uint64_t mask);
+/* the HIP device a stream was placed on (>= 0), or LHIP_ERR_BAD_HANDLE */
+int lhip_stream_device(const lhip_stream* s);
 
 /* Frame-range sharding of ONE stream (extension; SURVEY.md 8e, second mode).  A long stream can be cut at frame boundaries and the
  * pieces encoded side by side (other GPUs, other processes): the state at a cut is SPECULATED -- lhip_seek puts a fresh stream at an

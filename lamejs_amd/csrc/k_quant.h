@@ -25,6 +25,7 @@ struct GI {   // wave-uniform scalar part of the reference's GrInfo
     int region0_count, region1_count, preflag, scalefac_scale, count1table_select;
     int part2_length, sfb_lmax, sfb_smin, psy_lmax, sfbmax, psymax, sfbdivide;
     int count1bits, max_nonzero_coeff;
+    int firstcut;               // first band reaching past max_nonzero_coeff (64: none): fixed once max_nonzero_coeff is (q_set_firstcut)
 };
 
 struct NoiseRes { double max_noise; int over_count, over_SSD, bits; };
@@ -41,7 +42,7 @@ LHIP_DEV void uni_gi(GI& g) {
     g.region0_count = uni(g.region0_count); g.region1_count = uni(g.region1_count); g.preflag = uni(g.preflag); g.scalefac_scale = uni(g.scalefac_scale);
     g.count1table_select = uni(g.count1table_select); g.part2_length = uni(g.part2_length); g.sfb_lmax = uni(g.sfb_lmax); g.sfb_smin = uni(g.sfb_smin);
     g.psy_lmax = uni(g.psy_lmax); g.sfbmax = uni(g.sfbmax); g.psymax = uni(g.psymax); g.sfbdivide = uni(g.sfbdivide);
-    g.count1bits = uni(g.count1bits); g.max_nonzero_coeff = uni(g.max_nonzero_coeff);
+    g.count1bits = uni(g.count1bits); g.max_nonzero_coeff = uni(g.max_nonzero_coeff); g.firstcut = uni(g.firstcut);
 }
 
 // optional phase profiling (build with -DLHIP_PHASE_PROF; never in the product library)
@@ -89,7 +90,7 @@ struct QuantTabs {
     uint8_t hlen[HL_END];        // code-length pool: tables 1-3, 5-15, then the two ESC length tables (layout: hl_off)
     uint8_t t32l[16], t33l[16];
     uint8_t l2s_long[576], l2s_short[576];
-    uint8_t bv_scf[576];
+    uint32_t bvtab[289];         // count_bits, NORM blocks, by big_values / 2: region borders, region counts, sfb_count1 (Tables::bvtab)
     uint8_t huf_tbl_noESC[16], ht_xlen[34];
     uint16_t ht_linmax[34];
     // Huffman region plans by region maximum (count_bits): entries 0..15 = the maximum itself, 16..28 = bit length 1..13
@@ -121,7 +122,7 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int i = tid; i < SBMAX_l; i += nthr) Q.pretab[i] = T.pretab[i];
     for (int i = tid; i < 16; i += nthr)
         Q.sbc[i] = (uint32_t)T.slen1_n[i] | ((uint32_t)T.slen2_n[i] << 8) | ((uint32_t)T.scale_long[i] << 16) | ((uint32_t)T.scale_short[i] << 24);
-    for (int i = tid; i < 576; i += nthr) Q.bv_scf[i] = (uint8_t)T.bv_scf[i];
+    for (int i = tid; i < 289; i += nthr) Q.bvtab[i] = (uint32_t)T.bvtab[i];
     for (int i = tid; i < 15; i += nthr) Q.huf_tbl_noESC[i] = (uint8_t)T.huf_tbl_noESC[i];
     for (int i = tid; i < 34; i += nthr) { Q.ht_xlen[i] = (uint8_t)T.ht_xlen[i]; Q.ht_linmax[i] = (uint16_t)T.ht_linmax[i]; }
     // Huffman code-length pool
@@ -330,7 +331,7 @@ LHIP_DEV void q_init_outer_loop(const Tables& T, const PowBase& pb10, double ath
     g.part2_length = 0; g.sfb_lmax = SBPSY_l; g.sfb_smin = SBPSY_s;
     g.psy_lmax = T.sfb21_extra ? SBMAX_l : SBPSY_l;
     g.psymax = g.psy_lmax; g.sfbmax = g.sfb_lmax; g.sfbdivide = 11;
-    g.count1bits = 0; g.max_nonzero_coeff = 575; g.xrpow_max = 0;
+    g.count1bits = 0; g.max_nonzero_coeff = 575; g.xrpow_max = 0; g.firstcut = 64;
     int nsfb;
     if (block_type == SHORT_TYPE) {
         g.sfb_smin = 0; g.sfb_lmax = 0;
@@ -410,6 +411,15 @@ LHIP_DEV int q_init_xrpow(GI& g, int lane, QuantLds& L, const QuantTabs& Q) {
     const int has = wave_sumd(sum) > 1E-20;
     wave_sync();
     return has;
+}
+
+// the first band that reaches past max_nonzero_coeff (quantize_xrpow's walk ends inside it, Takehiro.js:212-250); 64 if none does
+LHIP_DEV void q_set_firstcut(GI& g, int lane, const QuantLds& L) {
+    const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
+    uint64_t m = 0;
+    LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1) if (L.start[sfb] + L.width[sfb] > g.max_nonzero_coeff) m |= 1ull << sfb;
+    m = wave_lane_bits(m);
+    g.firstcut = m ? (int)__builtin_ctzll(m) : 64;
 }
 
 // Ordered (line order) f64 sums of per-line terms over scalefactor bands, all bands at once, as a systolic fold:
@@ -514,6 +524,7 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
         }
         g.max_nonzero_coeff = 575;
     }
+    q_set_firstcut(g, lane, L);
     wave_sync();
 }
 
@@ -532,7 +543,6 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     const int may_big = !(g.xrpow_max * istep < (double)QT_N);
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
-    const int mnz = g.max_nonzero_coeff;
     // per-band decision as wave-uniform bit masks: cached (keep old values) / 0-1 shortcut; the first
     // non-cached band reaching past max_nonzero_coeff (sstar) is quantized partially and ends the walk
     unsigned long long tm_ = PH_NOW(); (void)tm_;
@@ -544,19 +554,19 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
         xa[j] = 0.f; xb[j] = 0.f;
         if (p < 576) { struct F2 { float x, y; }; const F2 xx = *(const F2*)(L.xrpow + p); xa[j] = xx.x; xb[j] = xx.y; }   // 8-byte aligned: p is even
     }
-    uint64_t m_cached = 0, m_zo = 0, m_cut = 0;       // bit sfb, produced by lane sfb (sfbmax < 64)
+    uint64_t m_cached = 0, m_zo = 0;                     // bit sfb, produced by lane sfb (sfbmax < 64)
     if (use_prev) {                                      // bin-search rounds have no cache and no 0/1 shortcut: nothing to decide
         LHIP_LANE_ONCE(sfb, 0, (sfbmax) + 1) {
             int step = -1;
+            const int pstep = L.pn_step[sfb];
             if (prev_data_use || g.block_type == NORM_TYPE) step = sf_step(Q, g, scalefac, L.window, sfb);
-            if (prev_data_use && L.pn_step[sfb] == step) m_cached |= 1ull << sfb;
-            else {
-                if (pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && L.pn_step[sfb] > 0 && step >= L.pn_step[sfb]) m_zo |= 1ull << sfb;
-                if (L.start[sfb] + L.width[sfb] > mnz) m_cut |= 1ull << sfb;
-            }
+            if (prev_data_use && pstep == step) m_cached |= 1ull << sfb;
+            else if (pn_sfb_count1 > 0 && sfb >= pn_sfb_count1 && pstep > 0 && step >= pstep) m_zo |= 1ull << sfb;
         }
     }
-    m_cached = wave_lane_bits(m_cached); m_zo = wave_lane_bits(m_zo); m_cut = wave_lane_bits(m_cut);
+    m_cached = wave_lane_bits(m_cached); m_zo = wave_lane_bits(m_zo);
+    // the bands reaching past max_nonzero_coeff are firstcut .. sfbmax; the walk ends in the first of them that is not cached
+    const uint64_t m_cut = (use_prev && g.firstcut <= sfbmax) ? ((~0ull << g.firstcut) & ((2ull << sfbmax) - 1) & ~m_cached) : 0;
     const int sstar = m_cut ? (int)__builtin_ctzll(m_cut) : 99;
     // The reference stops quantizing inside band sstar (at max_nonzero_coeff, rounded to a pair) and fills the rest with
     // zeros.  Every line from max_nonzero_coeff on has xrpow == 0 (it is the first of the spectrum's trailing zeros, or
@@ -813,16 +823,16 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
                                 if (c1_ > c2_) { bits = c2_; g.count1table_select = 1; } g.count1bits = bits; } while (0)
     PH_MARK(L, PH_C_QUADS, tm_);
     if (i == 0) { const int t = wave_sum(a12); COUNT1_FINISH(t); return bits; }
-    int use2 = 0;
+    int use2 = 0, cnt1_norm = 0;
     if (g.block_type == SHORT_TYPE) {
         a1 = 3 * Q.sfb_s[3];
         if (a1 > g.big_values) a1 = g.big_values;
         a2 = g.big_values;
     } else if (g.block_type == NORM_TYPE) {
-        a1 = g.region0_count = Q.bv_scf[i - 2];
-        a2 = g.region1_count = Q.bv_scf[i - 1];
-        a2 = Q.sfb_l[a1 + a2 + 2];
-        a1 = Q.sfb_l[a1 + 1];
+        const uint32_t bt = Q.bvtab[i >> 1];               // one look-up: region counts, region borders, sfb_count1
+        g.region0_count = (int)((bt >> 20) & 15u); g.region1_count = (int)((bt >> 24) & 7u);
+        a1 = (int)(bt & 1023u); a2 = (int)((bt >> 10) & 1023u);
+        cnt1_norm = (int)(bt >> 27);
         if (a2 < i) use2 = 1;
     } else {
         g.region0_count = 7;
@@ -905,34 +915,21 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     }
     (void)rj;
 #else
-    {
-        // in stages, every stage's loads independent of each other (a pair at a time costs two dependent LDS round trips per pair):
-        // the descriptors of all pairs, then all byte gathers, then the sums.  Pairs at or beyond big_values read region 2's
-        // descriptor (any valid address will do) and are counted with weight 0.
-        uint64_t dj[NPL];
+    // a pair at a time (descriptor of its region, three byte gathers, three multiply-adds): measured 1 % faster per launch than the
+    // same work in stages (all descriptors, all gathers, all sums), which keeps fifteen more values live
 #pragma unroll
-        for (int j = 0; j < NPL; j++) dj[j] = *(const uint64_t*)L.rdesc[rj[j] < 3 ? rj[j] : 2];
-        unsigned la[NPL], lb[NPL], lc[NPL];
-#pragma unroll
-        for (int j = 0; j < NPL; j++) {
-            const uint32_t d0 = (uint32_t)dj[j], d1 = (uint32_t)(dj[j] >> 32);
-            const unsigned xc = (unsigned)(vx[j] < 15 ? vx[j] : 15), yc = (unsigned)(vy[j] < 15 ? vy[j] : 15);
-            const unsigned idx = mul24(xc, d1 >> 16) + yc;
-            la[j] = Q.hlen[(d0 & 0xffffu) + idx]; lb[j] = Q.hlen[(d0 >> 16) + idx]; lc[j] = Q.hlen[(d1 & 0xffffu) + idx];
-        }
-#pragma unroll
-        for (int j = 0; j < NPL; j++) {
-            const unsigned mult = rj[j] < 3 ? 1u << (FB * rj[j]) : 0u;     // field of the pair's region; 24-bit multiply-add accumulates in one instruction
-            accA = mul24(la[j], mult) + accA;
-            accB = mul24(lb[j], mult) + accB;
-            accC = mul24(lc[j], mult) + accC;
-        }
-        if (any_esc) {
-#pragma unroll
-            for (int j = 0; j < NPL; j++) {
-                const unsigned mult = rj[j] < 3 ? 1u << (FB * rj[j]) : 0u;
-                accN = mul24((unsigned)((vx[j] > 14) + (vy[j] > 14)), mult) + accN;
-            }
+    for (int j = 0; j < NPL; j++) {
+        if (rj[j] < 3) {
+            const int r = rj[j];
+            const uint64_t d = *(const uint64_t*)L.rdesc[r];
+            const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
+            const int x = vx[j], y = vy[j];
+            const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
+            const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
+            accA = mul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
+            accB = mul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
+            accC = mul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
+            if (any_esc) accN = mul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
         }
     }
 #endif
@@ -974,7 +971,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 #undef LP_
 #undef PV_
     // first band whose start is >= big_values (PrevNoise.sfb_count1): one table look-up instead of a walk
-    if (use_prev && g.block_type == NORM_TYPE) *pn_sfb_count1 = g.big_values > 0 ? Q.l2s_long[g.big_values - 1] + 1 : 0;
+    if (use_prev && g.block_type == NORM_TYPE) *pn_sfb_count1 = cnt1_norm;       // big_values > 0 here (the table's entry)
     PH_MARK(L, PH_C_FIN, tm_);
     return bits;
 }
@@ -2433,6 +2430,7 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
                             t = wave_max(t);
                             g.max_nonzero_coeff = (t >= 575) ? 575 : t + 1;
                         }
+                        q_set_firstcut(g, lane, L);
                         inited = 1;
                     }
                     g.global_gain = gain;

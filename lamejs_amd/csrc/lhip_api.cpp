@@ -786,7 +786,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     // line 9 l + k is the first line of its scalefactor band, bit 16 + k = it is the last one ([0..63] long, [64..127] short blocks);
     // then the widest band among bands 0 .. b: 24 entries for long blocks, 40 for short ones (band = 3 * sfb + window)
     const size_t fold_at = extra.size();
-    extra.resize(fold_at + 128 + 24 + 40);
+    extra.resize(fold_at + 128 + 24 + 40 + 289);
     {
         const int32_t* h_sl = (const int32_t*)host_arr("sfb_l");
         const int32_t* h_ss = (const int32_t*)host_arr("sfb_s");
@@ -813,6 +813,19 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
         for (int i = 0; i < 24; i++) { if (i < SBMAX_l) { const int w = h_sl[i + 1] - h_sl[i]; if (mx < w) mx = w; } extra[fold_at + 128 + i] = mx; }
         mx = 0;
         for (int i = 0; i < 40; i++) { if (i < 3 * SBMAX_s) { const int w = h_ss[i / 3 + 1] - h_ss[i / 3]; if (mx < w) mx = w; } extra[fold_at + 128 + 24 + i] = mx; }
+        // count_bits, NORM blocks (Takehiro.js:575-590): everything it derives from big_values = 2 e in one word -- the region borders
+        // a1 = sfb_l[r0 + 1], a2 = sfb_l[r0 + r1 + 2] (10 bits each), the region counts r0 = bv_scf[i - 2], r1 = bv_scf[i - 1] (4 + 3 bits) and
+        // PrevNoise.sfb_count1 = the band of line i - 1, plus one (5 bits)
+        {
+            const int32_t* h_bv = (const int32_t*)host_arr("bv_scf");
+            extra[fold_at + 128 + 24 + 40] = 0;
+            for (int e = 1; e <= 288; e++) {
+                const int i = 2 * e, r0 = h_bv[i - 2], r1 = h_bv[i - 1];
+                if (r0 < 0 || r0 > 15 || r1 < 0 || r1 > 7 || r0 + r1 + 2 > SBMAX_l) { set_err("bv_scf outside the range count_bits' region table is packed for"); return false; }
+                const int a1 = h_sl[r0 + 1], a2 = h_sl[r0 + r1 + 2];
+                extra[fold_at + 128 + 24 + 40 + e] = (int32_t)((uint32_t)a1 | ((uint32_t)a2 << 10) | ((uint32_t)r0 << 20) | ((uint32_t)r1 << 24) | ((uint32_t)(band_l[i - 1] + 1) << 27));
+            }
+        }
     }
     // psyA's partition energies as a systolic fold (k_psy.h): lane l owns the FFT lines 8 l .. 8 l + 7; per lane three words -- marks
     // (bit k: line 8 l + k is the first of its partition, bit 8 + k: the last one, counting line 512 as part of the spectrum) and
@@ -846,7 +859,7 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     T.s3off_l = (const int32_t*)ts.d_extra; T.s3off_s = T.s3off_l + CBANDS; T.lineoff_l = T.s3off_l + 2 * CBANDS; T.lineoff_s = T.s3off_l + 3 * CBANDS;
     T.bo_l = T.s3off_l + 4 * CBANDS; T.bo_s = T.bo_l + SBMAX_l;
     T.amp_by_out = (const double*)(T.s3off_l + amp_at);
-    T.fold_marks = T.s3off_l + fold_at; T.wpre = T.fold_marks + 128;
+    T.fold_marks = T.s3off_l + fold_at; T.wpre = T.fold_marks + 128; T.bvtab = T.wpre + 64;
     T.psy_fold = T.s3off_l + psyfold_at;
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
@@ -890,8 +903,6 @@ struct Context {
     // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
     void* copy_stream = nullptr; void* ev_in[2] = {nullptr, nullptr}; void* ev_done[2] = {nullptr, nullptr};
     DevBuf chunk_in, chunk_out;
-    void* pin_in = nullptr; size_t pin_in_cap = 0;      // pinned staging, two halves each (hipHostMalloc): the caller's pageable memory reaches the
-    void* pin_out = nullptr; size_t pin_out_cap = 0;    // DMA engine through these (a pageable hipMemcpyAsync is a host-side copy at ~6 GB/s, measured)
     std::mutex chunk_mu;        // one chunked call at a time per device (they share the two staging halves); taken BEFORE mu, never inside it
 };
 
@@ -1342,6 +1353,11 @@ int lhip_set_devices(uint64_t mask) {
     return mask ? __builtin_popcountll(mask) : n;
 }
 
+int lhip_stream_device(const lhip_stream* s) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    return s->ctx->device;
+}
+
 const char* lhip_last_error(void) { return g_err.c_str(); }
 const char* lhip_version(void) {
 #ifdef LHIP_HOSTSIM
@@ -1459,29 +1475,34 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
 // reservoir (its byte counts are only known after each launch).
 #ifndef LHIP_HOSTSIM
 enum { HOST_CHUNK_FRAMES = 8192 };
-// a large host-to-host copy on a few threads (one core moves ~10 GB/s; the chunk must be staged faster than the GPU encodes it)
-static void par_memcpy(void* dst, const void* src, size_t n) {
-    static const unsigned nt = []() { unsigned h = std::thread::hardware_concurrency(); return h >= 8 ? 4u : h >= 4 ? 2u : 1u; }();
-    if (nt <= 1 || n < ((size_t)4 << 20)) { memcpy(dst, src, n); return; }
-    const size_t part = ((n / nt) + 4095) & ~(size_t)4095;
-    std::thread th[4];
-    unsigned started = 0;
-    for (unsigned i = 1; i < nt; i++) {
-        const size_t o = (size_t)i * part;
-        if (o >= n) break;
-        const size_t len = n - o < part ? n - o : part;
-        th[started++] = std::thread([=]() { memcpy((uint8_t*)dst + o, (const uint8_t*)src + o, len); });
+// chunk schedule: the first chunk is small (its copy is the part of the call nothing overlaps), every later one twice the one before up
+// to a cap -- a chunk's copy still fits inside the encode of the chunk before it, and large chunks keep the persistent quantization
+// kernel's waves busy (at 8192 frames a wave draws two frames and every launch ends on its slowest one: 1e5 stereo frames took 72.5 ms
+// in 8192-frame chunks, 58.3 ms with 8192 doubling to 32768, 60.0 ms as one batch with nothing overlapped; tests/tools/dropin_sweep.py).
+// LAMEJS_HIP_HOST_CHUNK_FRAMES=first[,cap] overrides (tuning).
+static void host_chunk_schedule(size_t* first, size_t* cap) {
+    static size_t f = 0, c = 0;
+    if (!f) {
+        size_t a = 8192, b2 = 32768;
+        if (const char* e = getenv("LAMEJS_HIP_HOST_CHUNK_FRAMES")) {
+            char* end = nullptr;
+            const unsigned long v = strtoul(e, &end, 10);
+            if (v >= 64 && v <= (1ul << 20)) { a = v; b2 = v; }
+            if (end && *end == ',') { const unsigned long w = strtoul(end + 1, nullptr, 10); if (w >= a && w <= (1ul << 20)) b2 = w; }
+        }
+        c = b2; f = a;
     }
-    memcpy(dst, src, part < n ? part : n);
-    for (unsigned i = 0; i < started; i++) th[i].join();
+    *first = f; *cap = c;
 }
 static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> chunk_lk(ctx->chunk_mu);
     const Tables& T = s->ts->T;
     const int C = T.channels_out;
-    const size_t chunk = (size_t)HOST_CHUNK_FRAMES * 576 * T.mode_gr * T.rs_ratio;
-    const size_t nchunks = (nsamples + chunk - 1) / chunk;
+    size_t first_frames, cap_frames;
+    host_chunk_schedule(&first_frames, &cap_frames);
+    const size_t spf = (size_t)576 * T.mode_gr * T.rs_ratio;             // input samples per frame
+    const size_t chunk = cap_frames * spf;                                // the largest chunk: what the staging halves are sized for
     // the whole call must fit the caller's buffer BEFORE anything is consumed (a failed call consumes nothing)
     {
         const int frame = 576 * T.mode_gr, mf_needed = 1024 + frame - 272;
@@ -1499,26 +1520,11 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
             for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&e[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return LHIP_ERR_INTERNAL; }
             ctx->copy_stream = cs; ctx->ev_in[0] = e[0]; ctx->ev_in[1] = e[1]; ctx->ev_done[0] = e[2]; ctx->ev_done[1] = e[3];
         }
-        const size_t out_chunk = (size_t)(HOST_CHUNK_FRAMES + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
+        const size_t out_chunk = (size_t)(cap_frames + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
         if (!ctx->chunk_in.ensure(2 * C * chunk * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk)) return LHIP_ERR_INTERNAL;
     }
-    const size_t out_chunk = (size_t)(HOST_CHUNK_FRAMES + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
+    const size_t out_chunk = (size_t)(cap_frames + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
     hipStream_t cs = (hipStream_t)ctx->copy_stream, ks = (hipStream_t)ctx->stream;
-    // pinned staging halves (grow-only, per context): the caller's samples are copied into them by a few host threads, the DMA engine
-    // takes them from there -- both really asynchronous, unlike a hipMemcpyAsync from pageable memory
-    static const bool no_pin = []() { const char* e = getenv("LAMEJS_HIP_NO_PINNED_STAGING"); return e && e[0] == '1'; }();
-    const size_t in_half = (size_t)C * chunk * 2;
-    bool pinned = !no_pin;
-    if (pinned) {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        auto grow = [&](void*& ptr, size_t& cap, size_t need) -> bool {
-            if (cap >= need) return true;
-            if (ptr) { (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
-            if (hipHostMalloc(&ptr, need, hipHostMallocDefault) != hipSuccess) { ptr = nullptr; return false; }
-            cap = need; return true;
-        };
-        if (!grow(ctx->pin_in, ctx->pin_in_cap, 2 * in_half) || !grow(ctx->pin_out, ctx->pin_out_cap, 2 * out_chunk)) pinned = false;   // fall back to pageable copies
-    }
     int64_t total = 0, pending_bytes = 0, frames_all = 0;      // pending: the chunk whose output is still on the device
     uint8_t* pending_dst = nullptr; int pending_par = 0; bool have_pending = false;
     auto fail = [&](const char* what) -> int64_t { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ks); if (what) set_err(what); return LHIP_ERR_INTERNAL; };
@@ -1527,27 +1533,19 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         have_pending = false;
         if (pending_bytes == 0) return true;
         if (hipStreamWaitEvent(cs, (hipEvent_t)ctx->ev_done[pending_par], 0) != hipSuccess) return false;
-        uint8_t* hdst = pinned ? (uint8_t*)ctx->pin_out + (size_t)pending_par * out_chunk : pending_dst;
-        if (hipMemcpyAsync(hdst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) return false;
-        if (hipStreamSynchronize(cs) != hipSuccess) return false;
-        if (pinned) memcpy(pending_dst, hdst, (size_t)pending_bytes);
-        return true;
+        if (hipMemcpyAsync(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) return false;
+        return hipStreamSynchronize(cs) == hipSuccess;
     };
-    for (size_t k = 0; k < nchunks; k++) {
+    size_t p0 = 0, cur = first_frames * spf;
+    for (size_t k = 0; p0 < nsamples; k++) {
         const int par = (int)(k & 1);
-        const size_t p0 = k * chunk, m = nsamples - p0 < chunk ? nsamples - p0 : chunk;
+        const size_t m = nsamples - p0 < cur ? nsamples - p0 : cur;
         int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * chunk;
-        // buffer `par` (device and pinned half alike) was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
-        if (pinned) {
-            int16_t* h_in = (int16_t*)((uint8_t*)ctx->pin_in + (size_t)par * in_half);
-            par_memcpy(h_in, left + p0, m * 2);
-            if (C == 2) par_memcpy(h_in + chunk, (right ? right : left) + p0, m * 2);
-            if (hipMemcpyAsync(d_in, h_in, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-            if (C == 2 && hipMemcpyAsync(d_in + chunk, h_in + chunk, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-        } else {
-            if (hipMemcpyAsync(d_in, left + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-            if (C == 2 && hipMemcpyAsync(d_in + chunk, (right ? right : left) + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-        }
+        // buffer `par` was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
+        // (copies straight from the caller's pageable memory: measured as fast as copies through pinned staging filled by four host
+        //  threads -- 72.5 vs 73.2 ms per 1e5 stereo frames at 8192-frame chunks -- so there is no staging layer)
+        if (hipMemcpyAsync(d_in, left + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
+        if (C == 2 && hipMemcpyAsync(d_in + chunk, (right ? right : left) + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
         if (hipEventRecord((hipEvent_t)ctx->ev_in[par], cs) != hipSuccess || hipStreamWaitEvent(ks, (hipEvent_t)ctx->ev_in[par], 0) != hipSuccess) return fail("event record / wait failed");
         std::vector<Job> jobs(1);
         jobs[0] = Job{s, d_in, C == 2 ? d_in + chunk : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};
@@ -1556,6 +1554,8 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         if (!drain()) return fail("copying a chunk's output failed");             // chunk k - 1, while chunk k is being encoded
         pending_bytes = jobs[0].written; pending_dst = out + total; pending_par = par; have_pending = true;
         total += jobs[0].written; frames_all += g_stat_frames;
+        p0 += m;
+        cur = 2 * cur < chunk ? 2 * cur : chunk;
     }
     if (!drain()) return fail("copying a chunk's output failed");
     g_stat_frames = frames_all;                    // lhip_last_batch_stats: frames of the whole call, repair counters of its last chunk

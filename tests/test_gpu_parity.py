@@ -604,3 +604,51 @@ def test_gpu_boundary_error_paths(lib):
     from oracle_py import oracle_encode
     run_boundary_checks(lib, oracle_encode)
     run_state_canonical_checks(lib)
+
+
+def test_gpu_two_devices_round_robin_and_concurrent_batches(lib):
+    """lhip_set_devices(0b11): default-device streams are dealt round-robin over both GPUs, and two host threads batching at the same
+    time, one per device, each give the oracle's bytes.  Needs two visible devices (the driver's multi-GPU box); skipped on one."""
+    import threading
+    import lamejs_amd, pcm
+    from oracle_py import oracle_encode
+    if lib.lhip_device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    lib.lhip_set_devices.restype = ctypes.c_int
+    lib.lhip_set_devices.argtypes = [ctypes.c_uint64]
+    lib.lhip_stream_device.restype = ctypes.c_int
+    lib.lhip_stream_device.argtypes = [ctypes.c_void_p]
+    assert lib.lhip_set_devices(0b11) == 2
+    try:
+        encs = [lamejs_amd.Mp3Encoder(2, 44100, 128) for _ in range(6)]
+        devs = [lib.lhip_stream_device(e._h) for e in encs]
+        assert devs == [devs[0], 1 - devs[0]] * 3 and set(devs) == {0, 1}, devs        # alternating placement
+        for e in encs:
+            e.close()
+        mats = [pcm.CORPORA["bursts"](1152 * 300, 2, seed=900 + i) for i in range(2)]
+        got, errs = [None, None], []
+
+        def work(i):
+            try:
+                parts = []
+                for rep in range(3):                                              # several batches per thread: the two contexts really overlap
+                    enc = lamejs_amd.Mp3Encoder(2, 44100, 128, device=i)
+                    assert lib.lhip_stream_device(enc._h) == i
+                    L, R = mats[i]
+                    parts.append(enc.encodeBuffer(L, R) + enc.flush())
+                    enc.close()
+                assert parts[0] == parts[1] == parts[2]
+                got[i] = parts[0]
+            except Exception as ex:                                               # noqa: BLE001 -- reported by the main thread
+                errs.append((i, repr(ex)))
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            L, R = mats[i]
+            assert got[i] == oracle_encode(2, 44100, 128, L, R)
+    finally:
+        lib.lhip_set_devices(0)
