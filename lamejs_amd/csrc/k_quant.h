@@ -578,59 +578,6 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     const uint8_t* l2s = line2sfb(Q, g.block_type);
     const int need_old = (m_cached != 0);
     const float istep_f = Q.ipow20[g.global_gain];     // the Float32Array value itself; `istep` above is its f64 image
-#if LHIP_NL != 1
-    // The first evaluation after an amplification runs at the gain calc_noise saw: every band that was not amplified is cached, and the
-    // amplified ones are few (3.5 on average at stereo 128 kbps).  Then only THEIR lines are quantized -- the lanes over a band's lines,
-    // band after band -- and every lane fetches its pairs from the working copy afterwards; the dense form below computes all 576 lines
-    // and throws most of them away.  Lines from max_nonzero_coeff on are zero in the working copy already (see above) and stay so.
-    if (need_old) {
-        const uint64_t m_fresh = ~m_cached & ((2ull << sfbmax) - 1);
-        if (__builtin_popcountll(m_fresh) <= 8) {
-            int lim = ((g.max_nonzero_coeff + 2) >> 1) << 1;
-            if (lim > 576) lim = 576;
-            float zo_thr = 0.f;
-            if (m_zo) {
-                const double compareval0 = (1.0 - 0.4054) / istep;
-                zo_thr = (float)compareval0;
-                if ((double)zo_thr < compareval0) zo_thr = f32_next_up(zo_thr);
-            }
-            int my_sw = 0;
-            LHIP_LANE_ONCE(b, 0, (SFBMAX) + 1) my_sw = (int)(uint16_t)L.start[b] | ((int)L.width[b] << 16);
-            uint64_t mm = m_fresh;
-            while (mm) {
-                const int b = (int)__builtin_ctzll(mm);
-                mm &= mm - 1;
-                const int sw = wave_bcast(my_sw, b), st = sw & 0xffff;
-                int e = st + (sw >> 16);
-                if (e > lim) e = lim;
-                const int zo = (int)((m_zo >> b) & 1);
-                for (int i = st + lane; i < e; i += LHIP_NL) {
-                    const float x = L.xrpow[i];
-                    int v;
-                    if (zo) v = (x < zo_thr) ? 0 : 1;
-                    else {
-                        const int r = q_floor_prod1(x, istep_f);
-                        float a = Q.adj43[r < QT_N ? r : QT_N - 1];
-                        if (may_big && r >= QT_N) a = T.adj43[r];
-                        v = q_floor_fma1(x, istep_f, a);
-                    }
-                    ix[i] = (int16_t)v;
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int j = 0; j < NPL; j++) {
-                const int p = 2 * (lane + LHIP_NL * j);
-                uint32_t w2 = 0;
-                if (p < 576) w2 = *(const uint32_t*)(ix + p);
-                vx[j] = (int)(w2 & 0xffffu); vy[j] = (int)(w2 >> 16);
-            }
-            wave_sync();
-            PH_MARK(L, PH_Q_LINES, tm_);
-            return;
-        }
-    }
-#endif
     // staged, branch-light form: all loads of a stage are independent so they overlap (LDS latency is the cost here); the two
     // truncations of every line are q_floor_prod / q_floor_fma (lhip_math.h)
     int ra[NPL], rb[NPL];
@@ -1373,30 +1320,6 @@ LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantL
 LHIP_DEV void q_amplify_flagged(GI& g, double amp, uint64_t m_amp, int lane, QuantLds& L, const QuantTabs& Q) {
     lane = fresh_lane(lane);
     float m = 0.f;
-#if LHIP_NL != 1
-    // Few bands are amplified per call (3.5 on average at stereo 128 kbps, 1.3 mono, almost never more than 8): walk THEM, the lanes
-    // over a band's lines, instead of sending all 288 pairs through the multiply.  Lane b holds band b's first line and width, so the
-    // walk needs no LDS round trip per band.
-    if (__builtin_popcountll(m_amp) <= 8) {
-        int my_sw = 0;
-        LHIP_LANE_ONCE(b, 0, (SFBMAX) + 1) my_sw = (int)(uint16_t)L.start[b] | ((int)L.width[b] << 16);
-        uint64_t mm = m_amp;
-        while (mm) {
-            const int b = (int)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            const int sw = wave_bcast(my_sw, b), st = sw & 0xffff, w = sw >> 16;
-            for (int i = lane; i < w; i += LHIP_NL) {
-                const float v = (float)((double)L.xrpow[st + i] * amp);
-                L.xrpow[st + i] = v;
-                m = fmax_nonneg(m, v);
-            }
-        }
-        m = wave_maxf_pos(m);
-        if ((double)m > g.xrpow_max) g.xrpow_max = m;
-        wave_sync();
-        return;
-    }
-#endif
     const uint8_t* l2s = line2sfb(Q, g.block_type);
     struct F2 { float x, y; };
     F2 xx[NPL]; int bnd[NPL];

@@ -171,28 +171,6 @@ template <int N> LHIP_DEV void q_floor_fma(const float (&xa)[N], const float (&x
 #endif
 }
 
-// the same two truncations for ONE value (the band-sparse path of q_quantize): rx = (int)(x * istep), then (int)(x * istep + adj)
-LHIP_DEV int q_floor_prod1(float x, float istep) {
-#ifdef LHIP_HOSTSIM
-    return (int)((double)x * (double)istep);
-#else
-    float a;
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\tv_mul_f32 %0, %1, %2\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
-                 : "=&v"(a) : "v"(x), "v"(istep));
-    return (int)a;
-#endif
-}
-LHIP_DEV int q_floor_fma1(float x, float istep, float adj) {
-#ifdef LHIP_HOSTSIM
-    return (int)((double)x * (double)istep + (double)adj);
-#else
-    float a;
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\tv_fma_f32 %0, %1, %2, %3\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
-                 : "=&v"(a) : "v"(x), "v"(istep), "v"(adj));
-    return (int)a;
-#endif
-}
-
 // v8_log10 for positive normal operands, +inf and NaN (x >= 2^-1022 or NaN) without data-dependent branches: in a wave program
 // every two-sided `if` on a per-lane value costs exec-mask bookkeeping on the (per-CU) scalar unit and both sides run anyway.
 // Same operations in the same order as v8_log10 / v8_log above -- the four return expressions of v8_log's main path and the two
