@@ -1,5 +1,5 @@
 # DEV TOOL (GPU box): A/B of library variants (lamejs_amd/lib/variants/*.so against the shipped library): g_quant time and bit-exactness of
-# the stereo and mono headline workloads, three repetitions each, interleaved.  Lands in gpurun_out/$1.
+# the stereo and mono headline workloads, three repetitions each, interleaved; then the phase cycles of the shipped library.  Lands in gpurun_out/$1.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-ab}; mkdir -p $O
 cd $R
 for rep in 1 2 3; do
@@ -12,4 +12,5 @@ print('$lib', 'config$c', 'rep$rep', 'quant_ms', d['kernels_ms']['quant']['ms'],
     done
   done
 done
-timeout 600 python tests/tools/dropin_sweep.py 2>&1 | tee $O/dropin_sweep.txt
+timeout 120 python tests/tools/phase_prof.py 20000 > $O/quant_phase_cycles.txt 2>&1
+sed -n 34,60p $O/quant_phase_cycles.txt
