@@ -492,7 +492,7 @@ def main():
             # gfx950 FETCH_SIZE x2 correction) and its instruction mix -- measured offline on this exact workload, under profiles/
             traffic = None
             prof = {}
-            pf = ROOT / "profiles" / f"r02_pmc_config{key}.json"
+            pf = next((q for q in (ROOT / "profiles" / f"r03_pmc_config{key}.json", ROOT / "profiles" / f"r02_pmc_config{key}.json") if q.exists()), ROOT / "profiles" / f"r03_pmc_config{key}.json")
             if wl.full and pf.exists():
                 try:
                     prof = json.loads(pf.read_text())
@@ -517,7 +517,7 @@ def main():
                 line["roofline_compute"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(ach, 1), "peak": ce[8], "unit": "G VALU wave-instructions/s",
                                             "frac": round(ach / ce[8], 4), "peak_at_kernel_occupancy": ce[occ], "frac_at_kernel_occupancy": round(ach / ce[occ], 4),
                                             "occupancy_waves_per_simd": occ, "valu_insts_per_launch": insts, "salu_insts_per_launch": rc["salu_insts_per_launch"],
-                                            "source": f"profiles/r02_pmc_config{key}.json (PMC of this workload) + profiles/r02_ubench_issue.json (ceiling of that mix)"}
+                                            "source": f"profiles/{pf.name} (PMC counts of this workload on the code of that measurement pass: they go stale with every kernel change) + the issue microbenchmark in it (ceiling of that mix)"}
 
     # ---- the other configurations (N = 1 only): each is its own short run, md5-checked like the main one ----
     if world == 1 and not args.no_extras and not args.frames and not args.streams:
