@@ -152,7 +152,9 @@ int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* lau
  * 3 1/x, 4 (double)(float)x, 5 ToInt32, 6 x/3 + x*0.1 (must not fuse), 7 log10 by the branch-free variant for positive
  * normal operands / +inf / NaN, 8 the quantizer's two truncations on records of 21 doubles [istep, xa[5], xb[5], adj_a[5], adj_b[5]]
  * (f32 values) -> [0, floor(x istep) x 10, floor(x istep + adj) x 10], 9 calc_noise's logarithm-free band class: noise_class(x)
- * + 1000 * class from the f64 log10 + 1e6 * class from its Float32 copy (the first must equal both others unless it is -1). */
+ * + 1000 * class from the f64 log10 + 1e6 * class from its Float32 copy (the first must equal both others unless it is -1), 10 calc_noise's
+ * division by a Float32 through its reciprocal on records of 2 doubles [a, b] -> [div_by_f32(a, (float)b), a / (float)b] (must be equal bit for bit),
+ * 11 mask_add's table index for x >= 1: ma_index16(x) (-1 = take the logarithm) + 1000 * ToInt32(log10(x) * 16). */
 int lhip_debug_math(int op, const double* in, double* out, size_t n);
 
 /* Test hook: the seed the speculative quantization pass assumes for the reference's bin-search chain

@@ -783,6 +783,28 @@ template <int NCH> struct PsyBLdsT : PsyBTabs {
 typedef PsyBLdsT<2> PsyBLds;
 typedef PsyBLdsT<4> PsyBLds4;
 
+// js_toint32(v8_log10_pos(ratio) * 16.0), the table index of mask_add (PsyModel.js:403-473), for 1 <= ratio < 2^20 -- without the
+// logarithm where that is safe: the index is a step function of ratio with steps at 10^(k / 16), and away from the steps any
+// approximation of 16 log10(ratio) with an error below the distance to the next integer gives the same integer.
+// t = log2_f32((float)ratio) * 16 log10(2): error < 2e-5 (one ulp of v_log_f32 at |log2| <= 20, the conversion of ratio, the f32
+// multiply); returns -1 within 2e-4 of an integer (the caller then takes the logarithm, as before; about 1 operand in 2500).
+LHIP_DEV int ma_index16(double ratio) {
+    const float t = fast_log2f((float)ratio) * 4.81647993062369912f;
+    const float k = __builtin_floorf(t);
+    const float fr = t - k;
+    int i = (int)k;
+    if (fr < 2e-4f || fr > 1.0f - 2e-4f) i = -1;
+#ifdef LHIP_HOSTSIM
+    if (i >= 0 && i != js_toint32(v8_log10_pos(ratio) * 16.0)) { fprintf(stderr, "hostsim: ma_index16 disagrees with the logarithm at %a\n", ratio); abort(); }
+#endif
+    return i;
+}
+LHIP_DEV int ma_index16_exact(double ratio) {
+    int i = ma_index16(ratio);
+    if (i < 0) i = js_toint32(v8_log10_pos(ratio) * 16.0);
+    return i;
+}
+
 LHIP_DEV double mask_add_l(const Tables& T, const PsyBTabs& L, double ath_cb, double m1, double m2, int b) {
     // PsyModel.js:403-473 (long blocks).  Every logarithm here has a positive, finite, normal operand -- `ratio` lies in
     // [1, ma_max_i2) and m1 / m2 in (1, ma_max_m) on the paths that take it -- so the branch-free v8_log10_pos applies (lhip_math.h)
@@ -797,10 +819,10 @@ LHIP_DEV double mask_add_l(const Tables& T, const PsyBTabs& L, double ath_cb, do
     m1 += m2;
     if ((b + 3) <= 3 + 3) {
         if (ratio >= T.ma_max_i1) return m1;
-        const int i = js_toint32(v8_log10_pos(ratio) * 16.0);
+        const int i = ma_index16_exact(ratio);
         return m1 * L.mt2[i];
     }
-    const int i = js_toint32(v8_log10_pos(ratio) * 16.0);
+    const int i = ma_index16_exact(ratio);
     m2 = ath_cb;
     if (m1 < T.ma_max_m * m2) {
         if (m1 > m2) {

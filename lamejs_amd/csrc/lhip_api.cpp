@@ -202,6 +202,14 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
 }
 
+// op 10: records of 2 doubles [a, b] -> [div_by_f32(a, (float)b, RN(1 / (float)b)), a / (float)b]: calc_noise's division by xmin through the reciprocal
+// against the division itself (must be bit-identical for finite a >= 0 and a positive Float32 divisor)
+LHIP_DEV void math_op10(const double* in, double* out) {
+    const double a = in[0], b = (double)(float)in[1], rb = recip_for_div(b);
+    out[0] = rb != 0.0 ? div_by_f32(a, b, rb) : a / b;
+    out[1] = a / b;
+}
+
 // op 8: records of 21 doubles [istep, xa0..4, xb0..4, adj_a0..4, adj_b0..4] (f32 values) -> [0, floor(x istep) x 10, floor(x istep + adj) x 10]
 LHIP_DEV void math_op8(const double* in, double* out) {
     float xa[5], xb[5], ja[5], jb[5]; int ra[5], rb[5], va[5], vb[5];
@@ -599,6 +607,7 @@ static const bool g_trace = []() { const char* e = getenv("LAMEJS_HIP_TRACE"); r
 __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase pb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (op == 8) { if (21 * i + 21 <= n) math_op8(in + 21 * i, out + 21 * i); return; }
+    if (op == 10) { if (2 * i + 2 <= n) math_op10(in + 2 * i, out + 2 * i); return; }
     if (i >= n) return;
     const double x = in[i];
     double r = 0;
@@ -611,6 +620,7 @@ __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase 
         case 5: r = (double)js_toint32(x); break;
         case 6: r = x / 3.0 + x * 0.1; break;
         case 7: r = v8_log10_pos(x); break;
+        case 11: r = (double)ma_index16(x) + 1000.0 * (double)js_toint32(v8_log10_pos(x) * 16.0); break;   // mask_add's table index: shortcut (-1: none) + 1000 * the logarithm's
         case 9: {   // calc_noise's shortcut: noise_class(x) + 1000 * class from the f64 logarithm + 1e6 * class from its Float32 copy
             const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
             r = (double)noise_class(x) + 1000.0 * (double)noise_class_of_log(l) + 1e6 * (double)noise_class_of_log((double)(float)l);
@@ -1847,6 +1857,7 @@ int lhip_debug_math(int op, const double* in, double* out, size_t n) {
 #else
     const PowBase pb = pow_log2_parts(10.0);
     if (op == 8) { for (size_t i = 0; 21 * i + 21 <= n; i++) math_op8(in + 21 * i, out + 21 * i); return 0; }
+    if (op == 10) { for (size_t i = 0; 2 * i + 2 <= n; i++) math_op10(in + 2 * i, out + 2 * i); return 0; }
     for (size_t i = 0; i < n; i++) {
         const double x = in[i];
         switch (op) {
@@ -1857,6 +1868,7 @@ int lhip_debug_math(int op, const double* in, double* out, size_t n) {
             case 4: out[i] = (double)(float)x; break;
             case 5: out[i] = (double)js_toint32(x); break;
             case 7: out[i] = v8_log10_pos(x); break;
+            case 11: out[i] = (double)ma_index16(x) + 1000.0 * (double)js_toint32(v8_log10_pos(x) * 16.0); break;
             case 9: { const double l = v8_log10_pos(x > 1E-20 ? x : 1E-20);
                       out[i] = (double)noise_class(x) + 1000.0 * (double)noise_class_of_log(l) + 1e6 * (double)noise_class_of_log((double)(float)l); } break;
             default: out[i] = x / 3.0 + x * 0.1; break;

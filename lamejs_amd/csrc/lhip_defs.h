@@ -19,6 +19,8 @@
 #ifdef LHIP_HOSTSIM
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #define LHIP_DEV static inline
 #ifdef LHIP_WAVESIM
 #define LHIP_NL 64      /* test-only: the 64-lane wave programs themselves, lanes as fibers (lhip_wave.h) */

@@ -82,6 +82,22 @@ def test_device_noise_class_shortcut(lib):
     assert took > 0.5 * n
 
 
+def test_device_mask_add_index_shortcut(lib):
+    """mask_add's table index ToInt32(log10(ratio) * 16) from v_log_f32 with a guard band (k_psy.h ma_index16): wherever the shortcut
+    answers on the device it is the index the f64 logarithm gives -- 0.6 M ratios incl. every step approached down to one ulp."""
+    from noise_class_check import check_ma_index
+    took, n = check_ma_index(lib)
+    assert took > 0.9 * n
+
+
+def test_device_division_by_reciprocal_is_the_division(lib):
+    """calc_noise divides every band's noise by xmin through xmin's reciprocal (lhip_math.h div_by_f32: a multiply and two fma on the
+    device); bit-identical to the device's f64 division on 0.9 M operand pairs (divisors down to Float32 subnormals, quotients next to
+    powers of two, zero numerators)."""
+    from noise_class_check import check_div_by_f32
+    assert check_div_by_f32(lib) > 500000
+
+
 def test_device_quantize_truncations(lib):
     """quantize_lines_xrpow's two truncations, (int)(x istep) and (int)(x istep + adj43[.]) in f64 (Takehiro.js:125-165), are ONE f32
     instruction each under round-toward-zero on the device (lhip_math.h q_floor_prod / q_floor_fma).  2.1 M operand triples,

@@ -301,3 +301,16 @@ def test_hostsim_noise_class_shortcut(sim):
     from noise_class_check import check_noise_class
     took, n = check_noise_class(sim)
     assert took > 0.5 * n
+
+
+def test_hostsim_division_by_reciprocal_is_the_division(sim):
+    """calc_noise's division by xmin through its reciprocal (lhip_math.h div_by_f32) against the division itself: bit-identical."""
+    from noise_class_check import check_div_by_f32
+    assert check_div_by_f32(sim) > 500000
+
+
+def test_hostsim_mask_add_index_shortcut(sim):
+    """mask_add's table index without the logarithm (k_psy.h ma_index16): the logarithm's index wherever it answers."""
+    from noise_class_check import check_ma_index
+    took, n = check_ma_index(sim)
+    assert took > 0.9 * n
