@@ -2186,7 +2186,8 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
 // of its state (the entropies, the reservoir record) through the frame
 template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
-                       int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr) {
+                       int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr,
+                       int* hint = nullptr) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -2212,6 +2213,14 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         seed0 = seed_before(W, sd, C, k, 0, 0);
         if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
     }
+#ifndef LHIP_NO_SEED_HINT
+    else if (hint && hint[0] == st) {
+        // speculation with a better guess than the reset seed: the gains this wave's previous frame OF THE SAME STREAM ended on (any seed
+        // is legitimate here -- the validation replays the search with the chain-implied one); a steady stream's chain seeds look like this
+        if (hint[1] >= 0) { seed0.start = hint[1]; seed0.step = 2; }
+        if (C > 1 && hint[2] >= 0) { seed1.start = hint[2]; seed1.step = 2; }
+    }
+#endif
     int gr0_bt0 = 0, gr0_bt1 = 0;
     const int Cp = T.psy_channels;
     const int mode_ext = (T.mode == 1) ? q_ms_decision(T, W, sd, k, lane, L) : 0;      // joint stereo: this frame M/S (2) or L/R (0)
@@ -2355,6 +2364,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         fr.ResvSize = rs; fr.ResvMax = ResvMax; fr.pefir_new = pefir_new; fr.pad_ = 0;
         W.fr[fidx] = fr;
     }
+    if (hint) { hint[0] = st; hint[1] = seed0.start; hint[2] = C > 1 ? seed1.start : -1; }
     if (chain == 1 && lane == 0) W.seed_flag[fidx] = 0;
     if (chain == 2 && lane == 0) {                            // OldValue / CurrentStep after this frame (every wave of a pair its own channel)
         int32_t* ps = W.seed + (int64_t)fslot * C * 2;

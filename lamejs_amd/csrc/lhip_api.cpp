@@ -396,10 +396,12 @@ template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_
 #ifdef LHIP_PHASE_PROF
     L[wv].prof[threadIdx.x & 63] = 0;                 // per-wave cycle sums, flushed once at the end (a flush per frame would
 #endif                                                // itself congest the memory pipeline it is trying to observe)
+    int hint[3] = {-1, -1, -1};                       // stream and bin-search results of this wave's previous frame (kb_quant: speculation seed)
     for (;;) {
         const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
         if (fslot >= A->nfs) break;
-        kb_quant<0, RESV>(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q);
+        kb_quant<0, RESV>(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q, -1, nullptr, nullptr, RESV ? nullptr : hint);
+        hint[0] = __builtin_amdgcn_readfirstlane(hint[0]); hint[1] = __builtin_amdgcn_readfirstlane(hint[1]); hint[2] = __builtin_amdgcn_readfirstlane(hint[2]);
     }
 #ifdef LHIP_PHASE_PROF
     atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
@@ -1181,7 +1183,22 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
 #define QUANT_RUN(chain_) WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
 #endif
-        for (int b = 0; b < nfs; b++) QUANT_RUN(0);
+        {   // the speculative pass as three "persistent waves" striding over the frame slots, each with its own seed hint -- what g_quant's
+            // waves do with the frames they draw (kb_quant: `hint`), so that the simulations cover that path too
+            int hints[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
+            for (int b = 0; b < nfs; b++) {
+#ifdef LHIP_WAVESIM
+                if (pair) { QUANT_RUN(0); continue; }
+                int hl[64][3];                                     // every lane fiber updates its own copy; they must agree (wave-uniform)
+                for (int l = 0; l < 64; l++) for (int q = 0; q < 3; q++) hl[l][q] = hints[b % 3][q];
+                WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, 0, lane_, LQ, QT, -1, nullptr, nullptr, hl[lane_]));
+                for (int l = 1; l < 64; l++) for (int q = 0; q < 3; q++) if (hl[l][q] != hl[0][q]) { set_err("wavesim: seed hint not wave-uniform"); return false; }
+                for (int q = 0; q < 3; q++) hints[b % 3][q] = hl[0][q];
+#else
+                WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, 0, lane_, LQ, QT, -1, nullptr, nullptr, hints[b % 3]));
+#endif
+            }
+        }
         for (;;) {
             W.nflagged[0] = 0; W.nflagged[1] = 0;
             for (int b = 0; b < nfs; b++) kb_validate_fast(T, W, dSD, b);
