@@ -4,7 +4,7 @@
 #   tools/gcov_hostsim.sh [out.txt]
 set -e
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/r02_gcov_hostsim.txt}
+OUT=${1:-profiles/r03_gcov_hostsim.txt}
 B=/tmp/lhip_gcov; rm -rf $B; mkdir -p $B
 g++ -O0 -g --coverage -ffp-contract=off -fno-fast-math -std=c++17 -fPIC -DLHIP_HOSTSIM -Wno-unused-function -Wno-unused-variable -shared \
     -o $B/liblamejs_hostsim_cov.so lamejs_amd/csrc/lhip_api.cpp
