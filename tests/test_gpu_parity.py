@@ -3,6 +3,7 @@ C ABI, must be BIT-EXACT against (a) the committed goldens of the unmodified ref
 oracle on seeded inputs.  Integer/byte work: tolerance is zero."""
 import ctypes
 import hashlib
+import sys
 
 import numpy as np
 import pytest
@@ -668,3 +669,28 @@ def test_gpu_two_devices_round_robin_and_concurrent_batches(lib):
             assert got[i] == oracle_encode(2, 44100, 128, L, R)
     finally:
         lib.lhip_set_devices(0)
+
+
+@pytest.mark.parametrize("ch,kbps,nfr,seed", [(2, 128, 10000, 81), (1, 128, 14000, 82), (2, 320, 9000, 83)])
+def test_gpu_long_random_stream_uses_wave_seed_hints(lib, ch, kbps, nfr, seed):
+    """Batches of more than 4096 frames: the waves of the persistent quantization kernel draw several frames each and speculate every
+    later frame's bin search from the gains of their previous one (kb_quant's `hint`) -- on random material (tones, noise, clicks, level
+    steps, silence gaps: tests/tools/fuzz_gpu.py) whose gains move, so that hints are often wrong and the validation / repair path has to
+    put them right.  One batch call and a chunked one against the oracle."""
+    import lamejs_amd
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    from oracle_py import oracle_encode
+    rng = np.random.default_rng(seed)
+    L, R = fuzz_gpu.material(rng, 1152 * nfr + 333, ch)
+    want = oracle_encode(ch, 44100, kbps, L, R)
+    enc = lamejs_amd.Mp3Encoder(ch, 44100, kbps)
+    got = enc.encodeBuffer(L, R) + enc.flush()
+    st = enc.last_batch_stats() if hasattr(enc, "last_batch_stats") else None
+    enc.close()
+    assert got == want, st
+    enc = lamejs_amd.Mp3Encoder(ch, 44100, kbps)
+    cut = 1152 * 5000 + 77
+    got2 = enc.encodeBuffer(L[:cut], None if R is None else R[:cut]) + enc.encodeBuffer(L[cut:], None if R is None else R[cut:]) + enc.flush()
+    enc.close()
+    assert got2 == want
