@@ -227,9 +227,12 @@ LHIP_DEV int sbgain(const GI& g, int w) {   // subblock_gain[w] without a dynami
     return w == 0 ? g.subblock_gain[0] : w == 1 ? g.subblock_gain[1] : w == 2 ? g.subblock_gain[2] : g.subblock_gain[3];
 }
 
+// the band's sub-block gain: only short blocks have one (every other block type keeps its bands in "window 3", whose gain stays 0 --
+// nothing ever increments subblock_gain[3]), so long blocks neither fetch the window nor select among the gains
+LHIP_DEV int band_sbgain(const GI& g, const int16_t* window, int sfb) { return g.block_type == SHORT_TYPE ? sbgain(g, window[sfb]) : 0; }
 LHIP_DEV int sf_step(const QuantTabs& Q, const GI& g, const int32_t* scalefac, const int16_t* window, int sfb) {
     return g.global_gain - ((scalefac[sfb] + (g.preflag != 0 ? Q.pretab[sfb] : 0)) << (g.scalefac_scale + 1))
-           - sbgain(g, window[sfb]) * 8;
+           - band_sbgain(g, window, sfb) * 8;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -583,9 +586,12 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     int ra[NPL], rb[NPL];
     q_floor_prod(xa, xb, istep_f, ra, rb);                                 // 0 <= x <= 8206: truncation == ToInt32
     float aa[NPL], ab[NPL];
+    if (!may_big) {                                                        // every product is below QT_N (see may_big): nothing to clamp
 #pragma unroll
-    for (int j = 0; j < NPL; j++) { aa[j] = Q.adj43[ra[j] < QT_N ? ra[j] : QT_N - 1]; ab[j] = Q.adj43[rb[j] < QT_N ? rb[j] : QT_N - 1]; }
-    if (may_big) {                                                         // rare: large quantized values
+        for (int j = 0; j < NPL; j++) { aa[j] = Q.adj43[ra[j]]; ab[j] = Q.adj43[rb[j]]; }
+    } else {                                                               // rare: large quantized values
+#pragma unroll
+        for (int j = 0; j < NPL; j++) { aa[j] = Q.adj43[ra[j] < QT_N ? ra[j] : QT_N - 1]; ab[j] = Q.adj43[rb[j] < QT_N ? rb[j] : QT_N - 1]; }
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             if (ra[j] >= QT_N) aa[j] = T.adj43[ra[j]];
@@ -917,19 +923,36 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 #else
     // a pair at a time (descriptor of its region, three byte gathers, three multiply-adds): measured 1 % faster per launch than the
     // same work in stages (all descriptors, all gathers, all sums), which keeps fifteen more values live
+    if (any_esc) {
 #pragma unroll
-    for (int j = 0; j < NPL; j++) {
-        if (rj[j] < 3) {
-            const int r = rj[j];
-            const uint64_t d = *(const uint64_t*)L.rdesc[r];
-            const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
-            const int x = vx[j], y = vy[j];
-            const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
-            const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
-            accA = mul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
-            accB = mul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
-            accC = mul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
-            if (any_esc) accN = mul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
+        for (int j = 0; j < NPL; j++) {
+            if (rj[j] < 3) {
+                const int r = rj[j];
+                const uint64_t d = *(const uint64_t*)L.rdesc[r];
+                const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
+                const int x = vx[j], y = vy[j];
+                const int idx = (x < 15 ? x : 15) * (int)(d1 >> 16) + (y < 15 ? y : 15);
+                const unsigned mult = 1u << (FB * r);                   // field of region r; 24-bit multiply-add accumulates in one instruction
+                accA = mul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
+                accB = mul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
+                accC = mul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
+                accN = mul24((unsigned)((x > 14) + (y > 14)), mult) + accN;
+            }
+        }
+    } else {
+        // no region holds a value above 15 (three calls in four at stereo 128 kbps): nothing to clamp, no escapes to count
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            if (rj[j] < 3) {
+                const int r = rj[j];
+                const uint64_t d = *(const uint64_t*)L.rdesc[r];
+                const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
+                const int idx = vx[j] * (int)(d1 >> 16) + vy[j];
+                const unsigned mult = 1u << (FB * r);
+                accA = mul24((unsigned)Q.hlen[(d0 & 0xffffu) + idx], mult) + accA;
+                accB = mul24((unsigned)Q.hlen[(d0 >> 16) + idx], mult) + accB;
+                accC = mul24((unsigned)Q.hlen[(d1 & 0xffffu) + idx], mult) + accC;
+            }
         }
     }
 #endif
@@ -1115,18 +1138,21 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         // exactly the reference's `noise += t` (or a fresh sum); no contraction is involved, the fma is explicit.
         // |xr| - pow43 * step: the product of two Float32 values is exact in f64, so the explicit fma's single rounding is the
         // reference's (a product, then a difference).
-#pragma unroll
-        for (int k = 0; k < NLN; k++) {
-            const int j = NLN * lane + k;
-            const int bnd = l2s[j];
-            const float bstep = L.bstep[bnd];
-            const float xa = L.xr[j]; const int iv = ix[j];
-            const float pw = Q.pow43[iv < QT_N ? iv : QT_N - 1];
-            const double x = __builtin_fma(-(double)pw, (double)bstep, d_abs((double)xa));
-            tq[k] = x * x;
-            keep[k] = one_unless_bit(marks, k);
-            lastb[k] = bnd;
+        // !may_big (the usual case): every quantized value is below QT_N (see above), nothing to clamp; else the clamped look-up is
+        // replaced in the pass that follows
+#define NOISE_TERMS(IDX) _Pragma("unroll") for (int k = 0; k < NLN; k++) { \
+            const int j = NLN * lane + k; \
+            const int bnd = l2s[j]; \
+            const float bstep = L.bstep[bnd]; \
+            const float xa = L.xr[j]; const int iv = ix[j]; \
+            const float pw = Q.pow43[IDX]; \
+            const double x = __builtin_fma(-(double)pw, (double)bstep, d_abs((double)xa)); \
+            tq[k] = x * x; \
+            keep[k] = one_unless_bit(marks, k); \
+            lastb[k] = bnd; \
         }
+        if (!may_big) { NOISE_TERMS(iv) } else { NOISE_TERMS(iv < QT_N ? iv : QT_N - 1) }
+#undef NOISE_TERMS
         if (may_big) {                                   // rare: quantized values beyond the part of pow43 staged in LDS
 #pragma unroll
             for (int k = 0; k < NLN; k++) {
@@ -1310,7 +1336,7 @@ LHIP_DEV int q_scale_bitcount_any(const Tables& T, const QuantTabs& Q, GI& g, in
 LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
     int z = 0;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax)
-        if (scalefac[sfb] + sbgain(g, L.window[sfb]) == 0) z = 1;
+        if (scalefac[sfb] + band_sbgain(g, L.window, sfb) == 0) z = 1;
     return !wave_any(z);
 }
 
@@ -1354,11 +1380,16 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
     float tr = 0.f;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax) if (tr < L.distort[sfb]) tr = L.distort[sfb];
     double trigger = wave_maxf_pos(tr);
+    // noise_shaping_amp == 1 with a distorted band: the trigger is sqrt(max distortion) (Quantize.js:612-617).  For Float32 values d and M,
+    // d < RN(sqrt(M)) <=> d * d < M with the square formed exactly in f64: a Float32 can only equal the correctly rounded root if it IS
+    // the root (a 53-bit neighbour of an irrational root is no 24-bit number, and d * d = M means d = sqrt(M)), so no Float32 lies between
+    // the root and its rounding -- the comparison needs no square root (a dozen f64 instructions per call, on every lane)
+    const int by_square = T.noise_shaping_amp == 1 && trigger > 1.0;
+    const double max_dist = trigger;
     switch (T.noise_shaping_amp) {
         case 2: break;
         case 1:
-            if (trigger > 1.0) trigger = d_sqrt(trigger);
-            else trigger *= .95;
+            if (!(trigger > 1.0)) trigger *= .95;
             break;
         default:
             if (trigger > 1.0) trigger = 1.0;
@@ -1366,15 +1397,18 @@ LHIP_DEV void q_amp_scalefac_bands(const Tables& T, GI& g, int32_t* scalefac, in
             break;
     }
     uint64_t m_amp = 0;                                  // bit sfb: band is amplified
-    LHIP_LANE_ONCE(sfb, 0, g.sfbmax)
-        if (!((double)L.distort[sfb] < trigger)) m_amp |= 1ull << sfb;
+    LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
+        const double d = (double)L.distort[sfb];
+        const int below = by_square ? (d * d < max_dist) : (d < trigger);
+        if (!below) m_amp |= 1ull << sfb;
+    }
     m_amp = wave_lane_bits(m_amp);
     if (T.noise_shaping_amp == 2 && m_amp) m_amp = 1ull << __builtin_ctzll(m_amp);     // amplify exactly one band
     int z = 0, bad = 0, m12 = 0;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
         const int v = scalefac[sfb] + (int)((m_amp >> sfb) & 1);
         scalefac[sfb] = v;
-        if (v + sbgain(g, L.window[sfb]) == 0) z = 1;
+        if (v + band_sbgain(g, L.window, sfb) == 0) z = 1;
         if (sfb >= 11 && sfb < SBPSY_l && v < Q.pretab[sfb]) bad = 1;
         m12 |= (sfb < g.sfbdivide) ? v : (v << 8);
     }
