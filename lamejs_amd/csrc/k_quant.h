@@ -4,11 +4,12 @@
 // granule-channel the *control flow* of the reference (Quantize.js outer_loop 871-1052,
 // bin_search_StepSize 322-381, balance_noise 793-846, ...) is executed uniformly by all lanes,
 // while every loop over the 576 spectral lines / the scalefactor bands is spread over the lanes:
-//   - quantize x^(3/4) lines (Takehiro.js:102-314): 9 lines per lane, per-sfb mode table in LDS
+//   - quantize x^(3/4) lines (Takehiro.js:102-314): five pairs per lane, per-band decisions as ballots
 //   - Huffman bit counting (Takehiro.js:319-628): region maxima and packed length sums by
 //     integer wave reductions (exact, order-free)
-//   - noise per scalefactor band (QuantizePVT.js:725-878): one lane per band, lines summed in the
-//     reference's order (f64 sums are order-sensitive, so they are never tree-reduced)
+//   - noise per scalefactor band (QuantizePVT.js:725-878): nine consecutive lines per lane, the bands' f64 sums in the
+//     reference's line order as a systolic fold over the lanes (f64 sums are order-sensitive, so they are never tree-reduced);
+//     the per-band rest (distortion ratio, class, cache) one lane per band
 // State (GrInfo scalars) is wave-uniform and lives in registers; spectra and per-band arrays live in LDS.
 #pragma once
 #include "lhip_defs.h"
@@ -1028,7 +1029,7 @@ LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16
 
 // ---------------------------------------------------------------------------------------------
 // calc_noise (QuantizePVT.js:784-878); distort -> L.distort, cache -> L.pn_*
-// One lane per band sums its lines in the reference's order (f64 sums are order-sensitive); all gathers hit LDS.
+// The bands' sums in the reference's line order (f64 sums are order-sensitive) as a systolic fold; all gathers hit LDS.
 // ---------------------------------------------------------------------------------------------
 // need_max: the caller will look at max_noise even if some band is over its threshold (quant_compare only reads max_noise of
 // results with over_count == 0, and of `best` only while best.over_count == 0), so the f64 wave maximum is skipped otherwise
