@@ -694,3 +694,23 @@ def test_gpu_long_random_stream_uses_wave_seed_hints(lib, ch, kbps, nfr, seed):
     got2 = enc.encodeBuffer(L[:cut], None if R is None else R[:cut]) + enc.encodeBuffer(L[cut:], None if R is None else R[cut:]) + enc.flush()
     enc.close()
     assert got2 == want
+
+
+def test_gpu_host_call_in_overlapped_chunks(lib):
+    """One lhip_encode call with HOST buffers long enough to be cut into chunks whose copies overlap the encode of the chunk before
+    (lhip_api.cpp encode_host_chunked: more than 16384 frames; chunks of 8192, 16384, ... frames): the bytes of the call and of the flush
+    against the oracle, on random material, and the stream usable afterwards like any other."""
+    import lamejs_amd
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    from oracle_py import oracle_encode
+    rng = np.random.default_rng(91)
+    nfr = 36000
+    L, _ = fuzz_gpu.material(rng, 1152 * nfr + 500, 1)
+    want = oracle_encode(1, 44100, 128, L, None)
+    enc = lamejs_amd.Mp3Encoder(1, 44100, 128)
+    head = enc.encodeBuffer(L[:1152 * 30000 + 77])                  # chunked: 8192 + 16384 + the rest
+    tail = enc.encodeBuffer(L[1152 * 30000 + 77:])                  # one ordinary batch on the same stream
+    got = head + tail + enc.flush()
+    enc.close()
+    assert got == want
