@@ -370,6 +370,11 @@ enum { QWAVES = 7 };      /* the profiling counters take LDS: 7 waves keep two w
 #else
 enum { QWAVES = 8 };
 #endif
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
+enum { PROF_BYTES = 512 + 16 * 8192 };   /* + (start, end) of every wave of the last g_quant launch (100 MHz ticks): the launch's tail */
+#else
+enum { PROF_BYTES = 512 };
+#endif
 #ifndef LHIP_PHASE_PROF
 // two workgroups must fit in the 160 KB of LDS of a CU, or occupancy silently halves
 static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
@@ -396,6 +401,9 @@ template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_
 #ifdef LHIP_PHASE_PROF
     L[wv].prof[threadIdx.x & 63] = 0;                 // per-wave cycle sums, flushed once at the end (a flush per frame would
 #endif                                                // itself congest the memory pipeline it is trying to observe)
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
+    const unsigned long long wave_t0_ = wall_clock64();
+#endif
     int hint[3] = {-1, -1, -1};                       // stream and bin-search results of this wave's previous frame (kb_quant: speculation seed)
     for (;;) {
         const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
@@ -405,6 +413,12 @@ template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_
     }
 #ifdef LHIP_PHASE_PROF
     atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
+#endif
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
+    {
+        const int wid = blockIdx.x * QWAVES + wv;
+        if ((threadIdx.x & 63) == 0 && wid < 8192) { A->W.prof[64 + 2 * wid] = wave_t0_; A->W.prof[64 + 2 * wid + 1] = wall_clock64(); }
+    }
 #endif
 }
 // Latency path for small stereo batches: one workgroup of two waves per frame, one wave per channel (kb_quant<1>).  A single
@@ -1029,7 +1043,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(fht, Cp == 4 ? (size_t)ngs * 2 * FHT_STRIDE * 4 : 64); ENS(hpf, Cp == 4 ? (size_t)ngs * 2 * 576 * 4 : 64); ENS(tot_ener, (size_t)ngs * 4 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
     ENS(seed_flag, FR * 4); ENS(reval, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
-    ENS(prof, 512);
+    ENS(prof, PROF_BYTES);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
     W.pcm = (float*)ctx->pcm.p;
@@ -1090,7 +1104,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (!rt::dzero(ctx->reval.p, FR * 4, st)) return false;
     if (resv && !rt::dzero(ctx->out_bytes.p, (size_t)S * 4, st)) return false;
     if (!rt::dzero(ctx->nflagged.p, 256, st)) return false;
-    if (!rt::dzero(ctx->prof.p, 512, st)) return false;
+    if (!rt::dzero(ctx->prof.p, PROF_BYTES, st)) return false;
     const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ctx->desc.p + o_sd);
     const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ctx->desc.p + o_io);
     W.io = dIO;
@@ -1506,28 +1520,35 @@ enum { HOST_CHUNK_FRAMES = 8192 };
 // to a cap -- a chunk's copy still fits inside the encode of the chunk before it, and large chunks keep the persistent quantization
 // kernel's waves busy (at 8192 frames a wave draws two frames and every launch ends on its slowest one: 1e5 stereo frames took 72.5 ms
 // in 8192-frame chunks, 58.3 ms with 8192 doubling to 32768, 60.0 ms as one batch with nothing overlapped; tests/tools/dropin_sweep.py).
-// LAMEJS_HIP_HOST_CHUNK_FRAMES=first[,cap] overrides (tuning).
-static void host_chunk_schedule(size_t* first, size_t* cap) {
-    static size_t f = 0, c = 0;
+// Two-channel streams take chunks of twice the frames (a stereo frame is four to five times the work of a mono frame, so a chunk's fixed
+// costs -- the launch tails -- weigh the same at twice the size, and its copy hides as well): 16384 doubling to 65536 measured 52.0 ms
+// against 53.8 ms with the mono schedule on the final code of round 3, mono the other way round (11.96 vs 12.52 ms;
+// profiles/r03_dropin_host_chunk_sweep.txt).  LAMEJS_HIP_HOST_CHUNK_FRAMES=first[,cap[,growth]] overrides both (tuning).
+static void host_chunk_schedule(int channels, size_t* first, size_t* cap, size_t* growth) {
+    static size_t f = 0, c = 0, g = 2; static bool fixed = false;
     if (!f) {
         size_t a = 8192, b2 = 32768;
         if (const char* e = getenv("LAMEJS_HIP_HOST_CHUNK_FRAMES")) {
             char* end = nullptr;
             const unsigned long v = strtoul(e, &end, 10);
-            if (v >= 64 && v <= (1ul << 20)) { a = v; b2 = v; }
-            if (end && *end == ',') { const unsigned long w = strtoul(end + 1, nullptr, 10); if (w >= a && w <= (1ul << 20)) b2 = w; }
+            if (v >= 64 && v <= (1ul << 20)) { a = v; b2 = v; fixed = true; }
+            if (end && *end == ',') {
+                const unsigned long w = strtoul(end + 1, &end, 10); if (w >= a && w <= (1ul << 20)) b2 = w;
+                if (end && *end == ',') { const unsigned long gr = strtoul(end + 1, nullptr, 10); if (gr >= 2 && gr <= 8) g = gr; }
+            }
         }
         c = b2; f = a;
     }
-    *first = f; *cap = c;
+    const size_t mul = (!fixed && channels == 2) ? 2 : 1;
+    *first = f * mul; *cap = c * mul; *growth = g;
 }
 static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> chunk_lk(ctx->chunk_mu);
     const Tables& T = s->ts->T;
     const int C = T.channels_out;
-    size_t first_frames, cap_frames;
-    host_chunk_schedule(&first_frames, &cap_frames);
+    size_t first_frames, cap_frames, growth;
+    host_chunk_schedule(C, &first_frames, &cap_frames, &growth);
     const size_t spf = (size_t)576 * T.mode_gr * T.rs_ratio;             // input samples per frame
     const size_t chunk = cap_frames * spf;                                // the largest chunk: what the staging halves are sized for
     // the whole call must fit the caller's buffer BEFORE anything is consumed (a failed call consumes nothing)
@@ -1566,7 +1587,8 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
     size_t p0 = 0, cur = first_frames * spf;
     for (size_t k = 0; p0 < nsamples; k++) {
         const int par = (int)(k & 1);
-        const size_t m = nsamples - p0 < cur ? nsamples - p0 : cur;
+        size_t m = nsamples - p0 < cur ? nsamples - p0 : cur;
+        if (nsamples - p0 - m < m / 4 && nsamples - p0 <= chunk) m = nsamples - p0;     // no short chunk at the end: a launch for a few frames costs a whole tail
         int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * chunk;
         // buffer `par` was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
         // (copies straight from the caller's pageable memory: measured as fast as copies through pinned staging filled by four host
@@ -1582,7 +1604,7 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         pending_bytes = jobs[0].written; pending_dst = out + total; pending_par = par; have_pending = true;
         total += jobs[0].written; frames_all += g_stat_frames;
         p0 += m;
-        cur = 2 * cur < chunk ? 2 * cur : chunk;
+        cur = growth * cur < chunk ? growth * cur : chunk;
     }
     if (!drain()) return fail("copying a chunk's output failed");
     g_stat_frames = frames_all;                    // lhip_last_batch_stats: frames of the whole call, repair counters of its last chunk
@@ -1823,7 +1845,7 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
         case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ctx->lastC * sizeof(GrSide); break;
         case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;
         case 6: src = W.peaks; n = GC * PK_STRIDE * 4; break;
-        case 7: src = W.prof; n = 512; break;
+        case 7: src = W.prof; n = PROF_BYTES; break;
         default: set_err("unknown tap"); return LHIP_ERR_INTERNAL;
     }
     if (n > cap) n = cap;

@@ -25,8 +25,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
         if rep > 0 and (best is None or dt < best): best = dt
     print(json.dumps({"ch": ch, "ms": round(best * 1e3, 2), "frames_per_s": round((nfr - 1) / best), "md5": hashlib.md5(hout[:nb].tobytes()).hexdigest()}))
 else:
-    for envs in ({}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "8192,65536"}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "16384,65536"}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "16384,131072"},
-                 {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "32768,131072"}, {"LAMEJS_HIP_NO_HOST_CHUNKS": "1"}):
+    for envs in ({}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "8192,32768"}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "8192,131072,4"}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "16384,131072,4"},
+                 {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "4096,65536,4"}, {"LAMEJS_HIP_HOST_CHUNK_FRAMES": "8192,65536,3"}):
         for ch in (2, 1):
             r = subprocess.run([sys.executable, __file__, "one", str(ch)], env=dict(os.environ, **envs), capture_output=True, text=True, timeout=300)
             print(envs, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
