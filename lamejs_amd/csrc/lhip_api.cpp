@@ -33,6 +33,12 @@ using namespace lhip;
 // ===========================================================================================
 static thread_local std::string g_err;
 static thread_local int64_t g_stat_frames = 0, g_stat_repaired = 0, g_stat_iters = 0;
+// profiling counters of the dev builds (tests/tools/phase_prof.py, wave_tail.py); the product only allocates and zeroes them
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
+enum { PROF_BYTES = 512 + 16 * 8192 };   /* + (start, end) of every wave of the last g_quant launch (100 MHz ticks): the launch's tail */
+#else
+enum { PROF_BYTES = 512 };
+#endif
 struct Context;
 static thread_local Context* g_stat_pending = nullptr;      // the last batch was enqueued without synchronisation: its repair statistics are still on the device
 static void set_err(const std::string& e) { g_err = e; }
@@ -369,11 +375,6 @@ __global__ __launch_bounds__(64) void g_mdct(Tables T, Workspace W, const Stream
 enum { QWAVES = 7 };      /* the profiling counters take LDS: 7 waves keep two workgroups per CU */
 #else
 enum { QWAVES = 8 };
-#endif
-#if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
-enum { PROF_BYTES = 512 + 16 * 8192 };   /* + (start, end) of every wave of the last g_quant launch (100 MHz ticks): the launch's tail */
-#else
-enum { PROF_BYTES = 512 };
 #endif
 #ifndef LHIP_PHASE_PROF
 // two workgroups must fit in the 160 KB of LDS of a CU, or occupancy silently halves
