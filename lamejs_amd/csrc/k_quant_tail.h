@@ -1,0 +1,232 @@
+// k_quant_tail.h -- EXPERIMENT, compiled only with -DLHIP_TAIL_HELP (the shipped library does not contain it).
+//
+// What it is for: a launch of the persistent quantization kernel ends with ~2 ms in which waves leave one by one (a two-channel frame is
+// 1.5-2 ms of one wave; measured: 1.29 ms of idle per wave and launch, profiles/r03_quant_wave_tail.txt).  Here a wave that finds the frame
+// dispenser empty stays and HELPS the waves of its workgroup that are still inside a frame: every owner offers the second channel of the
+// granule it is starting (the channels of a granule are independent given the granule's bit budget -- the reference's loop order,
+// Quantize.js:1406-1466, does channel 0 then channel 1 with nothing passing between them but the reservoir count afterwards) in a per-
+// workgroup table in LDS; a helper claims an offer, quantizes that granule-channel on its own LDS record and hands back the bits it used,
+// the next bin-search seed and the block type; an offer nobody has claimed when the owner has finished channel 0 is withdrawn and the owner
+// does channel 1 itself -- the worst case is the serial order of kb_quant.  Which wave quantizes a granule-channel is not observable in the
+// output: the unit is a pure function of (frame, granule, channel, seed, target bits) and the global records it writes are the same.
+//
+// State of an offer: 0 none, 1 open, 2 claimed, 3 done.  Owner: fields, release, 1 ... CAS(1 -> 0) withdraws; else wait for 3, read, 0.
+// Helper: CAS(1 -> 2), acquire, unit, results, release, 3.  Helpers leave when no wave of the workgroup can draw a frame any more.
+// Tested in the 64-lane simulation as a real 8-wave workgroup (tests/hostsim: liblamejs_wavesim_tailhelp.so); not yet measured on the GPU.
+#pragma once
+namespace lhip {
+
+struct TailOffer { int state, fslot, gr, mode_ext, targ, seed_start, seed_step, gr0_bt, bits, next_start, next_step, block_type, active, pad_[3]; };
+struct TailShare { int drawing, pad_[3]; TailOffer offer[8]; };
+
+#if defined(LHIP_WAVESIM)
+// how often each way was taken (printed at exit with LAMEJS_TAILHELP_STATS=1: the simulation must exercise both)
+struct TailStats { long claimed = 0, withdrawn = 0; ~TailStats() { if (getenv("LAMEJS_TAILHELP_STATS")) fprintf(stderr, "tail-help: %ld granule-channels by helpers, %ld offers withdrawn\n", claimed, withdrawn); } };
+inline TailStats& tail_stats() { static TailStats t; return t; }
+#define LHIP_TAIL_COUNT(f) do { if (lane == 0) tail_stats().f++; } while (0)
+// lane fibers run one at a time and only switch at wave primitives: plain accesses are atomic; wave_bcast is the switch point that lets the
+// other waves of the workgroup run while this one polls
+LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) { r = *p; if (r == expect) *p = desired; } return wave_bcast(r, 0); }
+LHIP_DEV int wg_load(const int* p, int lane) { int r = 0; if (lane == 0) r = *(const volatile int*)p; return wave_bcast(r, 0); }
+LHIP_DEV void wg_store(int* p, int v, int lane) { wave_sync(); if (lane == 0) *(volatile int*)p = v; wave_sync(); }
+LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) *p += v; wave_sync(); }
+LHIP_DEV void wg_idle() { wave_sync(); }
+LHIP_DEV void wg_acquire() { wave_sync(); }
+#else
+LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) r = atomicCAS(p, expect, desired); return __builtin_amdgcn_readfirstlane(r); }
+LHIP_DEV int wg_load(const int* p, int lane) { (void)lane; return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wave wrote to LDS before is visible to a wave that sees v
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
+LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
+LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#define LHIP_TAIL_COUNT(f) do { } while (0)
+#endif
+
+// One granule-channel of a frame, from the spectrum to the published record: init_outer_loop .. best_huffman_divide (the body of the
+// reference's per-channel loop, Quantize.js:1406-1466 CBR_iteration_loop + iteration_finish_one) on the calling wave's LDS record.
+// `used` = the bin-search seed, `gr0_bt` = this channel's block type in granule 0 (scfsi); L.sf_gr0[ch] is written by granule 0 and read
+// by granule 1 of the same channel.  Returns the bits spent (part2_3 + part2), the seed the next granule of this channel starts from
+// (valid if `active`) and the block type.
+struct UnitOut { int bits; Seed next; int block_type; int active; };
+#if defined(LHIP_TAIL_NOINLINE) && !defined(LHIP_HOSTSIM)
+#define LHIP_UNIT_FN __device__ __attribute__((noinline))     /* one copy of the unit's code for the owner's and the helper's call site */
+#else
+#define LHIP_UNIT_FN LHIP_DEV
+#endif
+LHIP_UNIT_FN UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
+                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q) {
+    UnitOut u; u.next = used;
+    GI g;
+    const int bt = W.blocktype[(int64_t)gslot * C + ch];
+    const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
+    const float* ratio = W.E + ((int64_t)(gslot - 1) * Cp + ch + mode_ext) * E_STRIDE;   // thresholds of the previous psy call (mid / side: channels 2, 3)
+    { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, xr_source(W, C, gslot, ch, mode_ext == 2), mode_ext == 2 ? nullptr : W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
+    int active = 0, bs_gain = 0;
+    if (q_init_xrpow(g, lane, L, Q)) {
+        active = 1;
+        { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
+        int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+        q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, lane, L, Q);
+        uni_gi(g); bs_gain = uni(bs_gain);
+        wave_sync();                                    // the kept spectrum was written by other lanes of this wave
+#if LHIP_NL == 1
+        for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
+#else
+        {   // all of a lane's words in flight at once (a lane-strided loop waits for every load by itself)
+            uint32_t kw[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)kept)[i < 288 ? i : 287]; }
+#pragma unroll
+            for (int j = 0; j < NPL; j++) LHIP_PIN_LOADED(kw[j]);
+#pragma unroll
+            for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
+        }
+#endif
+        wave_sync();
+        Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
+        u.next = nx;
+    } else {
+        for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = 0;
+        wave_sync();
+    }
+    int scfsi[4];
+    { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt, scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
+    uni_gi(g);
+    if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
+    uni_gi(g);
+    u.bits = g.part2_3_length + g.part2_length;
+    u.block_type = g.block_type;
+    if (gr == 0) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i]; }
+    // ---- publish the record and the signed quantized spectrum ----
+    GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
+    if (lane == 0) {
+        out->part2_3_length = g.part2_3_length; out->part2_length = g.part2_length; out->big_values = g.big_values;
+        out->count1 = g.count1; out->global_gain = g.global_gain; out->scalefac_compress = g.scalefac_compress;
+        out->block_type = g.block_type;
+        for (int i = 0; i < 3; i++) { out->table_select[i] = g.table_select[i]; out->subblock_gain[i] = g.subblock_gain[i]; }
+        out->region0_count = g.region0_count; out->region1_count = g.region1_count; out->preflag = g.preflag;
+        out->scalefac_scale = g.scalefac_scale; out->count1table_select = g.count1table_select;
+        out->sfbmax = g.sfbmax; out->sfbdivide = g.sfbdivide;
+        out->active = active; out->bs_start = used.start; out->bs_step_in = used.step; out->bs_gain = bs_gain;
+        out->targ_bits = targ_ch;
+        out->mode_ext = mode_ext;
+        out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
+    }
+    LHIP_LANE_ONCE(i, 0, SFBMAX) out->scalefac[i] = L.sfb[i];
+    if (!active && lane == 0) { out->bs_ntab = 0; out->bs_state = 0; }
+    int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+    for (int i = lane; i < 576; i += LHIP_NL) {
+        const int v = L.ixw[i];
+        l3o[i] = (int16_t)(((double)L.xr[i] < 0) ? -v : v);
+    }
+    wave_sync();
+    u.active = active;
+    return u;
+}
+
+// kb_quant for the persistent kernel's speculative pass (chain == 0, no reservoir) with the second channel of every granule on offer
+LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot, int lane, QuantLds& L,
+                          const QuantTabs& Q, int* hint, TailShare& TS, int wv) {
+    const int C = T.channels_out;
+    const int st = W.fslot_stream[fslot];
+    const StreamDesc sd = SD[st];
+    const int k = fslot - sd.fslot0 - 1;
+    if (k < 0) return;
+    const int fidx = sd.out_slot0 + k;
+    const double ath_adjust = W.ath_adjust[fslot];
+    const int padding = frame_padding(T, sd, k);
+    const int mean_bits = (frame_bits_of(T, padding) - T.sideinfo_len * 8) / T.mode_gr;
+    Seed seed0, seed1;
+    seed0.start = seed1.start = W.spec_start; seed0.step = seed1.step = W.spec_step;
+    if (k == 0) {
+        seed0 = seed_before(W, sd, C, k, 0, 0);
+        if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
+    } else if (hint[0] == st) {
+        if (hint[1] >= 0) { seed0.start = hint[1]; seed0.step = 2; }
+        if (C > 1 && hint[2] >= 0) { seed1.start = hint[2]; seed1.step = 2; }
+    }
+    int gr0_bt0 = 0, gr0_bt1 = 0;
+    const int Cp = T.psy_channels;
+    const int mode_ext = (T.mode == 1) ? q_ms_decision(T, W, sd, k, lane, L) : 0;
+    int ResvSize = 0;
+    q_ath_pseudo(T, pb10, ath_adjust, lane, L, Q);
+    TailOffer& o = TS.offer[wv];
+    for (int gr = 0; gr < T.mode_gr; gr++) {
+        const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
+        int targ[2] = {0, 0};
+        const double max_bits = (double)targ_bits_for(T, mean_bits, gr, ResvSize, targ);
+        if (mode_ext == 2) {
+            const float* te = W.tot_ener + (int64_t)(gslot - 1) * 4;
+            double r = (double)te[2] + (double)te[3];
+            if (r > 0) r = (double)te[3] / r;
+            q_reduce_side(targ, r, mean_bits, max_bits);
+        }
+        const int targ0 = uni(targ[0]), targ1 = uni(targ[1]);
+        if (C == 2) {                                  // channel 1 of this granule: on offer while this wave does channel 0
+            if (lane == 0) { o.fslot = fslot; o.gr = gr; o.mode_ext = mode_ext; o.targ = targ1; o.seed_start = seed1.start; o.seed_step = seed1.step; o.gr0_bt = gr0_bt1; }
+            wg_store(&o.state, 1, lane);
+        }
+        for (int ch = 0; ch < C; ch++) {               // ONE call site of the unit (code size decides the instruction cache's behaviour here)
+            if (ch == 1 && wg_cas(&o.state, 1, 0, lane) != 1) {
+                // a helper has channel 1: wait for its results (it wrote this channel's gr0 scalefactors into L.sf_gr0[1])
+                while (wg_load(&o.state, lane) != 3) wg_idle();
+                wg_acquire();
+                const int bits = uni(o.bits), act = uni(o.active), ns = uni(o.next_start), nstep = uni(o.next_step), bt = uni(o.block_type);
+                if (act) { seed1.start = ns; seed1.step = nstep; }
+                ResvSize = uni(ResvSize - bits);
+                if (gr == 0) gr0_bt1 = bt;
+                wg_store(&o.state, 0, lane);
+                continue;
+            }
+            if (ch == 1) LHIP_TAIL_COUNT(withdrawn);   // nobody took it: the serial order
+            const UnitOut u = q_unit(T, pb10, W, C, Cp, fidx, gslot, gr, ch, mode_ext, ath_adjust, ch == 0 ? targ0 : targ1, ch == 0 ? seed0 : seed1,
+                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q);
+            if (u.active) { if (ch == 0) seed0 = u.next; else seed1 = u.next; }
+            ResvSize = uni(ResvSize - u.bits);
+            if (gr == 0) { if (ch == 0) gr0_bt0 = u.block_type; else gr0_bt1 = u.block_type; }
+        }
+    }
+    hint[0] = st; hint[1] = seed0.start; hint[2] = C > 1 ? seed1.start : -1;
+}
+
+// a wave that has found the dispenser empty: take open offers of the workgroup until no wave can draw a frame any more
+LHIP_DEV void tail_help(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int lane, QuantLds* Lall, int wv, int nwaves,
+                        const QuantTabs& Q, TailShare& TS) {
+    QuantLds& L = Lall[wv];
+    const int C = T.channels_out, Cp = T.psy_channels;
+    wg_add(&TS.drawing, -1, lane);
+    for (;;) {
+        int took = 0;
+        for (int w = 0; w < nwaves; w++) {
+            if (w == wv) continue;
+            TailOffer& o = TS.offer[w];
+            if (wg_load(&o.state, lane) != 1) continue;
+            if (wg_cas(&o.state, 1, 2, lane) != 1) continue;
+            wg_acquire();
+            took = 1;
+            LHIP_TAIL_COUNT(claimed);
+            const int fslot = uni(o.fslot), gr = uni(o.gr), mode_ext = uni(o.mode_ext), targ = uni(o.targ), gr0_bt = uni(o.gr0_bt);
+            Seed seed; seed.start = uni(o.seed_start); seed.step = uni(o.seed_step);
+            const int st = W.fslot_stream[fslot];
+            const StreamDesc sd = SD[st];
+            const int k = fslot - sd.fslot0 - 1, fidx = sd.out_slot0 + k, gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
+            const double ath_adjust = W.ath_adjust[fslot];
+            q_ath_pseudo(T, pb10, ath_adjust, lane, L, Q);
+            if (gr == 1) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[1][i] = Lall[w].sf_gr0[1][i]; }
+            wave_sync();
+            const UnitOut u = q_unit(T, pb10, W, C, Cp, fidx, gslot, gr, 1, mode_ext, ath_adjust, targ, seed, gr0_bt, lane, L, Q);
+            if (gr == 0) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) Lall[w].sf_gr0[1][i] = L.sf_gr0[1][i]; }
+            if (lane == 0) { o.bits = u.bits; o.active = u.active; o.next_start = u.next.start; o.next_step = u.next.step; o.block_type = u.block_type; }
+            wg_store(&o.state, 3, lane);
+        }
+        if (!took) {
+            if (wg_load(&TS.drawing, lane) <= 0) break;
+            wg_idle();
+        }
+    }
+}
+
+}  // namespace lhip

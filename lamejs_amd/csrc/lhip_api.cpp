@@ -13,6 +13,9 @@
 #include "k_psy.h"
 #include "k_fb.h"
 #include "k_quant.h"
+#ifdef LHIP_TAIL_HELP
+#include "k_quant_tail.h"      // experiment: not part of the shipped library
+#endif
 #include "k_bits.h"
 
 #include <string>
@@ -397,6 +400,13 @@ template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_
     __shared__ QuantLds L[QWAVES];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     q_load_tabs(A->T, Q, threadIdx.x, 64 * QWAVES);
+#ifdef LHIP_TAIL_HELP
+    __shared__ TailShare TS;
+    static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) + sizeof(TailShare) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
+    if (threadIdx.x == 0) TS.drawing = QWAVES;
+    if (threadIdx.x < QWAVES) TS.offer[threadIdx.x].state = 0;
+    const bool tail_help_on = !RESV && A->T.channels_out == 2;
+#endif
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef LHIP_PHASE_PROF
@@ -409,9 +419,17 @@ template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_
     for (;;) {
         const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
         if (fslot >= A->nfs) break;
+#ifdef LHIP_TAIL_HELP
+        // (the kernel is only launched for the speculative pass, chain == 0: one copy of the per-frame program in the code, not two)
+        if constexpr (!RESV) kb_quant_th(A->T, A->pb, A->W, A->SD, fslot, threadIdx.x & 63, L[wv], Q, hint, TS, wv);
+        else
+#endif
         kb_quant<0, RESV>(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q, -1, nullptr, nullptr, RESV ? nullptr : hint);
         hint[0] = __builtin_amdgcn_readfirstlane(hint[0]); hint[1] = __builtin_amdgcn_readfirstlane(hint[1]); hint[2] = __builtin_amdgcn_readfirstlane(hint[2]);
     }
+#ifdef LHIP_TAIL_HELP
+    if (tail_help_on) tail_help(A->T, A->pb, A->W, A->SD, threadIdx.x & 63, L, wv, QWAVES, Q, TS);
+#endif
 #ifdef LHIP_PHASE_PROF
     atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
 #endif
@@ -1197,6 +1215,24 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
                                else WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT)); } while (0)
 #else
 #define QUANT_RUN(chain_) WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
+#endif
+#if defined(LHIP_WAVESIM) && defined(LHIP_TAIL_HELP)
+        if (!pair && C == 2) {   // the persistent kernel as a real 8-wave workgroup: frames drawn from a shared counter, then the waves help each other (k_quant_tail.h)
+            static QuantLds LQ8[8]; static TailShare TS;
+            int ctr = 0;
+            TS.drawing = 8; for (int w = 0; w < 8; w++) TS.offer[w].state = 0;
+            wsim::run_block(8, [&](int wave_, int lane_) {
+                int hint[3] = {-1, -1, -1};
+                for (;;) {
+                    int f = 0;
+                    if (lane_ == 0) f = ctr++;
+                    f = wave_bcast(f, 0);
+                    if (f >= nfs) break;
+                    kb_quant_th(T, ts.pb10, W, dSD, f, lane_, LQ8[wave_], QT, hint, TS, wave_);
+                }
+                tail_help(T, ts.pb10, W, dSD, lane_, LQ8, wave_, 8, QT, TS);
+            });
+        } else
 #endif
         {   // the speculative pass as three "persistent waves" striding over the frame slots, each with its own seed hint -- what g_quant's
             // waves do with the frames they draw (kb_quant: `hint`), so that the simulations cover that path too

@@ -55,12 +55,12 @@ RESAMPLE_CFGS = [(1, 44100, 32), (2, 44100, 48), (1, 48000, 24), (2, 48000, 64),
                  (1, 48000, 40), (1, 48000, 8), (2, 48000, 40), (2, 32000, 40), (1, 32000, 24), (2, 16000, 24)]
 
 
-def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False, max_frames=260):
+def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False, max_frames=260, stereo_only=False, whole=False):
     """Returns the list of mismatching case descriptions (empty = parity).  joint: the joint-stereo extension on the two-channel
     configurations; the material (same draws as tests/tools/fuzz_ref.py joint) has strongly correlated channels in half of the cases."""
     rng = np.random.default_rng(seed)
     cfgs = cfgs or MPEG1_CFGS
-    if joint:
+    if joint or stereo_only:
         cfgs = [c for c in cfgs if c[0] == 2]
     bad = []
     t0 = time.time()
@@ -77,6 +77,8 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
         except lamejs_amd.LhipError as e:
             print("skip", ch, sr, kbps, str(e)[:60]); continue
         chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
+        if whole:
+            chunk = len(L)
         got = b"".join(enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk]) for p in range(0, len(L), chunk)) + enc.flush()
         enc.close()
         want = oracle_encode(ch, sr, kbps, L, R, joint=joint, reservoir=reservoir)
@@ -92,7 +94,8 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
 
 
 def main():
-    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim|wavesim] [joint] [reservoir] [short]
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim|wavesim|tailhelp] [joint] [reservoir] [short] [stereo] [whole]
+    stereo: two-channel configurations only; whole: every case in ONE encodeBuffer call (one batch of all its frames)
     wavesim: the 64-lane wave programs as fibers on the CPU (slow: use `short`, at most 40 frames per case)"""
     cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else LOWRATE_CFGS if "lowrate" in sys.argv[3:] else MPEG1_CFGS
     lib = None
@@ -100,8 +103,10 @@ def main():
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))
     if "wavesim" in sys.argv[3:]:
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim.so"))
+    if "tailhelp" in sys.argv[3:]:       # the 64-lane simulation with the tail-help experiment (make -C tests/hostsim tailhelp)
+        lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim_tailhelp.so"))
     bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs, joint="joint" in sys.argv[3:], reservoir="reservoir" in sys.argv[3:],
-              max_frames=40 if "short" in sys.argv[3:] else 260)
+              max_frames=40 if "short" in sys.argv[3:] else 260, stereo_only="stereo" in sys.argv[3:], whole="whole" in sys.argv[3:])
     sys.exit(1 if bad else 0)
 
 
