@@ -44,6 +44,14 @@ LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
 LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #define LHIP_TAIL_COUNT(f) do { } while (0)
 #endif
+// A poll loop that has gone round this often (seconds; a launch's tail is milliseconds) is a protocol or compiler bug: fault instead of
+// hanging the device (lhip_api.cpp, g_fixup: a dispenser loop nested in another loop has been miscompiled into an exec-masked loop on this
+// toolchain before -- the first device run of this file is exactly the kind of code that can find the next one).
+#if defined(LHIP_HOSTSIM)
+#define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 34)) abort(); } while (0)
+#else
+#define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 24)) __builtin_trap(); } while (0)
+#endif
 
 // One granule-channel of a frame, from the spectrum to the published record: init_outer_loop .. best_huffman_divide (the body of the
 // reference's per-channel loop, Quantize.js:1406-1466 CBR_iteration_loop + iteration_finish_one) on the calling wave's LDS record.
@@ -172,7 +180,7 @@ LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace&
         for (int ch = 0; ch < C; ch++) {               // ONE call site of the unit (code size decides the instruction cache's behaviour here)
             if (ch == 1 && wg_cas(&o.state, 1, 0, lane) != 1) {
                 // a helper has channel 1: wait for its results (it wrote this channel's gr0 scalefactors into L.sf_gr0[1])
-                while (wg_load(&o.state, lane) != 3) wg_idle();
+                { long spins = 0; while (wg_load(&o.state, lane) != 3) { wg_idle(); LHIP_SPIN_GUARD(spins); } }
                 wg_acquire();
                 const int bits = uni(o.bits), act = uni(o.active), ns = uni(o.next_start), nstep = uni(o.next_step), bt = uni(o.block_type);
                 if (act) { seed1.start = ns; seed1.step = nstep; }
@@ -198,6 +206,7 @@ LHIP_DEV void tail_help(const Tables& T, const PowBase& pb10, const Workspace& W
     QuantLds& L = Lall[wv];
     const int C = T.channels_out, Cp = T.psy_channels;
     wg_add(&TS.drawing, -1, lane);
+    long idle_rounds = 0;
     for (;;) {
         int took = 0;
         for (int w = 0; w < nwaves; w++) {
@@ -225,6 +234,7 @@ LHIP_DEV void tail_help(const Tables& T, const PowBase& pb10, const Workspace& W
         if (!took) {
             if (wg_load(&TS.drawing, lane) <= 0) break;
             wg_idle();
+            LHIP_SPIN_GUARD(idle_rounds);
         }
     }
 }
