@@ -12,7 +12,8 @@
 //
 // State of an offer: 0 none, 1 open, 2 claimed, 3 done.  Owner: fields, release, 1 ... CAS(1 -> 0) withdraws; else wait for 3, read, 0.
 // Helper: CAS(1 -> 2), acquire, unit, results, release, 3.  Helpers leave when no wave of the workgroup can draw a frame any more.
-// Tested in the 64-lane simulation as a real 8-wave workgroup (tests/hostsim: liblamejs_wavesim_tailhelp.so); not yet measured on the GPU.
+// Tested in the 64-lane simulation as a real 8-wave workgroup (tests/hostsim: liblamejs_wavesim_tailhelp.so); first device runs at the end of
+// round 3: output unchanged, step 45.6 -> 45.2 ms, host-buffer call 51.9 -> 50.8 ms (profiles/r03_tail_help_experiment_first_device_runs.txt).
 #pragma once
 namespace lhip {
 
