@@ -60,12 +60,8 @@ LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup
 // by granule 1 of the same channel.  Returns the bits spent (part2_3 + part2), the seed the next granule of this channel starts from
 // (valid if `active`) and the block type.
 struct UnitOut { int bits; Seed next; int block_type; int active; };
-#if defined(LHIP_TAIL_NOINLINE) && !defined(LHIP_HOSTSIM)
-#define LHIP_UNIT_FN __device__ __attribute__((noinline))     /* one copy of the unit's code for the owner's and the helper's call site */
-#else
-#define LHIP_UNIT_FN LHIP_DEV
-#endif
-LHIP_UNIT_FN UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
+// (behind a call -- one copy of this code for the owner's and the helper's call site -- the kernel was a third slower: spills around the call)
+LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
                         double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q) {
     UnitOut u; u.next = used;
     GI g;
