@@ -105,10 +105,10 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
 }
 
 static napi_value make_i8(napi_env env, const uint8_t* src, size_t n) {
-    napi_value ab, ta; void* data;
-    napi_create_arraybuffer(env, n, &data, &ab);
+    napi_value ab, ta; void* data = NULL;
+    if (napi_create_arraybuffer(env, n, &data, &ab) != napi_ok || (n && !data)) { napi_throw_error(env, NULL, "could not allocate the output buffer"); return NULL; }
     if (n) memcpy(data, src, n);
-    napi_create_typedarray(env, napi_int8_array, n, ab, 0, &ta);
+    if (napi_create_typedarray(env, napi_int8_array, n, ab, 0, &ta) != napi_ok) { napi_throw_error(env, NULL, "could not create the output Int8Array"); return NULL; }
     return ta;
 }
 
