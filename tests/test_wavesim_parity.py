@@ -170,12 +170,12 @@ def test_wavesim_tail_help_experiment():
     subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "tailhelp"], check=True, capture_output=True)
     code = ("import sys; sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s'); import lamejs_amd, fuzz_gpu\n"
             "lib = lamejs_amd.load_library(r'%s')\n"
-            "bad = fuzz_gpu.run(8, 4401, lib=lib, verbose=False, stereo_only=True, whole=True, max_frames=40)\n"
-            "bad += fuzz_gpu.run(6, 4402, lib=lib, verbose=False, joint=True, whole=True, max_frames=40)\n"
-            "bad += fuzz_gpu.run(6, 4403, lib=lib, verbose=False, cfgs=fuzz_gpu.LSF_CFGS, stereo_only=True, whole=True, max_frames=40)\n"
+            "bad = fuzz_gpu.run(5, 4401, lib=lib, verbose=False, stereo_only=True, whole=True, max_frames=40)\n"
+            "bad += fuzz_gpu.run(4, 4402, lib=lib, verbose=False, joint=True, whole=True, max_frames=40)\n"
+            "bad += fuzz_gpu.run(4, 4403, lib=lib, verbose=False, cfgs=fuzz_gpu.LSF_CFGS, stereo_only=True, whole=True, max_frames=40)\n"
             "print('BAD', bad)\n") % (ROOT, ROOT / "tests", ROOT / "tests" / "tools", ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim_tailhelp.so")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LAMEJS_TAILHELP_STATS="1"), timeout=900)
     assert r.returncode == 0 and "BAD []" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
     import re
     m = re.search(r"tail-help: (\d+) granule-channels by helpers, (\d+) offers withdrawn", r.stderr)
-    assert m and int(m.group(1)) > 20 and int(m.group(2)) > 20, r.stderr[-500:]
+    assert m and int(m.group(1)) > 10 and int(m.group(2)) > 10, r.stderr[-500:]
