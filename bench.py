@@ -245,6 +245,19 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the MP3 bytes to rank 0 (N > 1)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` started plainly (no launcher, no WORLD_SIZE in the environment) launches its own N ranks: the same
+    # command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1, one rank per GPU.  Under a
+    # launcher (WORLD_SIZE set) nothing is re-launched and --gpus must agree with it.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -267,7 +280,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (start it plainly -- it launches its own ranks -- or with --nproc-per-node {args.gpus})")
     if sim:
         dev = torch.device("cpu")
         dev_ord = 0
@@ -561,21 +575,37 @@ def main():
             ent = table.get((p2["corpus"], p2["ch"], p2["kbps"], p2["frames"], p2["seed0"], False, False))
             dev_rate = line["value"] if k2 == key else others.get(f"config{k2}", {}).get("value")
             others[nm] = {"workload": f"ONE lhip_encode call, host Int16 buffers in pageable memory, {'stereo' if p2['ch'] == 2 else 'mono'} 44.1kHz {p2['kbps']}kbps, {p2['frames']} frames; "
-                                      "H2D + encode + D2H inside the clock (chunks of 8192 frames, copies overlapped with the encode of the chunk before)",
+                                      "H2D + encode + D2H inside the clock (chunks of 8192 frames doubling to 32768 -- twice that for two channels --, copies overlapped with the encode of the chunk before)",
                           "value": round((p2["frames"] - 1) / best, 1), "unit": "frames/s", "ms_per_call": round(1000.0 * best, 3),
                           "bit_exact_full": (None if ent is None else bool(ent[0] == hashlib.md5(whole).hexdigest() and ent[1] == len(whole))),
                           "vs_device_resident": (None if not dev_rate else round((p2["frames"] - 1) / best / dev_rate, 3))}
+        # ---- the mandated JavaScript surface: Mp3Encoder.encodeBuffer under Node (N-API addon; the library writes into the returned array),
+        # median of 5 calls after a full-size warm-up, and BASELINE configs[4]'s per-GPU share through encodeBatch
         node = __import__("shutil").which("node")
         if node and (ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node").exists():
             import subprocess
+            tool = str(ROOT / "tests" / "tools" / "bench_dropin.js")
+            for nm, k2, argv in (("dropin_node", 3, ["sine", "2", "128", "100000", "12345"]), ("dropin_node_mono", 2, ["sine", "1", "128", "100000", "12345"])):
+                try:
+                    r_ = subprocess.run([node, tool] + argv, capture_output=True, text=True, timeout=300)
+                    e = json.loads(r_.stdout.strip().splitlines()[-1])
+                    ent = table.get(("sine", int(argv[1]), 128, 100000, 12345, False, False))
+                    e["bit_exact_full"] = None if ent is None else bool(ent[0] == e["md5_encode_buffer"] and ent[1] == e["bytes_encode_buffer"])
+                    host = others.get("dropin_host" if k2 == 3 else "dropin_host_mono", {}).get("value")
+                    e["vs_c_abi_host_call"] = None if not host else round(e["frames_per_s"] / host, 3)
+                    others[nm] = e
+                except Exception as ex:      # the JavaScript surface is optional on a box without node
+                    others[nm] = {"error": (str(ex) + " " + (r_.stderr[-200:] if "r_" in dir() else ""))[:400]}
             try:
-                r_ = subprocess.run([node, str(ROOT / "tests" / "tools" / "bench_dropin.js"), "sine", "2", "128", "100000", "12345"], capture_output=True, text=True, timeout=300)
+                r_ = subprocess.run([node, tool, "batch", "128", "1000", "1000"], capture_output=True, text=True, timeout=300)
                 e = json.loads(r_.stdout.strip().splitlines()[-1])
-                ent = table.get(("sine", 2, 128, 100000, 12345, False, False))
-                e["bit_exact_full"] = None if ent is None else bool(ent[0] == e["md5_encode_buffer"] and ent[1] == e["bytes_encode_buffer"])
-                others["dropin_node"] = e
-            except Exception as ex:      # the JavaScript surface is optional on a box without node
-                others["dropin_node"] = {"error": str(ex)[:200]}
+                ents = [table.get(("sine", 1, 128, 1000, sd_, False, False)) for sd_ in e["seeds"]]
+                e["bit_exact_full"] = None if any(x is None for x in ents) else bool(all(x[0] == m_ and x[1] == b_ for x, m_, b_ in zip(ents, e["md5_encode_buffer"], e["bytes_encode_buffer"])))
+                for k_ in ("seeds", "md5_encode_buffer", "bytes_encode_buffer", "bytes_flush"):
+                    e.pop(k_, None)
+                others["dropin_node_batch"] = e
+            except Exception as ex:
+                others["dropin_node_batch"] = {"error": str(ex)[:300]}
         line["other_configs"] = others
 
     if rank == 0 and args.cpu_seconds > 0 and world == 1:       # the CPU baseline is reported at N = 1 only

@@ -107,6 +107,12 @@ void lhip_destroy(lhip_stream* s);
 /* Upper bound of the bytes lhip_encode can return for nsamples more samples on this stream. */
 size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples);
 
+/* Exactly the bytes the next lhip_encode(s, ..., nsamples, ...) will return: under CBR without the bit reservoir the frame sizes follow
+ * from the sample count and the padding accumulator alone, so a binding can allocate the returned array at its final size and let the
+ * library write into it -- no second buffer, no copy (the reference allocates a fresh exact-size Int8Array per call, index.js:129).
+ * With the bit reservoir (extension) the count is data-dependent and this returns lhip_max_output_bytes().  < 0: bad handle. */
+int64_t lhip_encode_output_bytes(const lhip_stream* s, size_t nsamples);
+
 /* Batch extension (BASELINE config 5: many independent streams, one launch): stream i receives
  * nsamples[i] samples from left[i]/right[i] and its frames are written to out[i] (capacity
  * out_cap[i]); written[i] receives the byte count or a negative code.  All streams must share one

@@ -58,6 +58,8 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     lib.lhip_destroy.argtypes = [ctypes.c_void_p]
     lib.lhip_max_output_bytes.restype = ctypes.c_size_t
     lib.lhip_max_output_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.lhip_encode_output_bytes.restype = ctypes.c_int64
+    lib.lhip_encode_output_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     for name in ("lhip_encode_batch", "lhip_flush_batch", "lhip_encode_batch_device"):
         getattr(lib, name).restype = ctypes.c_int
     lib.lhip_set_hip_stream.restype = ctypes.c_int
@@ -115,6 +117,7 @@ class Mp3Encoder:
         of a stream then form a serial chain, so only batches of many streams use the GPU well."""
         self._lib = lib or load_library()
         self.channels, self.samplerate, self.kbps = int(channels), int(samplerate), int(kbps)
+        self._resv = bool(reservoir)
         blob = tables_blob(self.channels, self.samplerate, self.kbps, joint, reservoir)
         cfg = _Config(self.channels, self.samplerate, self.kbps, device)
         h = ctypes.c_void_p()
@@ -169,11 +172,16 @@ class Mp3Encoder:
             raise ValueError("left/right length mismatch")
         if len(l) == 0:
             return b""
-        cap = self._lib.lhip_max_output_bytes(self._h, len(l))
+        # the N-API binding's protocol: the result array is allocated at lhip_encode_output_bytes() and written in place
+        cap = self._lib.lhip_encode_output_bytes(self._h, len(l))
+        if cap < 0:
+            raise LhipError(f"lhip_encode_output_bytes failed ({cap}): {self._lib.lhip_last_error().decode()}")
         out = np.empty(cap, dtype=np.uint8)
         n = self._lib.lhip_encode(self._h, l.ctypes.data, r.ctypes.data, len(l), out.ctypes.data, cap)
         if n < 0:
             raise LhipError(f"lhip_encode failed ({n}): {self._lib.lhip_last_error().decode()}")
+        if not self._resv and n != cap:      # exact without the bit reservoir: that is what lets a binding skip the copy
+            raise LhipError(f"lhip_encode returned {n} bytes, lhip_encode_output_bytes promised {cap}")
         return out[:n].tobytes()
 
     def flush(self) -> bytes:

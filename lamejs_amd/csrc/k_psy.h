@@ -792,8 +792,9 @@ LHIP_DEV int ma_index16(double ratio) {
     const float t = fast_log2f((float)ratio) * 4.81647993062369912f;
     const float k = __builtin_floorf(t);
     const float fr = t - k;
-    int i = (int)k;
-    if (fr < 2e-4f || fr > 1.0f - 2e-4f) i = -1;
+    // (written so that a ratio beyond Float32 or a NaN -- t infinite or NaN, fr NaN -- fails the test and takes the logarithm as well)
+    int i = -1;
+    if (fr >= 2e-4f && fr <= 1.0f - 2e-4f) i = (int)k;
 #ifdef LHIP_HOSTSIM
     if (i >= 0 && i != js_toint32(v8_log10_pos(ratio) * 16.0)) { fprintf(stderr, "hostsim: ma_index16 disagrees with the logarithm at %a\n", ratio); abort(); }
 #endif

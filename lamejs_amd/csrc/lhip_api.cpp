@@ -48,7 +48,9 @@ static void set_err(const std::string& e) { g_err = e; }
 
 #ifdef LHIP_HOSTSIM
 namespace rt {
-static int device_count() { return 1; }
+// LHIP_HOSTSIM_DEVICES=n (tests): the simulation pretends to have n devices -- one Context each, so that lhip_set_devices' round-robin
+// placement, lhip_stream_device and host threads batching on different contexts at the same time run in the CPU tier (ASan / TSan)
+static int device_count() { static const int n = []() { const char* e = getenv("LHIP_HOSTSIM_DEVICES"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }(); return n; }
 static bool set_device(int) { return true; }
 static void* dmalloc(size_t n) { return calloc(1, n ? n : 1); }
 static void dfree(void* p) { free(p); }
@@ -57,6 +59,12 @@ static bool d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); retu
 static bool d2d(void* d, const void* s, size_t n, void*) { memmove(d, s, n); return true; }
 static bool dzero(void* d, size_t n, void*) { memset(d, 0, n); return true; }
 static bool sync(void*) { return true; }
+// streams and events of the chunked host path: everything is synchronous here, so ordering holds trivially
+static bool stream_create(void** s) { *s = (void*)(uintptr_t)1; return true; }
+static bool event_create(void** e) { *e = (void*)(uintptr_t)1; return true; }
+static bool event_record(void*, void*) { return true; }
+static bool stream_wait_event(void*, void*) { return true; }
+static void* host_alloc_pinned(size_t n) { return calloc(1, n ? n : 1); }
 }  // namespace rt
 #else
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return false; } } while (0)
@@ -70,6 +78,11 @@ static bool d2h(void* d, const void* s, size_t n, void* st) { if (n) HIPCK(hipMe
 static bool d2d(void* d, const void* s, size_t n, void* st) { if (n) HIPCK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); return true; }
 static bool dzero(void* d, size_t n, void* st) { if (n) HIPCK(hipMemsetAsync(d, 0, n, (hipStream_t)st)); return true; }
 static bool sync(void* st) { HIPCK(hipStreamSynchronize((hipStream_t)st)); return true; }
+static bool stream_create(void** s) { hipStream_t t; HIPCK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); *s = t; return true; }
+static bool event_create(void** e) { hipEvent_t t; HIPCK(hipEventCreateWithFlags(&t, hipEventDisableTiming)); *e = t; return true; }
+static bool event_record(void* e, void* st) { HIPCK(hipEventRecord((hipEvent_t)e, (hipStream_t)st)); return true; }
+static bool stream_wait_event(void* st, void* e) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)e, 0)); return true; }
+static void* host_alloc_pinned(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 }  // namespace rt
 #endif
 
@@ -947,7 +960,7 @@ struct Context {
     // large host-buffer calls (the drop-in's encodeBuffer with a long Int16Array): chunks of the call are copied in on this stream
     // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
     void* copy_stream = nullptr; void* ev_in[2] = {nullptr, nullptr}; void* ev_done[2] = {nullptr, nullptr};
-    DevBuf chunk_in, chunk_out;
+    DevBuf chunk_in, chunk_out, chunk_fx, state_bak;     // staging halves (sized for the largest chunk a call has reached so far), the per-chunk repair verdicts, the stream state a failed call gives back
     std::mutex chunk_mu;        // one chunked call at a time per device (they share the two staging halves); taken BEFORE mu, never inside it
 };
 
@@ -1143,12 +1156,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
 #define WAVE_RUN(...) do { const int lane_ = 0; __VA_ARGS__; } while (0)
 #endif
-        static PsyALds LA; static PsyBLds4 LB; static MdctLds LM; static PolyLds LP; static QuantLds LQ; static BitsLds LBi; static QuantTabs QT;
+        // (thread_local: with LHIP_HOSTSIM_DEVICES > 1 host threads batch on different contexts at the same time)
+        static thread_local PsyALds LA; static thread_local PsyBLds4 LB; static thread_local MdctLds LM; static thread_local PolyLds LP; static thread_local QuantLds LQ; static thread_local BitsLds LBi; static thread_local QuantTabs QT;
         q_load_tabs(T, QT, 0, 1);
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = T.psy_channels == 4 ? 8 : 4;
-            static unsigned char UL[8][FR_LDS_PER_WAVE]; static int fmbox[4];
+            static thread_local unsigned char UL[8][FR_LDS_PER_WAVE]; static thread_local int fmbox[4];
             for (int s = 0; s < S; s++) {
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {
@@ -1176,16 +1190,16 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) kb_scan_attack(T, W, dSD, b);
         for (int b = 0; b < ngs; b++) kb_scan_blocktype(T, W, dSD, b);
 #ifdef LHIP_WAVESIM
-        { static AthLds LAth; for (int s = 0; s < S; s++) wsim::run_block(ATH_NT / 64, [&](int wave_, int lane_) { kb_scan_ath(T, W, dSD, s, 64 * wave_ + lane_, LAth); }); }
+        { static thread_local AthLds LAth; for (int s = 0; s < S; s++) wsim::run_block(ATH_NT / 64, [&](int wave_, int lane_) { kb_scan_ath(T, W, dSD, s, 64 * wave_ + lane_, LAth); }); }
 #else
-        { static AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
+        { static thread_local AthLds LAth; for (int s = 0; s < S; s++) kb_scan_ath(T, W, dSD, s, 0, LAth); }
 #endif
         if (!resv) for (int b = 0; b < ngs; b++) WAVE_RUN(kb_psyB<4>(T, ts.pb10, W, dSD, b, lane_, LB, -1));
         for (int b = 0; b < (ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE; b++) WAVE_RUN(kb_polyphase(T, W, dSD, dIO, b, ngs * C, lane_, LP));
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
         if (resv) {
             // the per-stream reservoir program (kb_resv_stage), as g_resv_stream runs it; the wave simulation as a real workgroup of four waves
-            static unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static int rmbox[4];
+            static thread_local unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static thread_local int rmbox[4];
             for (int s = 0; s < S; s++) {
                 ResvState RV = dIO[s].state->rv;
                 int32_t nout = 0;
@@ -1208,7 +1222,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         } else {
 #ifdef LHIP_WAVESIM
         // small stereo batches: the two-waves-per-frame latency kernel (kb_quant<1>), as run_batch chooses on the device
-        static QuantLds LQ2[2]; static int mbox[4];
+        static thread_local QuantLds LQ2[2]; static thread_local int mbox[4];
         static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : 12; }();
         const bool pair = (C == 2 && nfs <= pair_max);
 #define QUANT_RUN(chain_) do { if (pair) wsim::run_block(2, [&](int wave_, int lane_) { kb_quant<1, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ2[wave_], QT, wave_, mbox); }); \
@@ -1524,6 +1538,13 @@ size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples) {
     return (nsamples / frame + 3 + (FRAME / frame)) * (size_t)(s->ts->base_frame_bytes + 1) + (s->ts->T.disable_reservoir ? 0 : 4096);      // reservoir: slack for the per-launch bound
 }
 
+static int call_frames(const lhip_stream* s, size_t nsamples);
+int64_t lhip_encode_output_bytes(const lhip_stream* s, size_t nsamples) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    if (!s->ts->T.disable_reservoir) return (int64_t)lhip_max_output_bytes(s, nsamples);      // data-dependent: only a bound exists
+    return batch_bytes(*s->ts, s->slot_lag, call_frames(s, nsamples));
+}
+
 static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,
                        const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync, bool flush_stream = false) {
     if (n == 0) return 0;
@@ -1551,7 +1572,6 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
 // and the bytes of chunk k - 1 travel back -- PCIe needs about a sixth of the encode time, so it hides behind it.  Any chunking of a
 // sample stream gives the same bytes (the library's basic contract), so the result is what one batch gives.  Not for the bit
 // reservoir (its byte counts are only known after each launch).
-#ifndef LHIP_HOSTSIM
 enum { HOST_CHUNK_FRAMES = 8192 };
 // chunk schedule: the first chunk is small (its copy is the part of the call nothing overlaps), every later one twice the one before up
 // to a cap -- a chunk's copy still fits inside the encode of the chunk before it, and large chunks keep the persistent quantization
@@ -1560,106 +1580,148 @@ enum { HOST_CHUNK_FRAMES = 8192 };
 // Two-channel streams take chunks of twice the frames (a stereo frame is four to five times the work of a mono frame, so a chunk's fixed
 // costs -- the launch tails -- weigh the same at twice the size, and its copy hides as well): 16384 doubling to 65536 measured 52.0 ms
 // against 53.8 ms with the mono schedule on the final code of round 3, mono the other way round (11.96 vs 12.52 ms;
-// profiles/r03_dropin_host_chunk_sweep.txt).  LAMEJS_HIP_HOST_CHUNK_FRAMES=first[,cap[,growth]] overrides both (tuning).
-static void host_chunk_schedule(int channels, size_t* first, size_t* cap, size_t* growth) {
-    static size_t f = 0, c = 0, g = 2; static bool fixed = false;
-    if (!f) {
-        size_t a = 8192, b2 = 32768;
+// profiles/r03_dropin_host_chunk_sweep.txt).  LAMEJS_HIP_HOST_CHUNK_FRAMES=first[,cap[,growth]] overrides both (tuning, tests).
+struct ChunkSchedule { size_t first = HOST_CHUNK_FRAMES, cap = 4 * HOST_CHUNK_FRAMES, growth = 2; bool fixed = false; };
+static const ChunkSchedule& host_chunk_schedule() {
+    static const ChunkSchedule cs = []() {           // read once (function-local static: initialised exactly once, whichever thread comes first)
+        ChunkSchedule c;
         if (const char* e = getenv("LAMEJS_HIP_HOST_CHUNK_FRAMES")) {
             char* end = nullptr;
             const unsigned long v = strtoul(e, &end, 10);
-            if (v >= 64 && v <= (1ul << 20)) { a = v; b2 = v; fixed = true; }
+            if (v >= 1 && v <= (1ul << 20)) { c.first = v; c.cap = v; c.fixed = true; }
             if (end && *end == ',') {
-                const unsigned long w = strtoul(end + 1, &end, 10); if (w >= a && w <= (1ul << 20)) b2 = w;
-                if (end && *end == ',') { const unsigned long gr = strtoul(end + 1, nullptr, 10); if (gr >= 2 && gr <= 8) g = gr; }
+                const unsigned long w = strtoul(end + 1, &end, 10); if (w >= c.first && w <= (1ul << 20)) c.cap = w;
+                if (end && *end == ',') { const unsigned long gr = strtoul(end + 1, nullptr, 10); if (gr >= 2 && gr <= 8) c.growth = gr; }
             }
         }
-        c = b2; f = a;
-    }
-    const size_t mul = (!fixed && channels == 2) ? 2 : 1;
-    *first = f * mul; *cap = c * mul; *growth = g;
+        return c;
+    }();
+    return cs;
+}
+// whole frames (and their bytes: exact without the bit reservoir) that a call with `nsamples` more input samples completes on this stream
+static int call_frames(const lhip_stream* s, size_t nsamples) {
+    const Tables& T = s->ts->T;
+    const int frame = 576 * T.mode_gr, mf_needed = 1024 + frame - 272;
+    const int64_t n_out = T.rs_ratio == 1 ? (int64_t)nsamples : rs_outputs(s->rs_n_in + (int64_t)nsamples, T.rs_ratio) - rs_outputs(s->rs_n_in, T.rs_ratio);
+    const int64_t total = (int64_t)s->mf_size + n_out;
+    return total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
 }
 static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> chunk_lk(ctx->chunk_mu);
     const Tables& T = s->ts->T;
     const int C = T.channels_out;
-    size_t first_frames, cap_frames, growth;
-    host_chunk_schedule(C, &first_frames, &cap_frames, &growth);
+    const ChunkSchedule& cfg = host_chunk_schedule();
+    const size_t mul = (!cfg.fixed && C == 2) ? 2 : 1;
     const size_t spf = (size_t)576 * T.mode_gr * T.rs_ratio;             // input samples per frame
-    const size_t chunk = cap_frames * spf;                                // the largest chunk: what the staging halves are sized for
     // the whole call must fit the caller's buffer BEFORE anything is consumed (a failed call consumes nothing)
+    if ((size_t)batch_bytes(*s->ts, s->slot_lag, call_frames(s, nsamples)) > out_cap) { set_err("output buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
+    // ---- this call's chunks (samples per channel each); the staging halves are sized for the largest one the call really reaches
+    std::vector<size_t> sched;
+    size_t stride = 0;
     {
-        const int frame = 576 * T.mode_gr, mf_needed = 1024 + frame - 272;
-        const int64_t n_out = T.rs_ratio == 1 ? (int64_t)nsamples : rs_outputs(s->rs_n_in + (int64_t)nsamples, T.rs_ratio) - rs_outputs(s->rs_n_in, T.rs_ratio);
-        const int64_t total = (int64_t)s->mf_size + n_out;
-        const int F = total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
-        if ((size_t)batch_bytes(*s->ts, s->slot_lag, F) > out_cap) { set_err("output buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
+        const size_t cap = cfg.cap * mul * spf;
+        size_t p = 0, cur = cfg.first * mul * spf;
+        while (p < nsamples) {
+            size_t m = nsamples - p < cur ? nsamples - p : cur;
+            if (nsamples - p - m < m / 4 && nsamples - p <= cap) m = nsamples - p;     // no short chunk at the end: a launch for a few frames costs a whole tail
+            sched.push_back(m);
+            if (m > stride) stride = m;
+            p += m;
+            cur = cfg.growth * cur < cap ? cfg.growth * cur : cap;
+        }
+        stride = (stride + 63) & ~(size_t)63;
     }
+    const size_t out_chunk = (((stride / spf + 3) * (size_t)(s->ts->base_frame_bytes + 1) + 64) + 63) & ~(size_t)63;
+    // what a failed call must give back: the host-side counters and the device-side state record (a call that fails in chunk k > 0 would
+    // otherwise leave the stream k chunks further on with `out` half written -- "a failed call consumes nothing" has to hold here too)
+    const int snap_mf = s->mf_size, snap_ste = s->mf_samples_to_encode, snap_lag = s->slot_lag;
+    const int64_t snap_fn = s->frame_num, snap_rs = s->rs_n_in;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (!rt::set_device(ctx->device)) return LHIP_ERR_INTERNAL;
         if (!ctx->copy_stream) {
-            hipStream_t cs; hipEvent_t e[4];
-            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return LHIP_ERR_INTERNAL; }
-            for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&e[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return LHIP_ERR_INTERNAL; }
-            ctx->copy_stream = cs; ctx->ev_in[0] = e[0]; ctx->ev_in[1] = e[1]; ctx->ev_done[0] = e[2]; ctx->ev_done[1] = e[3];
+            void* cs = nullptr; void* e[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (!rt::stream_create(&cs)) return LHIP_ERR_INTERNAL;
+            for (int i = 0; i < 4; i++) if (!rt::event_create(&e[i])) return LHIP_ERR_INTERNAL;
+            ctx->ev_in[0] = e[0]; ctx->ev_in[1] = e[1]; ctx->ev_done[0] = e[2]; ctx->ev_done[1] = e[3]; ctx->copy_stream = cs;
         }
-        const size_t out_chunk = (size_t)(cap_frames + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
-        if (!ctx->chunk_in.ensure(2 * C * chunk * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk)) return LHIP_ERR_INTERNAL;
+        if (!ctx->chunk_in.ensure(2 * C * stride * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk) || !ctx->chunk_fx.ensure(sched.size() * 16 + 16) ||
+            !ctx->state_bak.ensure(sizeof(StreamState))) return LHIP_ERR_INTERNAL;
+        if (!rt::d2d(ctx->state_bak.p, s->d_state, sizeof(StreamState), ctx->stream)) return LHIP_ERR_INTERNAL;
     }
-    const size_t out_chunk = (size_t)(cap_frames + 2) * (size_t)(s->ts->base_frame_bytes + 1) + 64;
-    hipStream_t cs = (hipStream_t)ctx->copy_stream, ks = (hipStream_t)ctx->stream;
-    int64_t total = 0, pending_bytes = 0, frames_all = 0;      // pending: the chunk whose output is still on the device
+    void* cs = ctx->copy_stream; void* ks = ctx->stream;
+    int64_t total = 0, pending_bytes = 0, frames_all = 0, repaired_all = 0, iters_all = 0;      // pending: the chunk whose output is still on the device
     uint8_t* pending_dst = nullptr; int pending_par = 0; bool have_pending = false;
-    auto fail = [&](const char* what) -> int64_t { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ks); if (what) set_err(what); return LHIP_ERR_INTERNAL; };
-    auto drain = [&]() -> bool {               // copy the pending chunk's bytes out (waits for its kernels)
+    auto fail = [&](const char* what, int64_t code = LHIP_ERR_INTERNAL) -> int64_t {      // wait for everything in flight, then put the stream back where the call found it
+        const std::string why = what ? std::string(what) : g_err;
+        (void)rt::sync(cs); (void)rt::sync(ks);
+        (void)rt::d2d(s->d_state, ctx->state_bak.p, sizeof(StreamState), ks); (void)rt::sync(ks);
+        s->mf_size = snap_mf; s->mf_samples_to_encode = snap_ste; s->slot_lag = snap_lag; s->frame_num = snap_fn; s->rs_n_in = snap_rs;
+        set_err(why);
+        return code;
+    };
+    auto drain = [&]() -> bool {               // copy the pending chunk's bytes out; ALWAYS waits for that chunk's kernels (its input half is reused next)
         if (!have_pending) return true;
         have_pending = false;
-        if (pending_bytes == 0) return true;
-        if (hipStreamWaitEvent(cs, (hipEvent_t)ctx->ev_done[pending_par], 0) != hipSuccess) return false;
-        if (hipMemcpyAsync(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) return false;
-        return hipStreamSynchronize(cs) == hipSuccess;
+        if (!rt::stream_wait_event(cs, ctx->ev_done[pending_par])) return false;
+        if (pending_bytes > 0 && !rt::d2h(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, cs)) return false;
+        return rt::sync(cs);
     };
-    size_t p0 = 0, cur = first_frames * spf;
-    for (size_t k = 0; p0 < nsamples; k++) {
+    size_t p0 = 0;
+    for (size_t k = 0; k < sched.size(); k++) {
         const int par = (int)(k & 1);
-        size_t m = nsamples - p0 < cur ? nsamples - p0 : cur;
-        if (nsamples - p0 - m < m / 4 && nsamples - p0 <= chunk) m = nsamples - p0;     // no short chunk at the end: a launch for a few frames costs a whole tail
-        int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * chunk;
-        // buffer `par` was last used by chunk k - 2: its kernels are done (its output was drained, which waited for them)
+        const size_t m = sched[k];
+        int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * stride;
+        // buffer `par` was last used by chunk k - 2: its kernels are done (drain() waited for them before chunk k - 1 was enqueued)
         // (copies straight from the caller's pageable memory: measured as fast as copies through pinned staging filled by four host
         //  threads -- 72.5 vs 73.2 ms per 1e5 stereo frames at 8192-frame chunks -- so there is no staging layer)
-        if (hipMemcpyAsync(d_in, left + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-        if (C == 2 && hipMemcpyAsync(d_in + chunk, (right ? right : left) + p0, m * 2, hipMemcpyHostToDevice, cs) != hipSuccess) return fail("hipMemcpyAsync (input chunk) failed");
-        if (hipEventRecord((hipEvent_t)ctx->ev_in[par], cs) != hipSuccess || hipStreamWaitEvent(ks, (hipEvent_t)ctx->ev_in[par], 0) != hipSuccess) return fail("event record / wait failed");
+        if (!rt::h2d(d_in, left + p0, m * 2, cs)) return fail(nullptr);
+        if (C == 2 && !rt::h2d(d_in + stride, (right ? right : left) + p0, m * 2, cs)) return fail(nullptr);
+        if (!rt::event_record(ctx->ev_in[par], cs) || !rt::stream_wait_event(ks, ctx->ev_in[par])) return fail(nullptr);
         std::vector<Job> jobs(1);
-        jobs[0] = Job{s, d_in, C == 2 ? d_in + chunk : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};
-        if (!run_batch(ctx, jobs, true, false)) { (void)fail(nullptr); return jobs[0].written < 0 ? jobs[0].written : LHIP_ERR_INTERNAL; }
-        if (hipEventRecord((hipEvent_t)ctx->ev_done[par], ks) != hipSuccess) return fail("event record failed");
-        if (!drain()) return fail("copying a chunk's output failed");             // chunk k - 1, while chunk k is being encoded
+        jobs[0] = Job{s, d_in, C == 2 ? d_in + stride : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};
+        if (!run_batch(ctx, jobs, true, false)) return fail(nullptr, jobs[0].written < 0 ? jobs[0].written : LHIP_ERR_INTERNAL);
+#ifdef LHIP_HOSTSIM
+        // tests: a failure injected after chunk k has been consumed (the stream must come back as the call found it)
+        if (const char* e = getenv("LHIP_HOSTSIM_FAIL_CHUNK")) if (e[0] && (size_t)atoi(e) == k) return fail("injected failure (LHIP_HOSTSIM_FAIL_CHUNK)");
+        repaired_all += g_stat_repaired; iters_all += g_stat_iters;
+#else
+        // this chunk's repair verdict (g_fixup: repaired frames, iterations, "did not converge") stays on the device until the call ends:
+        // a stream-ordered copy into the call's log, read back once after the last chunk
+        if (g_stat_frames > 0 && !rt::d2d((int32_t*)ctx->chunk_fx.p + 4 * k, (const int32_t*)ctx->nflagged.p + FX_STATS, 12, ks)) return fail(nullptr);
+        if (g_stat_frames == 0 && !rt::dzero((int32_t*)ctx->chunk_fx.p + 4 * k, 12, ks)) return fail(nullptr);
+#endif
+        if (!rt::event_record(ctx->ev_done[par], ks)) return fail(nullptr);
+        if (!drain()) return fail(nullptr);             // chunk k - 1, while chunk k is being encoded
         pending_bytes = jobs[0].written; pending_dst = out + total; pending_par = par; have_pending = true;
         total += jobs[0].written; frames_all += g_stat_frames;
         p0 += m;
-        cur = growth * cur < chunk ? growth * cur : chunk;
     }
-    if (!drain()) return fail("copying a chunk's output failed");
-    g_stat_frames = frames_all;                    // lhip_last_batch_stats: frames of the whole call, repair counters of its last chunk
+    if (!drain()) return fail(nullptr);
+#ifndef LHIP_HOSTSIM
+    {
+        std::vector<int32_t> fx(4 * sched.size(), 0);
+        if (!rt::d2h(fx.data(), ctx->chunk_fx.p, fx.size() * 4, ks) || !rt::sync(ks)) return fail(nullptr);
+        bool bad = false;
+        for (size_t k = 0; k < sched.size(); k++) { repaired_all += fx[4 * k]; iters_all += fx[4 * k + 1]; bad |= fx[4 * k + 2] != 0; }
+        if (bad) return fail("seed-chain repair did not converge");
+    }
+    g_stat_pending = nullptr;
+#endif
+    g_stat_frames = frames_all; g_stat_repaired = repaired_all; g_stat_iters = iters_all;     // lhip_last_batch_stats: the whole call
     return total;
 }
-#endif
 
 int64_t lhip_encode(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
     if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
     if (nsamples == 0) return 0;
     if (!left) { set_err("null input"); return LHIP_ERR_INTERNAL; }
-#ifndef LHIP_HOSTSIM
     {
         static const bool no_chunk = []() { const char* e = getenv("LAMEJS_HIP_NO_HOST_CHUNKS"); return e && e[0] == '1'; }();
         const Tables& T = s->ts->T;
-        if (!no_chunk && T.disable_reservoir && nsamples > (size_t)2 * HOST_CHUNK_FRAMES * 576 * T.mode_gr * T.rs_ratio) return encode_host_chunked(s, left, right, nsamples, out, out_cap);
+        if (!no_chunk && T.disable_reservoir && nsamples > (size_t)2 * host_chunk_schedule().first * 576 * T.mode_gr * T.rs_ratio) return encode_host_chunked(s, left, right, nsamples, out, out_cap);
     }
-#endif
     int64_t w = 0;
     const int rc = encode_many(&s, 1, &left, &right, &nsamples, &out, &out_cap, &w, false, true);
     return rc < 0 ? rc : w;

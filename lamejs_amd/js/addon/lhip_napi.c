@@ -29,6 +29,7 @@ static int64_t (*p_encode)(lhip_stream*, const int16_t*, const int16_t*, size_t,
 static int64_t (*p_flush)(lhip_stream*, uint8_t*, size_t);
 static void (*p_destroy)(lhip_stream*);
 static size_t (*p_max_out)(const lhip_stream*, size_t);
+static int64_t (*p_out_bytes)(const lhip_stream*, size_t);
 static int (*p_encode_batch)(lhip_stream* const*, size_t, const int16_t* const*, const int16_t* const*, const size_t*, uint8_t* const*, const size_t*, int64_t*);
 static int (*p_flush_batch)(lhip_stream* const*, size_t, uint8_t* const*, const size_t*, int64_t*);
 static const char* (*p_last_error)(void);
@@ -58,7 +59,7 @@ static int load_lib(napi_env env) {
     SYM(p_destroy, "lhip_destroy") SYM(p_max_out, "lhip_max_output_bytes") SYM(p_last_error, "lhip_last_error")
     SYM(p_encode_batch, "lhip_encode_batch") SYM(p_flush_batch, "lhip_flush_batch") SYM(p_set_devices, "lhip_set_devices")
     SYM(p_state_bytes, "lhip_state_bytes") SYM(p_state_get, "lhip_state_get") SYM(p_state_set, "lhip_state_set")
-    SYM(p_seek_tail, "lhip_seek_tail_samples") SYM(p_seek, "lhip_seek")
+    SYM(p_seek_tail, "lhip_seek_tail_samples") SYM(p_seek, "lhip_seek") SYM(p_out_bytes, "lhip_encode_output_bytes")
 #undef SYM
     return 1;
 }
@@ -112,6 +113,23 @@ static napi_value make_i8(napi_env env, const uint8_t* src, size_t n) {
     return ta;
 }
 
+/* The returned Int8Array is allocated FIRST, at its final size (lhip_encode_output_bytes: exact under CBR without the reservoir), and
+ * the library writes the frames straight into it: one allocation per call, no intermediate buffer, no copy -- and the caller still owns
+ * a fresh array per call, which is the one semantic of the reference's `new Int8Array(mp3buf.subarray(0, _sz))` (index.js:129) to keep.
+ * Only when the count is not known beforehand (bit-reservoir extension) or the call fails is the result copied into an exact array. */
+static napi_value encode_into_new_array(napi_env env, lhip_stream* s, const int16_t* dl, const int16_t* dr, size_t nl) {
+    static uint8_t none[16];
+    const int64_t want = p_out_bytes(s, nl);
+    const size_t cap = want > 0 ? (size_t)want : 0;
+    napi_value ab, ta; void* data = NULL;
+    if (napi_create_arraybuffer(env, cap, &data, &ab) != napi_ok || (cap && !data)) { napi_throw_error(env, NULL, "could not allocate the output buffer"); return NULL; }
+    const int64_t n = p_encode(s, dl, dr, nl, cap ? (uint8_t*)data : none, cap);
+    /* the reference swallows negative codes and returns an empty array (index.js:128-129) */
+    if (n != (int64_t)cap) return make_i8(env, (const uint8_t*)data, n > 0 ? (size_t)n : 0);
+    if (napi_create_typedarray(env, napi_int8_array, cap, ab, 0, &ta) != napi_ok) { napi_throw_error(env, NULL, "could not create the output Int8Array"); return NULL; }
+    return ta;
+}
+
 static napi_value js_encode(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
     napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
@@ -124,14 +142,7 @@ static napi_value js_encode(napi_env env, napi_callback_info info) {
     if (vt != napi_null && vt != napi_undefined) {
         if (napi_get_typedarray_info(env, argv[2], &tt, &nr, &dr, NULL, NULL) != napi_ok || tt != napi_int16_array || nr != nl) { napi_throw_type_error(env, NULL, "right must be an Int16Array of the same length"); return NULL; }
     }
-    size_t cap = p_max_out(s, nl);
-    uint8_t* out = (uint8_t*)malloc(cap ? cap : 1);
-    if (!out) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
-    int64_t n = p_encode(s, (const int16_t*)dl, (const int16_t*)dr, nl, out, cap);
-    /* the reference swallows negative codes and returns an empty array (index.js:128-129) */
-    napi_value r = make_i8(env, out, n > 0 ? (size_t)n : 0);
-    free(out);
-    return r;
+    return encode_into_new_array(env, s, (const int16_t*)dl, (const int16_t*)dr, nl);
 }
 
 static napi_value js_flush(napi_env env, napi_callback_info info) {
@@ -168,6 +179,8 @@ static napi_value batch_common(napi_env env, napi_callback_info info, int is_flu
     const int16_t** L = (const int16_t**)calloc(n, sizeof *L); const int16_t** R = (const int16_t**)calloc(n, sizeof *R);
     size_t* ns = (size_t*)calloc(n, sizeof *ns); size_t* caps = (size_t*)calloc(n, sizeof *caps);
     uint8_t** outs = (uint8_t**)calloc(n, sizeof *outs); int64_t* wr = (int64_t*)calloc(n, sizeof *wr);
+    napi_value* abs_ = (napi_value*)calloc(n, sizeof *abs_);
+    static uint8_t none[16];
     const char* err = NULL;
     for (uint32_t i = 0; i < n && !err; i++) {
         napi_value h; napi_get_element(env, argv[0], i, &h);
@@ -186,16 +199,26 @@ static napi_value batch_common(napi_env env, napi_callback_info info, int is_flu
                 }
             }
         }
-        caps[i] = p_max_out(hs[i], is_flush ? 4 * 1152 : ns[i]);
-        outs[i] = (uint8_t*)malloc(caps[i] ? caps[i] : 1);
+        if (is_flush) { caps[i] = p_max_out(hs[i], 4 * 1152); outs[i] = (uint8_t*)malloc(caps[i] ? caps[i] : 1); }
+        else {   /* the stream's result array at its final size (see encode_into_new_array): the launch writes into it */
+            const int64_t want = p_out_bytes(hs[i], ns[i]);
+            void* data = NULL;
+            caps[i] = want > 0 ? (size_t)want : 0;
+            if (napi_create_arraybuffer(env, caps[i], &data, &abs_[i]) != napi_ok || (caps[i] && !data)) { err = "could not allocate an output buffer"; break; }
+            outs[i] = caps[i] ? (uint8_t*)data : none;
+        }
     }
     if (!err) {
         const int rc = is_flush ? p_flush_batch(hs, n, outs, caps, wr) : p_encode_batch(hs, n, L, R, ns, outs, caps, wr);
         if (rc != 0) err = p_last_error();
     }
-    if (!err) for (uint32_t i = 0; i < n; i++) napi_set_element(env, result, i, make_i8(env, outs[i], wr[i] > 0 ? (size_t)wr[i] : 0));
-    for (uint32_t i = 0; i < n; i++) free(outs[i]);
-    free(hs); free(L); free(R); free(ns); free(caps); free(outs); free(wr);
+    if (!err) for (uint32_t i = 0; i < n; i++) {
+        napi_value ta;
+        if (!is_flush && wr[i] == (int64_t)caps[i] && napi_create_typedarray(env, napi_int8_array, caps[i], abs_[i], 0, &ta) == napi_ok) napi_set_element(env, result, i, ta);
+        else napi_set_element(env, result, i, make_i8(env, outs[i], wr[i] > 0 ? (size_t)wr[i] : 0));
+    }
+    if (is_flush) for (uint32_t i = 0; i < n; i++) free(outs[i]);
+    free(hs); free(L); free(R); free(ns); free(caps); free(outs); free(wr); free(abs_);
     if (err) { napi_throw_error(env, NULL, err); return NULL; }
     return result;
 }

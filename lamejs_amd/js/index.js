@@ -27,6 +27,17 @@ function loadAddon() {
     return addon;
 }
 
+/* The table blob of a configuration is a pure function of (channels, samplerate, kbps, options): built once per process and shared by
+ * every encoder of that configuration (1024 streams of BASELINE config 5 = one build, not 1024; the library shares the uploaded copy
+ * between streams with identical blobs as well).  Configurations outside the envelope throw in buildBlob and are not cached. */
+const blobCache = new Map();
+function tablesBlob(channels, samplerate, kbps, opts) {
+    const key = [channels, samplerate, kbps, opts && opts.jointStereo ? 1 : 0, opts && opts.reservoir ? 1 : 0].join('|');
+    let blob = blobCache.get(key);
+    if (!blob) { blob = tables.buildBlob(channels, samplerate, kbps, opts).blob; blobCache.set(key, blob); }
+    return blob;
+}
+
 function Mp3Encoder(channels, samplerate, kbps, opts) {
     if (arguments.length != 3 && !(arguments.length == 4 && opts !== null && typeof opts == 'object')) {
         opts = undefined;
@@ -34,7 +45,7 @@ function Mp3Encoder(channels, samplerate, kbps, opts) {
         channels = 1; samplerate = 44100; kbps = 128;
     }
     const native = loadAddon();
-    const blob = tables.buildBlob(channels, samplerate, kbps, opts).blob;
+    const blob = tablesBlob(channels, samplerate, kbps, opts);
     const handle = native.create(blob, channels, samplerate, kbps, defaultDevice);
     Object.defineProperty(this, '_lhip', { value: { handle: handle, channels: channels }, enumerable: false });
 

@@ -696,21 +696,67 @@ def test_gpu_long_random_stream_uses_wave_seed_hints(lib, ch, kbps, nfr, seed):
     assert got2 == want
 
 
-def test_gpu_host_call_in_overlapped_chunks(lib):
-    """One lhip_encode call with HOST buffers long enough to be cut into chunks whose copies overlap the encode of the chunk before
-    (lhip_api.cpp encode_host_chunked: more than 16384 frames; chunks of 8192, 16384, ... frames): the bytes of the call and of the flush
-    against the oracle, on random material, and the stream usable afterwards like any other."""
-    import lamejs_amd
+def _segmented_material(seed, nfr, seg_frames=3000):
+    """`nfr` frames (+ an odd tail) of two-channel random material: segments of tests/tools/fuzz_gpu.material -- tones, noise, clicks,
+    bursts, level steps and silence gaps, another draw every `seg_frames` frames -- so that the waves' speculation seeds miss and frames
+    need the repair pass all along the stream (generating 1e5 frames in one piece would need gigabytes of float64 temporaries)."""
     sys.path.insert(0, str(ROOT / "tests" / "tools"))
     import fuzz_gpu
+    rng = np.random.default_rng(seed)
+    Ls, Rs, left = [], [], 1152 * nfr + 517
+    while left > 0:
+        n = min(left, 1152 * seg_frames)
+        l, r = fuzz_gpu.material(rng, n, 2)
+        Ls.append(l); Rs.append(r); left -= n
+    return np.concatenate(Ls), np.concatenate(Rs)
+
+
+def test_gpu_host_call_in_overlapped_chunks(lib, tmp_path):
+    """ONE lhip_encode call with HOST buffers, cut by the library into chunks whose copies overlap the encode of the chunk before
+    (lhip_api.cpp encode_host_chunked; two-channel schedule: 16384 frames, doubling, capped at 65536, a short remainder merged into the
+    chunk before it when that still fits the cap), on RANDOM two-channel material -- the case the steady bench stream never exercises:
+    speculation-seed misses and repairs inside a chunk, the carry across chunk edges, flush() after a chunked call.
+      * stereo, 120 000 frames: chunks of 16384 + 32768 + 65536 (the cap) + a short last one
+      * joint stereo, 55 000 frames: 16384 + a merged 38616
+      * the same joint-stereo call through Mp3Encoder.encodeBuffer under Node (N-API: the library writes into the returned array)
+    each followed by a second, ordinary call on the same stream and flush(), byte-compared with the oracle; lhip_last_batch_stats of
+    the chunked call covers all its chunks and must report repaired frames.  (The oracle runs beside the GPU on host threads.)"""
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    import lamejs_amd
     from oracle_py import oracle_encode
-    rng = np.random.default_rng(91)
-    nfr = 36000
-    L, _ = fuzz_gpu.material(rng, 1152 * nfr + 500, 1)
-    want = oracle_encode(1, 44100, 128, L, None)
-    enc = lamejs_amd.Mp3Encoder(1, 44100, 128)
-    head = enc.encodeBuffer(L[:1152 * 30000 + 77])                  # chunked: 8192 + 16384 + the rest
-    tail = enc.encodeBuffer(L[1152 * 30000 + 77:])                  # one ordinary batch on the same stream
-    got = head + tail + enc.flush()
-    enc.close()
-    assert got == want
+    cases = [("stereo", False, 120000, 7001), ("joint", True, 55000, 7002)]
+    mats = {name: _segmented_material(seed, nfr) for name, _, nfr, seed in cases}
+    extra = 5000
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        futs = {}
+        for name, joint, nfr, _ in cases:
+            L, R = mats[name]
+            futs[name] = pool.submit(oracle_encode, 2, 44100, 128, np.concatenate([L, L[:extra]]), np.concatenate([R, R[:extra]]), None, True, joint)
+        got = {}
+        for name, joint, nfr, _ in cases:
+            L, R = mats[name]
+            enc = lamejs_amd.Mp3Encoder(2, 44100, 128, joint=joint)
+            a = enc.encodeBuffer(L, R)                                   # the chunked call
+            st = enc.last_batch_stats()
+            assert st["frames"] == nfr, st                               # statistics of the whole call, not of its last chunk
+            assert st["repaired_frames"] > 0, st                         # the material does upset the seed chain inside the chunks
+            b = enc.encodeBuffer(L[:extra], R[:extra])                   # an ordinary batch on the same stream
+            got[name] = a + b + enc.flush()
+            enc.close()
+        node = shutil.which("node")
+        js = None
+        if node and (ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node").exists():
+            L, R = mats["joint"]
+            np.concatenate([L, L[:extra]]).astype("<i2").tofile(tmp_path / "l.s16")
+            np.concatenate([R, R[:extra]]).astype("<i2").tofile(tmp_path / "r.s16")
+            r = subprocess.run([node, str(ROOT / "tests" / "js_hostcall_check.js"), str(tmp_path / "l.s16"), str(tmp_path / "r.s16"), "128", str(len(L)), "joint"],
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            js = __import__("json").loads(r.stdout.strip().splitlines()[-1])
+        for name, _, _, _ in cases:
+            want = futs[name].result()
+            assert got[name] == want, name
+            if name == "joint" and js is not None:
+                assert js["bytes"] == len(want) and js["md5"] == hashlib.md5(want).hexdigest(), js

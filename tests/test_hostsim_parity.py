@@ -314,3 +314,84 @@ def test_hostsim_mask_add_index_shortcut(sim):
     from noise_class_check import check_ma_index
     took, n = check_ma_index(sim)
     assert took > 0.9 * n
+
+
+def test_hostsim_two_devices_tsan_asan(tmp_path):
+    """Two devices inside one process (the GPU tier's two-device test skips on a one-GPU box): the host simulation pretends to have two
+    (LHIP_HOSTSIM_DEVICES=2) and tests/tools/two_devices.c checks lhip_set_devices' round-robin placement, lhip_stream_device, a refused
+    device outside the mask, and two host threads -- one per device context -- encoding at the same time, every second repetition through
+    the chunked host path.  Built with ThreadSanitizer (any report fails the run) and AddressSanitizer; the bytes against the oracle."""
+    import os, shutil
+    import pcm
+    gcc = shutil.which("gcc")
+    tsan = subprocess.run([gcc, "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip() if gcc else ""
+    if not tsan or not os.path.isabs(tsan):
+        pytest.skip("libtsan not available")
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "tsan"], check=True, capture_output=True)
+    import lamejs_amd
+    blob = tmp_path / "t.bin"
+    blob.write_bytes(lamejs_amd.tables_blob(2, 44100, 128))
+    mats = []
+    for i in range(2):
+        L, R = pcm.bursts(1152 * 120, 2, seed=900 + i)
+        np.stack([L, R], axis=1).astype("<i2").tofile(tmp_path / f"pcm{i}.s16")
+        mats.append((L, R))
+    env = dict(os.environ, LHIP_HOSTSIM_DEVICES="2", LAMEJS_HIP_HOST_CHUNK_FRAMES="16,48", TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=0")
+    for build in ("tsan", "asan"):
+        exe = ROOT / "tests" / "hostsim" / "_build" / f"two_devices_{build}"
+        r = subprocess.run([str(exe), str(blob), str(tmp_path / "pcm0.s16"), str(tmp_path / "pcm1.s16"), str(tmp_path / "o0.mp3"), str(tmp_path / "o1.mp3")],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "OK two devices" in r.stdout and "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr, (build, r.stdout[-500:], r.stderr[-3000:])
+        for i, (L, R) in enumerate(mats):
+            assert (tmp_path / f"o{i}.mp3").read_bytes() == oracle_encode(2, 44100, 128, L, R), (build, i)
+
+
+def test_hostsim_host_call_in_chunks_random_material(sim):
+    """The chunked host path of lhip_encode (long Int16Arrays: chunks copied in, encoded and copied out side by side) on the material
+    that upsets the seed chain, in the CPU tier: small chunks forced through LAMEJS_HIP_HOST_CHUNK_FRAMES (first, cap, growth -- so the
+    doubling, the cap and the merged short remainder all occur), repairs forced by a poor speculation seed, a second ordinary call and
+    flush() after the chunked one, two channels / joint stereo / mono.  lhip_last_batch_stats must cover the whole call.
+    And a failure injected in chunk 2 must leave the stream exactly where the call found it (state blob and the bytes that follow)."""
+    import os
+    import lamejs_amd
+    import pcm
+    old = os.environ.get("LAMEJS_HIP_HOST_CHUNK_FRAMES")
+    # the schedule is read once per process: this test needs its own (a subprocess would also do; the variable is read at the first long call)
+    r = subprocess.run([__import__("sys").executable, "-c", """
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, lamejs_amd, pcm
+from oracle_py import oracle_encode
+sys.path.insert(0, %r)
+import fuzz_gpu
+lib = lamejs_amd.load_library(%r)
+lib.lhip_debug_set_spec_seed(255, 1)                 # a poor seed: the validation flags frames inside the chunks
+rng = np.random.default_rng(4242)
+for ch, joint, nfr in ((2, False, 420), (2, True, 300), (1, False, 350)):
+    L, R = fuzz_gpu.material(rng, 1152 * nfr + 517, ch)
+    enc = lamejs_amd.Mp3Encoder(ch, 44100, 128, lib=lib, joint=joint)
+    a = enc.encodeBuffer(L, R)
+    st = enc.last_batch_stats()
+    assert st["frames"] == nfr and st["repaired_frames"] > 0, st
+    b = enc.encodeBuffer(L[:4000], None if R is None else R[:4000])
+    c = enc.flush()
+    LL = np.concatenate([L, L[:4000]]); RR = None if R is None else np.concatenate([R, R[:4000]])
+    assert a + b + c == oracle_encode(ch, 44100, 128, LL, RR, joint=joint), (ch, joint)
+lib.lhip_debug_set_spec_seed(180, 4)
+L, R = pcm.bursts(1152 * 300, 2, seed=5)
+enc = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=lib)
+pre = enc.encodeBuffer(L[:3000], R[:3000])
+s0 = enc.state_get()
+os.environ["LHIP_HOSTSIM_FAIL_CHUNK"] = "2"
+try:
+    enc.encodeBuffer(L[3000:], R[3000:])
+    raise SystemExit("the injected failure did not surface")
+except lamejs_amd.LhipError as e:
+    assert "injected" in str(e)
+os.environ["LHIP_HOSTSIM_FAIL_CHUNK"] = ""
+assert enc.state_get() == s0
+assert pre + enc.encodeBuffer(L[3000:], R[3000:]) + enc.flush() == oracle_encode(2, 44100, 128, L, R)
+print("OK chunks")
+""" % (str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "tools"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))],
+                       capture_output=True, text=True, env=dict(os.environ, LAMEJS_HIP_HOST_CHUNK_FRAMES="16,96,2"), timeout=900)
+    assert r.returncode == 0 and "OK chunks" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

@@ -101,3 +101,56 @@ def test_bench_py_frame_range_shards_gloo(world, corpus, nfr):
         assert line["config"]["ranges_encoded_again"] >= 1
     else:
         assert line["config"]["cut_state_mismatches"] == 0
+
+
+def _check_streams(line, cfg, ch, kbps, ns, nfr, world):
+    c = line["config"]
+    assert line["n_gpus"] == world and c["bit_exact_prefix_vs_oracle"] is True and c["rccl_gather_of_outputs_rehashed_ok"] is True
+    for rank in range(world):
+        md5s = []
+        for i in range(ns):
+            seed = (12345 + rank) if cfg != "5" else 1000 + rank * ns + i
+            L, R = pcm.sine(1152 * nfr, ch, seed=seed)
+            md5s.append(hashlib.md5(oracle_encode(ch, 44100, kbps, L, R, flush=False)).hexdigest())
+        want = md5s[0] if ns == 1 else hashlib.md5("".join(md5s).encode()).hexdigest()
+        assert c["output_md5_per_rank"][rank] == want, (rank, c)
+
+
+@pytest.mark.parametrize("cfg,extra,ch,kbps", [("3", ["--frames", "6"], 2, 128), ("4", ["--frames", "5"], 2, 320), ("5", ["--streams", "2", "--frames", "5"], 1, 128)])
+def test_bench_py_plain_launch_spawns_its_ranks(cfg, extra, ch, kbps):
+    """`python bench.py --gpus 2` started PLAINLY -- no launcher, no WORLD_SIZE -- must start its own two ranks (it re-executes itself
+    under torch.distributed.run on 127.0.0.1) instead of dying on the world-size check: the shape of the driver's N = 1 command with N = 2.
+    gloo + the host simulation behind the same C ABI; every rank's stream against the oracle."""
+    if not HOSTSIM.exists():
+        pytest.skip("host simulation not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LAMEJS_HIP_LIB=str(HOSTSIM), LAMEJS_BENCH_HOSTSIM="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", cfg, "--cpu-seconds", "0"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ns = int(extra[extra.index("--streams") + 1]) if "--streams" in extra else 1
+    _check_streams(line, cfg, ch, kbps, ns, int(extra[extra.index("--frames") + 1]), 2)
+
+
+def test_bench_py_plain_launch_frame_range_shards():
+    """The same for --config shard3 (one stream cut into a range per rank)."""
+    if not HOSTSIM.exists():
+        pytest.skip("host simulation not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LAMEJS_HIP_LIB=str(HOSTSIM), LAMEJS_BENCH_HOSTSIM="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "shard3", "--cpu-seconds", "0",
+                        "--frames", "30", "--shard-warmup", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    L, R = pcm.sine(1152 * 30, 2, seed=12345)
+    assert line["n_gpus"] == 2 and line["config"]["output_md5"] == hashlib.md5(oracle_encode(2, 44100, 128, L, R, flush=False)).hexdigest()
+
+
+def test_bench_py_refuses_a_launcher_with_another_world_size():
+    """Under a launcher bench.py does not re-launch; a WORLD_SIZE that disagrees with --gpus is an error message, not an assertion trace."""
+    env = dict(os.environ, WORLD_SIZE="1", LAMEJS_BENCH_HOSTSIM="1", LAMEJS_HIP_LIB=str(HOSTSIM), LAMEJS_BENCH_NO_DIST="1")
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--frames", "4"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
