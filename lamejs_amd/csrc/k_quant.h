@@ -1575,8 +1575,10 @@ LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
 // with the roles of the first copy swapped (bin search on w, then g = w).
 // `kept` (HBM, this granule-channel's slot of W.l3) receives the quantized spectrum of the kept copy whenever a better
 // quantization is found; it is read back into L.ixw once the loop has finished (the working copy is dead then).
+// `dig` / `dn`: the granule-channel's validation digest (word w at dig[w * dn]; lhip_layout.h VD_*): the bin-search memo in the compact,
+// coalesced form the one-thread-per-frame validation reads
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
-                           int16_t* kept, GrSide* rec, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q) {
     enum { ST_BS, ST_BSUP, ST_A, ST_B };
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
@@ -1634,8 +1636,16 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             w.part2_3_length = nBits;
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
             wave_sync();
-            LHIP_LANE_ONCE(i, 0, nbs) { rec->bs_tab[i] = L.memo.bs_tab[i]; rec->bs_asg[i] = L.memo.bs_asg[i]; }
-            if (lane == 0) { rec->bs_ntab = nbs; rec->bs_state = pack_cond_fields(w, 0); }
+            LHIP_LANE_ONCE(i, 0, nbs) {
+                const int32_t e = L.memo.bs_tab[i], a = L.memo.bs_asg[i];
+                rec->bs_tab[i] = e; rec->bs_asg[i] = a;
+                if (i < VD_ENT) { dig[(VD_TAB + 2 * i) * dn] = (uint32_t)e; dig[(VD_TAB + 2 * i + 1) * dn] = (uint32_t)a; }
+            }
+            if (lane == 0) {
+                const int state = pack_cond_fields(w, 0);
+                rec->bs_ntab = nbs; rec->bs_state = state;
+                dig[VD_TARG * dn] = (uint32_t)targ_bits | ((uint32_t)nbs << 24); dig[VD_STATE * dn] = (uint32_t)state;
+            }
             wave_sync();
             if (0 == T.noise_shaping) {
                 g = w;
@@ -2209,6 +2219,85 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
     return tbits < MAX_BITS_PER_GRANULE ? tbits : MAX_BITS_PER_GRANULE;
 }
 
+// One granule-channel of a frame, from the spectrum to the published record: init_outer_loop .. best_huffman_divide (the body of the
+// reference's per-channel loop, Quantize.js:1406-1466 CBR_iteration_loop + iteration_finish_one) on the calling wave's LDS record.
+// `used` = the bin-search seed, `gr0_bt` = this channel's block type in granule 0 (scfsi); L.sf_gr0[ch] is written by granule 0 and read
+// by granule 1 of the same channel.  Returns the bits spent (part2_3 + part2), the seed the next granule of this channel starts from
+// (valid if `active`) and the block type.
+struct UnitOut { int bits; Seed next; int block_type; int active; };
+// Inlined at every call site: behind a call (one copy of the code for kb_quant's, the owner's and the helper's site) g_quant was a third slower -- spills around the call.
+LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
+                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q) {
+    UnitOut u; u.next = used;
+    GI g;
+    const int bt = W.blocktype[(int64_t)gslot * C + ch];
+    const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
+    const float* ratio = W.E + ((int64_t)(gslot - 1) * Cp + ch + mode_ext) * E_STRIDE;   // thresholds of the previous psy call (mid / side: channels 2, 3)
+    { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, xr_source(W, C, gslot, ch, mode_ext == 2), mode_ext == 2 ? nullptr : W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
+    int active = 0, bs_gain = 0;
+    if (q_init_xrpow(g, lane, L, Q)) {
+        active = 1;
+        { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
+        int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+        q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q);
+        uni_gi(g); bs_gain = uni(bs_gain);
+        wave_sync();                                    // the kept spectrum was written by other lanes of this wave
+#if LHIP_NL == 1
+        for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
+#else
+        {   // all of a lane's words in flight at once (a lane-strided loop waits for every load by itself)
+            uint32_t kw[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)kept)[i < 288 ? i : 287]; }
+#pragma unroll
+            for (int j = 0; j < NPL; j++) LHIP_PIN_LOADED(kw[j]);
+#pragma unroll
+            for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
+        }
+#endif
+        wave_sync();
+        Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
+        u.next = nx;
+    } else {
+        for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = 0;
+        wave_sync();
+    }
+    int scfsi[4];
+    { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt, scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
+    uni_gi(g);
+    if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
+    uni_gi(g);
+    u.bits = g.part2_3_length + g.part2_length;
+    u.block_type = g.block_type;
+    if (gr == 0) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i]; }
+    // ---- publish the record and the signed quantized spectrum ----
+    GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
+    if (lane == 0) {
+        out->part2_3_length = g.part2_3_length; out->part2_length = g.part2_length; out->big_values = g.big_values;
+        out->count1 = g.count1; out->global_gain = g.global_gain; out->scalefac_compress = g.scalefac_compress;
+        out->block_type = g.block_type;
+        for (int i = 0; i < 3; i++) { out->table_select[i] = g.table_select[i]; out->subblock_gain[i] = g.subblock_gain[i]; }
+        out->region0_count = g.region0_count; out->region1_count = g.region1_count; out->preflag = g.preflag;
+        out->scalefac_scale = g.scalefac_scale; out->count1table_select = g.count1table_select;
+        out->sfbmax = g.sfbmax; out->sfbdivide = g.sfbdivide;
+        out->active = active; out->bs_start = used.start; out->bs_step_in = used.step; out->bs_gain = bs_gain;
+        W.vdig[((int64_t)fidx * 2 + gr) * C + ch] = vd_head(active, used.start, used.step, bs_gain);      // digest word VD_HEAD
+        out->targ_bits = targ_ch;
+        out->mode_ext = mode_ext;
+        out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
+    }
+    LHIP_LANE_ONCE(i, 0, SFBMAX) out->scalefac[i] = L.sfb[i];
+    if (!active && lane == 0) { out->bs_ntab = 0; out->bs_state = 0; }
+    int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+    for (int i = lane; i < 576; i += LHIP_NL) {
+        const int v = L.ixw[i];
+        l3o[i] = (int16_t)(((double)L.xr[i] < 0) ? -v : v);
+    }
+    wave_sync();
+    u.active = active;
+    return u;
+}
+
 // One wave per frame slot.  chain == 0: speculative reset seed (exact for the first frame of a stream
 // batch, whose seed is the carried one); chain == 1: chain-implied seed (repair pass, flagged frames only);
 // chain == 2: the frames of the stream are quantized in order (bit reservoir: the persistent per-stream kernel), the seed is what the
@@ -2306,75 +2395,12 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         const int targ0 = uni(targ[0]), targ1 = uni(targ[1]);
         for (int ch = 0; ch < C; ch++) {
             if (PAIR && ch != my_ch) continue;
-            GI g;
-            const int bt = W.blocktype[(int64_t)gslot * C + ch];
-            const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
-            const float* ratio = W.E + ((int64_t)(gslot - 1) * Cp + ch + mode_ext) * E_STRIDE;   // thresholds of the previous psy call (mid / side: channels 2, 3)
-            { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, xr_source(W, C, gslot, ch, mode_ext == 2), mode_ext == 2 ? nullptr : W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
-            int active = 0, bs_gain = 0;
-            const Seed used = ch == 0 ? seed0 : seed1;
-            const int targ_ch = ch == 0 ? targ0 : targ1;
-            if (q_init_xrpow(g, lane, L, Q)) {
-                active = 1;
-                { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
-                int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-                q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, lane, L, Q);
-                uni_gi(g); bs_gain = uni(bs_gain);
-                wave_sync();                                    // the kept spectrum was written by other lanes of this wave
-#if LHIP_NL == 1
-                for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
-#else
-                {   // all of a lane's words in flight at once (a lane-strided loop waits for every load by itself)
-                    uint32_t kw[NPL];
-#pragma unroll
-                    for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)kept)[i < 288 ? i : 287]; }
-#pragma unroll
-                    for (int j = 0; j < NPL; j++) LHIP_PIN_LOADED(kw[j]);
-#pragma unroll
-                    for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
-                }
-#endif
-                wave_sync();
-                Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
-                if (ch == 0) seed0 = nx; else seed1 = nx;
-            } else {
-                for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = 0;
-                wave_sync();
-            }
-            int scfsi[4];
-            { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, ch == 0 ? gr0_bt0 : gr0_bt1, scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
-            uni_gi(g);
-            if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
-            uni_gi(g);
-            if (!PAIR) ResvSize = uni(ResvSize - (g.part2_3_length + g.part2_length));
-            else if (lane == 0) mbox[2 * gr + ch] = g.part2_3_length + g.part2_length;
-            if (gr == 0) {
-                if (ch == 0) gr0_bt0 = g.block_type; else gr0_bt1 = g.block_type;
-                LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i];
-            }
-            // ---- publish the record and the signed quantized spectrum ----
-            GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
-            if (lane == 0) {
-                out->part2_3_length = g.part2_3_length; out->part2_length = g.part2_length; out->big_values = g.big_values;
-                out->count1 = g.count1; out->global_gain = g.global_gain; out->scalefac_compress = g.scalefac_compress;
-                out->block_type = g.block_type;
-                for (int i = 0; i < 3; i++) { out->table_select[i] = g.table_select[i]; out->subblock_gain[i] = g.subblock_gain[i]; }
-                out->region0_count = g.region0_count; out->region1_count = g.region1_count; out->preflag = g.preflag;
-                out->scalefac_scale = g.scalefac_scale; out->count1table_select = g.count1table_select;
-                out->sfbmax = g.sfbmax; out->sfbdivide = g.sfbdivide;
-                out->active = active; out->bs_start = used.start; out->bs_step_in = used.step; out->bs_gain = bs_gain;
-                out->targ_bits = targ_ch;
-                out->mode_ext = mode_ext;
-                out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
-            }
-            LHIP_LANE_ONCE(i, 0, SFBMAX) out->scalefac[i] = L.sfb[i];
-            if (!active && lane == 0) { out->bs_ntab = 0; out->bs_state = 0; }
-            int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-            for (int i = lane; i < 576; i += LHIP_NL) {
-                const int v = L.ixw[i];
-                l3o[i] = (int16_t)(((double)L.xr[i] < 0) ? -v : v);
-            }
-            wave_sync();
+            const UnitOut u = q_unit(T, pb10, W, C, Cp, fidx, gslot, gr, ch, mode_ext, ath_adjust, ch == 0 ? targ0 : targ1, ch == 0 ? seed0 : seed1,
+                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q);
+            if (u.active) { if (ch == 0) seed0 = u.next; else seed1 = u.next; }
+            if (!PAIR) ResvSize = uni(ResvSize - u.bits);
+            else if (lane == 0) mbox[2 * gr + ch] = u.bits;
+            if (gr == 0) { if (ch == 0) gr0_bt0 = u.block_type; else gr0_bt1 = u.block_type; }
         }
         if (PAIR) {                                   // both waves have published this granule: take the other channel's bits
             wg_barrier();
@@ -2524,9 +2550,34 @@ LHIP_DEV void kb_validate(const Tables& T, const PowBase& pb10, const Workspace&
     }
 }
 
-// Memo-only replay, one THREAD per frame: the whole check is a few scalar look-ups in the side records, so it runs
-// as a plain grid over the frames without LDS tables.  Outcome per frame in W.seed_flag: 0 consistent, 1 re-quantize
-// with the chain-implied seed, 2 undecided (a gain the speculative pass never evaluated) -> kb_validate decides.
+// The chain-implied seed from the digests (what seed_before derives from the side records): gains of the last two active granules of the channel.
+LHIP_DEV Seed seed_before_dig(const Workspace& W, const StreamDesc& sd, int C, int k, int gr, int ch) {
+    const int32_t* carry = W.seed + ((int64_t)sd.fslot0 * C + ch) * 2;
+    int g1 = -1, g2 = -1;
+    const int GR = W.mode_gr;
+    for (int q = GR * k + gr - 1; q >= 0; q--) {
+        const uint32_t h = W.vdig[(((int64_t)sd.out_slot0 + q / GR) * 2 + q % GR) * C + ch];
+        if (vd_active(h)) {
+            if (g1 < 0) g1 = vd_gain(h);
+            else { g2 = vd_gain(h); break; }
+        }
+    }
+    Seed s;
+    if (g1 < 0) { s.start = carry[0]; s.step = carry[1]; }
+    else {
+        const int prev_start = (g2 < 0) ? carry[0] : g2;
+        s.start = g1;
+        s.step = (prev_start - g1 >= 4) ? 4 : 2;
+    }
+    return s;
+}
+
+// Memo-only replay, one THREAD per frame: the whole check is a few scalar look-ups, so it runs as a plain grid over the frames without
+// LDS tables.  It reads the granule-channels' DIGESTS (W.vdig: seed used, resulting gain, target, the first VD_ENT memo entries; word-major,
+// so the threads of a wave read neighbouring words) -- the side records, 464 bytes apart with the memo at their far end, cost one cache line
+// per thread and field (0.29 - 0.38 ms per 1e5 frames in round 3); only a search with more than VD_ENT memoised evaluations falls back to them.
+// Outcome per frame in W.seed_flag: 0 consistent, 1 re-quantize with the chain-implied seed, 2 undecided (a gain the speculative pass
+// never evaluated) -> kb_validate decides.
 // only_pass > 0: just the frames stamped for that pass (successors of frames the previous repair pass re-quantized)
 LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int only_pass = 0) {
     const int C = T.channels_out;
@@ -2536,20 +2587,31 @@ LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const Stream
     const int fidx = sd.out_slot0 + k;
     if (only_pass > 0 && W.reval[fidx] != only_pass) return;
     int verdict = 0;
+    const int64_t dn = W.vdig_n;
     for (int gr = 0; gr < T.mode_gr && verdict == 0; gr++)
         for (int ch = 0; ch < C && verdict == 0; ch++) {
-            const GrSide* rec = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
-            if (!rec->active) continue;
-            const Seed s = seed_before(W, sd, C, k, gr, ch);
-            if (s.start == rec->bs_start && s.step == rec->bs_step_in) continue;
-            const int ntab = rec->bs_ntab, desired_rate = rec->targ_bits;
+            const int64_t gc = ((int64_t)fidx * 2 + gr) * C + ch;
+            const uint32_t* dig = W.vdig + gc;
+            const uint32_t h = dig[0];
+            if (!vd_active(h)) continue;
+            const Seed s = seed_before_dig(W, sd, C, k, gr, ch);
+            if (s.start == vd_start(h) && s.step == vd_step(h)) continue;
+            const uint32_t tw = dig[VD_TARG * dn];
+            const int ntab = (int)(tw >> 24), desired_rate = (int)(tw & 0xffffffu);
+            const GrSide* rec = W.side + gc;
+            int32_t et[VD_ENT], ea[VD_ENT];
+#pragma unroll
+            for (int i = 0; i < VD_ENT; i++) { et[i] = -1; ea[i] = 0; if (i < ntab) { et[i] = (int32_t)dig[(VD_TAB + 2 * i) * dn]; ea[i] = (int32_t)dig[(VD_TAB + 2 * i + 1) * dn]; } }
             int gain = s.start, CurrentStep = s.step, flagGoneOver = 0, Direction = 0, up = 0;
             GI g0;
             g0.table_select[0] = g0.table_select[1] = g0.table_select[2] = 0; g0.region0_count = 0; g0.region1_count = 0;
             int cstate = pack_cond_fields(g0, 0);
             for (;;) {
                 int nBits = -1, asg = 0;
-                for (int i = 0; i < ntab; i++) { const int e = rec->bs_tab[i]; if ((int)((uint32_t)e >> 24) == gain) { nBits = e & 0xffffff; asg = rec->bs_asg[i]; break; } }
+#pragma unroll
+                for (int i = VD_ENT - 1; i >= 0; i--) if (i < ntab && (int)((uint32_t)et[i] >> 24) == gain) { nBits = et[i] & 0xffffff; asg = ea[i]; }   // the FIRST entry with that gain, as the record walk finds it
+                if (nBits < 0 && ntab > VD_ENT)      // a long search: the entries beyond the digest are in the side record
+                    for (int i = VD_ENT; i < ntab; i++) { const int e = rec->bs_tab[i]; if ((int)((uint32_t)e >> 24) == gain) { nBits = e & 0xffffff; asg = rec->bs_asg[i]; break; } }
                 if (nBits < 0) { verdict = 2; break; }
                 cstate = apply_cond_fields(cstate, asg);
                 if (!up) {
@@ -2576,7 +2638,7 @@ LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const Stream
                 if (nBits > desired_rate && gain < 255) { gain++; continue; }
                 break;
             }
-            if (verdict == 0 && (gain != rec->bs_gain || cstate != (rec->bs_state & ~15))) verdict = 1;
+            if (verdict == 0 && (gain != vd_gain(h) || cstate != (int)(dig[VD_STATE * dn] & ~15u))) verdict = 1;
         }
     W.seed_flag[fidx] = verdict;
     if (verdict) {

@@ -1,4 +1,4 @@
-// k_quant_tail.h -- EXPERIMENT, compiled only with -DLHIP_TAIL_HELP (the shipped library does not contain it).
+// k_quant_tail.h -- how a launch of the persistent quantization kernel ends (g_quant, lhip_api.cpp).
 //
 // What it is for: a launch of the persistent quantization kernel ends with ~2 ms in which waves leave one by one (a two-channel frame is
 // 1.5-2 ms of one wave; measured: 1.29 ms of idle per wave and launch, profiles/r03_quant_wave_tail.txt).  Here a wave that finds the frame
@@ -12,8 +12,9 @@
 //
 // State of an offer: 0 none, 1 open, 2 claimed, 3 done.  Owner: fields, release, 1 ... CAS(1 -> 0) withdraws; else wait for 3, read, 0.
 // Helper: CAS(1 -> 2), acquire, unit, results, release, 3.  Helpers leave when no wave of the workgroup can draw a frame any more.
-// Tested in the 64-lane simulation as a real 8-wave workgroup (tests/hostsim: liblamejs_wavesim_tailhelp.so); first device runs at the end of
-// round 3: output unchanged, step 45.6 -> 45.2 ms, host-buffer call 51.9 -> 50.8 ms (profiles/r03_tail_help_experiment_first_device_runs.txt).
+// Tested in the 64-lane simulation as a real 8-wave workgroup (tests/hostsim: liblamejs_wavesim.so runs two-channel batches this way).  Measured
+// (profiles/r03_tail_help_experiment_first_device_runs.txt, profiles/r04_ab_tail_help.txt): idle at the end of a launch 1.29 -> 0.81 ms per wave,
+// step 45.6 -> 45.2 ms, a 16384-frame chunk of the host path -2.3 %; shipped in round 4 after the full sweep.
 #pragma once
 namespace lhip {
 
@@ -54,84 +55,6 @@ LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup
 #define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 24)) __builtin_trap(); } while (0)
 #endif
 
-// One granule-channel of a frame, from the spectrum to the published record: init_outer_loop .. best_huffman_divide (the body of the
-// reference's per-channel loop, Quantize.js:1406-1466 CBR_iteration_loop + iteration_finish_one) on the calling wave's LDS record.
-// `used` = the bin-search seed, `gr0_bt` = this channel's block type in granule 0 (scfsi); L.sf_gr0[ch] is written by granule 0 and read
-// by granule 1 of the same channel.  Returns the bits spent (part2_3 + part2), the seed the next granule of this channel starts from
-// (valid if `active`) and the block type.
-struct UnitOut { int bits; Seed next; int block_type; int active; };
-// (behind a call -- one copy of this code for the owner's and the helper's call site -- the kernel was a third slower: spills around the call)
-LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
-                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q) {
-    UnitOut u; u.next = used;
-    GI g;
-    const int bt = W.blocktype[(int64_t)gslot * C + ch];
-    const double masking_lower = (bt != SHORT_TYPE) ? T.masking_lower_long : T.masking_lower_short;
-    const float* ratio = W.E + ((int64_t)(gslot - 1) * Cp + ch + mode_ext) * E_STRIDE;   // thresholds of the previous psy call (mid / side: channels 2, 3)
-    { PH_BEGIN(); q_init_outer_loop(T, pb10, ath_adjust, g, bt, xr_source(W, C, gslot, ch, mode_ext == 2), mode_ext == 2 ? nullptr : W.xr + ((int64_t)gslot * C + ch) * 576, 0, lane, L, Q); PH_END(L, PH_INIT); }
-    int active = 0, bs_gain = 0;
-    if (q_init_xrpow(g, lane, L, Q)) {
-        active = 1;
-        { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
-        int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-        q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, lane, L, Q);
-        uni_gi(g); bs_gain = uni(bs_gain);
-        wave_sync();                                    // the kept spectrum was written by other lanes of this wave
-#if LHIP_NL == 1
-        for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
-#else
-        {   // all of a lane's words in flight at once (a lane-strided loop waits for every load by itself)
-            uint32_t kw[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)kept)[i < 288 ? i : 287]; }
-#pragma unroll
-            for (int j = 0; j < NPL; j++) LHIP_PIN_LOADED(kw[j]);
-#pragma unroll
-            for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
-        }
-#endif
-        wave_sync();
-        Seed nx; nx.step = (used.start - bs_gain >= 4) ? 4 : 2; nx.start = bs_gain;
-        u.next = nx;
-    } else {
-        for (int i = lane; i < 576; i += LHIP_NL) L.ixw[i] = 0;
-        wave_sync();
-    }
-    int scfsi[4];
-    { PH_BEGIN(); q_best_scalefac_store(T, g, gr, ch, gr0_bt, scfsi, lane, L, Q); PH_END(L, PH_SFSTORE); }
-    uni_gi(g);
-    if (T.use_best_huffman == 1) { PH_BEGIN(); q_best_huffman_divide(T, g, lane, L, Q); PH_END(L, PH_HUFFDIV); }
-    uni_gi(g);
-    u.bits = g.part2_3_length + g.part2_length;
-    u.block_type = g.block_type;
-    if (gr == 0) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i]; }
-    // ---- publish the record and the signed quantized spectrum ----
-    GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
-    if (lane == 0) {
-        out->part2_3_length = g.part2_3_length; out->part2_length = g.part2_length; out->big_values = g.big_values;
-        out->count1 = g.count1; out->global_gain = g.global_gain; out->scalefac_compress = g.scalefac_compress;
-        out->block_type = g.block_type;
-        for (int i = 0; i < 3; i++) { out->table_select[i] = g.table_select[i]; out->subblock_gain[i] = g.subblock_gain[i]; }
-        out->region0_count = g.region0_count; out->region1_count = g.region1_count; out->preflag = g.preflag;
-        out->scalefac_scale = g.scalefac_scale; out->count1table_select = g.count1table_select;
-        out->sfbmax = g.sfbmax; out->sfbdivide = g.sfbdivide;
-        out->active = active; out->bs_start = used.start; out->bs_step_in = used.step; out->bs_gain = bs_gain;
-        out->targ_bits = targ_ch;
-        out->mode_ext = mode_ext;
-        out->scfsi = scfsi[0] | (scfsi[1] << 1) | (scfsi[2] << 2) | (scfsi[3] << 3);
-    }
-    LHIP_LANE_ONCE(i, 0, SFBMAX) out->scalefac[i] = L.sfb[i];
-    if (!active && lane == 0) { out->bs_ntab = 0; out->bs_state = 0; }
-    int16_t* l3o = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-    for (int i = lane; i < 576; i += LHIP_NL) {
-        const int v = L.ixw[i];
-        l3o[i] = (int16_t)(((double)L.xr[i] < 0) ? -v : v);
-    }
-    wave_sync();
-    u.active = active;
-    return u;
-}
-
 // kb_quant for the persistent kernel's speculative pass (chain == 0, no reservoir) with the second channel of every granule on offer
 LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot, int lane, QuantLds& L,
                           const QuantTabs& Q, int* hint, TailShare& TS, int wv) {
@@ -141,6 +64,9 @@ LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace&
     const int k = fslot - sd.fslot0 - 1;
     if (k < 0) return;
     const int fidx = sd.out_slot0 + k;
+#ifdef LHIP_PHASE_PROF
+    const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();     // L.prof is zeroed / flushed once per wave by g_quant
+#endif
     const double ath_adjust = W.ath_adjust[fslot];
     const int padding = frame_padding(T, sd, k);
     const int mean_bits = (frame_bits_of(T, padding) - T.sideinfo_len * 8) / T.mode_gr;
@@ -195,6 +121,9 @@ LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace&
         }
     }
     hint[0] = st; hint[1] = seed0.start; hint[2] = C > 1 ? seed1.start : -1;
+#ifdef LHIP_PHASE_PROF
+    if (lane == 0) { L.prof[PH_TOTAL] += (unsigned int)(__builtin_amdgcn_s_memtime() - ph_total0_); L.prof[32 + PH_TOTAL] += 1; }
+#endif
 }
 
 // a wave that has found the dispenser empty: take open offers of the workgroup until no wave can draw a frame any more

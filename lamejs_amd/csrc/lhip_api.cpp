@@ -13,8 +13,8 @@
 #include "k_psy.h"
 #include "k_fb.h"
 #include "k_quant.h"
-#ifdef LHIP_TAIL_HELP
-#include "k_quant_tail.h"      // experiment: not part of the shipped library
+#if !defined(LHIP_HOSTSIM) || defined(LHIP_WAVESIM)
+#include "k_quant_tail.h"      // how a launch of the persistent quantization kernel ends (the one-lane simulation has no workgroups: it runs kb_quant)
 #endif
 #include "k_bits.h"
 
@@ -28,6 +28,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 
 using namespace lhip;
 
@@ -392,10 +393,7 @@ enum { QWAVES = 7 };      /* the profiling counters take LDS: 7 waves keep two w
 #else
 enum { QWAVES = 8 };
 #endif
-#ifndef LHIP_PHASE_PROF
-// two workgroups must fit in the 160 KB of LDS of a CU, or occupancy silently halves
-static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
-#endif
+// (two workgroups must fit in the 160 KB of LDS of a CU, or occupancy silently halves: static_assert in g_quant)
 #ifndef LHIP_QOCC
 #define LHIP_QOCC 4     /* waves per SIMD the quantization kernels are register-budgeted for */
 #endif
@@ -411,15 +409,15 @@ struct QArgs { Tables T; PowBase pb; Workspace W; const StreamDesc* SD; int chai
 template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
+    __shared__ TailShare TS;
+#ifndef LHIP_PHASE_PROF
+    static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) + sizeof(TailShare) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
+#endif
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     q_load_tabs(A->T, Q, threadIdx.x, 64 * QWAVES);
-#ifdef LHIP_TAIL_HELP
-    __shared__ TailShare TS;
-    static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) + sizeof(TailShare) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
     if (threadIdx.x == 0) TS.drawing = QWAVES;
     if (threadIdx.x < QWAVES) TS.offer[threadIdx.x].state = 0;
-    const bool tail_help_on = !RESV && A->T.channels_out == 2;
-#endif
+    const bool tail_help_on = !RESV && A->T.channels_out == 2;       // a one-channel frame is one chain: nothing to offer
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef LHIP_PHASE_PROF
@@ -432,17 +430,14 @@ template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_
     for (;;) {
         const int fslot = next_frame_slot(A->W.work_ctr + A->ctr);
         if (fslot >= A->nfs) break;
-#ifdef LHIP_TAIL_HELP
-        // (the kernel is only launched for the speculative pass, chain == 0: one copy of the per-frame program in the code, not two)
+        // the speculative pass (chain == 0): the frame program with the second channel of every granule on offer to the workgroup's idle waves
+        // (k_quant_tail.h); with the reservoir the frames are a chain and this kernel is not launched (g_resv_stream)
         if constexpr (!RESV) kb_quant_th(A->T, A->pb, A->W, A->SD, fslot, threadIdx.x & 63, L[wv], Q, hint, TS, wv);
-        else
-#endif
-        kb_quant<0, RESV>(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q, -1, nullptr, nullptr, RESV ? nullptr : hint);
+        else kb_quant<0, RESV>(A->T, A->pb, A->W, A->SD, fslot, A->chain, threadIdx.x & 63, L[wv], Q, -1, nullptr, nullptr, nullptr);
         hint[0] = __builtin_amdgcn_readfirstlane(hint[0]); hint[1] = __builtin_amdgcn_readfirstlane(hint[1]); hint[2] = __builtin_amdgcn_readfirstlane(hint[2]);
     }
-#ifdef LHIP_TAIL_HELP
+    // the dispenser is empty: stay and take the second channels that this workgroup's waves still have ahead of them
     if (tail_help_on) tail_help(A->T, A->pb, A->W, A->SD, threadIdx.x & 63, L, wv, QWAVES, Q, TS);
-#endif
 #ifdef LHIP_PHASE_PROF
     atomicAdd((unsigned long long*)A->W.prof + (threadIdx.x & 63), (unsigned long long)L[wv].prof[threadIdx.x & 63]);
 #endif
@@ -950,7 +945,7 @@ struct Context {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes, vdig;
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
     int num_cus = 256;
@@ -1074,6 +1069,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(att_clean, GP * 4); ENS(nb1, GP * EBL_STRIDE * 4); ENS(nb2, GP * EBL_STRIDE * 4); ENS(fr, FR * sizeof(FrameResv)); ENS(out_bytes, (size_t)S * 4 + 64);
     ENS(fht, Cp == 4 ? (size_t)ngs * 2 * FHT_STRIDE * 4 : 64); ENS(hpf, Cp == 4 ? (size_t)ngs * 2 * 576 * 4 : 64); ENS(tot_ener, (size_t)ngs * 4 * 4);
     ENS(side, FR * 2 * C * sizeof(GrSide)); ENS(l3, FR * 2 * C * 576 * 2); ENS(seed, (size_t)nfs * C * 2 * 4);
+    ENS(vdig, FR * 2 * C * VD_WORDS * 4);
     ENS(seed_flag, FR * 4); ENS(reval, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
     ENS(prof, PROF_BYTES);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
@@ -1087,6 +1083,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.fht = (float*)ctx->fht.p; W.hpf = (float*)ctx->hpf.p; W.tot_ener = (float*)ctx->tot_ener.p;
     W.att_clean = (int32_t*)ctx->att_clean.p; W.nb1 = (float*)ctx->nb1.p; W.nb2 = (float*)ctx->nb2.p; W.fr = (FrameResv*)ctx->fr.p; W.out_bytes = (int32_t*)ctx->out_bytes.p;
     W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p; W.reval = (int32_t*)ctx->reval.p;
+    W.vdig = (uint32_t*)ctx->vdig.p; W.vdig_n = (int64_t)FR * 2 * C;
     W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 16; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
 
     // ---- descriptors / inputs ----
@@ -1162,7 +1159,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = T.psy_channels == 4 ? 8 : 4;
-            static thread_local unsigned char UL[8][FR_LDS_PER_WAVE]; static thread_local int fmbox[4];
+            alignas(16) static thread_local unsigned char UL[8][FR_LDS_PER_WAVE]; static thread_local int fmbox[4];
             for (int s = 0; s < S; s++) {
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {
@@ -1199,7 +1196,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
         if (resv) {
             // the per-stream reservoir program (kb_resv_stage), as g_resv_stream runs it; the wave simulation as a real workgroup of four waves
-            static thread_local unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static thread_local int rmbox[4];
+            alignas(16) static thread_local unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static thread_local int rmbox[4];
             for (int s = 0; s < S; s++) {
                 ResvState RV = dIO[s].state->rv;
                 int32_t nout = 0;
@@ -1230,7 +1227,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
 #define QUANT_RUN(chain_) WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
 #endif
-#if defined(LHIP_WAVESIM) && defined(LHIP_TAIL_HELP)
+#if defined(LHIP_WAVESIM)
         if (!pair && C == 2) {   // the persistent kernel as a real 8-wave workgroup: frames drawn from a shared counter, then the waves help each other (k_quant_tail.h)
             static QuantLds LQ8[8]; static TailShare TS;
             int ctr = 0;
@@ -1668,10 +1665,16 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         if (pending_bytes > 0 && !rt::d2h(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, cs)) return false;
         return rt::sync(cs);
     };
+    // LAMEJS_HIP_TRACE_CHUNKS=1: host-side timeline of the call on stderr (ms since the call began: after the input copies were issued, after the
+    // kernels were enqueued, after the previous chunk's bytes arrived) -- where a slow caller-side buffer shows
+    static const bool trace_chunks = []() { const char* e = getenv("LAMEJS_HIP_TRACE_CHUNKS"); return e && e[0] == '1'; }();
+    const auto t_call = std::chrono::steady_clock::now();
+    auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     size_t p0 = 0;
     for (size_t k = 0; k < sched.size(); k++) {
         const int par = (int)(k & 1);
         const size_t m = sched[k];
+        const double t_a = trace_chunks ? ms_now() : 0.0;
         int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * stride;
         // buffer `par` was last used by chunk k - 2: its kernels are done (drain() waited for them before chunk k - 1 was enqueued)
         // (copies straight from the caller's pageable memory: measured as fast as copies through pinned staging filled by four host
@@ -1679,6 +1682,7 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         if (!rt::h2d(d_in, left + p0, m * 2, cs)) return fail(nullptr);
         if (C == 2 && !rt::h2d(d_in + stride, (right ? right : left) + p0, m * 2, cs)) return fail(nullptr);
         if (!rt::event_record(ctx->ev_in[par], cs) || !rt::stream_wait_event(ks, ctx->ev_in[par])) return fail(nullptr);
+        const double t_b = trace_chunks ? ms_now() : 0.0;
         std::vector<Job> jobs(1);
         jobs[0] = Job{s, d_in, C == 2 ? d_in + stride : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};
         if (!run_batch(ctx, jobs, true, false)) return fail(nullptr, jobs[0].written < 0 ? jobs[0].written : LHIP_ERR_INTERNAL);
@@ -1693,12 +1697,15 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
         if (g_stat_frames == 0 && !rt::dzero((int32_t*)ctx->chunk_fx.p + 4 * k, 12, ks)) return fail(nullptr);
 #endif
         if (!rt::event_record(ctx->ev_done[par], ks)) return fail(nullptr);
+        const double t_c = trace_chunks ? ms_now() : 0.0;
         if (!drain()) return fail(nullptr);             // chunk k - 1, while chunk k is being encoded
+        if (trace_chunks) fprintf(stderr, "[lhip chunk %zu: %zu samples] begin %.2f  copies issued %.2f  kernels enqueued %.2f  previous chunk's bytes home %.2f ms\n", k, m, t_a, t_b, t_c, ms_now());
         pending_bytes = jobs[0].written; pending_dst = out + total; pending_par = par; have_pending = true;
         total += jobs[0].written; frames_all += g_stat_frames;
         p0 += m;
     }
     if (!drain()) return fail(nullptr);
+    if (trace_chunks) fprintf(stderr, "[lhip chunks] last chunk's bytes home %.2f ms\n", ms_now());
 #ifndef LHIP_HOSTSIM
     {
         std::vector<int32_t> fx(4 * sched.size(), 0);
@@ -1977,7 +1984,7 @@ int lhip_kernel_times(int idx, const char** name, double* total_ms, int64_t* lau
 }
 
 int lhip_debug_set_spec_seed(int start, int step) {
-    if (start < 0 || start > 255 || step < 1) return LHIP_ERR_INTERNAL;
+    if (start < 0 || start > 255 || step < 1 || step > 255) return LHIP_ERR_INTERNAL;
     g_spec_start = start; g_spec_step = step;
     return 0;
 }

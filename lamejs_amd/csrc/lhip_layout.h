@@ -144,6 +144,8 @@ struct Workspace {
     GrSide* side;               // [nframes_total][2][C]
     int16_t* l3;                // [nframes_total][2][C][576]  signed quantized spectrum
     int32_t* seed;              // [nfslots][C][2]  OldValue, CurrentStep after the frame in that slot
+    uint32_t* vdig;             // [VD_WORDS][vdig_n] validation digest per granule-channel (index = (frame * 2 + gr) * C + ch), word-major
+    int64_t vdig_n;             // nframes_total * 2 * C
     int32_t* seed_flag;         // [nframes_total] 1 = frame must be (re)quantized with the chain-implied seed
     int32_t* reval;             // [nframes_total] i > 0: repair pass i - 1 re-quantized the frame's predecessor -- validation pass i re-checks it
     int32_t* nflagged;          // [0] frames to re-quantize, [1] frames the memo-only validation could not decide
@@ -158,6 +160,17 @@ struct Workspace {
     int32_t mode_gr;            // granules per frame (2: MPEG-1, 1: MPEG-2/2.5 LSF)
     int32_t spec_start, spec_step;   // seed assumed by the speculative pass (Quantize.js reset values 180 / 4)
 };
+
+// Validation digest of a granule-channel (quantization -> g_validate_fast): what the seed-chain check reads, compact and word-major so that
+// one thread per frame reads it coalesced.  VD_HEAD: gain | seed start << 8 | seed step << 16 | active << 24; VD_TARG: target bits | memo
+// entries << 24; VD_STATE: the conditionally assigned fields at the end of the bin search (GrSide::bs_state); then the first VD_ENT memo
+// entries as (gain << 24 | bits, assignments) pairs.
+enum { VD_HEAD = 0, VD_TARG = 1, VD_STATE = 2, VD_TAB = 3, VD_ENT = 6, VD_WORDS = VD_TAB + 2 * VD_ENT };
+LHIP_DEV uint32_t vd_head(int active, int start, int step, int gain) { return (uint32_t)(gain & 255) | ((uint32_t)(start & 255) << 8) | ((uint32_t)(step & 255) << 16) | ((uint32_t)(active != 0) << 24); }
+LHIP_DEV int vd_active(uint32_t h) { return (int)((h >> 24) & 1u); }
+LHIP_DEV int vd_gain(uint32_t h) { return (int)(h & 255u); }
+LHIP_DEV int vd_start(uint32_t h) { return (int)((h >> 8) & 255u); }
+LHIP_DEV int vd_step(uint32_t h) { return (int)((h >> 16) & 255u); }
 
 LHIP_DEV PcmSrc pcm_source(const Tables& T, const Workspace& W, const StreamDesc& sd, const StreamIO& io, int ch) {
     PcmSrc P;

@@ -720,43 +720,46 @@ def test_gpu_host_call_in_overlapped_chunks(lib, tmp_path):
       * joint stereo, 55 000 frames: 16384 + a merged 38616
       * the same joint-stereo call through Mp3Encoder.encodeBuffer under Node (N-API: the library writes into the returned array)
     each followed by a second, ordinary call on the same stream and flush(), byte-compared with the oracle; lhip_last_batch_stats of
-    the chunked call covers all its chunks and must report repaired frames.  (The oracle runs beside the GPU on host threads.)"""
+    the chunked call covers all its chunks and must report repaired frames.  (The oracle runs beside the GPU in its own processes.)"""
     import shutil
     import subprocess
-    from concurrent.futures import ThreadPoolExecutor
     import lamejs_amd
-    from oracle_py import oracle_encode
     cases = [("stereo", False, 120000, 7001), ("joint", True, 55000, 7002)]
     mats = {name: _segmented_material(seed, nfr) for name, _, nfr, seed in cases}
     extra = 5000
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        futs = {}
-        for name, joint, nfr, _ in cases:
-            L, R = mats[name]
-            futs[name] = pool.submit(oracle_encode, 2, 44100, 128, np.concatenate([L, L[:extra]]), np.concatenate([R, R[:extra]]), None, True, joint)
-        got = {}
-        for name, joint, nfr, _ in cases:
-            L, R = mats[name]
-            enc = lamejs_amd.Mp3Encoder(2, 44100, 128, joint=joint)
-            a = enc.encodeBuffer(L, R)                                   # the chunked call
-            st = enc.last_batch_stats()
-            assert st["frames"] == nfr, st                               # statistics of the whole call, not of its last chunk
-            assert st["repaired_frames"] > 0, st                         # the material does upset the seed chain inside the chunks
-            b = enc.encodeBuffer(L[:extra], R[:extra])                   # an ordinary batch on the same stream
-            got[name] = a + b + enc.flush()
-            enc.close()
-        node = shutil.which("node")
-        js = None
-        if node and (ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node").exists():
-            L, R = mats["joint"]
-            np.concatenate([L, L[:extra]]).astype("<i2").tofile(tmp_path / "l.s16")
-            np.concatenate([R, R[:extra]]).astype("<i2").tofile(tmp_path / "r.s16")
-            r = subprocess.run([node, str(ROOT / "tests" / "js_hostcall_check.js"), str(tmp_path / "l.s16"), str(tmp_path / "r.s16"), "128", str(len(L)), "joint"],
-                               capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            js = __import__("json").loads(r.stdout.strip().splitlines()[-1])
-        for name, _, _, _ in cases:
-            want = futs[name].result()
-            assert got[name] == want, name
-            if name == "joint" and js is not None:
-                assert js["bytes"] == len(want) and js["md5"] == hashlib.md5(want).hexdigest(), js
+    # the oracle beside the GPU: one process per case (oracle/_ref/lo_cli -- the C oracle keeps static scratch, it is not for threads)
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "all"], check=True, capture_output=True)
+    procs = {}
+    for name, joint, nfr, _ in cases:
+        L, R = mats[name]
+        np.stack([np.concatenate([L, L[:extra]]), np.concatenate([R, R[:extra]])], axis=1).astype("<i2").tofile(tmp_path / f"{name}.pcm")
+        (tmp_path / f"{name}.bin").write_bytes(lamejs_amd.tables_blob(2, 44100, 128, joint))
+        procs[name] = subprocess.Popen([str(ROOT / "oracle" / "_ref" / "lo_cli"), str(tmp_path / f"{name}.bin"), str(tmp_path / f"{name}.pcm"), str(tmp_path / f"{name}.mp3"), "2", str(1152 * 500)],
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    got = {}
+    for name, joint, nfr, _ in cases:
+        L, R = mats[name]
+        enc = lamejs_amd.Mp3Encoder(2, 44100, 128, joint=joint)
+        a = enc.encodeBuffer(L, R)                                   # the chunked call
+        st = enc.last_batch_stats()
+        assert st["frames"] == nfr, st                               # statistics of the whole call, not of its last chunk
+        assert st["repaired_frames"] > 0, st                         # the material does upset the seed chain inside the chunks
+        b = enc.encodeBuffer(L[:extra], R[:extra])                   # an ordinary batch on the same stream
+        got[name] = a + b + enc.flush()
+        enc.close()
+    node = shutil.which("node")
+    js = None
+    if node and (ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node").exists():
+        L, R = mats["joint"]
+        np.concatenate([L, L[:extra]]).astype("<i2").tofile(tmp_path / "l.s16")
+        np.concatenate([R, R[:extra]]).astype("<i2").tofile(tmp_path / "r.s16")
+        r = subprocess.run([node, str(ROOT / "tests" / "js_hostcall_check.js"), str(tmp_path / "l.s16"), str(tmp_path / "r.s16"), "128", str(len(L)), "joint"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        js = __import__("json").loads(r.stdout.strip().splitlines()[-1])
+    for name, _, _, _ in cases:
+        assert procs[name].wait(timeout=600) == 0
+        want = (tmp_path / f"{name}.mp3").read_bytes()
+        assert got[name] == want, name
+        if name == "joint" and js is not None:
+            assert js["bytes"] == len(want) and js["md5"] == hashlib.md5(want).hexdigest(), js

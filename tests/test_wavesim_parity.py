@@ -161,19 +161,19 @@ def test_wavesim_ath_scan_segments(wsim):
     assert stage_taps.compare_stages(wsim, 1, 44100, 128, L, None) == []
 
 
-def test_wavesim_tail_help_experiment():
-    """The tail-help experiment (csrc/k_quant_tail.h, -DLHIP_TAIL_HELP; NOT in the shipped library): the persistent
-    quantization kernel as a real 8-wave workgroup in which waves that find the frame dispenser empty quantize the second channel of
-    granules their neighbours are working on.  Two-channel cases in one batch each (plain, joint stereo, MPEG-2) against the oracle,
+def test_wavesim_tail_help():
+    """How a launch of the persistent quantization kernel ends (csrc/k_quant_tail.h; the shipped g_quant since round 4): the kernel as a
+    real 8-wave workgroup in which waves that find the frame dispenser empty quantize the second channel of granules their neighbours
+    are working on.  Two-channel cases in one batch each (plain, joint stereo, MPEG-2) against the oracle,
     and both ways of an offer -- taken by a helper, withdrawn by its owner -- must have been exercised."""
     import sys
-    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "tailhelp"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
     code = ("import sys; sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s'); import lamejs_amd, fuzz_gpu\n"
             "lib = lamejs_amd.load_library(r'%s')\n"
             "bad = fuzz_gpu.run(5, 4401, lib=lib, verbose=False, stereo_only=True, whole=True, max_frames=40)\n"
             "bad += fuzz_gpu.run(4, 4402, lib=lib, verbose=False, joint=True, whole=True, max_frames=40)\n"
             "bad += fuzz_gpu.run(4, 4403, lib=lib, verbose=False, cfgs=fuzz_gpu.LSF_CFGS, stereo_only=True, whole=True, max_frames=40)\n"
-            "print('BAD', bad)\n") % (ROOT, ROOT / "tests", ROOT / "tests" / "tools", ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim_tailhelp.so")
+            "print('BAD', bad)\n") % (ROOT, ROOT / "tests", ROOT / "tests" / "tools", ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim.so")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LAMEJS_TAILHELP_STATS="1"), timeout=900)
     assert r.returncode == 0 and "BAD []" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
     import re

@@ -94,7 +94,7 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
 
 
 def main():
-    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim|wavesim|tailhelp] [joint] [reservoir] [short] [stereo] [whole]
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim|wavesim] [joint] [reservoir] [short] [stereo] [whole]
     stereo: two-channel configurations only; whole: every case in ONE encodeBuffer call (one batch of all its frames)
     wavesim: the 64-lane wave programs as fibers on the CPU (slow: use `short`, at most 40 frames per case)"""
     cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else LOWRATE_CFGS if "lowrate" in sys.argv[3:] else MPEG1_CFGS
@@ -103,8 +103,6 @@ def main():
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))
     if "wavesim" in sys.argv[3:]:
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim.so"))
-    if "tailhelp" in sys.argv[3:]:       # the 64-lane simulation with the tail-help experiment (make -C tests/hostsim tailhelp)
-        lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim_tailhelp.so"))
     bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs, joint="joint" in sys.argv[3:], reservoir="reservoir" in sys.argv[3:],
               max_frames=40 if "short" in sys.argv[3:] else 260, stereo_only="stereo" in sys.argv[3:], whole="whole" in sys.argv[3:])
     sys.exit(1 if bad else 0)

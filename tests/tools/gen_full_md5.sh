@@ -14,7 +14,7 @@ TMP=$(mktemp -d)
   for b in $(seq 0 31); do echo "sine 1 128 1000 $((1000 + 32 * b)) 32"; done  # config 5 (configs[4]): 1024 streams, seed 1000 + s
   for s in $(seq 12345 12352); do echo "centre_sine 2 128 100000 $s 1 joint"; done   # joint-stereo extension: every frame mid/side
   echo "bursts 2 128 100000 777 1 joint"                                        # joint-stereo extension: mid/side and left/right frames mixed
-  for b in $(seq 0 7); do echo "sine 1 128 1000 $((1000 + 16 * b)) 16 reservoir"; done   # bit-reservoir extension: 128 mono streams x 1000 frames (config 5 shape, rank 0)
+  for b in $(seq 0 31); do echo "sine 1 128 1000 $((1000 + 16 * b)) 16 reservoir"; done  # bit-reservoir extension: 512 mono streams x 1000 frames (config 5 shape: 128, 256 and 512 streams on one GPU)
 } > $TMP/jobs
 nl -ba $TMP/jobs | xargs -P $P -L 1 sh -c 'node tests/tools/gen_full_md5.js $1 $2 $3 $4 $5 $6 $7 $8 > '$TMP'/out.$0'
 python3 - "$TMP" "$OUT" <<'PY'
