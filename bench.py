@@ -52,6 +52,9 @@ PRESETS = {
     # bit-reservoir extension: the frames of a stream are a serial chain there (one frame per stream and launch), so
     # the shape that uses the GPU is many streams side by side -- BASELINE configs[4]'s 128 streams x 1000 frames
     "reservoir": dict(label="bit-reservoir extension", ch=1, kbps=128, streams=128, frames=1000, corpus="sine", seed0=1000, reservoir=True),
+    # the mode's only lever is streams side by side (a workgroup per stream walks its frames): 256 = one per CU, 512 = two
+    "reservoir256": dict(label="bit-reservoir extension, 256 streams", ch=1, kbps=128, streams=256, frames=1000, corpus="sine", seed0=1000, reservoir=True),
+    "reservoir512": dict(label="bit-reservoir extension, 512 streams", ch=1, kbps=128, streams=512, frames=1000, corpus="sine", seed0=1000, reservoir=True),
 }
 
 
@@ -270,7 +273,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint', 'joint_bursts', 'reservoir', or 'shard3' (ONE config-3 stream cut into frame ranges over the GPUs: strong scaling)")
+    ap.add_argument("--config", default="3", help="2 | 3 | 4 | 5 (SURVEY.md 8d numbering = BASELINE configs[n-1]), 'bursts', 'joint', 'joint_bursts', 'reservoir', 'reservoir256', 'reservoir512', or 'shard3' (ONE config-3 stream cut into frame ranges over the GPUs: strong scaling)")
     ap.add_argument("--shard-corpus", default="sine", help="shard3 only: the material (tests/pcm.py); 'bursts' has cuts whose speculated state misses")
     ap.add_argument("--shard-warmup", type=int, default=64, help="shard3 only: warm-up frames in front of a cut (64: the ATH adjustment has forgotten its past, DESIGN.md 7)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per stream (parity table then only covers a prefix check)")
@@ -280,6 +283,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs (they are only run at N = 1)")
     ap.add_argument("--no-cpu-aggregate", action="store_true", help="skip the all-cores leg of the CPU baseline")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the MP3 bytes to rank 0 (N > 1)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight (the steps strictly one after the other) instead of two")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` started plainly (no launcher, no WORLD_SIZE in the environment) launches its own N ranks: the same
@@ -415,9 +419,14 @@ def main():
                     lib.lhip_destroy(h)
             self.handles = []
 
-        def timed(self, steps, warmup):
-            """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+        def timed(self, steps, warmup, pipeline=True):
+            """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks.
+            pipeline: two batches in flight (lhip_set_pipeline(device, 2)) -- every step is a batch of fresh, independent streams, so
+            step k + 1's psychoacoustics / filterbank run while step k's quantization kernel drains and its validation and bit packing
+            finish; all K batches are complete when the closing synchronisation returns.  The bit reservoir's batches are synchronous."""
             sets = [self.new_streams() for _ in range(warmup + steps)]
+            if not sim:
+                assert lib.lhip_set_pipeline(dev_ord, 2 if pipeline else 1) == 0, lib.lhip_last_error()
             for w in range(warmup):
                 self.step(sets[w])
             dsync()
@@ -439,6 +448,8 @@ def main():
             a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
             lib.lhip_last_batch_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
             self.frames_per_step, self.repaired, self.repair_iters = a.value, b.value, c.value
+            if not sim:
+                assert lib.lhip_set_pipeline(dev_ord, 1) == 0, lib.lhip_last_error()
             self.nbytes = [int(self.wr[i]) for i in range(self.ns)]
             return dt
 
@@ -489,8 +500,10 @@ def main():
         return
     key = args.config if args.config in PRESETS else int(args.config)
     wl = Workload(key)
-    dt = wl.timed(args.steps, args.warmup)
+    pipe = not args.no_pipeline
+    dt = wl.timed(args.steps, args.warmup, pipeline=pipe)
     outs = wl.outputs()
+    dt_single = wl.timed(min(args.steps, 3), 1, pipeline=False) / min(args.steps, 3) if (pipe and not sim) else None      # the same step with one batch in flight (untimed extra)
     full, prefix, md5s = wl.check(outs)
     kern = wl.kernel_times() if not sim else {}
 
@@ -529,6 +542,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.describe(), "frames_per_step_per_gpu": wl.frames_per_step,
                        "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
+                       "batches_in_flight": (2 if pipe and not sim and not wl.resv else 1),
+                       "pipeline_note": "every step is one batch of fresh, independent streams; with two batches in flight (lhip_set_pipeline) step k + 1's psychoacoustics and filterbank "
+                                        "overlap step k's quantization tail, validation and bit packing -- all K batches are complete inside the timed region",
+                       "ms_per_step_one_batch_in_flight": (None if dt_single is None else round(1000.0 * dt_single, 3)),
                        "bit_exact_full": (None if any(f is None for f in all_full) else all(all_full)),
                        "bit_exact_full_note": "md5 + length of every stream's whole output vs tests/golden/full_md5.json (unmodified reference under node)",
                        "bit_exact_prefix_vs_oracle": (None if any(v[3] is None for v in verdicts) else all(v[3] for v in verdicts)),
@@ -576,7 +593,7 @@ def main():
     # ---- the other configurations (N = 1 only): each is its own short run, md5-checked like the main one ----
     if world == 1 and not args.no_extras and not args.frames and not args.streams:
         others = {}
-        for k2 in (2, 3, 4, 5, "bursts", "joint", "joint_bursts", "reservoir"):
+        for k2 in (2, 3, 4, 5, "bursts", "joint", "joint_bursts", "reservoir", "reservoir256", "reservoir512"):
             if k2 == key:
                 continue
             w2 = Workload(k2)

@@ -2572,74 +2572,69 @@ LHIP_DEV Seed seed_before_dig(const Workspace& W, const StreamDesc& sd, int C, i
     return s;
 }
 
-// Memo-only replay, one THREAD per frame: the whole check is a few scalar look-ups, so it runs as a plain grid over the frames without
-// LDS tables.  It reads the granule-channels' DIGESTS (W.vdig: seed used, resulting gain, target, the first VD_ENT memo entries; word-major,
-// so the threads of a wave read neighbouring words) -- the side records, 464 bytes apart with the memo at their far end, cost one cache line
-// per thread and field (0.29 - 0.38 ms per 1e5 frames in round 3); only a search with more than VD_ENT memoised evaluations falls back to them.
-// Outcome per frame in W.seed_flag: 0 consistent, 1 re-quantize with the chain-implied seed, 2 undecided (a gain the speculative pass
-// never evaluated) -> kb_validate decides.
-// only_pass > 0: just the frames stamped for that pass (successors of frames the previous repair pass re-quantized)
-LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int only_pass = 0) {
+// Memo-only replay of ONE granule-channel's bin search with the chain-implied seed: a few scalar look-ups in the granule-channels' DIGESTS
+// (W.vdig: seed used, resulting gain, target, the first VD_ENT memo entries; word-major, so the threads of a wave read neighbouring
+// words) -- the side records, 464 bytes apart with the memo at their far end, are only read by a search with more than VD_ENT memoised
+// evaluations.  Returns 0 consistent, 1 re-quantize the frame with the chain-implied seed, 2 undecided (a gain the speculative pass never
+// evaluated) -> kb_validate decides.
+LHIP_DEV int validate_fast_gc(const Tables& T, const Workspace& W, const StreamDesc& sd, int k, int fidx, int gr, int ch) {
     const int C = T.channels_out;
-    const StreamDesc sd = SD[W.fslot_stream[fslot]];
-    const int k = fslot - sd.fslot0 - 1;
-    if (k < 0) return;
-    const int fidx = sd.out_slot0 + k;
-    if (only_pass > 0 && W.reval[fidx] != only_pass) return;
-    int verdict = 0;
     const int64_t dn = W.vdig_n;
-    for (int gr = 0; gr < T.mode_gr && verdict == 0; gr++)
-        for (int ch = 0; ch < C && verdict == 0; ch++) {
-            const int64_t gc = ((int64_t)fidx * 2 + gr) * C + ch;
-            const uint32_t* dig = W.vdig + gc;
-            const uint32_t h = dig[0];
-            if (!vd_active(h)) continue;
-            const Seed s = seed_before_dig(W, sd, C, k, gr, ch);
-            if (s.start == vd_start(h) && s.step == vd_step(h)) continue;
-            const uint32_t tw = dig[VD_TARG * dn];
-            const int ntab = (int)(tw >> 24), desired_rate = (int)(tw & 0xffffffu);
-            const GrSide* rec = W.side + gc;
-            int32_t et[VD_ENT], ea[VD_ENT];
+    const int64_t gc = ((int64_t)fidx * 2 + gr) * C + ch;
+    const uint32_t* dig = W.vdig + gc;
+    const uint32_t h = dig[0];
+    if (!vd_active(h)) return 0;
+    const Seed s = seed_before_dig(W, sd, C, k, gr, ch);
+    if (s.start == vd_start(h) && s.step == vd_step(h)) return 0;
+    const uint32_t tw = dig[VD_TARG * dn];
+    const int ntab = (int)(tw >> 24), desired_rate = (int)(tw & 0xffffffu);
+    const GrSide* rec = W.side + gc;
+    int32_t et[VD_ENT], ea[VD_ENT];
 #pragma unroll
-            for (int i = 0; i < VD_ENT; i++) { et[i] = -1; ea[i] = 0; if (i < ntab) { et[i] = (int32_t)dig[(VD_TAB + 2 * i) * dn]; ea[i] = (int32_t)dig[(VD_TAB + 2 * i + 1) * dn]; } }
-            int gain = s.start, CurrentStep = s.step, flagGoneOver = 0, Direction = 0, up = 0;
-            GI g0;
-            g0.table_select[0] = g0.table_select[1] = g0.table_select[2] = 0; g0.region0_count = 0; g0.region1_count = 0;
-            int cstate = pack_cond_fields(g0, 0);
-            for (;;) {
-                int nBits = -1, asg = 0;
+    for (int i = 0; i < VD_ENT; i++) { et[i] = -1; ea[i] = 0; if (i < ntab) { et[i] = (int32_t)dig[(VD_TAB + 2 * i) * dn]; ea[i] = (int32_t)dig[(VD_TAB + 2 * i + 1) * dn]; } }
+    int gain = s.start, CurrentStep = s.step, flagGoneOver = 0, Direction = 0, up = 0;
+    GI g0;
+    g0.table_select[0] = g0.table_select[1] = g0.table_select[2] = 0; g0.region0_count = 0; g0.region1_count = 0;
+    int cstate = pack_cond_fields(g0, 0);
+    for (;;) {
+        int nBits = -1, asg = 0;
 #pragma unroll
-                for (int i = VD_ENT - 1; i >= 0; i--) if (i < ntab && (int)((uint32_t)et[i] >> 24) == gain) { nBits = et[i] & 0xffffff; asg = ea[i]; }   // the FIRST entry with that gain, as the record walk finds it
-                if (nBits < 0 && ntab > VD_ENT)      // a long search: the entries beyond the digest are in the side record
-                    for (int i = VD_ENT; i < ntab; i++) { const int e = rec->bs_tab[i]; if ((int)((uint32_t)e >> 24) == gain) { nBits = e & 0xffffff; asg = rec->bs_asg[i]; break; } }
-                if (nBits < 0) { verdict = 2; break; }
-                cstate = apply_cond_fields(cstate, asg);
-                if (!up) {
-                    if (CurrentStep == 1 || nBits == desired_rate) up = 1;
-                    else {
-                        int step;
-                        if (nBits > desired_rate) {
-                            if (Direction == 2) flagGoneOver = 1;
-                            if (flagGoneOver) CurrentStep /= 2;
-                            Direction = 1;
-                            step = CurrentStep;
-                        } else {
-                            if (Direction == 1) flagGoneOver = 1;
-                            if (flagGoneOver) CurrentStep /= 2;
-                            Direction = 2;
-                            step = -CurrentStep;
-                        }
-                        gain += step;
-                        if (gain < 0) { gain = 0; flagGoneOver = 1; }
-                        if (gain > 255) { gain = 255; flagGoneOver = 1; }
-                        continue;
-                    }
+        for (int i = VD_ENT - 1; i >= 0; i--) if (i < ntab && (int)((uint32_t)et[i] >> 24) == gain) { nBits = et[i] & 0xffffff; asg = ea[i]; }   // the FIRST entry with that gain, as the record walk finds it
+        if (nBits < 0 && ntab > VD_ENT)      // a long search: the entries beyond the digest are in the side record
+            for (int i = VD_ENT; i < ntab; i++) { const int e = rec->bs_tab[i]; if ((int)((uint32_t)e >> 24) == gain) { nBits = e & 0xffffff; asg = rec->bs_asg[i]; break; } }
+        if (nBits < 0) return 2;
+        cstate = apply_cond_fields(cstate, asg);
+        if (!up) {
+            if (CurrentStep == 1 || nBits == desired_rate) up = 1;
+            else {
+                int step;
+                if (nBits > desired_rate) {
+                    if (Direction == 2) flagGoneOver = 1;
+                    if (flagGoneOver) CurrentStep /= 2;
+                    Direction = 1;
+                    step = CurrentStep;
+                } else {
+                    if (Direction == 1) flagGoneOver = 1;
+                    if (flagGoneOver) CurrentStep /= 2;
+                    Direction = 2;
+                    step = -CurrentStep;
                 }
-                if (nBits > desired_rate && gain < 255) { gain++; continue; }
-                break;
+                gain += step;
+                if (gain < 0) { gain = 0; flagGoneOver = 1; }
+                if (gain > 255) { gain = 255; flagGoneOver = 1; }
+                continue;
             }
-            if (verdict == 0 && (gain != vd_gain(h) || cstate != (int)(dig[VD_STATE * dn] & ~15u))) verdict = 1;
         }
+        if (nBits > desired_rate && gain < 255) { gain++; continue; }
+        break;
+    }
+    return (gain != vd_gain(h) || cstate != (int)(dig[VD_STATE * dn] & ~15u)) ? 1 : 0;
+}
+
+// The frame's verdict from its granule-channels' (a definite "re-quantize" wins over "undecided": the re-quantization settles every
+// granule-channel of the frame) -> W.seed_flag, the counters and the list of undecided frames.
+LHIP_DEV void validate_fast_publish(const Workspace& W, int fslot, int fidx, int any1, int any2) {
+    const int verdict = any1 ? 1 : any2 ? 2 : 0;
     W.seed_flag[fidx] = verdict;
     if (verdict) {
 #ifdef LHIP_HOSTSIM
@@ -2650,5 +2645,46 @@ LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const Stream
         if (verdict == 2) W.slow_list[pos] = fslot;
     }
 }
+
+// One thread per frame (the persistent repair kernel's later passes, the host simulation).
+// only_pass > 0: just the frames stamped for that pass (successors of frames the previous repair pass re-quantized)
+LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int only_pass = 0) {
+    const int C = T.channels_out;
+    const StreamDesc sd = SD[W.fslot_stream[fslot]];
+    const int k = fslot - sd.fslot0 - 1;
+    if (k < 0) return;
+    const int fidx = sd.out_slot0 + k;
+    if (only_pass > 0 && W.reval[fidx] != only_pass) return;
+    int any1 = 0, any2 = 0;
+    for (int gr = 0; gr < T.mode_gr && !any1; gr++)
+        for (int ch = 0; ch < C && !any1; ch++) { const int v = validate_fast_gc(T, W, sd, k, fidx, gr, ch); any1 |= (v == 1); any2 |= (v == 2); }
+    validate_fast_publish(W, fslot, fidx, any1, any2);
+}
+
+#ifndef LHIP_HOSTSIM
+// The first pass over a whole batch (g_validate_fast): FOUR lanes per frame, one per granule-channel -- a frame's check is a chain of
+// dependent look-ups (the two previous granules' digests, then the memo), and one thread per frame left the chip with a wave and a half
+// per SIMD waiting on them (0.27 ms per 1e5 two-channel frames); the quad's verdicts meet through DPP and its first lane publishes.
+LHIP_DEV void kb_validate_fast_quad(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int sub, bool live) {
+    const int C = T.channels_out;
+    int v = 0, fidx = 0;
+    bool has = false;
+    if (live) {
+        const StreamDesc sd = SD[W.fslot_stream[fslot]];
+        const int k = fslot - sd.fslot0 - 1;
+        if (k >= 0) {
+            has = true;
+            fidx = sd.out_slot0 + k;
+            const int gr = sub / C, ch = sub - gr * C;
+            if (gr < T.mode_gr) v = validate_fast_gc(T, W, sd, k, fidx, gr, ch);
+        }
+    }
+    // OR over the four lanes of the quad (bit 0: some granule-channel says "re-quantize", bit 1: some is undecided)
+    int m = (v == 1 ? 1 : 0) | (v == 2 ? 2 : 0);
+    m |= __builtin_amdgcn_mov_dpp(m, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    m |= __builtin_amdgcn_mov_dpp(m, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    if (has && sub == 0) validate_fast_publish(W, fslot, fidx, m & 1, m & 2);
+}
+#endif
 
 }  // namespace lhip

@@ -45,6 +45,7 @@ enum { PROF_BYTES = 512 };
 #endif
 struct Context;
 static thread_local Context* g_stat_pending = nullptr;      // the last batch was enqueued without synchronisation: its repair statistics are still on the device
+static thread_local int g_stat_pending_set = 0;             // ... in this work set of the context
 static void set_err(const std::string& e) { g_err = e; }
 
 #ifdef LHIP_HOSTSIM
@@ -462,8 +463,8 @@ template <int RESV> __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pa
     kb_quant<1, RESV>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
 }
 __global__ __launch_bounds__(256) void g_validate_fast(Tables T, Workspace W, const StreamDesc* SD, int nfs) {
-    const int fslot = blockIdx.x * 256 + threadIdx.x;
-    if (fslot < nfs) kb_validate_fast(T, W, SD, fslot);
+    const int t = blockIdx.x * 256 + threadIdx.x, fslot = t >> 2;        // four lanes per frame slot (kb_validate_fast_quad)
+    kb_validate_fast_quad(T, W, SD, fslot < nfs ? fslot : 0, t & 3, fslot < nfs);
 }
 // ---- seed-chain validation + repair without the host (persistent, grid barriers) ------------------------------------------
 // One launch replaces the host's loop "validate -> read the flagged count back -> repair -> ...": every workgroup walks the same
@@ -570,7 +571,9 @@ __global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W, const 
     if (SD[blockIdx.x].flush) kb_resv_flush(T, W, blockIdx.x, threadIdx.x, L, W.io[blockIdx.x].state->rv, W.out_bytes + blockIdx.x);
 }
 // the per-stream reservoir program (kb_resv_stage): one workgroup of RS_WAVES waves per stream
-__global__ __launch_bounds__(64 * RS_WAVES) void g_resv_stream(QArgs a_unused) {
+// (two waves per SIMD: 256 registers instead of the 264 an unbounded build takes -- the second workgroup per CU is what lets 512 streams
+//  run side by side; the mode's throughput is streams in flight x one frame per 184 us)
+__global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ __attribute__((aligned(16))) unsigned char U[RS_WAVES][RS_LDS_PER_WAVE];
     __shared__ ResvState RV;
@@ -939,25 +942,47 @@ struct DevBuf {
     ~DevBuf() { rt::dfree(p); }
 };
 
+// Everything one batch in flight owns: the workspace arrays, the descriptor / host-I/O staging, and the side stream + events of the
+// ATH scan.  A context has two: normally only set 0 is used, on the caller's HIP stream; with lhip_set_pipeline(device, 2) consecutive
+// device-resident batches alternate between the sets, each on its own internal stream, so that batch k + 1's psychoacoustics and
+// filterbank fill the chip while batch k's persistent quantization kernel drains and its validation / bit packing run.
+struct WorkSet {
+    DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes, vdig;
+    // last batch (for debug taps)
+    Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
+    // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
+    // beside the filterbank kernels, which do not depend on it
+    void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
+    // pipeline mode: the set's own stream, "inputs are ready" (recorded on the caller's stream) and "this set's last batch is done"
+    void* stream = nullptr; void* ev_in = nullptr; void* ev_done = nullptr;
+    bool busy = false;           // a pipelined batch has been enqueued on `stream` and nobody has waited for it yet
+};
+
 struct Context {
     int device = 0;
     void* stream = nullptr;
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
-    DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes, vdig;
-    // last batch (for debug taps)
-    Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
+    WorkSet ws[2];
+    int pipe_depth = 1;          // lhip_set_pipeline: 1 = every batch on the caller's stream (set 0); 2 = device-resident batches alternate between the sets
+    unsigned pipe_next = 0;
+    int last_set = 0;            // the set the most recent batch used (debug taps, statistics)
     int num_cus = 256;
-    // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
-    // beside the filterbank kernels, which do not depend on it
-    void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
     // large host-buffer calls (the drop-in's encodeBuffer with a long Int16Array): chunks of the call are copied in on this stream
     // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
     void* copy_stream = nullptr; void* ev_in[2] = {nullptr, nullptr}; void* ev_done[2] = {nullptr, nullptr};
     DevBuf chunk_in, chunk_out, chunk_fx, state_bak;     // staging halves (sized for the largest chunk a call has reached so far), the per-chunk repair verdicts, the stream state a failed call gives back
     std::mutex chunk_mu;        // one chunked call at a time per device (they share the two staging halves); taken BEFORE mu, never inside it
 };
+
+// wait for the pipelined batches still in flight (ctx->mu held).  Everything that touches a stream's state outside the pipeline -- a
+// synchronous or host-buffer call, flush, the state calls, the statistics -- comes through here first.
+static bool pipeline_drain(Context* ctx) {
+    bool ok = true;
+    for (WorkSet& w : ctx->ws) if (w.busy) { ok = rt::sync(w.stream) && ok; w.busy = false; }
+    return ok;
+}
 
 static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<Context>> g_ctx;
@@ -986,6 +1011,7 @@ struct lhip_stream {
     int slot_lag = 0;
     int64_t frame_num = 0;
     int64_t rs_n_in = 0;           // resampling streams: input samples received so far
+    int pipe_set = -1;             // pipeline mode: the work set this stream's last batch ran on and may still be running on (-1: none)
     ~lhip_stream() { rt::dfree(d_state); magic = 0; }
 };
 
@@ -1014,11 +1040,34 @@ static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
     return (int64_t)F * ts.base_frame_bytes + npad;
 }
 
-static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
+static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync, bool may_pipeline = false) {
     if (jobs.empty()) return true;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(ctx->device)) return false;
+    // Pipeline mode (lhip_set_pipeline(device, 2)): an asynchronous device-resident batch takes the next work set and that set's own
+    // stream; everything else waits for the batches in flight and runs on set 0 / the caller's stream as always.
+    bool pipelined = false;
+#ifndef LHIP_HOSTSIM
+    pipelined = may_pipeline && dev_io && !want_sync && ctx->pipe_depth == 2 && !g_kt_on && jobs[0].s->ts->T.disable_reservoir;
+#else
+    (void)may_pipeline;
+#endif
+    if (!pipelined && !pipeline_drain(ctx)) return false;
+    const int set = pipelined ? (int)(ctx->pipe_next++ & 1u) : 0;
+    WorkSet& ws = ctx->ws[set];
     void* st = ctx->stream;
+#ifndef LHIP_HOSTSIM
+    if (pipelined) {
+        if (!ws.stream && (!rt::stream_create(&ws.stream) || !rt::event_create(&ws.ev_in) || !rt::event_create(&ws.ev_done))) return false;
+        // the batch starts once the caller's stream has reached this point (its inputs are ready) ...
+        if (!rt::event_record(ws.ev_in, ctx->stream) || !rt::stream_wait_event(ws.stream, ws.ev_in)) return false;
+        // ... and once the last batch of each of its streams is done, if that ran on the other set (this set's own stream orders the rest)
+        bool other = false;
+        for (const Job& j : jobs) other |= (j.s->pipe_set == 1 - set);
+        if (other && ctx->ws[1 - set].busy && !rt::stream_wait_event(ws.stream, ctx->ws[1 - set].ev_done)) return false;
+        st = ws.stream;
+    }
+#endif
     TableSet& ts = *jobs[0].s->ts;
     const Tables& T = ts.T;
     const int C = T.channels_out;
@@ -1060,7 +1109,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.nstreams = S; W.nframes_total = nfr; W.nfslots = nfs; W.ngslots = ngs; W.pcm_plane = pcm_plane;
     const int Cp = T.psy_channels;
     const size_t GC = (size_t)ngs * C, GP = (size_t)ngs * Cp, FR = (size_t)(nfr > 0 ? nfr : 1);
-#define ENS(buf, bytes) if (!ctx->buf.ensure(bytes)) return false
+#define ENS(buf, bytes) if (!ws.buf.ensure(bytes)) return false
     ENS(pcm, T.rs_ratio != 1 ? (size_t)pcm_plane * C * 4 + 64 : 64);
     ENS(peaks, GP * PK_STRIDE * 4); ENS(loud, GC * 4); ENS(eb_l, GP * EBL_STRIDE * 4); ENS(mask_idx, GP * EBL_STRIDE * 4);
     ENS(eb_s, GP * EBS_STRIDE * 4); ENS(ecb_s, GP * EBS_STRIDE * 4); ENS(att_raw, GP * 4); ENS(uselong, GC * 4); ENS(ul_tmp, GP * 4); ENS(last_attack, GP * 4);
@@ -1074,17 +1123,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(prof, PROF_BYTES);
     if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
-    W.pcm = (float*)ctx->pcm.p;
-    W.peaks = (float*)ctx->peaks.p; W.loud = (float*)ctx->loud.p; W.eb_l = (float*)ctx->eb_l.p; W.mask_idx = (int32_t*)ctx->mask_idx.p;
-    W.eb_s = (float*)ctx->eb_s.p; W.ecb_s = (float*)ctx->ecb_s.p; W.att_raw = (int32_t*)ctx->att_raw.p; W.uselong = (int32_t*)ctx->uselong.p; W.ul_tmp = (int32_t*)ctx->ul_tmp.p;
-    W.last_attack = (int32_t*)ctx->last_attack.p; W.tent = (int32_t*)ctx->tent.p; W.prev_short = (int32_t*)ctx->prev_short.p;
-    W.blocktype = (int32_t*)ctx->blocktype.p; W.ath_adjust = (double*)ctx->ath_adjust.p; W.ath_limit = (double*)ctx->ath_limit.p;
-    W.E = (float*)ctx->E.p; W.sb = (float*)ctx->sb.p; W.xr = (float*)ctx->xr.p; W.side = (GrSide*)ctx->side.p;
-    W.fht = (float*)ctx->fht.p; W.hpf = (float*)ctx->hpf.p; W.tot_ener = (float*)ctx->tot_ener.p;
-    W.att_clean = (int32_t*)ctx->att_clean.p; W.nb1 = (float*)ctx->nb1.p; W.nb2 = (float*)ctx->nb2.p; W.fr = (FrameResv*)ctx->fr.p; W.out_bytes = (int32_t*)ctx->out_bytes.p;
-    W.l3 = (int16_t*)ctx->l3.p; W.seed = (int32_t*)ctx->seed.p; W.seed_flag = (int32_t*)ctx->seed_flag.p; W.reval = (int32_t*)ctx->reval.p;
-    W.vdig = (uint32_t*)ctx->vdig.p; W.vdig_n = (int64_t)FR * 2 * C;
-    W.nflagged = (int32_t*)ctx->nflagged.p; W.work_ctr = (int32_t*)ctx->nflagged.p + 16; W.slow_list = (int32_t*)ctx->slow_list.p; W.frame_bytes = (int32_t*)ctx->frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ctx->prof.p;
+    W.pcm = (float*)ws.pcm.p;
+    W.peaks = (float*)ws.peaks.p; W.loud = (float*)ws.loud.p; W.eb_l = (float*)ws.eb_l.p; W.mask_idx = (int32_t*)ws.mask_idx.p;
+    W.eb_s = (float*)ws.eb_s.p; W.ecb_s = (float*)ws.ecb_s.p; W.att_raw = (int32_t*)ws.att_raw.p; W.uselong = (int32_t*)ws.uselong.p; W.ul_tmp = (int32_t*)ws.ul_tmp.p;
+    W.last_attack = (int32_t*)ws.last_attack.p; W.tent = (int32_t*)ws.tent.p; W.prev_short = (int32_t*)ws.prev_short.p;
+    W.blocktype = (int32_t*)ws.blocktype.p; W.ath_adjust = (double*)ws.ath_adjust.p; W.ath_limit = (double*)ws.ath_limit.p;
+    W.E = (float*)ws.E.p; W.sb = (float*)ws.sb.p; W.xr = (float*)ws.xr.p; W.side = (GrSide*)ws.side.p;
+    W.fht = (float*)ws.fht.p; W.hpf = (float*)ws.hpf.p; W.tot_ener = (float*)ws.tot_ener.p;
+    W.att_clean = (int32_t*)ws.att_clean.p; W.nb1 = (float*)ws.nb1.p; W.nb2 = (float*)ws.nb2.p; W.fr = (FrameResv*)ws.fr.p; W.out_bytes = (int32_t*)ws.out_bytes.p;
+    W.l3 = (int16_t*)ws.l3.p; W.seed = (int32_t*)ws.seed.p; W.seed_flag = (int32_t*)ws.seed_flag.p; W.reval = (int32_t*)ws.reval.p;
+    W.vdig = (uint32_t*)ws.vdig.p; W.vdig_n = (int64_t)FR * 2 * C;
+    W.nflagged = (int32_t*)ws.nflagged.p; W.work_ctr = (int32_t*)ws.nflagged.p + 16; W.slow_list = (int32_t*)ws.slow_list.p; W.frame_bytes = (int32_t*)ws.frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ws.prof.p;
 
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
@@ -1099,7 +1148,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (dev_io) {
             o.src[0] = j.l; o.src[1] = (C == 2 && j.r) ? j.r : j.l; o.out = j.out;
         } else {
-            int16_t* base = (int16_t*)ctx->in16.p;
+            int16_t* base = (int16_t*)ws.in16.p;
             o.src[0] = base + in_off;
             if (!rt::h2d((void*)o.src[0], j.l, j.n * 2, st)) return false;
             in_off += (int64_t)j.n;
@@ -1108,7 +1157,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
                 if (!rt::h2d((void*)o.src[1], j.r ? j.r : j.l, j.n * 2, st)) return false;
                 in_off += (int64_t)j.n;
             } else o.src[1] = o.src[0];
-            o.out = (uint8_t*)ctx->out8.p + sd[i].out_off;
+            o.out = (uint8_t*)ws.out8.p + sd[i].out_off;
         }
     }
     // All descriptors travel in ONE host-to-device copy (a small pageable copy costs ~10 us of host time each, and a 1-frame
@@ -1118,7 +1167,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     const size_t o_sd = 0, o_io = (o_sd + (size_t)S * sizeof(StreamDesc) + 15) & ~(size_t)15,
                  o_fm = (o_io + (size_t)S * sizeof(StreamIO) + 15) & ~(size_t)15, o_gm = (o_fm + (size_t)nfs * 4 + 15) & ~(size_t)15,
                  desc_bytes = o_gm + (size_t)ngs * 4;
-    if (!ctx->desc.ensure(desc_bytes)) return false;
+    if (!ws.desc.ensure(desc_bytes)) return false;
     {
         std::vector<uint8_t> stage(desc_bytes, 0);
         for (int i = 0; i < S; i++) sd[i].out_off = (int64_t)(uintptr_t)io[i].out;
@@ -1126,16 +1175,16 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         memcpy(stage.data() + o_io, io.data(), (size_t)S * sizeof(StreamIO));
         memcpy(stage.data() + o_fm, fmap.data(), (size_t)nfs * 4);
         memcpy(stage.data() + o_gm, gmap.data(), (size_t)ngs * 4);
-        if (!rt::h2d(ctx->desc.p, stage.data(), desc_bytes, st)) return false;
+        if (!rt::h2d(ws.desc.p, stage.data(), desc_bytes, st)) return false;
     }
-    W.fslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ctx->desc.p + o_gm);
-    if (!rt::dzero(ctx->seed_flag.p, FR * 4, st)) return false;
-    if (!rt::dzero(ctx->reval.p, FR * 4, st)) return false;
-    if (resv && !rt::dzero(ctx->out_bytes.p, (size_t)S * 4, st)) return false;
-    if (!rt::dzero(ctx->nflagged.p, 256, st)) return false;
-    if (!rt::dzero(ctx->prof.p, PROF_BYTES, st)) return false;
-    const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ctx->desc.p + o_sd);
-    const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ctx->desc.p + o_io);
+    W.fslot_stream = (const int32_t*)((const uint8_t*)ws.desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ws.desc.p + o_gm);
+    if (!rt::dzero(ws.seed_flag.p, FR * 4, st)) return false;
+    if (!rt::dzero(ws.reval.p, FR * 4, st)) return false;
+    if (resv && !rt::dzero(ws.out_bytes.p, (size_t)S * 4, st)) return false;
+    if (!rt::dzero(ws.nflagged.p, 256, st)) return false;
+    if (!rt::dzero(ws.prof.p, PROF_BYTES, st)) return false;
+    const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ws.desc.p + o_sd);
+    const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ws.desc.p + o_io);
     W.io = dIO;
 
     int64_t repaired = 0, iters = 0;
@@ -1306,23 +1355,23 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         ~AuxJoin() { if (aux) (void)hipStreamSynchronize((hipStream_t)aux); }
     } aux_guard;
     if (!g_kt_on) {
-        if (!ctx->aux_stream) {
+        if (!ws.aux_stream) {
             hipStream_t a; hipEvent_t e1, e2;
             if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) { ctx->aux_stream = a; ctx->ev_fork = e1; ctx->ev_join = e2; }
+                hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) { ws.aux_stream = a; ws.ev_fork = e1; ws.ev_join = e2; }
         }
-        if (ctx->aux_stream && hipEventRecord((hipEvent_t)ctx->ev_fork, (hipStream_t)st) == hipSuccess &&
-            hipStreamWaitEvent((hipStream_t)ctx->aux_stream, (hipEvent_t)ctx->ev_fork, 0) == hipSuccess) {
-            LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, ctx->aux_stream, T, W, dSD);
-            aux_guard.aux = ctx->aux_stream;
-            HIPCK(hipEventRecord((hipEvent_t)ctx->ev_join, (hipStream_t)ctx->aux_stream));
+        if (ws.aux_stream && hipEventRecord((hipEvent_t)ws.ev_fork, (hipStream_t)st) == hipSuccess &&
+            hipStreamWaitEvent((hipStream_t)ws.aux_stream, (hipEvent_t)ws.ev_fork, 0) == hipSuccess) {
+            LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, ws.aux_stream, T, W, dSD);
+            aux_guard.aux = ws.aux_stream;
+            HIPCK(hipEventRecord((hipEvent_t)ws.ev_join, (hipStream_t)ws.aux_stream));
             forked = true;
         }
     }
     if (!forked) LAUNCHB(KT_SCAN, g_scan_ath, S, ATH_NT, st, T, W, dSD);
     LAUNCH(KT_POLY, g_poly, XCD_GRID((ngs * C + POLY_PER_WAVE - 1) / POLY_PER_WAVE), st, T, W, dSD, dIO, ngs * C);
     LAUNCH(KT_MDCT, g_mdct, XCD_GRID(ngs), st, T, W, dSD);
-    if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ctx->ev_join, 0)); aux_guard.aux = nullptr; }
+    if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ws.ev_join, 0)); aux_guard.aux = nullptr; }
     if (resv) {
         // bit reservoir: psyB -> quantization -> bit packing of a stream's frames are a serial chain: one workgroup per stream walks them
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 2; qa.nfs = nfs; qa.ctr = 0;
@@ -1347,7 +1396,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (nfr > 0) {
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
-        LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 255) / 256, 256, st, T, W, dSD, nfs);
+        LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 63) / 64, 256, st, T, W, dSD, nfs);
         // one workgroup per CU at most: the memo-miss re-validation (a few hundred frames per 1e5 on steady material) is spread over
         // all of them -- a quarter-chip grid was tried and doubled this stage's time
         int fgrid = (nfs + 63) / 64;
@@ -1373,13 +1422,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // when somebody asks (lhip_last_batch_stats)
     int32_t fx[3] = {0, 0, 0};
     const bool fetch_fx = nfr > 0 && (!dev_io || want_sync || g_kt_on);
-    if (fetch_fx && !rt::d2h(fx, (const int32_t*)ctx->nflagged.p + FX_STATS, sizeof fx, st)) return false;
+    if (fetch_fx && !rt::d2h(fx, (const int32_t*)ws.nflagged.p + FX_STATS, sizeof fx, st)) return false;
 #endif
     // ---- outputs ----
     std::vector<int32_t> ob;
     if (resv) {                                   // how much each stream really wrote
         ob.assign((size_t)S, 0);
-        if (!rt::d2h(ob.data(), ctx->out_bytes.p, (size_t)S * 4, st) || !rt::sync(st)) return false;
+        if (!rt::d2h(ob.data(), ws.out_bytes.p, (size_t)S * 4, st) || !rt::sync(st)) return false;
         for (int i = 0; i < S; i++) jobs[i].bytes = ob[i];
     }
     if (!dev_io) {
@@ -1417,10 +1466,18 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (fetch_fx) {
         repaired = fx[0]; iters = fx[1];
         if (fx[2]) { set_err("seed-chain repair did not converge"); return false; }
-    } else if (nfr > 0) g_stat_pending = ctx;
+    } else if (nfr > 0) { g_stat_pending = ctx; g_stat_pending_set = set; }
 #endif
     g_stat_frames = nfr; g_stat_repaired = repaired; g_stat_iters = iters;
-    ctx->lastW = W; ctx->lastC = C; ctx->lastCp = T.psy_channels; ctx->have_last = true;
+    ws.lastW = W; ws.lastC = C; ws.lastCp = T.psy_channels; ws.have_last = true;
+    ctx->last_set = set;
+#ifndef LHIP_HOSTSIM
+    if (pipelined) {
+        if (!rt::event_record(ws.ev_done, ws.stream)) return false;
+        ws.busy = true;
+    }
+#endif
+    for (int i = 0; i < S; i++) jobs[i].s->pipe_set = pipelined ? set : -1;
     return true;
 }
 
@@ -1522,6 +1579,7 @@ void lhip_destroy(lhip_stream* s) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     rt::set_device(ctx->device);
+    if (s->pipe_set >= 0) (void)pipeline_drain(ctx);          // its last batch may still be reading the state record
     std::shared_ptr<TableSet> ts = s->ts;
     delete s;
     // the cache entry goes with the last stream that uses it (one reference is the map's, one is `ts` here)
@@ -1543,7 +1601,7 @@ int64_t lhip_encode_output_bytes(const lhip_stream* s, size_t nsamples) {
 }
 
 static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,
-                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync, bool flush_stream = false) {
+                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync, bool flush_stream = false, bool may_pipeline = false) {
     if (n == 0) return 0;
     std::vector<Job> jobs(n);
     for (size_t i = 0; i < n; i++) {
@@ -1558,7 +1616,7 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
     const Tables& T0 = streams[0]->ts->T;
     const bool resv = !T0.disable_reservoir;
     if (resv) for (size_t i = 0; i < n; i++) jobs[i].flush = flush_stream && ns[i] > 0;
-    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync || resv);
+    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync || resv, may_pipeline);
     for (size_t i = 0; i < n; i++) if (written) written[i] = ok ? jobs[i].written : (jobs[i].written < 0 ? jobs[i].written : LHIP_ERR_INTERNAL);
     if (!ok) { for (auto& j : jobs) if (j.written < 0) return (int)j.written; return LHIP_ERR_INTERNAL; }
     return 0;
@@ -1603,37 +1661,35 @@ static int call_frames(const lhip_stream* s, size_t nsamples) {
     const int64_t total = (int64_t)s->mf_size + n_out;
     return total >= mf_needed ? (int)((total - mf_needed) / frame) + 1 : 0;
 }
-static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
-    Context* ctx = s->ctx;
+// One piece of host input for one stream: `n` samples per channel from l / r; its frames' bytes go to the stream's destination (running).
+struct HostPiece { int si; const int16_t* l; const int16_t* r; size_t n; };
+// The overlapped host path, in general form: `units` are processed in order, each a batch of pieces (one per stream at most) -- unit k + 1
+// travels to the device (copy stream) while unit k is encoded (launch stream) and the bytes of unit k - 1 travel back.  For ONE long stream
+// the units are consecutive sample ranges of its input (encode_host_chunked); for MANY streams (lhip_encode_batch with host buffers,
+// BASELINE configs[4] through the JavaScript encodeBatch) they are groups of streams.  dst[si] / cap[si]: stream si's output buffer;
+// written[si] receives its byte count.  A failed call gives every stream back as it found it.
+static int encode_host_pipelined(Context* ctx, const std::vector<lhip_stream*>& strs, const std::vector<std::vector<HostPiece>>& units,
+                                 uint8_t* const* dst, int64_t* written) {
     std::lock_guard<std::mutex> chunk_lk(ctx->chunk_mu);
-    const Tables& T = s->ts->T;
+    const size_t NS = strs.size();
+    const Tables& T = strs[0]->ts->T;
     const int C = T.channels_out;
-    const ChunkSchedule& cfg = host_chunk_schedule();
-    const size_t mul = (!cfg.fixed && C == 2) ? 2 : 1;
+    const size_t obytes = (size_t)(strs[0]->ts->base_frame_bytes + 1);
     const size_t spf = (size_t)576 * T.mode_gr * T.rs_ratio;             // input samples per frame
-    // the whole call must fit the caller's buffer BEFORE anything is consumed (a failed call consumes nothing)
-    if ((size_t)batch_bytes(*s->ts, s->slot_lag, call_frames(s, nsamples)) > out_cap) { set_err("output buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
-    // ---- this call's chunks (samples per channel each); the staging halves are sized for the largest one the call really reaches
-    std::vector<size_t> sched;
-    size_t stride = 0;
-    {
-        const size_t cap = cfg.cap * mul * spf;
-        size_t p = 0, cur = cfg.first * mul * spf;
-        while (p < nsamples) {
-            size_t m = nsamples - p < cur ? nsamples - p : cur;
-            if (nsamples - p - m < m / 4 && nsamples - p <= cap) m = nsamples - p;     // no short chunk at the end: a launch for a few frames costs a whole tail
-            sched.push_back(m);
-            if (m > stride) stride = m;
-            p += m;
-            cur = cfg.growth * cur < cap ? cfg.growth * cur : cap;
-        }
-        stride = (stride + 63) & ~(size_t)63;
+    // staging halves sized for the largest unit of THIS call: samples per channel (pieces back to back, each rounded up to 64) and output bytes
+    size_t in_max = 0, out_max = 0;
+    for (const auto& u : units) {
+        size_t a = 0, o = 0;
+        for (const HostPiece& pc : u) { a += (pc.n + 63) & ~(size_t)63; o += ((pc.n / spf + 3) * obytes + 63) & ~(size_t)63; }
+        if (a > in_max) in_max = a;
+        if (o > out_max) out_max = o;
     }
-    const size_t out_chunk = (((stride / spf + 3) * (size_t)(s->ts->base_frame_bytes + 1) + 64) + 63) & ~(size_t)63;
-    // what a failed call must give back: the host-side counters and the device-side state record (a call that fails in chunk k > 0 would
-    // otherwise leave the stream k chunks further on with `out` half written -- "a failed call consumes nothing" has to hold here too)
-    const int snap_mf = s->mf_size, snap_ste = s->mf_samples_to_encode, snap_lag = s->slot_lag;
-    const int64_t snap_fn = s->frame_num, snap_rs = s->rs_n_in;
+    const size_t stride = in_max, out_chunk = out_max + 64;
+    // what a failed call must give back: the host-side counters and the device-side state record of every stream (a call that fails in unit
+    // k > 0 would otherwise leave streams k units further on with `out` half written -- "a failed call consumes nothing" has to hold here too)
+    struct Snap { int mf, ste, lag; int64_t fn, rs; };
+    std::vector<Snap> snap(NS);
+    for (size_t i = 0; i < NS; i++) snap[i] = Snap{strs[i]->mf_size, strs[i]->mf_samples_to_encode, strs[i]->slot_lag, strs[i]->frame_num, strs[i]->rs_n_in};
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (!rt::set_device(ctx->device)) return LHIP_ERR_INTERNAL;
@@ -1643,81 +1699,153 @@ static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const in
             for (int i = 0; i < 4; i++) if (!rt::event_create(&e[i])) return LHIP_ERR_INTERNAL;
             ctx->ev_in[0] = e[0]; ctx->ev_in[1] = e[1]; ctx->ev_done[0] = e[2]; ctx->ev_done[1] = e[3]; ctx->copy_stream = cs;
         }
-        if (!ctx->chunk_in.ensure(2 * C * stride * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk) || !ctx->chunk_fx.ensure(sched.size() * 16 + 16) ||
-            !ctx->state_bak.ensure(sizeof(StreamState))) return LHIP_ERR_INTERNAL;
-        if (!rt::d2d(ctx->state_bak.p, s->d_state, sizeof(StreamState), ctx->stream)) return LHIP_ERR_INTERNAL;
+        if (!ctx->chunk_in.ensure(2 * C * stride * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk) || !ctx->chunk_fx.ensure(units.size() * 16 + 16) ||
+            !ctx->state_bak.ensure(NS * sizeof(StreamState))) return LHIP_ERR_INTERNAL;
+        if (!pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
+        for (size_t i = 0; i < NS; i++)
+            if (!rt::d2d((uint8_t*)ctx->state_bak.p + i * sizeof(StreamState), strs[i]->d_state, sizeof(StreamState), ctx->stream)) return LHIP_ERR_INTERNAL;
     }
     void* cs = ctx->copy_stream; void* ks = ctx->stream;
-    int64_t total = 0, pending_bytes = 0, frames_all = 0, repaired_all = 0, iters_all = 0;      // pending: the chunk whose output is still on the device
-    uint8_t* pending_dst = nullptr; int pending_par = 0; bool have_pending = false;
-    auto fail = [&](const char* what, int64_t code = LHIP_ERR_INTERNAL) -> int64_t {      // wait for everything in flight, then put the stream back where the call found it
+    int64_t frames_all = 0, repaired_all = 0, iters_all = 0;
+    std::vector<int64_t> total(NS, 0);
+    struct Pending { uint8_t* dst; const uint8_t* src; int64_t bytes; };
+    std::vector<Pending> pending; int pending_par = 0; bool have_pending = false;      // the unit whose output is still on the device
+    auto fail = [&](const char* what, int64_t code = LHIP_ERR_INTERNAL) -> int {      // wait for everything in flight, then put the streams back where the call found them
         const std::string why = what ? std::string(what) : g_err;
         (void)rt::sync(cs); (void)rt::sync(ks);
-        (void)rt::d2d(s->d_state, ctx->state_bak.p, sizeof(StreamState), ks); (void)rt::sync(ks);
-        s->mf_size = snap_mf; s->mf_samples_to_encode = snap_ste; s->slot_lag = snap_lag; s->frame_num = snap_fn; s->rs_n_in = snap_rs;
+        for (size_t i = 0; i < NS; i++) {
+            (void)rt::d2d(strs[i]->d_state, (const uint8_t*)ctx->state_bak.p + i * sizeof(StreamState), sizeof(StreamState), ks);
+            strs[i]->mf_size = snap[i].mf; strs[i]->mf_samples_to_encode = snap[i].ste; strs[i]->slot_lag = snap[i].lag; strs[i]->frame_num = snap[i].fn; strs[i]->rs_n_in = snap[i].rs;
+        }
+        (void)rt::sync(ks);
         set_err(why);
-        return code;
+        return (int)code;
     };
-    auto drain = [&]() -> bool {               // copy the pending chunk's bytes out; ALWAYS waits for that chunk's kernels (its input half is reused next)
+    auto drain = [&]() -> bool {               // copy the pending unit's bytes out; ALWAYS waits for that unit's kernels (its input half is reused next)
         if (!have_pending) return true;
         have_pending = false;
         if (!rt::stream_wait_event(cs, ctx->ev_done[pending_par])) return false;
-        if (pending_bytes > 0 && !rt::d2h(pending_dst, (uint8_t*)ctx->chunk_out.p + (size_t)pending_par * out_chunk, (size_t)pending_bytes, cs)) return false;
+        for (const Pending& q : pending) if (q.bytes > 0 && !rt::d2h(q.dst, q.src, (size_t)q.bytes, cs)) return false;
         return rt::sync(cs);
     };
     // LAMEJS_HIP_TRACE_CHUNKS=1: host-side timeline of the call on stderr (ms since the call began: after the input copies were issued, after the
-    // kernels were enqueued, after the previous chunk's bytes arrived) -- where a slow caller-side buffer shows
+    // kernels were enqueued, after the previous unit's bytes arrived) -- where a slow caller-side buffer shows
     static const bool trace_chunks = []() { const char* e = getenv("LAMEJS_HIP_TRACE_CHUNKS"); return e && e[0] == '1'; }();
     const auto t_call = std::chrono::steady_clock::now();
     auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
-    size_t p0 = 0;
-    for (size_t k = 0; k < sched.size(); k++) {
+    for (size_t k = 0; k < units.size(); k++) {
         const int par = (int)(k & 1);
-        const size_t m = sched[k];
+        const std::vector<HostPiece>& u = units[k];
         const double t_a = trace_chunks ? ms_now() : 0.0;
         int16_t* d_in = (int16_t*)ctx->chunk_in.p + (size_t)par * C * stride;
-        // buffer `par` was last used by chunk k - 2: its kernels are done (drain() waited for them before chunk k - 1 was enqueued)
+        uint8_t* d_out = (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk;
+        // buffer `par` was last used by unit k - 2: its kernels are done (drain() waited for them before unit k - 1 was enqueued)
         // (copies straight from the caller's pageable memory: measured as fast as copies through pinned staging filled by four host
         //  threads -- 72.5 vs 73.2 ms per 1e5 stereo frames at 8192-frame chunks -- so there is no staging layer)
-        if (!rt::h2d(d_in, left + p0, m * 2, cs)) return fail(nullptr);
-        if (C == 2 && !rt::h2d(d_in + stride, (right ? right : left) + p0, m * 2, cs)) return fail(nullptr);
+        std::vector<Job> jobs(u.size());
+        size_t io = 0, oo = 0;
+        for (size_t j = 0; j < u.size(); j++) {
+            const HostPiece& pc = u[j];
+            if (!rt::h2d(d_in + io, pc.l, pc.n * 2, cs)) return fail(nullptr);
+            if (C == 2 && !rt::h2d(d_in + stride + io, pc.r ? pc.r : pc.l, pc.n * 2, cs)) return fail(nullptr);
+            const size_t ocap = ((pc.n / spf + 3) * obytes + 63) & ~(size_t)63;
+            jobs[j] = Job{strs[pc.si], d_in + io, C == 2 ? d_in + stride + io : nullptr, pc.n, d_out + oo, ocap, 0, 0, 0, 0};
+            io += (pc.n + 63) & ~(size_t)63; oo += ocap;
+        }
         if (!rt::event_record(ctx->ev_in[par], cs) || !rt::stream_wait_event(ks, ctx->ev_in[par])) return fail(nullptr);
         const double t_b = trace_chunks ? ms_now() : 0.0;
-        std::vector<Job> jobs(1);
-        jobs[0] = Job{s, d_in, C == 2 ? d_in + stride : nullptr, m, (uint8_t*)ctx->chunk_out.p + (size_t)par * out_chunk, out_chunk, 0, 0, 0, 0};
-        if (!run_batch(ctx, jobs, true, false)) return fail(nullptr, jobs[0].written < 0 ? jobs[0].written : LHIP_ERR_INTERNAL);
+        if (!run_batch(ctx, jobs, true, false)) { int64_t code = LHIP_ERR_INTERNAL; for (const Job& j : jobs) if (j.written < 0) { code = j.written; break; } return fail(nullptr, code); }
 #ifdef LHIP_HOSTSIM
-        // tests: a failure injected after chunk k has been consumed (the stream must come back as the call found it)
+        // tests: a failure injected after unit k has been consumed (the streams must come back as the call found them)
         if (const char* e = getenv("LHIP_HOSTSIM_FAIL_CHUNK")) if (e[0] && (size_t)atoi(e) == k) return fail("injected failure (LHIP_HOSTSIM_FAIL_CHUNK)");
         repaired_all += g_stat_repaired; iters_all += g_stat_iters;
 #else
-        // this chunk's repair verdict (g_fixup: repaired frames, iterations, "did not converge") stays on the device until the call ends:
-        // a stream-ordered copy into the call's log, read back once after the last chunk
-        if (g_stat_frames > 0 && !rt::d2d((int32_t*)ctx->chunk_fx.p + 4 * k, (const int32_t*)ctx->nflagged.p + FX_STATS, 12, ks)) return fail(nullptr);
+        // this unit's repair verdict (g_fixup: repaired frames, iterations, "did not converge") stays on the device until the call ends:
+        // a stream-ordered copy into the call's log, read back once after the last unit
+        if (g_stat_frames > 0 && !rt::d2d((int32_t*)ctx->chunk_fx.p + 4 * k, (const int32_t*)ctx->ws[0].nflagged.p + FX_STATS, 12, ks)) return fail(nullptr);
         if (g_stat_frames == 0 && !rt::dzero((int32_t*)ctx->chunk_fx.p + 4 * k, 12, ks)) return fail(nullptr);
 #endif
         if (!rt::event_record(ctx->ev_done[par], ks)) return fail(nullptr);
         const double t_c = trace_chunks ? ms_now() : 0.0;
-        if (!drain()) return fail(nullptr);             // chunk k - 1, while chunk k is being encoded
-        if (trace_chunks) fprintf(stderr, "[lhip chunk %zu: %zu samples] begin %.2f  copies issued %.2f  kernels enqueued %.2f  previous chunk's bytes home %.2f ms\n", k, m, t_a, t_b, t_c, ms_now());
-        pending_bytes = jobs[0].written; pending_dst = out + total; pending_par = par; have_pending = true;
-        total += jobs[0].written; frames_all += g_stat_frames;
-        p0 += m;
+        if (!drain()) return fail(nullptr);             // unit k - 1, while unit k is being encoded
+        if (trace_chunks) fprintf(stderr, "[lhip unit %zu: %zu piece(s)] begin %.2f  copies issued %.2f  kernels enqueued %.2f  previous unit's bytes home %.2f ms\n", k, u.size(), t_a, t_b, t_c, ms_now());
+        pending.clear();
+        for (size_t j = 0; j < u.size(); j++) {
+            const int si = u[j].si;
+            pending.push_back(Pending{dst[si] + total[si], jobs[j].out, jobs[j].written});
+            total[si] += jobs[j].written;
+        }
+        pending_par = par; have_pending = true;
+        frames_all += g_stat_frames;
     }
     if (!drain()) return fail(nullptr);
-    if (trace_chunks) fprintf(stderr, "[lhip chunks] last chunk's bytes home %.2f ms\n", ms_now());
+    if (trace_chunks) fprintf(stderr, "[lhip units] last unit's bytes home %.2f ms\n", ms_now());
 #ifndef LHIP_HOSTSIM
     {
-        std::vector<int32_t> fx(4 * sched.size(), 0);
+        std::vector<int32_t> fx(4 * units.size(), 0);
         if (!rt::d2h(fx.data(), ctx->chunk_fx.p, fx.size() * 4, ks) || !rt::sync(ks)) return fail(nullptr);
         bool bad = false;
-        for (size_t k = 0; k < sched.size(); k++) { repaired_all += fx[4 * k]; iters_all += fx[4 * k + 1]; bad |= fx[4 * k + 2] != 0; }
+        for (size_t k = 0; k < units.size(); k++) { repaired_all += fx[4 * k]; iters_all += fx[4 * k + 1]; bad |= fx[4 * k + 2] != 0; }
         if (bad) return fail("seed-chain repair did not converge");
     }
     g_stat_pending = nullptr;
 #endif
     g_stat_frames = frames_all; g_stat_repaired = repaired_all; g_stat_iters = iters_all;     // lhip_last_batch_stats: the whole call
-    return total;
+    for (size_t i = 0; i < NS; i++) written[i] = total[i];
+    return 0;
+}
+
+// ONE long stream: consecutive sample ranges of the call (chunk schedule above)
+static int64_t encode_host_chunked(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
+    const Tables& T = s->ts->T;
+    const ChunkSchedule& cfg = host_chunk_schedule();
+    const size_t mul = (!cfg.fixed && T.channels_out == 2) ? 2 : 1;
+    const size_t spf = (size_t)576 * T.mode_gr * T.rs_ratio;
+    // the whole call must fit the caller's buffer BEFORE anything is consumed (a failed call consumes nothing)
+    if ((size_t)batch_bytes(*s->ts, s->slot_lag, call_frames(s, nsamples)) > out_cap) { set_err("output buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
+    std::vector<std::vector<HostPiece>> units;
+    {
+        const size_t cap = cfg.cap * mul * spf;
+        size_t p = 0, cur = cfg.first * mul * spf;
+        while (p < nsamples) {
+            size_t m = nsamples - p < cur ? nsamples - p : cur;
+            if (nsamples - p - m < m / 4 && nsamples - p <= cap) m = nsamples - p;     // no short chunk at the end: a launch for a few frames costs a whole tail
+            units.push_back({HostPiece{0, left + p, right ? right + p : nullptr, m}});
+            p += m;
+            cur = cfg.growth * cur < cap ? cfg.growth * cur : cap;
+        }
+    }
+    int64_t w = 0;
+    uint8_t* d = out;
+    const int rc = encode_host_pipelined(s->ctx, {s}, units, &d, &w);
+    return rc < 0 ? rc : w;
+}
+
+// MANY streams with host buffers (lhip_encode_batch): groups of streams as units -- a group's copies hide behind the encode of the group before
+static int encode_host_groups(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r, const size_t* ns,
+                              uint8_t* const* out, const size_t* cap, int64_t* written) {
+    const Tables& T = streams[0]->ts->T;
+    const size_t spf = (size_t)576 * T.mode_gr * T.rs_ratio;
+    for (size_t i = 0; i < n; i++)
+        if ((size_t)batch_bytes(*streams[i]->ts, streams[i]->slot_lag, call_frames(streams[i], ns[i])) > cap[i]) {
+            for (size_t k = 0; k < n; k++) if (written) written[k] = LHIP_ERR_BUFFER_TOO_SMALL;
+            set_err("output buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL;
+        }
+    // groups of about 2 x the first chunk of the one-stream schedule (16384 one-channel frames): large enough for the persistent kernel,
+    // small enough that the first group's copy -- the part nothing overlaps -- stays short
+    const size_t target = 2 * host_chunk_schedule().first * spf * (T.channels_out == 2 ? 1 : 1);
+    std::vector<std::vector<HostPiece>> units(1);
+    size_t acc = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (acc >= target) { units.emplace_back(); acc = 0; }
+        units.back().push_back(HostPiece{(int)i, l[i], r ? r[i] : nullptr, ns[i]});
+        acc += ns[i];
+    }
+    std::vector<lhip_stream*> strs(streams, streams + n);
+    std::vector<int64_t> w(n, 0);
+    const int rc = encode_host_pipelined(streams[0]->ctx, strs, units, out, w.data());
+    for (size_t i = 0; i < n; i++) if (written) written[i] = rc < 0 ? (int64_t)rc : w[i];
+    return rc;
 }
 
 int64_t lhip_encode(lhip_stream* s, const int16_t* left, const int16_t* right, size_t nsamples, uint8_t* out, size_t out_cap) {
@@ -1789,6 +1917,21 @@ int64_t lhip_flush(lhip_stream* s, uint8_t* out, size_t out_cap) {
 
 int lhip_encode_batch(lhip_stream* const* streams, size_t nstreams, const int16_t* const* left, const int16_t* const* right,
                       const size_t* nsamples, uint8_t* const* out, const size_t* out_cap, int64_t* written) {
+    // many streams with a lot of input: groups of streams go through the overlapped host path (copies behind the encode of the group before)
+    if (nstreams > 1 && streams && left && nsamples && out && out_cap) {
+        static const bool no_chunk = []() { const char* e = getenv("LAMEJS_HIP_NO_HOST_CHUNKS"); return e && e[0] == '1'; }();
+        bool ok = !no_chunk;
+        size_t total = 0;
+        for (size_t i = 0; i < nstreams && ok; i++) {
+            ok = streams[i] && streams[i]->magic == 0x4c484950 && streams[i]->ctx == streams[0]->ctx && streams[i]->ts.get() == streams[0]->ts.get() && left[i] && nsamples[i] > 0;
+            if (ok) for (size_t k = 0; k < i; k++) if (streams[k] == streams[i]) { ok = false; break; }      // (a handle twice in one batch: the plain path reports it)
+            total += nsamples[i];
+        }
+        if (ok && streams[0]->ts->T.disable_reservoir) {
+            const Tables& T = streams[0]->ts->T;
+            if (total > (size_t)4 * host_chunk_schedule().first * 576 * T.mode_gr * T.rs_ratio) return encode_host_groups(streams, nstreams, left, right, nsamples, out, out_cap, written);
+        }
+    }
     return encode_many(streams, nstreams, left, right, nsamples, out, out_cap, written, false, true);
 }
 
@@ -1809,7 +1952,7 @@ int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* cons
 
 int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const int16_t* const* d_left, const int16_t* const* d_right,
                              const size_t* nsamples, uint8_t* const* d_out, const size_t* out_cap, int64_t* written, int sync) {
-    return encode_many(streams, nstreams, d_left, d_right, nsamples, d_out, out_cap, written, true, sync != 0);
+    return encode_many(streams, nstreams, d_left, d_right, nsamples, d_out, out_cap, written, true, sync != 0, false, true);
 }
 
 // ---- frame-range sharding of ONE stream (second mode): speculate the state at a cut, verify it, transplant on a miss ----
@@ -1833,6 +1976,7 @@ int lhip_state_get(lhip_stream* s, void* buf, size_t cap) {
     if (!buf || cap < lhip_state_bytes(s)) { set_err("state buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
     StateHdr h; memset(&h, 0, sizeof h);
     h.magic = 0x5453484cu; h.bytes = (uint32_t)lhip_state_bytes(s);
     h.mf_size = s->mf_size; h.mf_samples_to_encode = s->mf_samples_to_encode; h.slot_lag = s->slot_lag; h.frame_num = s->frame_num; h.rs_n_in = s->rs_n_in;
@@ -1862,6 +2006,7 @@ int lhip_state_set(lhip_stream* s, const void* buf, size_t n) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes || h.config != state_config_tag(s->ts->T)) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
+    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
     if (!rt::set_device(ctx->device) || !rt::h2d(s->d_state, (const uint8_t*)buf + sizeof h, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
     s->mf_size = h.mf_size; s->mf_samples_to_encode = h.mf_samples_to_encode; s->slot_lag = h.slot_lag; s->frame_num = h.frame_num; s->rs_n_in = h.rs_n_in;
     return 0;
@@ -1916,6 +2061,34 @@ int lhip_set_hip_stream(int device, void* hip_stream) {
     return 0;
 }
 
+int lhip_set_pipeline(int device, int depth) {
+    if (depth != 1 && depth != 2) { set_err("lhip_set_pipeline: depth must be 1 or 2"); return LHIP_ERR_INTERNAL; }
+#ifndef LHIP_HOSTSIM
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return LHIP_ERR_INTERNAL; }
+#else
+    if (device < 0) device = 0;
+#endif
+    if (device >= rt::device_count()) { set_err("no such HIP device"); return LHIP_ERR_INTERNAL; }
+    Context* ctx = get_context(device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
+    ctx->pipe_depth = depth;
+    return 0;
+}
+
+int lhip_device_wait(int device) {
+#ifndef LHIP_HOSTSIM
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return LHIP_ERR_INTERNAL; }
+#else
+    if (device < 0) device = 0;
+#endif
+    if (device >= rt::device_count()) { set_err("no such HIP device"); return LHIP_ERR_INTERNAL; }
+    Context* ctx = get_context(device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    return 0;
+}
+
 void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations) {
 #ifndef LHIP_HOSTSIM
     if (g_stat_pending) {                      // asynchronous batch: wait for it and fetch the device-side counters
@@ -1923,7 +2096,9 @@ void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* r
         g_stat_pending = nullptr;
         std::lock_guard<std::mutex> lk(ctx->mu);
         int32_t fx[3] = {0, 0, 0};
-        if (rt::set_device(ctx->device) && rt::d2h(fx, (const int32_t*)ctx->nflagged.p + FX_STATS, sizeof fx, ctx->stream) && rt::sync(ctx->stream)) {
+        WorkSet& ws = ctx->ws[g_stat_pending_set];
+        void* st = ws.busy ? ws.stream : ctx->stream;          // a pipelined batch lives on its set's stream
+        if (rt::set_device(ctx->device) && rt::d2h(fx, (const int32_t*)ws.nflagged.p + FX_STATS, sizeof fx, st) && rt::sync(st)) {
             g_stat_repaired = fx[0]; g_stat_iters = fx[1];
             if (fx[2]) set_err("seed-chain repair did not converge");
         }
@@ -1936,19 +2111,21 @@ void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* r
 
 int64_t lhip_debug_read(int what, void* dst, size_t cap) {
     Context* ctx = nullptr;
-    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto& kv : g_ctx) if (kv.second->have_last) ctx = kv.second.get(); }
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto& kv : g_ctx) if (kv.second->ws[kv.second->last_set].have_last) ctx = kv.second.get(); }
     if (!ctx) { set_err("no batch has run"); return LHIP_ERR_INTERNAL; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     rt::set_device(ctx->device);
-    const Workspace& W = ctx->lastW;
-    const size_t GC = (size_t)W.ngslots * ctx->lastC;
+    if (!pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
+    const WorkSet& ws = ctx->ws[ctx->last_set];
+    const Workspace& W = ws.lastW;
+    const size_t GC = (size_t)W.ngslots * ws.lastC;
     const void* src = nullptr; size_t n = 0;
     switch (what) {
         case 0: src = W.xr; n = GC * 576 * 4; break;
         case 1: src = W.blocktype; n = GC * 4; break;
-        case 2: src = W.E; n = (size_t)W.ngslots * ctx->lastCp * E_STRIDE * 4; break;
+        case 2: src = W.E; n = (size_t)W.ngslots * ws.lastCp * E_STRIDE * 4; break;
         case 3: src = W.ath_adjust; n = (size_t)W.nfslots * 8; break;
-        case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ctx->lastC * sizeof(GrSide); break;
+        case 4: src = W.side; n = (size_t)W.nframes_total * 2 * ws.lastC * sizeof(GrSide); break;
         case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;
         case 6: src = W.peaks; n = GC * PK_STRIDE * 4; break;
         case 7: src = W.prof; n = PROF_BYTES; break;

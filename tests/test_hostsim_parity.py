@@ -395,3 +395,36 @@ print("OK chunks")
 """ % (str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "tools"), str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so"))],
                        capture_output=True, text=True, env=dict(os.environ, LAMEJS_HIP_HOST_CHUNK_FRAMES="16,96,2"), timeout=900)
     assert r.returncode == 0 and "OK chunks" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_hostsim_pipeline_calls_are_harmless(sim):
+    """lhip_set_pipeline / lhip_device_wait exist in every build; the simulation runs everything synchronously, so depth 2 changes nothing:
+    asynchronous "device" batches (host pointers here) of two streams, interleaved, still give the oracle's bytes."""
+    import lamejs_amd
+    import pcm
+    sim.lhip_set_pipeline.argtypes = [ctypes.c_int, ctypes.c_int]
+    sim.lhip_device_wait.argtypes = [ctypes.c_int]
+    assert sim.lhip_set_pipeline(0, 3) < 0 and sim.lhip_set_pipeline(0, 2) == 0
+    try:
+        nfr = 12
+        mats = [pcm.bursts(1152 * nfr * 2, 2, seed=70 + i) for i in range(2)]
+        encs = [lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim) for _ in range(2)]
+        got = [b"", b""]
+        cap = (nfr + 4) * 420
+        for half in range(2):
+            for i in range(2):
+                L, R = mats[i]
+                l, r = np.ascontiguousarray(L[1152 * nfr * half: 1152 * nfr * (half + 1)]), np.ascontiguousarray(R[1152 * nfr * half: 1152 * nfr * (half + 1)])
+                out = np.empty(cap, dtype=np.uint8)
+                wr = (ctypes.c_int64 * 1)()
+                rc = sim.lhip_encode_batch_device((ctypes.c_void_p * 1)(encs[i]._h), 1, (ctypes.c_void_p * 1)(l.ctypes.data), (ctypes.c_void_p * 1)(r.ctypes.data),
+                                                  (ctypes.c_size_t * 1)(len(l)), (ctypes.c_void_p * 1)(out.ctypes.data), (ctypes.c_size_t * 1)(cap), wr, 0)
+                assert rc == 0, sim.lhip_last_error()
+                assert sim.lhip_device_wait(0) == 0
+                got[i] += out[: wr[0]].tobytes()
+        for i in range(2):
+            got[i] += encs[i].flush()
+            encs[i].close()
+            assert got[i] == oracle_encode(2, 44100, 128, *mats[i])
+    finally:
+        assert sim.lhip_set_pipeline(0, 1) == 0
