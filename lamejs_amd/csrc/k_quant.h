@@ -217,10 +217,10 @@ LHIP_DEV double athAdjust(const Tables& T, const PowBase& pb10, double a, double
     const double v = a * a;
     double w = 0.0;
     u -= athFloor;
-    if (v > 1E-20) w = 1. + v8_log10(v) * (10.0 / o);
+    if (v > 1E-20) w = 1. + v8_log10(v) * const_here(10.0 / o);
     if (w < 0) w = 0.;
     u *= w;
-    u += athFloor + o - p;
+    u += athFloor + const_here(o) - const_here(p);
     return v8_pow_base(pb10, 0.1 * u);
 }
 
@@ -261,6 +261,7 @@ LHIP_DEV float xr_at(const XrSrc& X, int i) {
 // sfb21 / sfb12): functions of the frame's ATH adjustment alone, so they are formed once per frame -- [0..5] for long blocks,
 // [6..11] for short ones -- and not once per granule and channel.
 LHIP_DEV void q_ath_pseudo(const Tables& T, const PowBase& pb10, double ath_adjust, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = lane_anew(lane);
     wave_sync();
     LHIP_LANE_ONCE(e, 0, PSFB21 + PSFB12) {
         double a = athAdjust(T, pb10, ath_adjust, Q.ath_psfb[e], T.ATH_floor);
@@ -275,6 +276,7 @@ LHIP_DEV void q_ath_pseudo(const Tables& T, const PowBase& pb10, double ath_adju
 // consecutive runs).  All loads of a lane are issued before the first one is needed (a lane-strided loop compiles to one load per
 // trip, each waited for by itself: nine round trips to memory).
 LHIP_DEV void q_load_lines(const XrSrc& X, int is_short, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
 #if LHIP_NL == 1
     for (int d = 0; d < 576; d++) {
         int src = d;
@@ -1335,6 +1337,7 @@ LHIP_DEV int q_scale_bitcount_any(const Tables& T, const QuantTabs& Q, GI& g, in
 // amplification helpers (Quantize.js:453-460, 597-778)
 // ---------------------------------------------------------------------------------------------
 LHIP_DEV int q_loop_break(const GI& g, const int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     int z = 0;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax)
         if (scalefac[sfb] + band_sbgain(g, L.window, sfb) == 0) z = 1;
@@ -1447,6 +1450,7 @@ LHIP_DEV int q_scale_bitcount_from(const QuantTabs& Q, GI& g, int32_t* scalefac,
 }
 
 LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     uint64_t m_amp = 0;
     LHIP_LANE_ONCE(sfb, 0, g.sfbmax) {
         int s = scalefac[sfb];
@@ -1463,6 +1467,7 @@ LHIP_DEV void q_inc_scalefac_scale(const Tables& T, GI& g, int32_t* scalefac, in
 
 // inc_subblock_gain (Quantize.js:705-778); returns 1 on failure.  Short blocks only (sfb_lmax == 0).
 LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     for (int window = 0; window < 3; window++) {
         int s1 = 0, s2 = 0;
         LHIP_LANE_ONCE3(sfb, window, g.sfbmax) {
@@ -1510,6 +1515,7 @@ LHIP_DEV int q_inc_subblock_gain(const Tables& T, GI& g, int32_t* scalefac, int 
 
 // balance_noise (Quantize.js:793-846); returns 1 to continue the outer loop
 LHIP_DEV int q_balance_noise(const Tables& T, GI& g, int32_t* scalefac, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     unsigned long long tb_ = PH_NOW(); (void)tb_;
     int all_nonzero, pre_bad, m12;
     q_amp_scalefac_bands(T, g, scalefac, &all_nonzero, &pre_bad, &m12, lane, L, Q);
@@ -1547,6 +1553,7 @@ LHIP_DEV int q_quant_compare(const NoiseRes& best, const NoiseRes& calc) {   // 
 // one GrInfo (the working copy) in scalar registers instead of two, which is most of what used to spill.  Fields the loop never
 // changes (block type, band limits, max_nonzero_coeff) are the same in both copies and are not stored.
 LHIP_DEV void gi_keep_store(QuantLds& L, const GI& w, int lane) {
+    lane = fresh_lane(lane);
     if (lane == 0) {
         int32_t* k = L.gkeep;
         k[0] = w.part2_3_length; k[1] = w.big_values; k[2] = w.count1; k[3] = w.global_gain; k[4] = w.scalefac_compress;
@@ -1579,6 +1586,7 @@ LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
 // coalesced form the one-thread-per-frame validation reads
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
                            int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = fresh_lane(lane);
     enum { ST_BS, ST_BSUP, ST_A, ST_B };
     NoiseRes best, ni;
     PrevNoise pn; pn.gain = 0; pn.sfb_count1 = 0;
@@ -2065,26 +2073,26 @@ LHIP_DEV double q_pecalc(const float* E, int is_short, double masking_lower) {
     const double LOG10 = 2.30258509299404568402;
     double pe;
     if (is_short) {
-        pe = 1236.28 / 4;
+        pe = const_here(1236.28 / 4);
         for (int sb = 0; sb < SBMAX_s - 1; sb++)
             for (int sblock = 0; sblock < 3; sblock++) {
                 const double thm = E[E_THM_S + sb * 3 + sblock];
                 if (thm > 0.0) {
                     const double x = thm * masking_lower, en = E[E_EN_S + sb * 3 + sblock];
                     if (en > x) {
-                        if (en > x * 1e10) pe += regcoef_s[sb] * (10.0 * LOG10);
+                        if (en > x * 1e10) pe += regcoef_s[sb] * const_here(10.0 * LOG10);
                         else pe += regcoef_s[sb] * v8_log10(en / x);
                     }
                 }
             }
     } else {
-        pe = 1124.23 / 4;
+        pe = const_here(1124.23 / 4);
         for (int sb = 0; sb < SBMAX_l - 1; sb++) {
             const double thm = E[E_THM_L + sb];
             if (thm > 0.0) {
                 const double x = thm * masking_lower, en = E[E_EN_L + sb];
                 if (en > x) {
-                    if (en > x * 1e10) pe += regcoef_l[sb] * (10.0 * LOG10);
+                    if (en > x * 1e10) pe += regcoef_l[sb] * const_here(10.0 * LOG10);
                     else pe += regcoef_l[sb] * v8_log10(en / x);
                 }
             }
@@ -2201,7 +2209,7 @@ LHIP_DEV void q_reduce_side(int* targ, double ms_ener_ratio, int mean_bits, doub
 // returns max_bits of on_pe (tbits + extra_bits, extra_bits = 0 here, capped at the per-granule limit)
 LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize, int* targ) {
     // on_pe + ResvMaxBits(cbr = gr) with the reservoir disabled (QuantizePVT.js:421-484, Reservoir.js:190-229)
-    const int C = T.channels_out;
+    const int C = uni_here(T.channels_out);
     int rs = ResvSize, tbits, bits = 0;
     if (gr != 0) rs += mean_bits;
     tbits = mean_bits;
@@ -2228,6 +2236,7 @@ struct UnitOut { int bits; Seed next; int block_type; int active; };
 // Inlined at every call site: behind a call (one copy of the code for kb_quant's, the owner's and the helper's site) g_quant was a third slower -- spills around the call.
 LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
                         double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q) {
+    lane = lane_anew(lane);        // (here and below: lane-derived LDS / HBM addresses are formed where they are used, not parked in scratch across the search)
     UnitOut u; u.next = used;
     GI g;
     const int bt = W.blocktype[(int64_t)gslot * C + ch];
@@ -2241,6 +2250,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
         int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
         q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q);
         uni_gi(g); bs_gain = uni(bs_gain);
+        lane = lane_anew(lane);
         wave_sync();                                    // the kept spectrum was written by other lanes of this wave
 #if LHIP_NL == 1
         for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)L.ixw)[i] = ((const uint32_t*)kept)[i];
@@ -2271,6 +2281,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
     u.block_type = g.block_type;
     if (gr == 0) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[ch][i] = (int8_t)L.sfb[i]; }
     // ---- publish the record and the signed quantized spectrum ----
+    lane = lane_anew(lane);
     GrSide* out = W.side + ((int64_t)fidx * 2 + gr) * C + ch;
     if (lane == 0) {
         out->part2_3_length = g.part2_3_length; out->part2_length = g.part2_length; out->big_values = g.big_values;

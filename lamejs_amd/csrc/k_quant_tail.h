@@ -58,23 +58,25 @@ LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup
 // kb_quant for the persistent kernel's speculative pass (chain == 0, no reservoir) with the second channel of every granule on offer
 LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot, int lane, QuantLds& L,
                           const QuantTabs& Q, int* hint, TailShare& TS, int wv) {
+    lane = lane_anew(lane);
     const int C = T.channels_out;
-    const int st = W.fslot_stream[fslot];
+    const int st = uni(W.fslot_stream[fslot]);            // (frame-level values in scalar registers: as vector values they were parked in scratch memory across the search)
     const StreamDesc sd = SD[st];
-    const int k = fslot - sd.fslot0 - 1;
+    const int k = uni(fslot - sd.fslot0 - 1);
     if (k < 0) return;
-    const int fidx = sd.out_slot0 + k;
+    const int fidx = uni(sd.out_slot0 + k);
 #ifdef LHIP_PHASE_PROF
     const unsigned long long ph_total0_ = __builtin_amdgcn_s_memtime();     // L.prof is zeroed / flushed once per wave by g_quant
 #endif
-    const double ath_adjust = W.ath_adjust[fslot];
-    const int padding = frame_padding(T, sd, k);
-    const int mean_bits = (frame_bits_of(T, padding) - T.sideinfo_len * 8) / T.mode_gr;
+    const double ath_adjust = unid(W.ath_adjust[fslot]);      // (scalar registers: as a vector value it was parked in scratch memory across the search)
+    const int padding = uni(frame_padding(T, sd, k));
+    const int mean_bits = uni((frame_bits_of(T, padding) - T.sideinfo_len * 8) / T.mode_gr);
     Seed seed0, seed1;
     seed0.start = seed1.start = W.spec_start; seed0.step = seed1.step = W.spec_step;
     if (k == 0) {
         seed0 = seed_before(W, sd, C, k, 0, 0);
         if (C > 1) seed1 = seed_before(W, sd, C, k, 0, 1);
+        seed0.start = uni(seed0.start); seed0.step = uni(seed0.step); seed1.start = uni(seed1.start); seed1.step = uni(seed1.step);
     } else if (hint[0] == st) {
         if (hint[1] >= 0) { seed0.start = hint[1]; seed0.step = 2; }
         if (C > 1 && hint[2] >= 0) { seed1.start = hint[2]; seed1.step = 2; }
@@ -129,6 +131,7 @@ LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace&
 // a wave that has found the dispenser empty: take open offers of the workgroup until no wave can draw a frame any more
 LHIP_DEV void tail_help(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int lane, QuantLds* Lall, int wv, int nwaves,
                         const QuantTabs& Q, TailShare& TS) {
+    lane = lane_anew(lane);
     QuantLds& L = Lall[wv];
     const int C = T.channels_out, Cp = T.psy_channels;
     wg_add(&TS.drawing, -1, lane);
@@ -142,13 +145,14 @@ LHIP_DEV void tail_help(const Tables& T, const PowBase& pb10, const Workspace& W
             if (wg_cas(&o.state, 1, 2, lane) != 1) continue;
             wg_acquire();
             took = 1;
+            lane = lane_anew(lane);
             LHIP_TAIL_COUNT(claimed);
             const int fslot = uni(o.fslot), gr = uni(o.gr), mode_ext = uni(o.mode_ext), targ = uni(o.targ), gr0_bt = uni(o.gr0_bt);
             Seed seed; seed.start = uni(o.seed_start); seed.step = uni(o.seed_step);
-            const int st = W.fslot_stream[fslot];
+            const int st = uni(W.fslot_stream[fslot]);
             const StreamDesc sd = SD[st];
-            const int k = fslot - sd.fslot0 - 1, fidx = sd.out_slot0 + k, gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
-            const double ath_adjust = W.ath_adjust[fslot];
+            const int k = uni(fslot - sd.fslot0 - 1), fidx = uni(sd.out_slot0 + k), gslot = uni(sd.gslot0 + 1 + T.mode_gr * k + gr);
+            const double ath_adjust = unid(W.ath_adjust[fslot]);
             q_ath_pseudo(T, pb10, ath_adjust, lane, L, Q);
             if (gr == 1) { LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sf_gr0[1][i] = Lall[w].sf_gr0[1][i]; }
             wave_sync();

@@ -407,7 +407,14 @@ LHIP_DEV int next_frame_slot(int32_t* ctr) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 struct QArgs { Tables T; PowBase pb; Workspace W; const StreamDesc* SD; int chain, nfs, ctr; };
-template <int RESV> __global__ __launch_bounds__(64 * QWAVES, LHIP_QOCC) void g_quant(QArgs a_unused) {
+#ifdef LHIP_QVGPR      /* experiment builds only: cap g_quant's register budget at what 5 / 6 waves per SIMD would leave it (96 / 80).  The backend doubles an
+                          "amdgpu-num-vgpr" request on gfx90a+ (unified VGPR + AGPR file) and clamps it to the range the waves-per-EU bounds imply, so the upper
+                          bound must be opened too */
+#define LHIP_QUANT_BOUNDS __attribute__((amdgpu_flat_work_group_size(1, 64 * QWAVES), amdgpu_waves_per_eu(LHIP_QOCC, 8), amdgpu_num_vgpr((LHIP_QVGPR) / 2)))
+#else
+#define LHIP_QUANT_BOUNDS __launch_bounds__(64 * QWAVES, LHIP_QOCC)
+#endif
+template <int RESV> __global__ LHIP_QUANT_BOUNDS void g_quant(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     __shared__ TailShare TS;
@@ -956,6 +963,7 @@ struct WorkSet {
     void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
     // pipeline mode: the set's own stream, "inputs are ready" (recorded on the caller's stream) and "this set's last batch is done"
     void* stream = nullptr; void* ev_in = nullptr; void* ev_done = nullptr;
+    void* ev_quant = nullptr;    // "this set's quantization kernel has finished": the other set's quantization kernel is launched behind it (run_batch)
     bool busy = false;           // a pipelined batch has been enqueued on `stream` and nobody has waited for it yet
 };
 
@@ -1058,7 +1066,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     void* st = ctx->stream;
 #ifndef LHIP_HOSTSIM
     if (pipelined) {
-        if (!ws.stream && (!rt::stream_create(&ws.stream) || !rt::event_create(&ws.ev_in) || !rt::event_create(&ws.ev_done))) return false;
+        if (!ws.stream && (!rt::stream_create(&ws.stream) || !rt::event_create(&ws.ev_in) || !rt::event_create(&ws.ev_done) || !rt::event_create(&ws.ev_quant))) return false;
         // the batch starts once the caller's stream has reached this point (its inputs are ready) ...
         if (!rt::event_record(ws.ev_in, ctx->stream) || !rt::stream_wait_event(ws.stream, ws.ev_in)) return false;
         // ... and once the last batch of each of its streams is done, if that ran on the other set (this set's own stream orders the rest)
@@ -1391,8 +1399,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : -1; }();
     const bool pair = (C == 2 && nfs <= (pair_max >= 0 ? pair_max : 6 * ctx->num_cus));
 #endif
+    // Two batches in flight: the persistent quantization kernels of the two sets must not share the chip.  Measured (round 4, 1e5 stereo
+    // frames per batch): launched side by side each gets half the CUs for its whole length, both end together with the same tail, and the
+    // step takes 55.0 ms against 45.7 ms with one batch in flight.  Launched BEHIND the other set's, this set's kernel finds the chip free
+    // the moment that one's last wave leaves, and what overlaps is what can: this batch's psychoacoustics / filterbank and the other
+    // batch's validation / bit packing run in the slots the draining kernel gives up.  LAMEJS_HIP_PIPE_QUANT_ORDER=0: side by side (A/B).
+    static const bool quant_order = []() { const char* e = getenv("LAMEJS_HIP_PIPE_QUANT_ORDER"); return !(e && atoi(e) == 0); }();
+    if (pipelined && quant_order && ctx->ws[1 - set].busy && ctx->ws[1 - set].ev_quant &&
+        !rt::stream_wait_event(st, ctx->ws[1 - set].ev_quant)) return false;
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
       if (pair) LAUNCHB(KT_QUANT, g_quant_pair<0>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<0>, qgrid, 64 * QWAVES, st, qa); }
+    if (pipelined && !rt::event_record(ws.ev_quant, st)) return false;
     if (nfr > 0) {
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;

@@ -32,6 +32,9 @@ LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return v; }
 LHIP_DEV void wg_barrier() {}                  // multi-wave workgroups only exist on the device and in the wave simulation
 LHIP_DEV int uni(int v) { return v; }
 LHIP_DEV int fresh_lane(int lane) { return lane; }
+LHIP_DEV int lane_anew(int lane) { return lane; }
+LHIP_DEV double const_here(double c) { return c; }
+LHIP_DEV int uni_here(int v) { return v; }
 LHIP_DEV double unid(double v) { return v; }
 LHIP_DEV double wave_shr1d(double v, double first) { (void)v; return first; }
 // strictly sequential (index order) f64 sum of LHIP_NL * K values, lane l holding elements [l*K, (l+1)*K)
@@ -202,6 +205,9 @@ LHIP_DEV int uni(int v) {
 }
 LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
 LHIP_DEV int fresh_lane(int lane) { return lane; }
+LHIP_DEV int lane_anew(int lane) { return lane; }
+LHIP_DEV double const_here(double c) { return c; }
+LHIP_DEV int uni_here(int v) { return v; }
 LHIP_DEV unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 LHIP_DEV double wave_shr1d(double v, double first) { uint64_t a[64]; wsim::exchange(13, wsim::bits_of(v), a); const int me = wsim::my_lane(); return me == 0 ? first : wsim::from_bits<double>(a[me - 1]); }
 // the device's systolic fold, literally: 64 steps of "add my K values onto the sum handed over by lane - 1"
@@ -314,6 +320,24 @@ LHIP_DEV uint64_t wave_lane_bits(uint64_t v) { return __ballot(v != 0); }
 // An opaque copy of the lane index: addresses derived from it cannot be merged with (and hoisted like) the ones
 // derived from other copies, which keeps loop-invariant address registers from piling up and spilling.
 LHIP_DEV int fresh_lane(int lane) { asm volatile("" : "+v"(lane)); __builtin_assume(lane >= 0 && lane < LHIP_NL); return lane; }   // the copy keeps its range
+// The lane index formed anew (two VALU instructions) instead of copied: for the entries of once-per-frame / once-per-granule code, where a copy
+// would keep the ORIGINAL index alive across the quantization loop (it was parked in scratch memory and reloaded at every such entry).
+LHIP_DEV int lane_anew(int lane) {
+    (void)lane;
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    __builtin_assume(l >= 0 && l < LHIP_NL);
+    return l;
+}
+// A double-precision literal materialised where it is used (two scalar moves): the compiler forms 64-bit literals of once-per-frame code
+// in the kernel prologue and, register pairs not being rematerialisable for it, parked them in scratch memory for the whole kernel.
+LHIP_DEV double const_here(double c) {
+    union { double d; uint32_t u[2]; } x; x.d = c;
+    asm volatile("" : "+s"(x.u[0]), "+s"(x.u[1]));
+    return x.d;
+}
+// the same for a wave-uniform integer whose CONVERSIONS would otherwise be formed once per kernel and parked ((double)channels, ...)
+LHIP_DEV int uni_here(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
 // asserts to the compiler that v is wave-uniform (moves it to an SGPR)
 LHIP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // value of lane - 1 (lane 0 receives `first`): two DPP moves (wave_shr:1), no LDS round trip
