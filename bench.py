@@ -283,8 +283,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs (they are only run at N = 1)")
     ap.add_argument("--no-cpu-aggregate", action="store_true", help="skip the all-cores leg of the CPU baseline")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the MP3 bytes to rank 0 (N > 1)")
-    ap.add_argument("--pipeline", action="store_true", help="two batches in flight (lhip_set_pipeline(device, 2)) instead of one; the default line reports the other mode's step time beside its own")
-    ap.add_argument("--no-pipeline", action="store_true", help="(the default since round 4 pass 4; accepted for older scripts)")
+    ap.add_argument("--no-pipeline", action="store_true", help="(accepted for older scripts: there is only one batch in flight since round 4 -- two were measured slower and removed)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` started plainly (no launcher, no WORLD_SIZE in the environment) launches its own N ranks: the same
@@ -420,14 +419,10 @@ def main():
                     lib.lhip_destroy(h)
             self.handles = []
 
-        def timed(self, steps, warmup, pipeline=False):
-            """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks.
-            pipeline: two batches in flight (lhip_set_pipeline(device, 2)) -- every step is a batch of fresh, independent streams, so
-            step k + 1's psychoacoustics / filterbank run while step k's quantization kernel drains and its validation and bit packing
-            finish; all K batches are complete when the closing synchronisation returns.  The bit reservoir's batches are synchronous."""
+        def timed(self, steps, warmup):
+            """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks.  Every step is one batch of
+            fresh, independent streams, enqueued on torch's current stream (lhip_encode_batch_device(sync = 0) only enqueues)."""
             sets = [self.new_streams() for _ in range(warmup + steps)]
-            if not sim:
-                assert lib.lhip_set_pipeline(dev_ord, 2 if pipeline else 1) == 0, lib.lhip_last_error()
             for w in range(warmup):
                 self.step(sets[w])
             dsync()
@@ -449,8 +444,6 @@ def main():
             a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
             lib.lhip_last_batch_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
             self.frames_per_step, self.repaired, self.repair_iters = a.value, b.value, c.value
-            if not sim:
-                assert lib.lhip_set_pipeline(dev_ord, 1) == 0, lib.lhip_last_error()
             self.nbytes = [int(self.wr[i]) for i in range(self.ns)]
             return dt
 
@@ -501,11 +494,8 @@ def main():
         return
     key = args.config if args.config in PRESETS else int(args.config)
     wl = Workload(key)
-    pipe = args.pipeline and not args.no_pipeline
-    dt = wl.timed(args.steps, args.warmup, pipeline=pipe)
+    dt = wl.timed(args.steps, args.warmup)
     outs = wl.outputs()
-    n_other = min(args.steps, 4)
-    dt_other = wl.timed(n_other, 1, pipeline=not pipe) / n_other if (not sim and not wl.resv and world == 1) else None      # the same step in the other mode (an extra, outside the timed region)
     full, prefix, md5s = wl.check(outs)
     kern = wl.kernel_times() if not sim else {}
 
@@ -544,10 +534,6 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.describe(), "frames_per_step_per_gpu": wl.frames_per_step,
                        "input": "Int16 PCM resident in HBM", "output": "MP3 bytes in HBM",
-                       "batches_in_flight": (2 if pipe and not sim and not wl.resv else 1),
-                       "pipeline_note": "every step is one batch of fresh, independent streams; with two batches in flight (lhip_set_pipeline, --pipeline) step k + 1's psychoacoustics and filterbank "
-                                        "overlap step k's quantization tail, validation and bit packing -- all K batches are complete inside the timed region",
-                       ("ms_per_step_one_batch_in_flight" if pipe else "ms_per_step_two_batches_in_flight"): (None if dt_other is None else round(1000.0 * dt_other, 3)),
                        "bit_exact_full": (None if any(f is None for f in all_full) else all(all_full)),
                        "bit_exact_full_note": "md5 + length of every stream's whole output vs tests/golden/full_md5.json (unmodified reference under node)",
                        "bit_exact_prefix_vs_oracle": (None if any(v[3] is None for v in verdicts) else all(v[3] for v in verdicts)),

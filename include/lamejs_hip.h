@@ -138,16 +138,6 @@ int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const
 /* Use this hipStream_t (passed as void*) for all work of streams on `device` (-1 = current). */
 int lhip_set_hip_stream(int device, void* hip_stream);
 
-/* Pipeline mode (extension, off by default).  depth = 2: consecutive lhip_encode_batch_device(sync = 0) calls alternate between two
- * workspaces, each on an internal HIP stream that starts after the caller's stream has reached the call (so inputs produced on that
- * stream are ready) -- batch k + 1's psychoacoustics and filterbank then fill the chip while batch k's persistent quantization kernel
- * drains and its validation / bit packing run.  Batches that share a stream handle are still ordered.  The caller's stream does NOT
- * wait for such a batch: its output is valid after lhip_device_wait(device) (or a device-wide synchronisation; lhip_last_batch_stats
- * waits for the batch it reports).  Every other entry point first waits for the batches in flight, so mixing calls is safe.
- * depth = 1 restores the default (everything on the stream of lhip_set_hip_stream). */
-int lhip_set_pipeline(int device, int depth);
-int lhip_device_wait(int device);
-
 /* Statistics of the most recent batch on the calling thread: frames encoded, frames that needed
  * the bin-search seed repair pass, repair iterations. */
 void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations);

@@ -45,7 +45,6 @@ enum { PROF_BYTES = 512 };
 #endif
 struct Context;
 static thread_local Context* g_stat_pending = nullptr;      // the last batch was enqueued without synchronisation: its repair statistics are still on the device
-static thread_local int g_stat_pending_set = 0;             // ... in this work set of the context
 static void set_err(const std::string& e) { g_err = e; }
 
 #ifdef LHIP_HOSTSIM
@@ -949,10 +948,9 @@ struct DevBuf {
     ~DevBuf() { rt::dfree(p); }
 };
 
-// Everything one batch in flight owns: the workspace arrays, the descriptor / host-I/O staging, and the side stream + events of the
-// ATH scan.  A context has two: normally only set 0 is used, on the caller's HIP stream; with lhip_set_pipeline(device, 2) consecutive
-// device-resident batches alternate between the sets, each on its own internal stream, so that batch k + 1's psychoacoustics and
-// filterbank fill the chip while batch k's persistent quantization kernel drains and its validation / bit packing run.
+// Everything a batch in flight owns: the workspace arrays, the descriptor / host-I/O staging, and the side stream + events of the ATH scan.
+// (Round 4 measured a second set with two batches in flight -- the persistent quantization kernels side by side or one behind the other -- as
+// slower than one batch at a time in every form, profiles/r04_pass5_ab_*.txt, and removed it: DESIGN.md, measured and discarded.)
 struct WorkSet {
     DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
         ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes, vdig;
@@ -961,10 +959,6 @@ struct WorkSet {
     // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
     // beside the filterbank kernels, which do not depend on it
     void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
-    // pipeline mode: the set's own stream, "inputs are ready" (recorded on the caller's stream) and "this set's last batch is done"
-    void* stream = nullptr; void* ev_in = nullptr; void* ev_done = nullptr;
-    void* ev_quant = nullptr;    // "this set's quantization kernel has finished": the other set's quantization kernel is launched behind it (run_batch)
-    bool busy = false;           // a pipelined batch has been enqueued on `stream` and nobody has waited for it yet
 };
 
 struct Context {
@@ -972,10 +966,7 @@ struct Context {
     void* stream = nullptr;
     std::mutex mu;
     std::map<std::string, std::shared_ptr<TableSet>> tables;
-    WorkSet ws[2];
-    int pipe_depth = 1;          // lhip_set_pipeline: 1 = every batch on the caller's stream (set 0); 2 = device-resident batches alternate between the sets
-    unsigned pipe_next = 0;
-    int last_set = 0;            // the set the most recent batch used (debug taps, statistics)
+    WorkSet ws;
     int num_cus = 256;
     // large host-buffer calls (the drop-in's encodeBuffer with a long Int16Array): chunks of the call are copied in on this stream
     // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
@@ -983,14 +974,6 @@ struct Context {
     DevBuf chunk_in, chunk_out, chunk_fx, state_bak;     // staging halves (sized for the largest chunk a call has reached so far), the per-chunk repair verdicts, the stream state a failed call gives back
     std::mutex chunk_mu;        // one chunked call at a time per device (they share the two staging halves); taken BEFORE mu, never inside it
 };
-
-// wait for the pipelined batches still in flight (ctx->mu held).  Everything that touches a stream's state outside the pipeline -- a
-// synchronous or host-buffer call, flush, the state calls, the statistics -- comes through here first.
-static bool pipeline_drain(Context* ctx) {
-    bool ok = true;
-    for (WorkSet& w : ctx->ws) if (w.busy) { ok = rt::sync(w.stream) && ok; w.busy = false; }
-    return ok;
-}
 
 static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<Context>> g_ctx;
@@ -1019,7 +1002,6 @@ struct lhip_stream {
     int slot_lag = 0;
     int64_t frame_num = 0;
     int64_t rs_n_in = 0;           // resampling streams: input samples received so far
-    int pipe_set = -1;             // pipeline mode: the work set this stream's last batch ran on and may still be running on (-1: none)
     ~lhip_stream() { rt::dfree(d_state); magic = 0; }
 };
 
@@ -1048,34 +1030,12 @@ static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
     return (int64_t)F * ts.base_frame_bytes + npad;
 }
 
-static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync, bool may_pipeline = false) {
+static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
     if (jobs.empty()) return true;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(ctx->device)) return false;
-    // Pipeline mode (lhip_set_pipeline(device, 2)): an asynchronous device-resident batch takes the next work set and that set's own
-    // stream; everything else waits for the batches in flight and runs on set 0 / the caller's stream as always.
-    bool pipelined = false;
-#ifndef LHIP_HOSTSIM
-    pipelined = may_pipeline && dev_io && !want_sync && ctx->pipe_depth == 2 && !g_kt_on && jobs[0].s->ts->T.disable_reservoir;
-#else
-    (void)may_pipeline;
-#endif
-    if (!pipelined && !pipeline_drain(ctx)) return false;
-    const int set = pipelined ? (int)(ctx->pipe_next++ & 1u) : 0;
-    WorkSet& ws = ctx->ws[set];
+    WorkSet& ws = ctx->ws;
     void* st = ctx->stream;
-#ifndef LHIP_HOSTSIM
-    if (pipelined) {
-        if (!ws.stream && (!rt::stream_create(&ws.stream) || !rt::event_create(&ws.ev_in) || !rt::event_create(&ws.ev_done) || !rt::event_create(&ws.ev_quant))) return false;
-        // the batch starts once the caller's stream has reached this point (its inputs are ready) ...
-        if (!rt::event_record(ws.ev_in, ctx->stream) || !rt::stream_wait_event(ws.stream, ws.ev_in)) return false;
-        // ... and once the last batch of each of its streams is done, if that ran on the other set (this set's own stream orders the rest)
-        bool other = false;
-        for (const Job& j : jobs) other |= (j.s->pipe_set == 1 - set);
-        if (other && ctx->ws[1 - set].busy && !rt::stream_wait_event(ws.stream, ctx->ws[1 - set].ev_done)) return false;
-        st = ws.stream;
-    }
-#endif
     TableSet& ts = *jobs[0].s->ts;
     const Tables& T = ts.T;
     const int C = T.channels_out;
@@ -1399,17 +1359,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     static const int pair_max = []() { const char* e = getenv("LAMEJS_HIP_PAIR_MAX_FRAMES"); return e ? atoi(e) : -1; }();
     const bool pair = (C == 2 && nfs <= (pair_max >= 0 ? pair_max : 6 * ctx->num_cus));
 #endif
-    // Two batches in flight: the persistent quantization kernels of the two sets must not share the chip.  Measured (round 4, 1e5 stereo
-    // frames per batch): launched side by side each gets half the CUs for its whole length, both end together with the same tail, and the
-    // step takes 55.0 ms against 45.7 ms with one batch in flight.  Launched BEHIND the other set's, this set's kernel finds the chip free
-    // the moment that one's last wave leaves, and what overlaps is what can: this batch's psychoacoustics / filterbank and the other
-    // batch's validation / bit packing run in the slots the draining kernel gives up.  LAMEJS_HIP_PIPE_QUANT_ORDER=0: side by side (A/B).
-    static const bool quant_order = []() { const char* e = getenv("LAMEJS_HIP_PIPE_QUANT_ORDER"); return !(e && atoi(e) == 0); }();
-    if (pipelined && quant_order && ctx->ws[1 - set].busy && ctx->ws[1 - set].ev_quant &&
-        !rt::stream_wait_event(st, ctx->ws[1 - set].ev_quant)) return false;
     { QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
       if (pair) LAUNCHB(KT_QUANT, g_quant_pair<0>, nfs, 128, st, qa); else LAUNCHB(KT_QUANT, g_quant<0>, qgrid, 64 * QWAVES, st, qa); }
-    if (pipelined && !rt::event_record(ws.ev_quant, st)) return false;
     if (nfr > 0) {
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
@@ -1483,18 +1434,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (fetch_fx) {
         repaired = fx[0]; iters = fx[1];
         if (fx[2]) { set_err("seed-chain repair did not converge"); return false; }
-    } else if (nfr > 0) { g_stat_pending = ctx; g_stat_pending_set = set; }
+    } else if (nfr > 0) g_stat_pending = ctx;
 #endif
     g_stat_frames = nfr; g_stat_repaired = repaired; g_stat_iters = iters;
     ws.lastW = W; ws.lastC = C; ws.lastCp = T.psy_channels; ws.have_last = true;
-    ctx->last_set = set;
-#ifndef LHIP_HOSTSIM
-    if (pipelined) {
-        if (!rt::event_record(ws.ev_done, ws.stream)) return false;
-        ws.busy = true;
-    }
-#endif
-    for (int i = 0; i < S; i++) jobs[i].s->pipe_set = pipelined ? set : -1;
     return true;
 }
 
@@ -1596,7 +1539,6 @@ void lhip_destroy(lhip_stream* s) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     rt::set_device(ctx->device);
-    if (s->pipe_set >= 0) (void)pipeline_drain(ctx);          // its last batch may still be reading the state record
     std::shared_ptr<TableSet> ts = s->ts;
     delete s;
     // the cache entry goes with the last stream that uses it (one reference is the map's, one is `ts` here)
@@ -1618,7 +1560,7 @@ int64_t lhip_encode_output_bytes(const lhip_stream* s, size_t nsamples) {
 }
 
 static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,
-                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync, bool flush_stream = false, bool may_pipeline = false) {
+                       const size_t* ns, uint8_t* const* out, const size_t* cap, int64_t* written, bool dev_io, bool sync, bool flush_stream = false) {
     if (n == 0) return 0;
     std::vector<Job> jobs(n);
     for (size_t i = 0; i < n; i++) {
@@ -1633,7 +1575,7 @@ static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* con
     const Tables& T0 = streams[0]->ts->T;
     const bool resv = !T0.disable_reservoir;
     if (resv) for (size_t i = 0; i < n; i++) jobs[i].flush = flush_stream && ns[i] > 0;
-    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync || resv, may_pipeline);
+    const bool ok = run_batch(streams[0]->ctx, jobs, dev_io, sync || resv);
     for (size_t i = 0; i < n; i++) if (written) written[i] = ok ? jobs[i].written : (jobs[i].written < 0 ? jobs[i].written : LHIP_ERR_INTERNAL);
     if (!ok) { for (auto& j : jobs) if (j.written < 0) return (int)j.written; return LHIP_ERR_INTERNAL; }
     return 0;
@@ -1718,7 +1660,6 @@ static int encode_host_pipelined(Context* ctx, const std::vector<lhip_stream*>& 
         }
         if (!ctx->chunk_in.ensure(2 * C * stride * 2 + 64) || !ctx->chunk_out.ensure(2 * out_chunk) || !ctx->chunk_fx.ensure(units.size() * 16 + 16) ||
             !ctx->state_bak.ensure(NS * sizeof(StreamState))) return LHIP_ERR_INTERNAL;
-        if (!pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
         for (size_t i = 0; i < NS; i++)
             if (!rt::d2d((uint8_t*)ctx->state_bak.p + i * sizeof(StreamState), strs[i]->d_state, sizeof(StreamState), ctx->stream)) return LHIP_ERR_INTERNAL;
     }
@@ -1779,7 +1720,7 @@ static int encode_host_pipelined(Context* ctx, const std::vector<lhip_stream*>& 
 #else
         // this unit's repair verdict (g_fixup: repaired frames, iterations, "did not converge") stays on the device until the call ends:
         // a stream-ordered copy into the call's log, read back once after the last unit
-        if (g_stat_frames > 0 && !rt::d2d((int32_t*)ctx->chunk_fx.p + 4 * k, (const int32_t*)ctx->ws[0].nflagged.p + FX_STATS, 12, ks)) return fail(nullptr);
+        if (g_stat_frames > 0 && !rt::d2d((int32_t*)ctx->chunk_fx.p + 4 * k, (const int32_t*)ctx->ws.nflagged.p + FX_STATS, 12, ks)) return fail(nullptr);
         if (g_stat_frames == 0 && !rt::dzero((int32_t*)ctx->chunk_fx.p + 4 * k, 12, ks)) return fail(nullptr);
 #endif
         if (!rt::event_record(ctx->ev_done[par], ks)) return fail(nullptr);
@@ -1969,7 +1910,7 @@ int lhip_flush_batch(lhip_stream* const* streams, size_t nstreams, uint8_t* cons
 
 int lhip_encode_batch_device(lhip_stream* const* streams, size_t nstreams, const int16_t* const* d_left, const int16_t* const* d_right,
                              const size_t* nsamples, uint8_t* const* d_out, const size_t* out_cap, int64_t* written, int sync) {
-    return encode_many(streams, nstreams, d_left, d_right, nsamples, d_out, out_cap, written, true, sync != 0, false, true);
+    return encode_many(streams, nstreams, d_left, d_right, nsamples, d_out, out_cap, written, true, sync != 0);
 }
 
 // ---- frame-range sharding of ONE stream (second mode): speculate the state at a cut, verify it, transplant on a miss ----
@@ -1993,7 +1934,7 @@ int lhip_state_get(lhip_stream* s, void* buf, size_t cap) {
     if (!buf || cap < lhip_state_bytes(s)) { set_err("state buffer too small"); return LHIP_ERR_BUFFER_TOO_SMALL; }
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
+    if (!rt::set_device(ctx->device)) return LHIP_ERR_INTERNAL;
     StateHdr h; memset(&h, 0, sizeof h);
     h.magic = 0x5453484cu; h.bytes = (uint32_t)lhip_state_bytes(s);
     h.mf_size = s->mf_size; h.mf_samples_to_encode = s->mf_samples_to_encode; h.slot_lag = s->slot_lag; h.frame_num = s->frame_num; h.rs_n_in = s->rs_n_in;
@@ -2023,7 +1964,7 @@ int lhip_state_set(lhip_stream* s, const void* buf, size_t n) {
     Context* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (h.magic != 0x5453484cu || h.bytes != lhip_state_bytes(s) || n < h.bytes || h.config != state_config_tag(s->ts->T)) { set_err("state blob does not belong to this build / configuration"); return LHIP_ERR_INTERNAL; }
-    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
+    if (!rt::set_device(ctx->device)) return LHIP_ERR_INTERNAL;
     if (!rt::set_device(ctx->device) || !rt::h2d(s->d_state, (const uint8_t*)buf + sizeof h, sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
     s->mf_size = h.mf_size; s->mf_samples_to_encode = h.mf_samples_to_encode; s->slot_lag = h.slot_lag; s->frame_num = h.frame_num; s->rs_n_in = h.rs_n_in;
     return 0;
@@ -2078,34 +2019,6 @@ int lhip_set_hip_stream(int device, void* hip_stream) {
     return 0;
 }
 
-int lhip_set_pipeline(int device, int depth) {
-    if (depth != 1 && depth != 2) { set_err("lhip_set_pipeline: depth must be 1 or 2"); return LHIP_ERR_INTERNAL; }
-#ifndef LHIP_HOSTSIM
-    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return LHIP_ERR_INTERNAL; }
-#else
-    if (device < 0) device = 0;
-#endif
-    if (device >= rt::device_count()) { set_err("no such HIP device"); return LHIP_ERR_INTERNAL; }
-    Context* ctx = get_context(device);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
-    ctx->pipe_depth = depth;
-    return 0;
-}
-
-int lhip_device_wait(int device) {
-#ifndef LHIP_HOSTSIM
-    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return LHIP_ERR_INTERNAL; }
-#else
-    if (device < 0) device = 0;
-#endif
-    if (device >= rt::device_count()) { set_err("no such HIP device"); return LHIP_ERR_INTERNAL; }
-    Context* ctx = get_context(device);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!rt::set_device(ctx->device) || !pipeline_drain(ctx) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
-    return 0;
-}
-
 void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* repair_iterations) {
 #ifndef LHIP_HOSTSIM
     if (g_stat_pending) {                      // asynchronous batch: wait for it and fetch the device-side counters
@@ -2113,8 +2026,8 @@ void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* r
         g_stat_pending = nullptr;
         std::lock_guard<std::mutex> lk(ctx->mu);
         int32_t fx[3] = {0, 0, 0};
-        WorkSet& ws = ctx->ws[g_stat_pending_set];
-        void* st = ws.busy ? ws.stream : ctx->stream;          // a pipelined batch lives on its set's stream
+        WorkSet& ws = ctx->ws;
+        void* st = ctx->stream;
         if (rt::set_device(ctx->device) && rt::d2h(fx, (const int32_t*)ws.nflagged.p + FX_STATS, sizeof fx, st) && rt::sync(st)) {
             g_stat_repaired = fx[0]; g_stat_iters = fx[1];
             if (fx[2]) set_err("seed-chain repair did not converge");
@@ -2128,12 +2041,11 @@ void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* r
 
 int64_t lhip_debug_read(int what, void* dst, size_t cap) {
     Context* ctx = nullptr;
-    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto& kv : g_ctx) if (kv.second->ws[kv.second->last_set].have_last) ctx = kv.second.get(); }
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto& kv : g_ctx) if (kv.second->ws.have_last) ctx = kv.second.get(); }
     if (!ctx) { set_err("no batch has run"); return LHIP_ERR_INTERNAL; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     rt::set_device(ctx->device);
-    if (!pipeline_drain(ctx)) return LHIP_ERR_INTERNAL;
-    const WorkSet& ws = ctx->ws[ctx->last_set];
+    const WorkSet& ws = ctx->ws;
     const Workspace& W = ws.lastW;
     const size_t GC = (size_t)W.ngslots * ws.lastC;
     const void* src = nullptr; size_t n = 0;

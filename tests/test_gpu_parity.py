@@ -555,20 +555,17 @@ def test_gpu_async_batch_and_device_mask(lib):
             hip.hipFree(p)
 
 
-def test_gpu_pipeline_two_batches_in_flight(lib):
-    """lhip_set_pipeline(device, 2): consecutive asynchronous device-resident batches alternate between two workspaces on internal streams
-    (batch k + 1's front kernels overlap batch k's quantization tail, validation and bit packing).  Six batches back to back without a
-    host synchronisation: A, B, A, C, B, A -- stream A's second batch lands on the other work set (it must wait for its first), B's on the
-    same one -- then ONE lhip_device_wait; every stream's concatenated bytes against the oracle, the stream calls that leave the pipeline
-    (flush, state blob) mixed in afterwards, and the statistics of the last batch."""
+def test_gpu_async_batches_back_to_back(lib):
+    """Six asynchronous device-resident batches (lhip_encode_batch_device, sync = 0) enqueued back to back without a host synchronisation:
+    streams A, B, A, C, B, A -- every call only enqueues, the workspace is reused by the next batch in stream order -- then ONE device
+    synchronisation; every stream's concatenated bytes against the oracle, the synchronous stream calls (flush, state blob) mixed in
+    afterwards, and the statistics of the last batch."""
     import lamejs_amd, pcm
     from oracle_py import oracle_encode
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     hip.hipFree.argtypes = [ctypes.c_void_p]
-    lib.lhip_set_pipeline.argtypes = [ctypes.c_int, ctypes.c_int]
-    lib.lhip_device_wait.argtypes = [ctypes.c_int]
     assert hip.hipSetDevice(0) == 0
     bufs = []
 
@@ -589,7 +586,6 @@ def test_gpu_pipeline_two_batches_in_flight(lib):
     encs = {k: lamejs_amd.Mp3Encoder(2, 44100, 128, device=0) for k in "ABC"}
     cap = (nfr + 4) * 420
     try:
-        assert lib.lhip_set_pipeline(0, 2) == 0
         pos = {k: 0 for k in "ABC"}
         parts = {k: [] for k in "ABC"}
         for k in order:
@@ -602,7 +598,7 @@ def test_gpu_pipeline_two_batches_in_flight(lib):
             wr = (ctypes.c_int64 * 1)()
             assert lib.lhip_encode_batch_device(H, 1, a_l, a_r, a_n, a_o, a_c, wr, 0) == 0, lib.lhip_last_error()
             parts[k].append((out, int(wr[0])))
-        assert lib.lhip_device_wait(0) == 0
+        assert hip.hipDeviceSynchronize() == 0
         st = encs["A"].last_batch_stats()
         assert st["frames"] == nfr
         for k in "ABC":
@@ -611,13 +607,12 @@ def test_gpu_pipeline_two_batches_in_flight(lib):
                 h = np.empty(n, dtype=np.uint8)
                 assert hip.hipMemcpy(h.ctypes.data, out, n, 2) == 0
                 got += h.tobytes()
-            blob = encs[k].state_get()                                    # a call that leaves the pipeline
+            blob = encs[k].state_get()
             assert len(blob) > 0
             got += encs[k].flush()
             L, R = mats[k]
             assert got == oracle_encode(2, 44100, 128, L, R), k
     finally:
-        lib.lhip_set_pipeline(0, 1)
         for e in encs.values():
             e.close()
         for q in bufs:
