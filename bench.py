@@ -551,7 +551,8 @@ def main():
             # gfx950 FETCH_SIZE x2 correction) and its instruction mix -- measured offline on this exact workload, under profiles/
             traffic = None
             prof = {}
-            pf = next((q for q in (ROOT / "profiles" / f"r03_pmc_config{key}.json", ROOT / "profiles" / f"r02_pmc_config{key}.json") if q.exists()), ROOT / "profiles" / f"r03_pmc_config{key}.json")
+            cands = [ROOT / "profiles" / f"r0{r}_pmc_config{key}.json" for r in (4, 3, 2)]       # the newest measurement pass that has this workload
+            pf = next((q for q in cands if q.exists()), cands[0])
             if wl.full and pf.exists():
                 try:
                     prof = json.loads(pf.read_text())

@@ -1791,7 +1791,7 @@ static int encode_host_groups(lhip_stream* const* streams, size_t n, const int16
         }
     // groups of about 2 x the first chunk of the one-stream schedule (16384 one-channel frames): large enough for the persistent kernel,
     // small enough that the first group's copy -- the part nothing overlaps -- stays short
-    const size_t target = 2 * host_chunk_schedule().first * spf * (T.channels_out == 2 ? 1 : 1);
+    const size_t target = 2 * host_chunk_schedule().first * spf;
     std::vector<std::vector<HostPiece>> units(1);
     size_t acc = 0;
     for (size_t i = 0; i < n; i++) {
@@ -2058,6 +2058,7 @@ int64_t lhip_debug_read(int what, void* dst, size_t cap) {
         case 5: src = W.sb; n = GC * SB_STRIDE * 4; break;
         case 6: src = W.peaks; n = GC * PK_STRIDE * 4; break;
         case 7: src = W.prof; n = PROF_BYTES; break;
+        case 8: src = W.nflagged; n = 256; break;           // validation counters of the last batch: [0] frames flagged by the first pass, [1] frames its memo could not decide, [32..34] repair statistics
         default: set_err("unknown tap"); return LHIP_ERR_INTERNAL;
     }
     if (n > cap) n = cap;

@@ -1,0 +1,26 @@
+# DEV TOOL (GPU box): round 4's final pass on the final code -- GPU tier, bench line, the RCCL path at world 1, the randomised sweep, kernel stats of configs 3 and 2.
+# Lands in gpurun_out/r04m/; every step under its own timeout.  (tools/measure_round4_a.sh, the counter pass, runs first.)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04m; mkdir -p $O
+cd $R
+timeout 400 python -m pytest tests -m gpu -q --timeout 200 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 420 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.err
+python - <<'PY'
+import json,os
+d=json.loads(open(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/r04m/bench_default.json').read().strip().splitlines()[-1])
+print('value', d['value'], 'ms', d['ms_per_step'], 'bit_exact_full', d['config']['bit_exact_full'])
+for k,v in d.get('other_configs',{}).items(): print(k, {a:b for a,b in v.items() if a in ('value','frames_per_s','ms_per_step','ms_per_call','bit_exact_full','vs_device_resident','vs_c_abi_host_call','error')})
+print(d['kernels_ms']); print(d.get('roofline'))
+PY
+LAMEJS_BENCH_FORCE_DIST=1 timeout 200 python bench.py --config 3 --no-extras --cpu-seconds 0 --steps 2 > $O/bench_nccl_world1_config3.json 2> $O/bench_nccl_world1_config3.err; tail -c 200 $O/bench_nccl_world1_config3.err
+{
+echo "GPU fuzz on the final code of round 4 (tests/tools/fuzz_gpu.py <n> <seed> <family>: random material, random chunking, GPU output vs the CPU oracle)"
+for spec in "700 640001 mpeg1" "400 640002 lsf" "200 640003 resample" "100 640004 lowrate" "300 640005 mpeg1 joint" "150 640006 mpeg1 reservoir" "200 640007 mpeg1 stereo whole"; do
+  echo "  python tests/tools/fuzz_gpu.py $spec    -> $(timeout 200 python tests/tools/fuzz_gpu.py $spec 2>&1 | tail -1)"
+done
+} | tee $O/fuzz_gpu_final_code.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt3 -- python $R/bench.py --cpu-seconds 0 --no-extras --steps 6 --check-frames 0 > $O/kt3.log 2>&1
+python $R/tools/pmc_summary.py stats /tmp/kt3 $O/kernel_stats_config3.csv; head -12 $O/kernel_stats_config3.csv | cut -c1-150
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python $R/bench.py --cpu-seconds 0 --no-extras --steps 6 --check-frames 0 --config 2 > $O/kt2.log 2>&1
+python $R/tools/pmc_summary.py stats /tmp/kt2 $O/kernel_stats_config2.csv; head -12 $O/kernel_stats_config2.csv | cut -c1-150
+ls $O
