@@ -14,8 +14,8 @@ PY
 LAMEJS_BENCH_FORCE_DIST=1 timeout 200 python bench.py --config 3 --no-extras --cpu-seconds 0 --steps 2 > $O/bench_nccl_world1_config3.json 2> $O/bench_nccl_world1_config3.err; tail -c 200 $O/bench_nccl_world1_config3.err
 {
 echo "GPU fuzz on the final code of round 4 (tests/tools/fuzz_gpu.py <n> <seed> <family>: random material, random chunking, GPU output vs the CPU oracle)"
-for spec in "700 640001 mpeg1" "400 640002 lsf" "200 640003 resample" "100 640004 lowrate" "300 640005 mpeg1 joint" "150 640006 mpeg1 reservoir" "200 640007 mpeg1 stereo whole"; do
-  echo "  python tests/tools/fuzz_gpu.py $spec    -> $(timeout 200 python tests/tools/fuzz_gpu.py $spec 2>&1 | tail -1)"
+for spec in "3000 640001 mpeg1" "1600 640002 lsf" "800 640003 resample" "400 640004 lowrate" "1200 640005 mpeg1 joint" "510 640006 mpeg1 reservoir" "400 640007 mpeg1 stereo whole"; do
+  echo "  python tests/tools/fuzz_gpu.py $spec    -> $(timeout 400 python tests/tools/fuzz_gpu.py $spec 2>&1 | tail -1)"
 done
 } | tee $O/fuzz_gpu_final_code.txt
 cd /tmp && export TMPDIR=/tmp
