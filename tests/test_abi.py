@@ -61,3 +61,32 @@ def test_set_devices_argument_handling():
     else:
         assert lib.lhip_set_devices(1 << 63) < 0
         assert lib.lhip_set_devices(0) == n
+
+
+def test_device_code_resources(tmp_path):
+    """The resource usage the design rests on, read from the shipped library's own gfx950 code object (no GPU needed): the persistent
+    quantization kernel spills nothing to scratch memory, stays within 128 registers (4 waves per SIMD) and two of its workgroups fit the
+    160 KB of LDS of a CU; the batch kernels of the steady-state path use no scratch either."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = f"{llvm}/llvm-objdump", f"{llvm}/llvm-readelf"
+    so = ROOT / "lamejs_amd" / "lib" / "liblamejs_hip.so"
+    if not (shutil.which(objdump) and shutil.which(readelf) and so.exists()):
+        pytest.skip("llvm tools or the built library not present")
+    shutil.copy(so, tmp_path / "l.so")
+    subprocess.run([objdump, "--offloading", "l.so"], cwd=tmp_path, capture_output=True, check=True)
+    co = [p for p in tmp_path.iterdir() if "amdgcn" in p.name]
+    assert len(co) == 1 and "gfx950" in co[0].name, [p.name for p in tmp_path.iterdir()]
+    notes = subprocess.run([readelf, "--notes", str(co[0])], capture_output=True, text=True, check=True).stdout
+    kern = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        f = {k: v for k, v in re.findall(r"\.(name|private_segment_fixed_size|vgpr_count|group_segment_fixed_size):\s+(\S+)", blk)}
+        kern[f["name"]] = {k: int(v) for k, v in f.items() if k != "name"}
+    q = next(v for k, v in kern.items() if k.startswith("_Z7g_quantILi0"))
+    assert q["private_segment_fixed_size"] == 0, q
+    assert q["vgpr_count"] <= 128 and 2 * q["group_segment_fixed_size"] <= 160 * 1024, q
+    for name in ("g_psyA", "g_psyB", "g_poly", "g_mdct", "g_bits", "g_validate_fast", "g_fixup", "g_scan_ath", "g_quant_pair", "g_load", "g_save"):
+        ks = [v for k, v in kern.items() if re.match(rf"_Z\d+{name}(I|N|5|E)", k)]
+        assert ks, name
+        assert all(v["private_segment_fixed_size"] == 0 for v in ks), (name, ks)
