@@ -2676,7 +2676,8 @@ LHIP_DEV void kb_validate_fast(const Tables& T, const Workspace& W, const Stream
 // The first pass over a whole batch (g_validate_fast): FOUR lanes per frame, one per granule-channel -- a frame's check is a chain of
 // dependent look-ups (the two previous granules' digests, then the memo), and one thread per frame left the chip with a wave and a half
 // per SIMD waiting on them (0.27 ms per 1e5 two-channel frames); the quad's verdicts meet through DPP and its first lane publishes.
-LHIP_DEV void kb_validate_fast_quad(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int sub, bool live) {
+struct ValidateShare { int total[2], base[2], woff[4][2]; };      // g_validate_fast: 256 threads = 4 waves
+LHIP_DEV void kb_validate_fast_quad(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int sub, bool live, ValidateShare& S) {
     const int C = T.channels_out;
     int v = 0, fidx = 0;
     bool has = false;
@@ -2694,7 +2695,26 @@ LHIP_DEV void kb_validate_fast_quad(const Tables& T, const Workspace& W, const S
     int m = (v == 1 ? 1 : 0) | (v == 2 ? 2 : 0);
     m |= __builtin_amdgcn_mov_dpp(m, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
     m |= __builtin_amdgcn_mov_dpp(m, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
-    if (has && sub == 0) validate_fast_publish(W, fslot, fidx, m & 1, m & 2);
+    // The quad's first lane publishes.  The counters are bumped ONCE PER WORKGROUP: on steady material a quarter to a third of the frames are
+    // "undecided" (profiles/r04_pass6_validate_stats.txt), and 23-32 k returning atomics on one address serialise in the L2 -- that, not the
+    // replay, was this kernel's time (0.26 ms stereo / 0.37 ms mono per 1e5 frames, in proportion to the undecided frames).  Every wave ranks
+    // its publishing lanes with ballots, the waves meet in LDS, one thread per counter talks to global memory, and the list slots follow from
+    // the ranks.  (The order of W.slow_list is immaterial: g_fixup spreads its entries over its waves.)
+    const bool pub = has && sub == 0;
+    const int verdict = pub ? ((m & 1) ? 1 : (m & 2) ? 2 : 0) : 0;
+    if (pub) W.seed_flag[fidx] = verdict;
+    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+    const uint64_t b1 = __ballot(verdict == 1), b2 = __ballot(verdict == 2);
+    if (threadIdx.x < 2) S.total[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0) {                                 // this wave's offsets inside the workgroup's share (LDS atomics: cheap, returning)
+        S.woff[wv][0] = b1 ? atomicAdd(&S.total[0], (int)__builtin_popcountll(b1)) : 0;
+        S.woff[wv][1] = b2 ? atomicAdd(&S.total[1], (int)__builtin_popcountll(b2)) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) { const int n = S.total[threadIdx.x]; S.base[threadIdx.x] = n ? atomicAdd(W.nflagged + threadIdx.x, n) : 0; }
+    __syncthreads();
+    if (verdict == 2) W.slow_list[S.base[1] + S.woff[wv][1] + (int)__builtin_popcountll(b2 & ((1ull << lane) - 1))] = fslot;
 }
 #endif
 

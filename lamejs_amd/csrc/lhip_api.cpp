@@ -469,8 +469,9 @@ template <int RESV> __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pa
     kb_quant<1, RESV>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
 }
 __global__ __launch_bounds__(256) void g_validate_fast(Tables T, Workspace W, const StreamDesc* SD, int nfs) {
+    __shared__ ValidateShare S;
     const int t = blockIdx.x * 256 + threadIdx.x, fslot = t >> 2;        // four lanes per frame slot (kb_validate_fast_quad)
-    kb_validate_fast_quad(T, W, SD, fslot < nfs ? fslot : 0, t & 3, fslot < nfs);
+    kb_validate_fast_quad(T, W, SD, fslot < nfs ? fslot : 0, t & 3, fslot < nfs, S);
 }
 // ---- seed-chain validation + repair without the host (persistent, grid barriers) ------------------------------------------
 // One launch replaces the host's loop "validate -> read the flagged count back -> repair -> ...": every workgroup walks the same

@@ -165,7 +165,10 @@ struct Workspace {
 // one thread per frame reads it coalesced.  VD_HEAD: gain | seed start << 8 | seed step << 16 | active << 24; VD_TARG: target bits | memo
 // entries << 24; VD_STATE: the conditionally assigned fields at the end of the bin search (GrSide::bs_state); then the first VD_ENT memo
 // entries as (gain << 24 | bits, assignments) pairs.
-enum { VD_HEAD = 0, VD_TARG = 1, VD_STATE = 2, VD_TAB = 3, VD_ENT = 6, VD_WORDS = VD_TAB + 2 * VD_ENT };
+#ifndef LHIP_VD_ENT
+#define LHIP_VD_ENT 6
+#endif
+enum { VD_HEAD = 0, VD_TARG = 1, VD_STATE = 2, VD_TAB = 3, VD_ENT = LHIP_VD_ENT, VD_WORDS = VD_TAB + 2 * VD_ENT };
 LHIP_DEV uint32_t vd_head(int active, int start, int step, int gain) { return (uint32_t)(gain & 255) | ((uint32_t)(start & 255) << 8) | ((uint32_t)(step & 255) << 16) | ((uint32_t)(active != 0) << 24); }
 LHIP_DEV int vd_active(uint32_t h) { return (int)((h >> 24) & 1u); }
 LHIP_DEV int vd_gain(uint32_t h) { return (int)(h & 255u); }
