@@ -498,8 +498,13 @@ LHIP_DEV void grid_barrier(int32_t* bar, int nblocks) {
     }
     __syncthreads();
 }
-// one workgroup per CU at most (2 waves per SIMD): the register budget is 256 VGPRs, nothing needs to spill
-__global__ __launch_bounds__(64 * QWAVES, 2) void g_fixup(QArgs a_unused) {
+// Two workgroups per CU at 128 registers (like g_quant) rather than one at 256: the phases of this kernel are spread over all its waves, and twice the
+// waves beat the 128 B per lane the smaller budget spills (round 4, profiles/r04_pass9_ab_fixup_two_workgroups_per_cu.txt: validation + repair
+// 0.32 -> 0.27 ms per 1e5 two-channel frames, `bursts` 2.2 -> 2.0 ms).  LHIP_FIXUP_OCC=2 builds the old shape.
+#ifndef LHIP_FIXUP_OCC
+#define LHIP_FIXUP_OCC 4
+#endif
+__global__ __launch_bounds__(64 * QWAVES, LHIP_FIXUP_OCC) void g_fixup(QArgs a_unused) {
     __shared__ QuantTabs Q;
     __shared__ QuantLds L[QWAVES];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1366,10 +1371,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         // validation of the seed chain + repair of the flagged frames, decided on the device (no host round trip in the pipeline)
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 1; qa.nfs = nfs; qa.ctr = 0;
         LAUNCHB(KT_VALIDATE, g_validate_fast, (nfs + 63) / 64, 256, st, T, W, dSD, nfs);
-        // one workgroup per CU at most: the memo-miss re-validation (a few hundred frames per 1e5 on steady material) is spread over
-        // all of them -- a quarter-chip grid was tried and doubled this stage's time
+        // as many workgroups as can be resident (two per CU): the memo-miss re-validation (a quarter to a third of the frames of steady
+        // material) is spread over all of them -- a quarter-chip grid was tried and doubled this stage's time
         int fgrid = (nfs + 63) / 64;
-        if (fgrid > ctx->num_cus) fgrid = ctx->num_cus;
+        if (fgrid > ctx->num_cus * (LHIP_FIXUP_OCC / 2)) fgrid = ctx->num_cus * (LHIP_FIXUP_OCC / 2);
         if (fgrid < 1) fgrid = 1;
         if (fgrid == 1) LAUNCHB(KT_VALIDATE, g_fixup, 1, 64 * QWAVES, st, qa);
         else {
