@@ -166,7 +166,7 @@ struct Workspace {
 // entries << 24; VD_STATE: the conditionally assigned fields at the end of the bin search (GrSide::bs_state); then the first VD_ENT memo
 // entries as (gain << 24 | bits, assignments) pairs.
 #ifndef LHIP_VD_ENT
-#define LHIP_VD_ENT 6
+#define LHIP_VD_ENT 6      /* memo entries kept in the digest; 10 and 12 were measured in round 4 (profiles/r04_pass7_*): no effect on the validation's time */
 #endif
 enum { VD_HEAD = 0, VD_TARG = 1, VD_STATE = 2, VD_TAB = 3, VD_ENT = LHIP_VD_ENT, VD_WORDS = VD_TAB + 2 * VD_ENT };
 LHIP_DEV uint32_t vd_head(int active, int start, int step, int gain) { return (uint32_t)(gain & 255) | ((uint32_t)(start & 255) << 8) | ((uint32_t)(step & 255) << 16) | ((uint32_t)(active != 0) << 24); }
