@@ -1251,7 +1251,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #define QUANT_RUN(chain_) WAVE_RUN(kb_quant<0, 0>(T, ts.pb10, W, dSD, b, chain_, lane_, LQ, QT))
 #endif
 #if defined(LHIP_WAVESIM)
-        if (!pair && C == 2) {   // the persistent kernel as a real 8-wave workgroup: frames drawn from a shared counter, then the waves help each other (k_quant_tail.h)
+        if (!pair) {   // the persistent kernel as a real 8-wave workgroup: frames drawn from a shared counter (kb_quant_th, what g_quant runs for one- and
+                        // two-channel streams alike), then -- two channels -- the waves help each other (k_quant_tail.h)
             static QuantLds LQ8[8]; static TailShare TS;
             int ctr = 0;
             TS.drawing = 8; for (int w = 0; w < 8; w++) TS.offer[w].state = 0;
@@ -1264,7 +1265,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
                     if (f >= nfs) break;
                     kb_quant_th(T, ts.pb10, W, dSD, f, lane_, LQ8[wave_], QT, hint, TS, wave_);
                 }
-                tail_help(T, ts.pb10, W, dSD, lane_, LQ8, wave_, 8, QT, TS);
+                if (C == 2) tail_help(T, ts.pb10, W, dSD, lane_, LQ8, wave_, 8, QT, TS);
             });
         } else
 #endif
