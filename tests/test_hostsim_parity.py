@@ -422,3 +422,42 @@ def test_hostsim_interleaved_async_batches(sim):
             got[i] += encs[i].flush()
             encs[i].close()
             assert got[i] == oracle_encode(2, 44100, 128, *mats[i])
+
+
+def test_hostsim_validation_counters_tap(sim):
+    """lhip_debug_read(8): the seed-chain validation's counters of the last batch ([0] frames flagged by the memo-only pass, [1] frames it could not decide).
+    With the speculation seed forced far from every chain seed the first pass must flag or leave undecided a good part of a batch; with the usual seed on a
+    steady tone nothing is flagged -- and the bytes are the oracle's either way."""
+    import lamejs_amd
+    import pcm
+    sim.lhip_debug_set_spec_seed.argtypes = [ctypes.c_int, ctypes.c_int]
+    L, R = pcm.sine(1152 * 30, 2, seed=5)
+    want = oracle_encode(2, 44100, 128, L, R)
+    buf = (ctypes.c_int32 * 64)()
+    try:
+        for seed, expect_trouble in (((180, 4), False), ((255, 1), True)):
+            sim.lhip_debug_set_spec_seed(*seed)
+            enc = lamejs_amd.Mp3Encoder(2, 44100, 128, lib=sim)
+            got = enc.encodeBuffer(L, R)
+            assert sim.lhip_debug_read(8, buf, 256) == 256, sim.lhip_last_error()
+            got += enc.flush()
+            enc.close()
+            assert got == want
+            assert buf[0] >= 0 and buf[1] >= 0
+            if not expect_trouble:
+                assert buf[0] == 0
+    finally:
+        sim.lhip_debug_set_spec_seed(180, 4)
+
+
+def test_experiment_patches_apply(tmp_path):
+    """tools/experiments/*.patch are ideas waiting for GPU minutes, kept against HEAD: they must keep applying (a patch that no longer does is stale and goes)."""
+    import shutil
+    patches = sorted((ROOT / "tools" / "experiments").glob("*.patch"))
+    if not patches or not shutil.which("patch"):
+        pytest.skip("no experiment patches (or no patch tool)")
+    for p in patches:
+        dst = tmp_path / p.stem
+        shutil.copytree(ROOT / "lamejs_amd" / "csrc", dst / "lamejs_amd" / "csrc")
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", str(p)], cwd=dst, capture_output=True, text=True)
+        assert r.returncode == 0, (p.name, r.stdout[-800:], r.stderr[-400:])
