@@ -1,6 +1,6 @@
-# DEV TOOL (GPU box), round 4 pass 7: A/B of library variants under lamejs_amd/lib/variants/ against the shipped library (step, quantization and validation times,
+# DEV TOOL (GPU box): A/B of library variants under lamejs_amd/lib/variants/ against the shipped library (step, quantization and validation times,
 # bit-exactness) on configs 3, 2 and bursts, two interleaved repetitions.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_pass7; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab; mkdir -p $O
 cd $R
 line() { python -c "
 import json,sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # DEV TOOL: an experiment kept as a patch (tools/experiments/*.patch), not as a switch in the product tree.  Applies it to a scratch copy of HEAD,
 # checks the kernel logic in the 64-lane simulation (a short randomised sweep against the oracle), prints g_quant's resource usage, and builds the device
-# library of the variant into lamejs_amd/lib/variants/ for an A/B on the GPU box (tools/r04_gpu_pass7.sh compares every library found there with the shipped one).
+# library of the variant into lamejs_amd/lib/variants/ for an A/B on the GPU box (tools/ab_libraries_gpu.sh compares every library found there with the shipped one).
 #   usage: tools/experiments/try_patch.sh tools/experiments/<name>.patch [cases per family, default 40]
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
@@ -22,4 +22,4 @@ PY
 (cd $X && bash tools/isa_build.sh /tmp/isa/kg_$NAME.s | grep -E "g_quantILi0|g_fixup")
 mkdir -p $R/lamejs_amd/lib/variants
 ${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -fPIC -shared -x hip $X/lamejs_amd/csrc/lhip_api.cpp -o $R/lamejs_amd/lib/variants/liblamejs_hip_$NAME.so
-echo "variant library: lamejs_amd/lib/variants/liblamejs_hip_$NAME.so (A/B: gpurun -- 'bash tools/r04_gpu_pass7.sh')"
+echo "variant library: lamejs_amd/lib/variants/liblamejs_hip_$NAME.so (A/B: gpurun -- 'bash tools/ab_libraries_gpu.sh')"
