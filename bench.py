@@ -244,27 +244,64 @@ def node_dropin_lines(table):
     if not node or not (ROOT / "lamejs_amd" / "js" / "addon" / "lhip_napi.node").exists():
         return out
     tool = str(ROOT / "tests" / "tools" / "bench_dropin.js")
-    for nm, argv in (("dropin_node", ["sine", "2", "128", "100000", "12345"]), ("dropin_node_mono", ["sine", "1", "128", "100000", "12345"])):
+    failed = []
+
+    def run_node(nm, argv, timeout):
+        """One Node process; after the first failure (a wedged addon or GPU) the remaining lines are skipped rather than waited for."""
+        if failed:
+            out[nm] = {"error": f"skipped: {failed[0]} failed"}
+            return None
         r_ = None
         try:
-            r_ = subprocess.run([node, tool] + argv, capture_output=True, text=True, timeout=300)
-            e = json.loads(r_.stdout.strip().splitlines()[-1])
-            ent = table.get(("sine", int(argv[1]), 128, 100000, 12345, False, False))
-            e["bit_exact_full"] = None if ent is None else bool(ent[0] == e["md5_encode_buffer"] and ent[1] == e["bytes_encode_buffer"])
-            e["note"] = "own Node process, alone on the GPU (started before bench.py opened the device)"
-            out[nm] = e
+            r_ = subprocess.run([node, tool] + argv, capture_output=True, text=True, timeout=timeout)
+            return json.loads(r_.stdout.strip().splitlines()[-1])
         except Exception as ex:      # the JavaScript surface is optional on a box without node
             out[nm] = {"error": (str(ex) + " " + (r_.stderr[-200:] if r_ is not None else ""))[:400]}
+            failed.append(nm)
+            return None
+
+    # ---- the reference's DOCUMENTED call pattern (README.md:69-74, 103-108; Tests.js:19-33): 1152 samples per encodeBuffer() call.
+    # On the reference's own fixture (md5 = the one Tests.js' outputs have, SURVEY.md 8c) and on 2000 frames of the bench stream
+    # (md5 from the unmodified reference: tests/golden/calls_md5.json), stereo and mono; then the same pattern over 64 streams per call.
+    fix = {}
     try:
-        r_ = subprocess.run([node, tool, "batch", "128", "1000", "1000"], capture_output=True, text=True, timeout=300)
-        e = json.loads(r_.stdout.strip().splitlines()[-1])
+        for c_ in json.loads((ROOT / "tests" / "golden" / "golden.json").read_text())["cases"]:
+            if c_["corpus"] == "wavfull" and c_["kbps"] == 128:
+                fix[c_["channels"]] = (c_["mp3_md5"], c_["mp3_len"])
+        calls = {e_["channels"]: (e_["md5"], e_["bytes"], e_["frames"]) for e_ in json.loads((ROOT / "tests" / "golden" / "calls_md5.json").read_text())["entries"]}
+    except Exception:
+        calls = {}
+    for nm, ch_, src in (("dropin_node_1152", 2, "fixture"), ("dropin_node_1152_mono", 1, "fixture"), ("dropin_node_1152_sine", 2, "sine"), ("dropin_node_1152_sine_mono", 1, "sine")):
+        e = run_node(nm, ["calls", str(ch_), "128", src, "2000", "3"], 120)
+        if e is None:
+            continue
+        want = fix.get(ch_) if src == "fixture" else calls.get(ch_, (None, None))[:2]
+        e["bit_exact_full"] = None if not want or want[0] is None else bool(want[0] == e["md5"] and want[1] == e["bytes"])
+        e["note"] = "own Node process, alone on the GPU; every call returns before the next is made (the reference's API is synchronous)"
+        out[nm] = e
+    e = run_node("dropin_node_1152_batch64", ["callsbatch", "64", "1000", "1000", "3"], 180)
+    if e is not None:
+        ents = [table.get(("sine", 1, 128, 1000, sd_, False, False)) for sd_ in e["seeds"]]
+        e["bit_exact_full"] = None if any(x is None for x in ents) else bool(all(x[0] == m_ and x[1] == b_ for x, m_, b_ in zip(ents, e["md5_encode_buffer"], e["bytes_encode_buffer"])))
+        for k_ in ("seeds", "md5_encode_buffer", "bytes_encode_buffer"):
+            e.pop(k_, None)
+        out["dropin_node_1152_batch64"] = e
+    # ---- ONE large call (the shape the GPU is good at; no documented use of lamejs has it)
+    for nm, argv in (("dropin_node", ["sine", "2", "128", "100000", "12345"]), ("dropin_node_mono", ["sine", "1", "128", "100000", "12345"])):
+        e = run_node(nm, argv, 150)
+        if e is None:
+            continue
+        ent = table.get(("sine", int(argv[1]), 128, 100000, 12345, False, False))
+        e["bit_exact_full"] = None if ent is None else bool(ent[0] == e["md5_encode_buffer"] and ent[1] == e["bytes_encode_buffer"])
+        e["note"] = "own Node process, alone on the GPU (started before bench.py opened the device)"
+        out[nm] = e
+    e = run_node("dropin_node_batch", ["batch", "128", "1000", "1000"], 150)
+    if e is not None:
         ents = [table.get(("sine", 1, 128, 1000, sd_, False, False)) for sd_ in e["seeds"]]
         e["bit_exact_full"] = None if any(x is None for x in ents) else bool(all(x[0] == m_ and x[1] == b_ for x, m_, b_ in zip(ents, e["md5_encode_buffer"], e["bytes_encode_buffer"])))
         for k_ in ("seeds", "md5_encode_buffer", "bytes_encode_buffer", "bytes_flush"):
             e.pop(k_, None)
         out["dropin_node_batch"] = e
-    except Exception as ex:
-        out["dropin_node_batch"] = {"error": str(ex)[:300]}
     return out
 
 
@@ -290,12 +327,8 @@ def main():
     # command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1, one rank per GPU.  Under a
     # launcher (WORLD_SIZE set) nothing is re-launched and --gpus must agree with it.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               str(Path(__file__).resolve())] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0",
+               "--local-addr", "127.0.0.1", str(Path(__file__).resolve())] + sys.argv[1:]
         sys.stdout.flush()
         os.execv(sys.executable, cmd)
 
@@ -621,7 +654,7 @@ def main():
             ent = table.get((p2["corpus"], p2["ch"], p2["kbps"], p2["frames"], p2["seed0"], False, False))
             dev_rate = line["value"] if k2 == key else others.get(f"config{k2}", {}).get("value")
             others[nm] = {"workload": f"ONE lhip_encode call, host Int16 buffers in pageable memory, {'stereo' if p2['ch'] == 2 else 'mono'} 44.1kHz {p2['kbps']}kbps, {p2['frames']} frames; "
-                                      "H2D + encode + D2H inside the clock (chunks of 8192 frames doubling to 32768 -- twice that for two channels --, copies overlapped with the encode of the chunk before)",
+                                      "H2D + encode + D2H inside the clock (chunks of 8192 one-channel / 16384 two-channel frames doubling to 32768 / 65536, a short remainder merged into the last; copies overlapped with the encode of the chunk before)",
                           "value": round((p2["frames"] - 1) / best, 1), "unit": "frames/s", "ms_per_call": round(1000.0 * best, 3),
                           "bit_exact_full": (None if ent is None else bool(ent[0] == hashlib.md5(whole).hexdigest() and ent[1] == len(whole))),
                           "vs_device_resident": (None if not dev_rate else round((p2["frames"] - 1) / best / dev_rate, 3))}
@@ -670,21 +703,52 @@ def main():
                                                      "logical_cores_of_host": ncores, "usable_cores": usable, "kind": "port", "same_box": True,
                                                      "sample": f"{len(res)} processes (one per usable core), each feeding the same stream to the plain-C oracle in 250-frame calls for "
                                                                f"{secs_box:.0f} s, clocks started together; {sum(f for f, _ in res)} frames in {tmax:.2f} s (longest worker)"}
+        # ---- the reference itself on THIS box (north_star: "the reference's single-threaded Node.js path timed on the same box's host cores"):
+        # oracle/_ref/lame.all.js is the reference's own single-file build, copied there by `make -C oracle ref_js` and shipped with the lease
+        # (tests/tools/ref_bundle.js); never part of the timed region, never loaded by the product
+        import shutil
+        import subprocess
+        node = shutil.which("node")
+        bundle = ROOT / "oracle" / "_ref" / "lame.all.js"
+        if node and bundle.exists():
+            tool = str(ROOT / "tests" / "tools" / "time_reference.js")
+            env = dict(os.environ, LAMEJS_USE_BUNDLE="1")
+            try:
+                r_ = subprocess.run([node, tool, str(wl.ch), str(wl.kbps), "3000"], capture_output=True, text=True, timeout=240, env=env)
+                e = json.loads(r_.stdout.strip().splitlines()[-1])
+                line["cpu_baseline"]["reference_node"] = {
+                    "value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": True, "kind": "reference", "channels": wl.ch, "kbps": wl.kbps, "frames": e["frames"],
+                    "node": e.get("node"), "host_cpu": e.get("host", {}).get("cpu"),
+                    "sample": "first 3000 frames of the same stream in 1152-sample encodeBuffer calls (the reference's documented call pattern), unmodified lamejs "
+                              "(its own build lame.all.js) under this host's Node.js, 1 thread, after a 500-frame JIT warm-up"}
+                if not args.no_cpu_aggregate and usable > 1:
+                    start = time.time() + 4.0 + 0.02 * usable
+                    procs = [subprocess.Popen([node, tool, str(wl.ch), str(wl.kbps), "1500", repr(start)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(usable)]
+                    res = []
+                    for p_ in procs:
+                        try:
+                            o_, _ = p_.communicate(timeout=240)
+                            ee = json.loads(o_.strip().splitlines()[-1])
+                            res.append((ee["frames"], ee["seconds"]))
+                        except Exception:
+                            p_.kill()
+                    if res:
+                        tmax = max(t for _, t in res)
+                        line["cpu_baseline"]["reference_node"]["aggregate"] = {
+                            "value": round(sum(f for f, _ in res) / tmax, 1), "unit": "frames/s", "cores": len(res), "processes": len(res), "usable_cores": usable, "same_box": True,
+                            "sample": f"{len(res)} Node.js processes (one per usable core), 1500 frames each of the same stream, clocks started together; longest {tmax:.2f} s"}
+            except Exception as ex:
+                line["cpu_baseline"]["reference_node"] = {"error": str(ex)[:300]}
         rn = ROOT / "profiles" / "r02_reference_node_cpu.jsonl"
-        if rn.exists():
+        if rn.exists():                 # what earlier rounds recorded in the build container (a different host): kept for comparison, labelled
             shapes = {}
             for l_ in rn.read_text().splitlines():
                 try:
                     e = json.loads(l_)
                 except ValueError:
                     continue
-                ent = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": False, "channels": e.get("channels"), "kbps": e.get("kbps"),
-                       "what": e.get("what"), "frames": e.get("frames"), "host": e.get("host")}
-                shapes[f"{'mono' if e.get('channels') == 1 else 'stereo'}{e.get('kbps')}"] = ent
-                if e.get("channels") == wl.ch and e.get("kbps") == wl.kbps:
-                    line["cpu_baseline"]["reference_node"] = dict(ent, note="unmodified lamejs under Node.js (tests/tools/time_reference.js); measured in the build container "
-                                                                       "(/root/reference does not exist on the GPU box), NOT on this host: same_box = false")
-            line["cpu_baseline"]["reference_node_all_shapes"] = shapes
+                shapes[f"{'mono' if e.get('channels') == 1 else 'stereo'}{e.get('kbps')}"] = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": False, "frames": e.get("frames"), "host": e.get("host")}
+            line["cpu_baseline"]["reference_node_build_container"] = shapes
     if rank == 0:
         print(json.dumps(line))
     wl.close()

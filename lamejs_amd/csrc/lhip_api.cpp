@@ -39,7 +39,8 @@ static thread_local std::string g_err;
 static thread_local int64_t g_stat_frames = 0, g_stat_repaired = 0, g_stat_iters = 0;
 // profiling counters of the dev builds (tests/tools/phase_prof.py, wave_tail.py); the product only allocates and zeroes them
 #if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
-enum { PROF_BYTES = 512 + 16 * 8192 };   /* + (start, end) of every wave of the last g_quant launch (100 MHz ticks): the launch's tail */
+enum { PROF_BYTES = 512 + 16 * 8192 + 512 };   /* + (start, end) of every wave of the last g_quant launch (100 MHz ticks): the launch's tail; + the stage stamps of g_frame */
+enum { FRAME_PROF_BASE = 64 + 2 * 8192 };      /* u64 index of g_frame's stage stamps */
 #else
 enum { PROF_BYTES = 512 };
 #endif
@@ -617,12 +618,26 @@ template <int RESV, int NW> __global__ __launch_bounds__(64 * NW) void g_frame(Q
     __shared__ int mbox[4];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#ifdef LHIP_PHASE_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES + 1] = wall_clock64(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 3] = __builtin_amdgcn_s_memtime(); }
+#endif
     q_load_tabs(A->T, Q, threadIdx.x, 64 * NW);
     __syncthreads();
     for (int stage = 0; stage < FR_STAGES; stage++) {
+#ifdef LHIP_PHASE_PROF
+        // profiling build (tests/tools/frame_prof.py): when every stage of stream 0's frame starts, and the quantization phases of its wave 0
+        if (blockIdx.x == 0 && threadIdx.x == 0) A->W.prof[FRAME_PROF_BASE + stage] = __builtin_amdgcn_s_memtime();
+        if (stage == FS_QUANT) ((QuantLds*)U[wv])->prof[lane] = 0;
+#endif
         kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, NW, lane, U[wv], Q, mbox);
+#ifdef LHIP_PHASE_PROF
+        if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0) A->W.prof[lane] = ((QuantLds*)U[wv])->prof[lane];
+#endif
         __syncthreads();
     }
+#ifdef LHIP_PHASE_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES] = __builtin_amdgcn_s_memtime(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 2] = wall_clock64(); }
+#endif
 }
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
 enum { KT_LOAD, KT_PREP, KT_PSYA, KT_SCAN, KT_PSYB, KT_POLY, KT_MDCT, KT_QUANT, KT_VALIDATE, KT_REPAIR, KT_BITS, KT_SAVE, KT_N };
@@ -1036,8 +1051,19 @@ static int64_t batch_bytes(const TableSet& ts, int slot_lag, int F) {
     return (int64_t)F * ts.base_frame_bytes + npad;
 }
 
+#ifdef LHIP_PHASE_PROF
+// profiling build: where the host side of a batch spends its time (seconds, summed; [7] = batches) -- lhip_debug_read(9)
+static double g_call_prof[8];
+#define CALL_STAMP(i) do { const auto n_ = std::chrono::steady_clock::now(); g_call_prof[i] += std::chrono::duration<double>(n_ - cp_t_).count(); cp_t_ = n_; } while (0)
+#else
+#define CALL_STAMP(i) do {} while (0)
+#endif
 static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
     if (jobs.empty()) return true;
+#ifdef LHIP_PHASE_PROF
+    auto cp_t_ = std::chrono::steady_clock::now();
+    g_call_prof[7] += 1;
+#endif
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!rt::set_device(ctx->device)) return false;
     WorkSet& ws = ctx->ws;
@@ -1109,6 +1135,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.vdig = (uint32_t*)ws.vdig.p; W.vdig_n = (int64_t)FR * 2 * C;
     W.nflagged = (int32_t*)ws.nflagged.p; W.work_ctr = (int32_t*)ws.nflagged.p + 16; W.slow_list = (int32_t*)ws.slow_list.p; W.frame_bytes = (int32_t*)ws.frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ws.prof.p;
 
+    CALL_STAMP(0);                                  // plan + workspace
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
     int64_t in_off = 0;
@@ -1160,6 +1187,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ws.desc.p + o_sd);
     const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ws.desc.p + o_io);
     W.io = dIO;
+    CALL_STAMP(1);                                  // input copies, descriptors, counters zeroed: enqueued
 
     int64_t repaired = 0, iters = 0;
     // at most one frame per stream: the whole frame program in one launch (kb_frame_stage); LAMEJS_HIP_NO_FRAME_KERNEL=1 keeps the separate kernels
@@ -1392,6 +1420,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     LAUNCH(KT_SAVE, g_save, S, st, T, W, dSD, dIO);
     }
 #endif
+    CALL_STAMP(2);                                  // kernels enqueued
 #ifndef LHIP_HOSTSIM
     // repair statistics live on the device; they travel with the final synchronisation when there is one, else they are fetched
     // when somebody asks (lhip_last_batch_stats)
@@ -1416,6 +1445,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #ifndef LHIP_HOSTSIM
     if (g_kt_on) { if (!rt::sync(st)) return false; kt_collect(); }
 #endif
+    CALL_STAMP(3);                                  // output copies + synchronisation
     // ---- host-side stream bookkeeping (Lame.js:1629-1661) ----
     for (int i = 0; i < S; i++) {
         Job& j = jobs[i];
@@ -2047,6 +2077,9 @@ void lhip_last_batch_stats(int64_t* frames, int64_t* repaired_frames, int64_t* r
 }
 
 int64_t lhip_debug_read(int what, void* dst, size_t cap) {
+#ifdef LHIP_PHASE_PROF
+    if (what == 9) { const size_t n = cap < sizeof g_call_prof ? cap : sizeof g_call_prof; memcpy(dst, g_call_prof, n); return (int64_t)n; }
+#endif
     Context* ctx = nullptr;
     { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto& kv : g_ctx) if (kv.second->ws.have_last) ctx = kv.second.get(); }
     if (!ctx) { set_err("no batch has run"); return LHIP_ERR_INTERNAL; }

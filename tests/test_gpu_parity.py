@@ -827,3 +827,49 @@ def test_gpu_host_call_in_overlapped_chunks(lib, tmp_path):
         assert got[name] == want, name
         if name == "joint" and js is not None:
             assert js["bytes"] == len(want) and js["md5"] == hashlib.md5(want).hexdigest(), js
+
+
+def test_gpu_vs_live_reference_under_node(lib, tmp_path):
+    """The HIP library against the UNMODIFIED reference running on this very box: oracle/_ref/lame.all.js -- the reference's own
+    single-file build, copied there by `make -C oracle ref_js` and shipped with the lease -- under Node (tests/tools/ref_bundle.js,
+    ref_encode_file.js), on fresh random material per run.  No golden and no oracle in between.  About 300 frames per family:
+    MPEG-1, LSF (MPEG-2 / 2.5), the integer-ratio resampler, the lowest bit budgets, and -- the reference's modules wired as its
+    index.js wires them with the one setting changed -- joint stereo and the bit reservoir.  The reference encodes in worker
+    processes beside the GPU."""
+    import shutil
+    import subprocess
+    import time
+    node = shutil.which("node")
+    if not node or not (ROOT / "oracle" / "_ref" / "lame.all.js").exists():
+        pytest.skip("needs node and oracle/_ref/lame.all.js (make -C oracle ref_js where /root/reference exists)")
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    seed = int(time.time()) & 0x7fffffff
+    rng = np.random.default_rng(seed)
+    fams = [("mpeg1", fuzz_gpu.MPEG1_CFGS, False, False), ("lsf", fuzz_gpu.LSF_CFGS, False, False), ("resample", fuzz_gpu.RESAMPLE_CFGS, False, False),
+            ("lowrate", fuzz_gpu.LOWRATE_CFGS, False, False), ("joint", [c for c in fuzz_gpu.MPEG1_CFGS + fuzz_gpu.LSF_CFGS if c[0] == 2], True, False),
+            ("reservoir", fuzz_gpu.MPEG1_CFGS + fuzz_gpu.LSF_CFGS, False, True)]
+    cases, procs = [], []
+    for fam, cfgs, joint, resv in fams:
+        for c in range(3):
+            ch, sr, kbps = cfgs[int(rng.integers(0, len(cfgs)))]
+            nfr = int(rng.integers(70, 131))
+            L, R = fuzz_gpu.material(rng, 1152 * nfr + int(rng.integers(0, 1152)), ch)
+            chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
+            tag = f"{fam}{c}"
+            (L if R is None else np.stack([L, R], axis=1).reshape(-1)).astype("<i2").tofile(tmp_path / f"{tag}.pcm")
+            cmd = [node, str(ROOT / "tests" / "tools" / "ref_encode_file.js"), str(tmp_path / f"{tag}.pcm"), str(tmp_path / f"{tag}.mp3"), str(ch), str(sr), str(kbps), str(chunk)]
+            cmd += (["joint"] if joint else []) + (["reservoir"] if resv else [])
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env={**__import__("os").environ, "LAMEJS_REF": "/nonexistent"}))
+            cases.append((tag, ch, sr, kbps, L, R, chunk, joint, resv, nfr))
+    bad, frames = [], 0
+    for (tag, ch, sr, kbps, L, R, chunk, joint, resv, nfr), p in zip(cases, procs):
+        got = _encode(ch, kbps, L, R, chunk, sr=sr, joint=joint, reservoir=resv)
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        want = (tmp_path / f"{tag}.mp3").read_bytes()
+        frames += nfr
+        if got != want:
+            bad.append(f"{tag}: ch={ch} sr={sr} kbps={kbps} frames={nfr} chunk={chunk} lens {len(got)} {len(want)}")
+    assert not bad, f"seed {seed}: GPU differs from the live reference: {bad}"
+    assert frames >= 1200

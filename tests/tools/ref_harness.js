@@ -1,5 +1,6 @@
 /*
- * TEST INFRASTRUCTURE (only usable where /root/reference is mounted).
+ * TEST INFRASTRUCTURE (needs the reference: /root/reference, or -- where that does not exist, i.e. on the GPU box -- the reference's
+ * own single-file build oracle/_ref/lame.all.js, tests/tools/ref_bundle.js).
  *
  * Builds an *unmodified* reference encoder with its internals exposed, by repeating
  * the module wiring of the reference's index.js:73-111 (the public Mp3Encoder hides
@@ -13,7 +14,9 @@ const S = path.join(REF, 'src', 'js');
 
 /* opts.jointStereo: gfp.mode = JOINT_STEREO instead of the STEREO that index.js:105 hard-codes -- still the unmodified reference
  * code, only driven with the one setting its public wrapper does not offer (SURVEY.md 8f #3) */
+const HAVE_SRC = require('fs').existsSync(path.join(S, 'index.js'));
 function refEncoder(channels, samplerate, kbps, opts) {
+    if (!HAVE_SRC) return require('./ref_bundle.js').refEncoder(channels, samplerate, kbps, opts);
     const Lame = require(path.join(S, 'Lame.js'));
     const Presets = require(path.join(S, 'Presets.js'));
     const GainAnalysis = require(path.join(S, 'GainAnalysis.js'));
@@ -74,6 +77,6 @@ function refEncoder(channels, samplerate, kbps, opts) {
 }
 
 /* the public, unmodified reference encoder */
-function refPublic() { return require(path.join(S, 'index.js')); }
+function refPublic() { return HAVE_SRC ? require(path.join(S, 'index.js')) : require('./ref_bundle.js').load(); }
 
 module.exports = { refEncoder, refPublic, REF };
