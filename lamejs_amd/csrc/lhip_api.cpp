@@ -67,6 +67,7 @@ static bool event_create(void** e) { *e = (void*)(uintptr_t)1; return true; }
 static bool event_record(void*, void*) { return true; }
 static bool stream_wait_event(void*, void*) { return true; }
 static void* host_alloc_pinned(size_t n) { return calloc(1, n ? n : 1); }
+static void host_free_pinned(void* p) { free(p); }
 }  // namespace rt
 #else
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return false; } } while (0)
@@ -85,6 +86,7 @@ static bool event_create(void** e) { hipEvent_t t; HIPCK(hipEventCreateWithFlags
 static bool event_record(void* e, void* st) { HIPCK(hipEventRecord((hipEvent_t)e, (hipStream_t)st)); return true; }
 static bool stream_wait_event(void* st, void* e) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)e, 0)); return true; }
 static void* host_alloc_pinned(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
+static void host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 }  // namespace rt
 #endif
 
@@ -969,12 +971,27 @@ struct DevBuf {
     ~DevBuf() { rt::dfree(p); }
 };
 
+// grow-only pinned host staging (small host-buffer calls: one copy in, one copy out -- run_batch)
+struct PinBuf {
+    void* p = nullptr; size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        rt::host_free_pinned(p);
+        cap = n + n / 4 + 4096;
+        p = rt::host_alloc_pinned(cap);
+        if (!p) { cap = 0; return false; }
+        return true;
+    }
+    ~PinBuf() { rt::host_free_pinned(p); }
+};
+
 // Everything a batch in flight owns: the workspace arrays, the descriptor / host-I/O staging, and the side stream + events of the ATH scan.
 // (Round 4 measured a second set with two batches in flight -- the persistent quantization kernels side by side or one behind the other -- as
 // slower than one batch at a time in every form, profiles/r04_pass5_ab_*.txt, and removed it: DESIGN.md, measured and discarded.)
 struct WorkSet {
     DevBuf pcm, peaks, loud, eb_l, mask_idx, eb_s, ecb_s, att_raw, uselong, ul_tmp, last_attack, tent, prev_short, blocktype,
-        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes, vdig;
+        ath_adjust, ath_limit, E, sb, xr, side, l3, seed, seed_flag, nflagged, slow_list, frame_bytes, desc, in16, out8, prof, fht, hpf, tot_ener, reval, att_clean, nb1, nb2, fr, out_bytes, vdig, small;
+    PinBuf pin_in, pin_out;     // small host-buffer calls (run_batch): everything that travels in / out, staged once in pinned memory
     // last batch (for debug taps)
     Workspace lastW; int lastC = 0, lastCp = 0; bool have_last = false;
     // side stream for the one kernel that cannot fill the chip (the ATH recurrence: one workgroup per stream); it runs
@@ -1058,6 +1075,13 @@ static double g_call_prof[8];
 #else
 #define CALL_STAMP(i) do {} while (0)
 #endif
+enum { FX_STATS_OFF = 32 * 4 };      // byte offset of the repair statistics inside the counter block (FX_STATS of g_fixup)
+#ifndef LHIP_HOSTSIM
+static inline bool g_kt_on_() { return g_kt_on; }
+static_assert(FX_STATS_OFF == FX_STATS * 4, "counter block layout");
+#else
+static inline bool g_kt_on_() { return false; }
+#endif
 static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
     if (jobs.empty()) return true;
 #ifdef LHIP_PHASE_PROF
@@ -1121,7 +1145,23 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     ENS(vdig, FR * 2 * C * VD_WORDS * 4);
     ENS(seed_flag, FR * 4); ENS(reval, FR * 4); ENS(nflagged, 256); ENS(slow_list, (size_t)nfs * 4); ENS(frame_bytes, FR * 4);
     ENS(prof, PROF_BYTES);
-    if (!dev_io) { ENS(in16, (size_t)in_total * 2 * C + 64); ENS(out8, (size_t)out_total + 64); }
+    // Small host-buffer calls (the drop-in's own 1152-sample call pattern, small encodeBatch calls): everything that travels is laid out as ONE
+    // device block   [ output bytes | counters (nflagged, out_bytes) | seed_flag | reval | descriptors | Int16 input ]
+    // mirrored in pinned host memory, so that a call is ONE copy in (counters arrive as the zeros they must start from), the kernels, ONE copy
+    // out (bytes + counters) and one synchronisation -- instead of three pageable copies in, five memsets and two to three copies out, each of
+    // which is a stream operation the frame's single launch waits behind (profiles/r05_*frame_prof*.txt).
+    enum { SMALL_CALL_BYTES = 1 << 20 };
+    auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t desc_sd = 0, desc_io = a16(desc_sd + (size_t)S * sizeof(StreamDesc)), desc_fm = a16(desc_io + (size_t)S * sizeof(StreamIO)),
+                 desc_gm = a16(desc_fm + (size_t)nfs * 4), desc_bytes = desc_gm + (size_t)ngs * 4;
+    const size_t in_bytes = (size_t)in_total * 2 * C;
+    const size_t sm_out = 0, sm_nfl = a16((size_t)out_total + 64), sm_ob = sm_nfl + 256, sm_sf = a16(sm_ob + (size_t)S * 4 + 64), sm_rv = sm_sf + a16(FR * 4),
+                 sm_desc = sm_rv + a16(FR * 4), sm_in = a16(sm_desc + desc_bytes), sm_end = sm_in + in_bytes + 64;
+    static const bool no_small = []() { const char* e = getenv("LAMEJS_HIP_NO_SMALL_CALLS"); return e && e[0] == '1'; }();
+    bool small = !dev_io && !no_small && sm_end <= SMALL_CALL_BYTES;
+    if (small && !(ws.pin_in.ensure(sm_end - sm_nfl) && ws.pin_out.ensure(sm_sf))) small = false;       // no pinned memory: the general path
+    if (small) { ENS(small, sm_end); }
+    else if (!dev_io) { ENS(in16, in_bytes + 64); ENS(out8, (size_t)out_total + 64); }
 #undef ENS
     W.pcm = (float*)ws.pcm.p;
     W.peaks = (float*)ws.peaks.p; W.loud = (float*)ws.loud.p; W.eb_l = (float*)ws.eb_l.p; W.mask_idx = (int32_t*)ws.mask_idx.p;
@@ -1134,11 +1174,20 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     W.l3 = (int16_t*)ws.l3.p; W.seed = (int32_t*)ws.seed.p; W.seed_flag = (int32_t*)ws.seed_flag.p; W.reval = (int32_t*)ws.reval.p;
     W.vdig = (uint32_t*)ws.vdig.p; W.vdig_n = (int64_t)FR * 2 * C;
     W.nflagged = (int32_t*)ws.nflagged.p; W.work_ctr = (int32_t*)ws.nflagged.p + 16; W.slow_list = (int32_t*)ws.slow_list.p; W.frame_bytes = (int32_t*)ws.frame_bytes.p; W.out = nullptr; W.prof = (unsigned long long*)ws.prof.p;
+    uint8_t* const smb = (uint8_t*)ws.small.p;
+    uint8_t* const desc_dev = small ? smb + sm_desc : nullptr;        // (the general path sizes ws.desc below)
+    if (small) {
+        W.nflagged = (int32_t*)(smb + sm_nfl); W.work_ctr = W.nflagged + 16; W.out_bytes = (int32_t*)(smb + sm_ob);
+        W.seed_flag = (int32_t*)(smb + sm_sf); W.reval = (int32_t*)(smb + sm_rv);
+    }
 
     CALL_STAMP(0);                                  // plan + workspace
     // ---- descriptors / inputs ----
     std::vector<int32_t> fmap(nfs), gmap(ngs);
+    std::vector<int64_t> out_rel(S);              // a stream's output offset inside the output area (sd.out_off becomes the absolute address below)
     int64_t in_off = 0;
+    uint8_t* const pin = small ? (uint8_t*)ws.pin_in.p : nullptr;       // mirrors the device block from sm_nfl on
+    if (small) memset(pin, 0, sm_desc - sm_nfl);                       // the counters start from zero
     for (int i = 0; i < S; i++) {
         Job& j = jobs[i];
         for (int k = 0; k <= j.F; k++) fmap[sd[i].fslot0 + k] = i;
@@ -1146,46 +1195,57 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         StreamIO& o = io[i];
         o.state = j.s->d_state; o.n_new = (int)j.n_out; o.mf_size = j.s->mf_size; o.n_in = (int)j.n;
         o.rs_p0 = T.rs_ratio == 1 ? 0 : (int)(rs_outputs(j.s->rs_n_in, T.rs_ratio) * T.rs_ratio - 16 - j.s->rs_n_in);
+        out_rel[i] = sd[i].out_off;
         if (dev_io) {
             o.src[0] = j.l; o.src[1] = (C == 2 && j.r) ? j.r : j.l; o.out = j.out;
         } else {
-            int16_t* base = (int16_t*)ws.in16.p;
+            int16_t* base = small ? (int16_t*)(smb + sm_in) : (int16_t*)ws.in16.p;
+            int16_t* hbase = small ? (int16_t*)(pin + (sm_in - sm_nfl)) : nullptr;
             o.src[0] = base + in_off;
-            if (!rt::h2d((void*)o.src[0], j.l, j.n * 2, st)) return false;
+            if (small) memcpy(hbase + in_off, j.l, j.n * 2);
+            else if (!rt::h2d((void*)o.src[0], j.l, j.n * 2, st)) return false;
             in_off += (int64_t)j.n;
             if (C == 2) {
                 o.src[1] = base + in_off;
-                if (!rt::h2d((void*)o.src[1], j.r ? j.r : j.l, j.n * 2, st)) return false;
+                if (small) memcpy(hbase + in_off, j.r ? j.r : j.l, j.n * 2);
+                else if (!rt::h2d((void*)o.src[1], j.r ? j.r : j.l, j.n * 2, st)) return false;
                 in_off += (int64_t)j.n;
             } else o.src[1] = o.src[0];
-            o.out = (uint8_t*)ws.out8.p + sd[i].out_off;
+            o.out = (small ? smb + sm_out : (uint8_t*)ws.out8.p) + sd[i].out_off;
         }
     }
     // All descriptors travel in ONE host-to-device copy (a small pageable copy costs ~10 us of host time each, and a 1-frame
     // call is only ~0.4 ms long): [StreamDesc x S | StreamIO x S | frame-slot map | granule-slot map], 16-byte aligned parts.
     // The out pointer per stream is carried in StreamIO; kb_bits reads W.out + sd.out_off, so W.out is a zero base and
     // out_off holds the absolute address (the device address space is 64-bit).
-    const size_t o_sd = 0, o_io = (o_sd + (size_t)S * sizeof(StreamDesc) + 15) & ~(size_t)15,
-                 o_fm = (o_io + (size_t)S * sizeof(StreamIO) + 15) & ~(size_t)15, o_gm = (o_fm + (size_t)nfs * 4 + 15) & ~(size_t)15,
-                 desc_bytes = o_gm + (size_t)ngs * 4;
-    if (!ws.desc.ensure(desc_bytes)) return false;
+    if (!small && !ws.desc.ensure(desc_bytes)) return false;
+    uint8_t* const ddesc = small ? desc_dev : (uint8_t*)ws.desc.p;
     {
-        std::vector<uint8_t> stage(desc_bytes, 0);
+        std::vector<uint8_t> stage_v;
+        uint8_t* stage = nullptr;
+        if (small) stage = pin + (sm_desc - sm_nfl);
+        else { stage_v.assign(desc_bytes, 0); stage = stage_v.data(); }
+        if (small) memset(stage, 0, sm_in - sm_desc);
         for (int i = 0; i < S; i++) sd[i].out_off = (int64_t)(uintptr_t)io[i].out;
-        memcpy(stage.data() + o_sd, sd.data(), (size_t)S * sizeof(StreamDesc));
-        memcpy(stage.data() + o_io, io.data(), (size_t)S * sizeof(StreamIO));
-        memcpy(stage.data() + o_fm, fmap.data(), (size_t)nfs * 4);
-        memcpy(stage.data() + o_gm, gmap.data(), (size_t)ngs * 4);
-        if (!rt::h2d(ws.desc.p, stage.data(), desc_bytes, st)) return false;
+        memcpy(stage + desc_sd, sd.data(), (size_t)S * sizeof(StreamDesc));
+        memcpy(stage + desc_io, io.data(), (size_t)S * sizeof(StreamIO));
+        memcpy(stage + desc_fm, fmap.data(), (size_t)nfs * 4);
+        memcpy(stage + desc_gm, gmap.data(), (size_t)ngs * 4);
+        if (small) { if (!rt::h2d(smb + sm_nfl, pin, sm_end - 64 - sm_nfl, st)) return false; }      // counters (zeros) + descriptors + input: one copy from pinned memory
+        else if (!rt::h2d(ddesc, stage, desc_bytes, st)) return false;
     }
-    W.fslot_stream = (const int32_t*)((const uint8_t*)ws.desc.p + o_fm); W.gslot_stream = (const int32_t*)((const uint8_t*)ws.desc.p + o_gm);
-    if (!rt::dzero(ws.seed_flag.p, FR * 4, st)) return false;
-    if (!rt::dzero(ws.reval.p, FR * 4, st)) return false;
-    if (resv && !rt::dzero(ws.out_bytes.p, (size_t)S * 4, st)) return false;
-    if (!rt::dzero(ws.nflagged.p, 256, st)) return false;
-    if (!rt::dzero(ws.prof.p, PROF_BYTES, st)) return false;
-    const StreamDesc* dSD = (const StreamDesc*)((const uint8_t*)ws.desc.p + o_sd);
-    const StreamIO* dIO = (const StreamIO*)((const uint8_t*)ws.desc.p + o_io);
+    W.fslot_stream = (const int32_t*)(ddesc + desc_fm); W.gslot_stream = (const int32_t*)(ddesc + desc_gm);
+    if (!small) {
+        if (!rt::dzero(ws.seed_flag.p, FR * 4, st)) return false;
+        if (!rt::dzero(ws.reval.p, FR * 4, st)) return false;
+        if (resv && !rt::dzero(ws.out_bytes.p, (size_t)S * 4, st)) return false;
+        if (!rt::dzero(ws.nflagged.p, 256, st)) return false;
+    }
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_WAVE_TIMES)
+    if (!rt::dzero(ws.prof.p, PROF_BYTES, st)) return false;      // (the product never reads these counters)
+#endif
+    const StreamDesc* dSD = (const StreamDesc*)(ddesc + desc_sd);
+    const StreamIO* dIO = (const StreamIO*)(ddesc + desc_io);
     W.io = dIO;
     CALL_STAMP(1);                                  // input copies, descriptors, counters zeroed: enqueued
 
@@ -1421,26 +1481,33 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     }
 #endif
     CALL_STAMP(2);                                  // kernels enqueued
-#ifndef LHIP_HOSTSIM
     // repair statistics live on the device; they travel with the final synchronisation when there is one, else they are fetched
     // when somebody asks (lhip_last_batch_stats)
     int32_t fx[3] = {0, 0, 0};
-    const bool fetch_fx = nfr > 0 && (!dev_io || want_sync || g_kt_on);
-    if (fetch_fx && !rt::d2h(fx, (const int32_t*)ws.nflagged.p + FX_STATS, sizeof fx, st)) return false;
-#endif
+    const bool fetch_fx = nfr > 0 && (!dev_io || want_sync || g_kt_on_());
     // ---- outputs ----
-    std::vector<int32_t> ob;
-    if (resv) {                                   // how much each stream really wrote
-        ob.assign((size_t)S, 0);
-        if (!rt::d2h(ob.data(), ws.out_bytes.p, (size_t)S * 4, st) || !rt::sync(st)) return false;
-        for (int i = 0; i < S; i++) jobs[i].bytes = ob[i];
-    }
-    if (!dev_io) {
-        for (int i = 0; i < S; i++)
-            if (jobs[i].bytes > 0 && !rt::d2h(jobs[i].out, io[i].out, (size_t)jobs[i].bytes, st)) return false;
-        if (!rt::sync(st)) return false;
-    } else if (want_sync) {
-        if (!rt::sync(st)) return false;
+    if (small) {
+        // one copy out: [output bytes | counters | out_bytes], then the callers' buffers are filled from the pinned mirror
+        const uint8_t* po = (const uint8_t*)ws.pin_out.p;
+        if (!rt::d2h(ws.pin_out.p, smb, sm_sf, st) || !rt::sync(st)) return false;
+        memcpy(fx, po + sm_nfl + FX_STATS_OFF, sizeof fx);
+        if (resv) for (int i = 0; i < S; i++) jobs[i].bytes = ((const int32_t*)(po + sm_ob))[i];
+        for (int i = 0; i < S; i++) if (jobs[i].bytes > 0) memcpy(jobs[i].out, po + sm_out + out_rel[i], (size_t)jobs[i].bytes);
+    } else {
+        if (fetch_fx && !rt::d2h(fx, (const int32_t*)ws.nflagged.p + FX_STATS_OFF / 4, sizeof fx, st)) return false;
+        std::vector<int32_t> ob;
+        if (resv) {                                   // how much each stream really wrote
+            ob.assign((size_t)S, 0);
+            if (!rt::d2h(ob.data(), ws.out_bytes.p, (size_t)S * 4, st) || !rt::sync(st)) return false;
+            for (int i = 0; i < S; i++) jobs[i].bytes = ob[i];
+        }
+        if (!dev_io) {
+            for (int i = 0; i < S; i++)
+                if (jobs[i].bytes > 0 && !rt::d2h(jobs[i].out, io[i].out, (size_t)jobs[i].bytes, st)) return false;
+            if (!rt::sync(st)) return false;
+        } else if (want_sync) {
+            if (!rt::sync(st)) return false;
+        }
     }
 #ifndef LHIP_HOSTSIM
     if (g_kt_on) { if (!rt::sync(st)) return false; kt_collect(); }
