@@ -83,7 +83,7 @@ LHIP_DEV int hl_off(int t) {
         case 12: return HL_T12; case 13: return HL_T13; case 14: return HL_T14; case 15: return HL_T15; default: return 0;
     }
 }
-struct QuantTabs {
+struct alignas(16) QuantTabs {
     float pow43[QT_N], adj43[QT_N];
     float ipow20[Q_MAX], pow20[Q_MAX + Q_MAX2 + 1];
     int32_t sfb_l[SBMAX_l + 1], sfb_s[SBMAX_s + 1], pretab[SBMAX_l];
@@ -154,6 +154,17 @@ LHIP_DEV void q_load_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
     for (int e = tid; e < 2 * 64; e += nthr) Q.fold_marks[e >> 6][e & 63] = (uint32_t)T.fold_marks[e];
     for (int e = tid; e < 24; e += nthr) Q.wpre_long[e] = (uint16_t)T.wpre[e];
     for (int e = tid; e < 40; e += nthr) Q.wpre_short[e] = (uint16_t)T.wpre[24 + e];
+}
+
+// The tables do not change after lhip_create: they are gathered ONCE per configuration into an image in HBM (g_build_qtabs) and a workgroup
+// copies that image flat -- 16 bytes per thread and step -- instead of repeating q_load_tabs' gathers from fifteen source tables, which cost a
+// one-frame launch 19 us of dependent global loads before its first stage (profiles/r05_pass1_frame_prof_*.txt).
+LHIP_DEV void q_copy_tabs(const Tables& T, QuantTabs& Q, int tid, int nthr) {
+    static_assert(sizeof(QuantTabs) % 16 == 0, "QuantTabs is copied in 16-byte pieces");
+    struct alignas(16) V4 { uint32_t a, b, c, d; };
+    const V4* src = (const V4*)T.qtabs_img;
+    V4* dst = (V4*)&Q;
+    for (int i = tid; i < (int)(sizeof(QuantTabs) / 16); i += nthr) dst[i] = src[i];
 }
 
 struct QuantLds {

@@ -26,34 +26,10 @@ struct TailShare { int drawing, pad_[3]; TailOffer offer[8]; };
 struct TailStats { long claimed = 0, withdrawn = 0; ~TailStats() { if (getenv("LAMEJS_TAILHELP_STATS")) fprintf(stderr, "tail-help: %ld granule-channels by helpers, %ld offers withdrawn\n", claimed, withdrawn); } };
 inline TailStats& tail_stats() { static TailStats t; return t; }
 #define LHIP_TAIL_COUNT(f) do { if (lane == 0) tail_stats().f++; } while (0)
-// lane fibers run one at a time and only switch at wave primitives: plain accesses are atomic; wave_bcast is the switch point that lets the
-// other waves of the workgroup run while this one polls
-LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) { r = *p; if (r == expect) *p = desired; } return wave_bcast(r, 0); }
-LHIP_DEV int wg_load(const int* p, int lane) { int r = 0; if (lane == 0) r = *(const volatile int*)p; return wave_bcast(r, 0); }
-LHIP_DEV void wg_store(int* p, int v, int lane) { wave_sync(); if (lane == 0) *(volatile int*)p = v; wave_sync(); }
-LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) *p += v; wave_sync(); }
-LHIP_DEV void wg_idle() { wave_sync(); }
-LHIP_DEV void wg_acquire() { wave_sync(); }
 #else
-LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) r = atomicCAS(p, expect, desired); return __builtin_amdgcn_readfirstlane(r); }
-LHIP_DEV int wg_load(const int* p, int lane) { (void)lane; return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
-LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wave wrote to LDS before is visible to a wave that sees v
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
-LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
-LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #define LHIP_TAIL_COUNT(f) do { } while (0)
 #endif
-// A poll loop that has gone round this often (seconds; a launch's tail is milliseconds) is a protocol or compiler bug: fault instead of
-// hanging the device (lhip_api.cpp, g_fixup: a dispenser loop nested in another loop has been miscompiled into an exec-masked loop on this
-// toolchain before -- the first device run of this file is exactly the kind of code that can find the next one).
-#if defined(LHIP_HOSTSIM)
-#define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 34)) abort(); } while (0)
-#else
-#define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 24)) __builtin_trap(); } while (0)
-#endif
+// (the workgroup-scope signalling primitives wg_cas / wg_load / wg_store / wg_idle / wg_acquire and LHIP_SPIN_GUARD live in lhip_wave.h)
 
 // kb_quant for the persistent kernel's speculative pass (chain == 0, no reservoir) with the second channel of every granule on offer
 LHIP_DEV void kb_quant_th(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot, int lane, QuantLds& L,

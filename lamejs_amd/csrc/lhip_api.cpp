@@ -94,19 +94,22 @@ static void host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 // device-resident per-stream state (what the reference carries from frame to frame)
 // ===========================================================================================
 // load carried state into the stream's carry slots and build its sample segment (tail + new samples)
-LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
+// (`part` of `nparts`: the copies are dealt round-robin over the waves of a workgroup that calls this with several -- the one-frame launch)
+LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane, int part = 0, int nparts = 1) {
     const int C = T.channels_out;
     const StreamDesc sd = SD[st];
     const StreamIO io = IO[st];
     const StreamState* S = io.state;
+    int job = 0;
+#define LOAD_JOB() (nparts == 1 || (job++ % nparts) == part)
     for (int ch = 0; ch < C; ch++) {
-        if (T.rs_ratio != 1) {                                   // resampling: the segment is materialised (PcmSrc::plane)
+        if (T.rs_ratio != 1 && LOAD_JOB()) {                     // resampling: the segment is materialised (PcmSrc::plane)
             float* seg = W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off;
             for (int i = lane; i < io.mf_size; i += LHIP_NL) seg[i] = S->pcm_tail[ch][i];
         }
         const int64_t o = (int64_t)sd.gslot0 * C + ch;
-        for (int i = lane; i < SB_STRIDE; i += LHIP_NL) W.sb[o * SB_STRIDE + i] = S->sb[ch][i];
-        if (lane == 0) {
+        if (LOAD_JOB()) for (int i = lane; i < SB_STRIDE; i += LHIP_NL) W.sb[o * SB_STRIDE + i] = S->sb[ch][i];
+        if (LOAD_JOB() && lane == 0) {
             W.loud[o] = S->loud[ch];
             W.tent[o] = S->tent[ch];
             W.blocktype[o] = S->last_bt[ch];
@@ -117,14 +120,19 @@ LHIP_DEV void kb_load(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const int Cp = T.psy_channels;
     for (int chn = 0; chn < Cp; chn++) {                         // psy channels: L, R and -- joint stereo -- mid, side
         const int64_t o = (int64_t)sd.gslot0 * Cp + chn;
-        for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[chn][i];
-        for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[chn][i];
-        for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[chn][i];
-        if (!T.disable_reservoir) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { W.nb1[o * EBL_STRIDE + i] = S->nb1[chn][i]; W.nb2[o * EBL_STRIDE + i] = S->nb2[chn][i]; }
-        if (lane == 0) W.last_attack[o] = S->last_attack[chn];
+        if (LOAD_JOB()) for (int i = lane; i < E_STRIDE; i += LHIP_NL) W.E[o * E_STRIDE + i] = S->E[chn][i];
+        if (LOAD_JOB()) for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) W.ecb_s[o * EBS_STRIDE + i] = S->ecb_s[chn][i];
+        if (LOAD_JOB()) {
+            for (int i = lane; i < PK_STRIDE; i += LHIP_NL) W.peaks[o * PK_STRIDE + i] = S->peaks[chn][i];
+            if (lane == 0) W.last_attack[o] = S->last_attack[chn];
+        }
+        if (!T.disable_reservoir && LOAD_JOB()) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { W.nb1[o * EBL_STRIDE + i] = S->nb1[chn][i]; W.nb2[o * EBL_STRIDE + i] = S->nb2[chn][i]; }
     }
-    if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) W.tot_ener[(int64_t)sd.gslot0 * 4 + i] = S->tot_ener[i];
-    if (lane == 0) { W.ath_adjust[sd.fslot0] = S->ath_adjust; W.ath_limit[sd.fslot0] = S->ath_limit; }
+    if (LOAD_JOB()) {
+        if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) W.tot_ener[(int64_t)sd.gslot0 * 4 + i] = S->tot_ener[i];
+        if (lane == 0) { W.ath_adjust[sd.fslot0] = S->ath_adjust; W.ath_limit[sd.fslot0] = S->ath_limit; }
+    }
+#undef LOAD_JOB
 }
 
 // fill_buffer_resample (Lame.js:1719-1843) for an integer ratio r.  There filter_l = 32, bpc = 1, every clock value
@@ -163,7 +171,7 @@ LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD,
     for (int st = 0; st < nstreams; st++) kb_prep_stream(T, W, SD, IO, st, tid, nthreads);
 }
 
-LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane) {
+LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int st, int lane, int part = 0, int nparts = 1) {
     const int C = T.channels_out;
     const StreamDesc sd = SD[st];
     const StreamIO io = IO[st];
@@ -171,22 +179,26 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
     const int F = sd.nframes;
     const int frame = 576 * T.mode_gr;
     const int total = io.mf_size + io.n_new, keep = total - frame * F;
+    int job = 0;
+#define SAVE_JOB() (nparts == 1 || (job++ % nparts) == part)
     for (int ch = 0; ch < C; ch++) {
         // new tail = segment[frame * F ...): read through the same accessor the kernels use.  In place: a chunk of 64 is read
         // completely before it is written, and later chunks only read positions above everything written so far
-        const PcmSrc P = pcm_source(T, W, sd, io, ch);
-        for (int base = 0; base < keep; base += LHIP_NL) {
-            const int i = base + lane;
-            float v = 0.f;
-            if (i < keep) v = pcm_at(P, frame * F + i);
-            wave_sync();
-            if (i < keep) S->pcm_tail[ch][i] = v;
-            wave_sync();
+        if (SAVE_JOB()) {
+            const PcmSrc P = pcm_source(T, W, sd, io, ch);
+            for (int base = 0; base < keep; base += LHIP_NL) {
+                const int i = base + lane;
+                float v = 0.f;
+                if (i < keep) v = pcm_at(P, frame * F + i);
+                wave_sync();
+                if (i < keep) S->pcm_tail[ch][i] = v;
+                wave_sync();
+            }
         }
         if (F == 0) continue;
         const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * C + ch;
-        for (int i = lane; i < SB_STRIDE; i += LHIP_NL) S->sb[ch][i] = W.sb[o * SB_STRIDE + i];
-        if (lane == 0) {
+        if (SAVE_JOB()) for (int i = lane; i < SB_STRIDE; i += LHIP_NL) S->sb[ch][i] = W.sb[o * SB_STRIDE + i];
+        if (SAVE_JOB() && lane == 0) {
             S->loud[ch] = W.loud[o];
             S->tent[ch] = W.tent[o];
             S->last_bt[ch] = W.blocktype[o];
@@ -200,16 +212,20 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
         const int Cp = T.psy_channels;
         for (int chn = 0; chn < Cp; chn++) {
             const int64_t o = (int64_t)(sd.gslot0 + T.mode_gr * F) * Cp + chn;
-            for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[chn][i] = W.E[o * E_STRIDE + i];
-            for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[chn][i] = W.ecb_s[o * EBS_STRIDE + i];
-            for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = i < 9 ? W.peaks[o * PK_STRIDE + i] : 0.f;   // 9 peaks; the pad words are never written by anybody (stale workspace bytes must not reach the state record)
-            if (!T.disable_reservoir) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { S->nb1[chn][i] = W.nb1[o * EBL_STRIDE + i]; S->nb2[chn][i] = W.nb2[o * EBL_STRIDE + i]; }
-            if (lane == 0) S->last_attack[chn] = W.last_attack[o];
+            if (SAVE_JOB()) for (int i = lane; i < E_STRIDE; i += LHIP_NL) S->E[chn][i] = W.E[o * E_STRIDE + i];
+            if (SAVE_JOB()) for (int i = lane; i < EBS_STRIDE; i += LHIP_NL) S->ecb_s[chn][i] = W.ecb_s[o * EBS_STRIDE + i];
+            if (SAVE_JOB()) {
+                for (int i = lane; i < PK_STRIDE; i += LHIP_NL) S->peaks[chn][i] = i < 9 ? W.peaks[o * PK_STRIDE + i] : 0.f;   // 9 peaks; the pad words are never written by anybody (stale workspace bytes must not reach the state record)
+                if (lane == 0) S->last_attack[chn] = W.last_attack[o];
+            }
+            if (!T.disable_reservoir && SAVE_JOB()) for (int i = lane; i < EBL_STRIDE; i += LHIP_NL) { S->nb1[chn][i] = W.nb1[o * EBL_STRIDE + i]; S->nb2[chn][i] = W.nb2[o * EBL_STRIDE + i]; }
         }
-        if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) S->tot_ener[i] = W.tot_ener[(int64_t)(sd.gslot0 + T.mode_gr * F) * 4 + i];
+        if (SAVE_JOB()) {
+            if (Cp == 4) for (int i = lane; i < 4; i += LHIP_NL) S->tot_ener[i] = W.tot_ener[(int64_t)(sd.gslot0 + T.mode_gr * F) * 4 + i];
+            if (lane == 0) { S->ath_adjust = W.ath_adjust[sd.fslot0 + F]; S->ath_limit = W.ath_limit[sd.fslot0 + F]; }
+        }
     }
-    if (lane == 0 && F > 0) { S->ath_adjust = W.ath_adjust[sd.fslot0 + F]; S->ath_limit = W.ath_limit[sd.fslot0 + F]; }
-    if (T.rs_ratio != 1) {
+    if (T.rs_ratio != 1 && SAVE_JOB()) {
         // the last 32 input samples seen so far (carried tail ++ this call's input), as the scaled floats the filter reads
         const bool do_scale = !(T.scale == 0.0) && !(T.scale == 1.0);
         for (int ch = 0; ch < C; ch++)
@@ -226,6 +242,7 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
                 wave_sync();
             }
     }
+#undef SAVE_JOB
 }
 
 // op 10: records of 2 doubles [a, b] -> [div_by_f32(a, (float)b, RN(1 / (float)b)), a / (float)b]: calc_noise's division by xmin through the reciprocal
@@ -254,11 +271,19 @@ LHIP_DEV void math_op8(const double* in, double* out) {
 // through all stages, a workgroup barrier between them; every stage is the same kb_* body the separate kernels run, so the bytes
 // cannot differ.  The LDS of a wave is a union of the stages' structures.
 // ===========================================================================================
-enum { FS_LOAD, FS_PREP, FS_PSYA, FS_PSYA_MS, FS_SCAN_RAW, FS_SCAN_ATTACK, FS_SCAN_BT, FS_PSYB0, FS_PSYB1, FS_POLY, FS_MDCT, FS_QUANT, FS_BITS, FS_SAVE,
-       FR_STAGES, FR_LDS_PER_WAVE = (sizeof(PolyLds) + 15) & ~15 };
+// Stages of the frame program (workgroup barriers in between).  Stages that do not depend on each other share a slot on different waves
+// (round 5: the launch's critical path is  load | psyA | scans | psyB | quantization | bit packing;  the polyphase filterbank runs beside
+// psyA, the MDCT beside psyB, the state save beside the bit packing -- profiles/r05_pass1_frame_prof_*.txt has the stage times this is
+// built on).  FR_WAVES waves per workgroup whatever the channel mode.
+enum { FS_LOAD, FS_PREP, FS_PSYA_POLY, FS_PSYA_MS, FS_SCAN_RAW, FS_SCAN_ATTACK, FS_SCAN_BT, FS_PSYB0_MDCT, FS_PSYB1, FS_QUANT, FS_BITS_SAVE,
+       FR_STAGES, FR_WAVES = 8, FR_LDS_PER_WAVE = (sizeof(PolyLds) + 15) & ~15 };
 static_assert(sizeof(PsyALds) <= FR_LDS_PER_WAVE && sizeof(PsyBLds4) <= FR_LDS_PER_WAVE && sizeof(MdctLds) <= FR_LDS_PER_WAVE &&
               sizeof(QuantLds) <= FR_LDS_PER_WAVE && sizeof(BitsLds) <= FR_LDS_PER_WAVE, "frame kernel: the per-wave LDS union is sized by PolyLds");
-// stage `stage` of the frame program for wave `wv` (of `nw`) of the workgroup that owns stream `st`.  PAIRQ: stereo quantization by
+// a stage nobody has work in for this configuration (wave-uniform: a function of the tables and the instantiation) -- skipped with its barrier
+template <int RESV> LHIP_DEV bool frame_stage_empty(int stage, const Tables& T) {
+    return (stage == FS_PREP && T.rs_ratio == 1) || (stage == FS_PSYA_MS && T.psy_channels != 4) || (stage == FS_PSYB1 && !(RESV && T.mode_gr == 2));
+}
+// stage `stage` of the frame program for wave `wv` (of `nw` >= 6) of the workgroup that owns stream `st`.  PAIRQ: stereo quantization by
 // two waves (kb_quant<1>, which meets once per granule at a workgroup barrier: the other waves keep the barrier count).
 template <int RESV, int PAIRQ>
 LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO,
@@ -268,10 +293,14 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
     const bool has = sd.nframes > 0;                          // this launch completes a frame of the stream (else only the state moves)
     const int g1 = sd.gslot0 + 1, fslot = sd.fslot0 + 1;
     ResvState* rv = RESV ? &IO[st].state->rv : nullptr;       // one-frame launches work on the record in global memory
+    const int side0 = nw - 2;                                 // the two waves that run the filterbank beside the psychoacoustics
     switch (stage) {
-        case FS_LOAD: if (wv == 0) kb_load(T, W, SD, IO, st, lane); break;
+        case FS_LOAD: kb_load(T, W, SD, IO, st, lane, wv, nw); break;
         case FS_PREP: if (T.rs_ratio != 1) kb_prep_stream(T, W, SD, IO, st, (int64_t)wv * LHIP_NL + lane, (int64_t)nw * LHIP_NL); break;
-        case FS_PSYA: if (has && wv < GR * C) kb_psyA(T, W, SD, IO, g1 + wv / C, wv % C, lane, *(PsyALds*)lds); break;
+        case FS_PSYA_POLY:
+            if (has && wv < GR * C) kb_psyA(T, W, SD, IO, g1 + wv / C, wv % C, lane, *(PsyALds*)lds);
+            else if (has && wv >= side0 && wv - side0 < C) kb_poly_run(T, W, SD, IO, g1, wv - side0, GR, lane, *(PolyLds*)lds);
+            break;
         case FS_PSYA_MS: if (has && Cp == 4 && wv < GR * 2) kb_psyA(T, W, SD, IO, g1 + wv / 2, 2 + wv % 2, lane, *(PsyALds*)lds); break;
         case FS_SCAN_RAW: if (has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_raw(T, W, SD, g1 + g); break;
         case FS_SCAN_ATTACK: if (has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_attack(T, W, SD, g1 + g); break;
@@ -285,20 +314,21 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
                 }
             }
             break;
-        case FS_PSYB0:   // bit reservoir: the frame's granules one after the other (FS_PSYB1 takes the second)
+        case FS_PSYB0_MDCT:   // bit reservoir: the frame's granules one after the other (FS_PSYB1 takes the second); the MDCT needs the block types (scans) and the polyphase output
             if (has && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
+            else if (has && wv >= side0 && wv - side0 < GR) kb_mdct(T, W, SD, g1 + (wv - side0), lane, *(MdctLds*)lds);
             break;
         case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax); break;
-        case FS_POLY: if (has && wv < C) kb_poly_run(T, W, SD, IO, g1, wv, GR, lane, *(PolyLds*)lds); break;
-        case FS_MDCT: if (has && wv < GR) kb_mdct(T, W, SD, g1 + wv, lane, *(MdctLds*)lds); break;
         case FS_QUANT:
             if (PAIRQ && C == 2) {
                 if (has && wv < 2) kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv);
                 else for (int gr = 0; gr < GR; gr++) wg_barrier();
             } else if (has && wv == 0) kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv);
             break;
-        case FS_BITS: if (has && wv == 0) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds, rv, W.out_bytes + st); break;
-        case FS_SAVE: if (wv == 0) kb_save(T, W, SD, IO, st, lane); break;
+        case FS_BITS_SAVE:   // the state record's reservoir part belongs to the bit packer, everything else to the save: disjoint words
+            if (wv == 0) { if (has) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds, rv, W.out_bytes + st); }
+            else kb_save(T, W, SD, IO, st, lane, wv - 1, nw - 1);
+            break;
         default: break;
     }
 }
@@ -424,7 +454,7 @@ template <int RESV> __global__ LHIP_QUANT_BOUNDS void g_quant(QArgs a_unused) {
     static_assert(QWAVES * sizeof(QuantLds) + sizeof(QuantTabs) + sizeof(TailShare) <= 80 * 1024, "g_quant: LDS budget for 2 workgroups per CU exceeded");
 #endif
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    q_load_tabs(A->T, Q, threadIdx.x, 64 * QWAVES);
+    q_copy_tabs(A->T, Q, threadIdx.x, 64 * QWAVES);
     if (threadIdx.x == 0) TS.drawing = QWAVES;
     if (threadIdx.x < QWAVES) TS.offer[threadIdx.x].state = 0;
     const bool tail_help_on = !RESV && A->T.channels_out == 2;       // a one-channel frame is one chain: nothing to offer
@@ -466,7 +496,7 @@ template <int RESV> __global__ __launch_bounds__(128, LHIP_QOCC) void g_quant_pa
     __shared__ QuantLds L[2];
     __shared__ int mbox[4];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    q_load_tabs(A->T, Q, threadIdx.x, 128);
+    q_copy_tabs(A->T, Q, threadIdx.x, 128);
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     kb_quant<1, RESV>(A->T, A->pb, A->W, A->SD, blockIdx.x, A->chain, threadIdx.x & 63, L[wv], Q, wv, mbox);
@@ -538,7 +568,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_FIXUP_OCC) void g_fixup(QArgs a_u
         // exec-masked loop whose first-active-lane read of the dispensed index span forever on hardware (seen on ROCm 7.2, gfx950).
         const int gw = blockIdx.x * QWAVES + wv, nw = nblocks * QWAVES;
         if (nslow > 0) {                                                      // frames whose replay asked for a gain never evaluated
-            if (!tabs) { q_load_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
+            if (!tabs) { q_copy_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
             for (int i = gw; i < nslow; i += nw)
                 kb_validate(A->T, A->pb, W, A->SD, __builtin_amdgcn_readfirstlane(W.slow_list[i]), lane, L[wv], Q);
             grid_barrier(base + FX_BAR, nblocks);
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(64 * QWAVES, LHIP_FIXUP_OCC) void g_fixup(QArgs a_u
         // number of waves (lane = every nw-th slot): flagged frames come in runs (a burst upsets the seeds of the frames after it),
         // and a frame is one wave's serial search of 1-2 ms, so a run must land on different waves -- owning 64 CONSECUTIVE slots
         // made one wave re-quantize a whole run back to back (8.7 ms for 49 frames on the `bursts` material).
-        if (!tabs) { q_load_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
+        if (!tabs) { q_copy_tabs(A->T, Q, threadIdx.x, nthr); __syncthreads(); tabs = true; }
         for (int b0 = gw; b0 < nfs; b0 += 64 * nw) {
             int flagged = 0;
             const int f = b0 + nw * lane;
@@ -596,7 +626,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     __shared__ int32_t nout;
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, st = blockIdx.x;
-    q_load_tabs(A->T, Q, threadIdx.x, 64 * RS_WAVES);
+    q_copy_tabs(A->T, Q, threadIdx.x, 64 * RS_WAVES);
     static_assert(sizeof(ResvState) % 4 == 0, "the reservoir record is copied as words");
     ResvState* grv = &A->W.io[st].state->rv;
     for (int i = threadIdx.x; i < (int)(sizeof(ResvState) / 4); i += 64 * RS_WAVES) ((uint32_t*)&RV)[i] = ((const uint32_t*)grv)[i];
@@ -613,25 +643,25 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     for (int i = threadIdx.x; i < (int)(sizeof(ResvState) / 4); i += 64 * RS_WAVES) ((uint32_t*)grv)[i] = ((const uint32_t*)&RV)[i];
     if (threadIdx.x == 0) A->W.out_bytes[st] = nout;
 }
-// one workgroup per stream, one frame per stream (see kb_frame_stage); NW = 4 waves, 8 in joint stereo (two granules x four psy channels)
-template <int RESV, int NW> __global__ __launch_bounds__(64 * NW) void g_frame(QArgs a_unused, const StreamIO* IO) {
+// one workgroup of FR_WAVES waves per stream, one frame per stream (see kb_frame_stage)
+template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QArgs a_unused, const StreamIO* IO) {
     __shared__ QuantTabs Q;
-    __shared__ __attribute__((aligned(16))) unsigned char U[NW][FR_LDS_PER_WAVE];
+    __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
     __shared__ int mbox[4];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #ifdef LHIP_PHASE_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES + 1] = wall_clock64(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 3] = __builtin_amdgcn_s_memtime(); }
 #endif
-    q_load_tabs(A->T, Q, threadIdx.x, 64 * NW);
-    __syncthreads();
+    q_copy_tabs(A->T, Q, threadIdx.x, 64 * FR_WAVES);       // (first read by the quantization stage: the barriers in between order it)
     for (int stage = 0; stage < FR_STAGES; stage++) {
 #ifdef LHIP_PHASE_PROF
         // profiling build (tests/tools/frame_prof.py): when every stage of stream 0's frame starts, and the quantization phases of its wave 0
         if (blockIdx.x == 0 && threadIdx.x == 0) A->W.prof[FRAME_PROF_BASE + stage] = __builtin_amdgcn_s_memtime();
         if (stage == FS_QUANT) ((QuantLds*)U[wv])->prof[lane] = 0;
 #endif
-        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, NW, lane, U[wv], Q, mbox);
+        if (frame_stage_empty<RESV>(stage, A->T)) continue;
+        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox);
 #ifdef LHIP_PHASE_PROF
         if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0) A->W.prof[lane] = ((QuantLds*)U[wv])->prof[lane];
 #endif
@@ -679,6 +709,8 @@ static const bool g_trace = []() { const char* e = getenv("LAMEJS_HIP_TRACE"); r
 #define LAUNCH(id, kern, nblk, st, ...) do { if ((nblk) > 0) { kt_begin(id, st); hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, (hipStream_t)(st), __VA_ARGS__); kt_end(st); TRACE_SYNC(kern, st); \
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string(#kern) + ": " + hipGetErrorString(e_)); return false; } } } while (0)
 
+// lhip_create: the quantization kernels' tables gathered once into an HBM image (q_copy_tabs)
+__global__ __launch_bounds__(256) void g_build_qtabs(Tables T, QuantTabs* img) { q_load_tabs(T, *img, threadIdx.x, 256); }
 __global__ void g_math(int op, const double* in, double* out, size_t n, PowBase pb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (op == 8) { if (21 * i + 21 <= n) math_op8(in + 21 * i, out + 21 * i); return; }
@@ -717,9 +749,10 @@ struct TableSet {
     std::vector<uint8_t> blob;
     void* d_blob = nullptr;
     void* d_extra = nullptr;
+    void* d_qtabs = nullptr;
     int device = 0;
     int base_frame_bytes = 0;
-    ~TableSet() { rt::dfree(d_blob); rt::dfree(d_extra); }
+    ~TableSet() { rt::dfree(d_blob); rt::dfree(d_extra); rt::dfree(d_qtabs); }
 };
 
 static const lhtb_entry* find_entry(const uint8_t* b, const char* name) {
@@ -946,6 +979,18 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     T.amp_by_out = (const double*)(T.s3off_l + amp_at);
     T.fold_marks = T.s3off_l + fold_at; T.wpre = T.fold_marks + 128; T.bvtab = T.wpre + 64;
     T.psy_fold = T.s3off_l + psyfold_at;
+    // the quantization kernels' LDS tables as one image (q_copy_tabs)
+    ts.d_qtabs = rt::dmalloc(sizeof(QuantTabs));
+    if (!ts.d_qtabs) { set_err("hipMalloc failed"); return false; }
+    if (!rt::dzero(ts.d_qtabs, sizeof(QuantTabs), stream)) return false;          // padding bytes: a defined image
+#ifdef LHIP_HOSTSIM
+    q_load_tabs(T, *(QuantTabs*)ts.d_qtabs, 0, 1);
+#else
+    hipLaunchKernelGGL(g_build_qtabs, dim3(1), dim3(256), 0, (hipStream_t)stream, T, (QuantTabs*)ts.d_qtabs);
+    { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err(std::string("g_build_qtabs: ") + hipGetErrorString(e_)); return false; } }
+    if (!rt::sync(stream)) return false;
+#endif
+    T.qtabs_img = ts.d_qtabs;
     ts.pb10 = pow_log2_parts(10.0);
     ts.base_frame_bytes = (int)((double)((T.version + 1) * 72000 * T.brate) / T.out_samplerate);
     // kb_bits assembles a frame in BitsLds (and zeroes one word past its last one): the largest frame of this configuration must fit
@@ -1269,12 +1314,13 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         q_load_tabs(T, QT, 0, 1);
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
-            const int NW = T.psy_channels == 4 ? 8 : 4;
-            alignas(16) static thread_local unsigned char UL[8][FR_LDS_PER_WAVE]; static thread_local int fmbox[4];
+            const int NW = FR_WAVES;
+            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[4];
             for (int s = 0; s < S; s++) {
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {
                     for (int stage = 0; stage < FR_STAGES; stage++) {
+                        if (resv ? frame_stage_empty<1>(stage, T) : frame_stage_empty<0>(stage, T)) continue;
                         if (resv) kb_frame_stage<1, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox);
                         else kb_frame_stage<0, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox);
                         wg_barrier();
@@ -1283,8 +1329,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
                 for (int stage = 0; stage < FR_STAGES; stage++)
                     for (int wv = 0; wv < NW; wv++) {
-                        if (resv) kb_frame_stage<1, 0>(stage, T, ts.pb10, W, dSD, dIO, s, wv, 1, 0, UL[wv], QT, fmbox);
-                        else kb_frame_stage<0, 0>(stage, T, ts.pb10, W, dSD, dIO, s, wv, 1, 0, UL[wv], QT, fmbox);
+                        if (resv) kb_frame_stage<1, 0>(stage, T, ts.pb10, W, dSD, dIO, s, wv, NW, 0, UL[wv], QT, fmbox);
+                        else kb_frame_stage<0, 0>(stage, T, ts.pb10, W, dSD, dIO, s, wv, NW, 0, UL[wv], QT, fmbox);
                     }
 #endif
             }
@@ -1393,8 +1439,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #else
     if (use_frame) {
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 0; qa.nfs = nfs; qa.ctr = 0;
-        if (T.psy_channels == 4) { if (resv) LAUNCHB(KT_QUANT, (g_frame<1, 8>), S, 512, st, qa, dIO); else LAUNCHB(KT_QUANT, (g_frame<0, 8>), S, 512, st, qa, dIO); }
-        else { if (resv) LAUNCHB(KT_QUANT, (g_frame<1, 4>), S, 256, st, qa, dIO); else LAUNCHB(KT_QUANT, (g_frame<0, 4>), S, 256, st, qa, dIO); }
+        if (resv) LAUNCHB(KT_QUANT, g_frame<1>, S, 64 * FR_WAVES, st, qa, dIO); else LAUNCHB(KT_QUANT, g_frame<0>, S, 64 * FR_WAVES, st, qa, dIO);
         if (resv) { bool any_flush = false; for (int i = 0; i < S; i++) any_flush |= sd[i].flush != 0; if (any_flush) LAUNCH(KT_BITS, g_resv_flush, S, st, T, W, dSD); }
     } else {
     LAUNCH(KT_LOAD, g_load, S, st, T, W, dSD, dIO);

@@ -109,6 +109,7 @@ struct Tables {
     int amp_mask;                           // bit i: amp_by_out[i] != 1.0
     const int32_t *psy_fold; int psy_maxlen_l; // psyA's partition fold: [64][3] marks | partition numbers of the lane's 8 lines; longest long partition
     const int32_t *bvtab;                   // count_bits: [289] by big_values / 2: a1 | a2 << 10 | region0_count << 20 | region1_count << 24 | sfb_count1 << 27
+    const void *qtabs_img;                  // the quantization kernels' LDS tables (QuantTabs, k_quant.h) as one prebuilt image: a workgroup copies it flat instead of gathering it from the source tables
     const int32_t *fold_marks, *wpre;       // calc_noise's fold: band-start / band-end marks per lane [2][64]; widest band among bands 0 .. b [24 long | 40 short]
 };
 

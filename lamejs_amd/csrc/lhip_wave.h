@@ -366,4 +366,45 @@ template <int K> LHIP_DEV double wave_seq_sum(const double (&p)[K]) {
 LHIP_DEV double unid(double v) { union { double d; int i[2]; } u; u.d = v; u.i[0] = uni(u.i[0]); u.i[1] = uni(u.i[1]); return u.d; }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Signalling between the waves of ONE workgroup through words in LDS (k_quant_tail.h: tail help; k_quant.h: count_bits on a second wave).
+// wg_store publishes everything the wave wrote to LDS before it; a wave that has seen the value calls wg_acquire before reading.
+// ---------------------------------------------------------------------------------------------------------------------
+#if defined(LHIP_HOSTSIM) && LHIP_NL == 1
+// the one-lane simulation has no workgroups: nothing ever polls
+LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { (void)lane; const int r = *p; if (r == expect) *p = desired; return r; }
+LHIP_DEV int wg_load(const int* p, int lane) { (void)lane; return *p; }
+LHIP_DEV void wg_store(int* p, int v, int lane) { (void)lane; *p = v; }
+LHIP_DEV void wg_add(int* p, int v, int lane) { (void)lane; *p += v; }
+LHIP_DEV void wg_idle() {}
+LHIP_DEV void wg_acquire() {}
+#elif defined(LHIP_HOSTSIM)
+// lane fibers run one at a time and only switch at wave primitives: plain accesses are atomic; wave_bcast is the switch point that lets the
+// other waves of the workgroup run while this one polls
+LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) { r = *p; if (r == expect) *p = desired; } return wave_bcast(r, 0); }
+LHIP_DEV int wg_load(const int* p, int lane) { int r = 0; if (lane == 0) r = *(const volatile int*)p; return wave_bcast(r, 0); }
+LHIP_DEV void wg_store(int* p, int v, int lane) { wave_sync(); if (lane == 0) *(volatile int*)p = v; wave_sync(); }
+LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) *p += v; wave_sync(); }
+LHIP_DEV void wg_idle() { wave_sync(); }
+LHIP_DEV void wg_acquire() { wave_sync(); }
+#else
+LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) r = atomicCAS(p, expect, desired); return __builtin_amdgcn_readfirstlane(r); }
+LHIP_DEV int wg_load(const int* p, int lane) { (void)lane; return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wave wrote to LDS before is visible to a wave that sees v
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
+LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
+LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#endif
+// A poll loop that has gone round this often (seconds; a launch's tail is milliseconds) is a protocol or compiler bug: fault instead of
+// hanging the device (lhip_api.cpp, g_fixup: a dispenser loop nested in another loop has been miscompiled into an exec-masked loop on this
+// toolchain before).
+#if defined(LHIP_HOSTSIM)
+#define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 34)) abort(); } while (0)
+#else
+#define LHIP_SPIN_GUARD(n) do { if (++(n) > (1l << 24)) __builtin_trap(); } while (0)
+#endif
+
 }  // namespace lhip
