@@ -1046,8 +1046,20 @@ LHIP_DEV int q_count_bits(const Tables& T, GI& g, const int32_t* scalefac, int16
 // ---------------------------------------------------------------------------------------------
 // need_max: the caller will look at max_noise even if some band is over its threshold (quant_compare only reads max_noise of
 // results with over_count == 0, and of `best` only while best.over_count == 0), so the f64 wave maximum is skipped otherwise
+// What a calc_noise call would write into the noise cache (PrevNoise / L.pn_*), held by lane = band: a call made SPECULATIVELY (count_bits
+// of the same quantization still running on another wave, q_count_bits_piped) must not touch the cache before its evaluation is known to
+// be the one the reference makes -- q_noise_commit writes it then; a discarded call leaves no trace the reference could see.
+struct NoiseCommit { int fresh, step, cls; float dist; double x; };
+LHIP_DEV void q_noise_commit(const GI& g, const NoiseCommit& nc, PrevNoise& pn, int lane, QuantLds& L) {
+    lane = fresh_lane(lane);
+    LHIP_LANE_ONCE(sfb, 0, g.psymax) {
+        if (nc.fresh) { L.pn_step[sfb] = nc.step; L.pn_dist[sfb] = nc.dist; L.pn_x[sfb] = nc.x; L.pn_cls[sfb] = (int16_t)nc.cls; }
+    }
+    pn.gain = g.global_gain;
+    wave_sync();
+}
 LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q, NoiseCommit* defer = nullptr) {
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     // 1) per band: its step and whether the cache answers for it.  The reference walks a start line from band to band and sums the
@@ -1218,7 +1230,8 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             double xf = div_by_f32(nf, b, rb);
             if (rb == 0.0) { x = noise / b; xf = nf / b; }         // never on sane material: an xmin outside div_by_f32's proof
             L.distort[sfb] = (float)x;
-            if (use_pn) { L.pn_step[sfb] = my_step; L.pn_dist[sfb] = (float)xf; }
+            if (defer) { defer->step = my_step; defer->dist = (float)xf; }
+            else if (use_pn) { L.pn_step[sfb] = my_step; L.pn_dist[sfb] = (float)xf; }
             cls = need_max ? -1 : noise_class(x);          // the logarithm will be formed anyway: no shortcut
         }
     }
@@ -1236,11 +1249,12 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         have_log = 1;
     }
     int over = 0, ssd = 0;
+    if (defer) { defer->fresh = 0; LHIP_LANE_ONCE(sfb, 0, g.psymax) { defer->fresh = use_pn && fresh; defer->x = x; defer->cls = cls_cache; } }
     LHIP_LANE_ONCE(sfb, 0, g.psymax) {
-        if (use_pn && fresh) { L.pn_x[sfb] = x; L.pn_cls[sfb] = (int16_t)cls_cache; }
+        if (!defer && use_pn && fresh) { L.pn_x[sfb] = x; L.pn_cls[sfb] = (int16_t)cls_cache; }
         if (cls > 0) { ssd = cls * cls; over = 1; }
     }
-    if (use_pn) pn.gain = g.global_gain;
+    if (use_pn && !defer) pn.gain = g.global_gain;
     {   // over <= 39 bands and over_SSD <= 39 * 400^2 < 2^25: one packed integer reduction
         const int os = wave_sum((ssd << 6) | over);
         res->over_count = os & 63; res->over_SSD = os >> 6;
@@ -1268,6 +1282,103 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
     q_calc_noise_(T, g, scalefac, ix, res, use_pn, pn, need_max, lane, L, Q);
     PH_END(L, PH_NOISE);
 }
+
+// ---------------------------------------------------------------------------------------------
+// count_bits on a second wave (latency kernels: a workgroup per frame with idle waves -- g_frame).
+// One evaluation of the outer loop is  quantize -> count_bits -> [fits?] -> calc_noise  and calc_noise needs the quantized values but
+// nothing count_bits produces.  So the owner of a granule-channel quantizes, hands the Huffman count of that quantization (noquant_count_bits,
+// Takehiro.js:521-628: a pure function of the quantized values, the block type and the region fields it may leave untouched) to a
+// helper wave through a record in LDS, and runs calc_noise itself MEANWHILE -- speculatively: its cache writes are held back
+// (NoiseCommit) until the count is in and the loop's decisions say that this evaluation is the one calc_noise follows
+// (Quantize.js:986-1018); otherwise the result is dropped and nothing of it remains (calc_noise's other outputs -- distort, the band sums
+// -- are rewritten by the next call before anybody reads them).  Same values, same order of the reference's decisions; only the clock changes.
+// CountShare::state: CS_REQ request posted (owner), CS_DONE reply posted (helper), CS_BARRIER the owner is about to wait at a workgroup
+// barrier and the helper must keep the count, CS_QUIT the owner's frame is finished.
+// ---------------------------------------------------------------------------------------------
+struct CountShare { int state, block_type, max_nonzero_coeff, cnt1_in, r0, r1, t0, t1, t2, c1sel, c1bits;          // request (the fields the count may leave as they are)
+                    int bits, count1, big_values, o_c1sel, o_c1bits, o_r0, o_r1, o_t0, o_t1, o_t2, cnt1, amask, pad_[9]; };
+enum { CS_IDLE = 0, CS_REQ = 1, CS_DONE = 2, CS_BARRIER = 8, CS_QUIT = 9 };
+#if defined(LHIP_WAVESIM)
+// how often each way was taken (printed at exit with LAMEJS_PIPE_STATS=1: the simulation must exercise both)
+struct PipeStats { long piped = 0, committed = 0; ~PipeStats() { if (getenv("LAMEJS_PIPE_STATS")) fprintf(stderr, "count helper: %ld evaluations counted on the helper wave, %ld of the calc_noise calls made beside them committed\n", piped, committed); } };
+inline PipeStats& pipe_stats() { static PipeStats t; return t; }
+#define LHIP_PIPE_COUNT(f) do { if (lane == 0) pipe_stats().f++; } while (0)
+#else
+#define LHIP_PIPE_COUNT(f) do { } while (0)
+#endif
+#if LHIP_NL != 1
+// the helper: serves one owner's requests until it is told to leave.  Lo = the owner's LDS record (the quantized values), L = this wave's own (scratch).
+LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo, QuantLds& L, const QuantTabs& Q, int lane) {
+    long spins = 0;
+    for (;;) {
+        const int s = wg_load(&cs.state, lane);
+        if (s == CS_QUIT) break;
+        if (s == CS_BARRIER) { wg_store(&cs.state, CS_IDLE, lane); wg_barrier(); continue; }     // (the owner posts again only after the barrier)
+        if (s != CS_REQ) { wg_idle(); LHIP_SPIN_GUARD(spins); continue; }
+        wg_acquire();
+        spins = 0;
+        lane = lane_anew(lane);
+        GI g;
+        g.block_type = uni(cs.block_type); g.max_nonzero_coeff = uni(cs.max_nonzero_coeff);
+        g.region0_count = uni(cs.r0); g.region1_count = uni(cs.r1);
+        g.table_select[0] = uni(cs.t0); g.table_select[1] = uni(cs.t1); g.table_select[2] = uni(cs.t2);
+        g.count1table_select = uni(cs.c1sel); g.count1bits = uni(cs.c1bits); g.count1 = 0; g.big_values = 0;
+        int cnt1 = uni(cs.cnt1_in), amask = 0;
+        int vx[NPL], vy[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int i = lane + LHIP_NL * j;
+            const uint32_t w = i < 288 ? ((const uint32_t*)Lo.ixw)[i] : 0u;
+            vx[j] = (int)(w & 0xffffu); vy[j] = (int)(w >> 16);
+        }
+        const int bits = q_noquant_count_bits(T, g, Lo.ixw, vx, vy, 1, &cnt1, &amask, lane, L, Q);
+        if (lane == 0) {
+            cs.bits = bits; cs.count1 = g.count1; cs.big_values = g.big_values; cs.o_c1sel = g.count1table_select; cs.o_c1bits = g.count1bits;
+            cs.o_r0 = g.region0_count; cs.o_r1 = g.region1_count; cs.o_t0 = g.table_select[0]; cs.o_t1 = g.table_select[1]; cs.o_t2 = g.table_select[2];
+            cs.cnt1 = cnt1; cs.amask = amask;
+        }
+        wg_store(&cs.state, CS_DONE, lane);
+    }
+}
+// the owner's side: q_count_bits (use_pn = 1) with the count on the helper and calc_noise run beside it.  *spec = 1: `ni` / `nc` hold a calc_noise
+// of this quantization that has not been committed (q_noise_commit)
+LHIP_DEV int q_count_bits_piped(const Tables& T, GI& g, const int32_t* scalefac, int16_t* ix, PrevNoise& pn, int* asg, CountShare& cs,
+                                NoiseRes* ni, NoiseCommit* nc, int need_max, int* spec, int lane, QuantLds& L, const QuantTabs& Q) {
+    *asg = 0; *spec = 0;
+    {   // Takehiro.js:635-638 (see q_count_bits)
+        const double ip = ipow20(Q, g.global_gain);
+        if (g.xrpow_max * ip > (double)IXMAX_VAL * (1.0 - 0x1p-50)) {
+            const double w = (double)IXMAX_VAL / ip;
+            if (g.xrpow_max > w) return LARGE_BITS;
+        }
+    }
+    {
+        int vx[NPL], vy[NPL];
+        PH_BEGIN(); q_quantize(T, g, scalefac, ix, 1, pn.gain, pn.sfb_count1, vx, vy, lane, L, Q); PH_END(L, PH_QUANTIZE);
+        (void)vx; (void)vy;                          // the helper reads the pairs back from LDS
+    }
+    if (lane == 0) {
+        cs.block_type = g.block_type; cs.max_nonzero_coeff = g.max_nonzero_coeff; cs.cnt1_in = pn.sfb_count1;
+        cs.r0 = g.region0_count; cs.r1 = g.region1_count; cs.t0 = g.table_select[0]; cs.t1 = g.table_select[1]; cs.t2 = g.table_select[2];
+        cs.c1sel = g.count1table_select; cs.c1bits = g.count1bits;
+    }
+    wg_store(&cs.state, CS_REQ, lane);
+    LHIP_PIPE_COUNT(piped);
+    { PH_BEGIN(); q_calc_noise_(T, g, scalefac, ix, ni, 1, pn, need_max, lane, L, Q, nc); PH_END(L, PH_NOISE); }
+    *spec = 1;
+    PH_BEGIN();
+    { long spins = 0; while (wg_load(&cs.state, lane) != CS_DONE) { wg_idle(); LHIP_SPIN_GUARD(spins); } }
+    wg_acquire();
+    const int bits = uni(cs.bits);
+    g.count1 = uni(cs.count1); g.big_values = uni(cs.big_values); g.count1table_select = uni(cs.o_c1sel); g.count1bits = uni(cs.o_c1bits);
+    g.region0_count = uni(cs.o_r0); g.region1_count = uni(cs.o_r1);
+    g.table_select[0] = uni(cs.o_t0); g.table_select[1] = uni(cs.o_t1); g.table_select[2] = uni(cs.o_t2);
+    *asg = pack_cond_fields(g, uni(cs.amask));
+    pn.sfb_count1 = uni(cs.cnt1);
+    PH_END(L, PH_COUNT);                             // (profiling builds: the part of the count the owner still had to wait for)
+    return bits;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // scale_bitcount (Takehiro.js:980-1030), MPEG-1, no mixed blocks.  returns 1 on failure
@@ -1595,8 +1706,10 @@ LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
 // quantization is found; it is read back into L.ixw once the loop has finished (the working copy is dead then).
 // `dig` / `dn`: the granule-channel's validation digest (word w at dig[w * dn]; lhip_layout.h VD_*): the bin-search memo in the compact,
 // coalesced form the one-thread-per-frame validation reads
+// `cs` (latency kernels only): the record through which a helper wave takes the Huffman count of the outer loop's evaluations while this wave
+// runs calc_noise beside it (q_count_bits_piped); nullptr: everything on this wave
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
-                           int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q) {
+                           int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr) {
     lane = fresh_lane(lane);
     enum { ST_BS, ST_BSUP, ST_A, ST_B };
     NoiseRes best, ni;
@@ -1625,7 +1738,13 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
 #endif
         int asg = 0;
         const int cnt1_seen = pn.sfb_count1;                  // what this evaluation's 0/1 shortcut is decided with
-        const int nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site
+        int nBits, spec = 0;
+        NoiseCommit nc; nc.fresh = 0; nc.step = 0; nc.cls = 0; nc.dist = 0.f; nc.x = 0.0;
+#if LHIP_NL != 1
+        if (cs != nullptr && st >= ST_A) nBits = q_count_bits_piped(T, w, L.sfw, L.ixw, pn, &asg, *cs, &ni, &nc, best.over_count == 0, &spec, lane, L, Q);
+        else
+#endif
+        nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site (but for the two-wave form above)
         // memo of the bin search: collected in LDS and written to the side record in one burst when the search ends (a global
         // store per step would sit in front of every later memory wait of the wave -- the VMEM counter retires in order)
         if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) { L.memo.bs_tab[nbs] = (w.global_gain << 24) | nBits; L.memo.bs_asg[nbs] = asg; } nbs++; }
@@ -1693,7 +1812,8 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
         }
-        q_calc_noise(T, w, L.sfw, L.ixw, &ni, 1, pn, best.over_count == 0, lane, L, Q);                 // the only call site
+        if (spec) { q_noise_commit(w, nc, pn, lane, L); LHIP_PIPE_COUNT(committed); }          // made beside the count, on exactly these inputs: now it counts
+        else q_calc_noise(T, w, L.sfw, L.ixw, &ni, 1, pn, best.over_count == 0, lane, L, Q);                 // the only call site
         ni.bits = w.part2_3_length;
         int keep;
         if (first) keep = 1;
@@ -2246,7 +2366,7 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
 struct UnitOut { int bits; Seed next; int block_type; int active; };
 // Inlined at every call site: behind a call (one copy of the code for kb_quant's, the owner's and the helper's site) g_quant was a third slower -- spills around the call.
 LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
-                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q) {
+                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr) {
     lane = lane_anew(lane);        // (here and below: lane-derived LDS / HBM addresses are formed where they are used, not parked in scratch across the search)
     UnitOut u; u.next = used;
     GI g;
@@ -2259,7 +2379,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
         active = 1;
         { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
         int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-        q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q);
+        q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs);
         uni_gi(g); bs_gain = uni(bs_gain);
         lane = lane_anew(lane);
         wave_sync();                                    // the kept spectrum was written by other lanes of this wave
@@ -2333,7 +2453,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
 template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
                        int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr,
-                       int* hint = nullptr) {
+                       int* hint = nullptr, CountShare* cs = nullptr) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -2418,13 +2538,14 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         for (int ch = 0; ch < C; ch++) {
             if (PAIR && ch != my_ch) continue;
             const UnitOut u = q_unit(T, pb10, W, C, Cp, fidx, gslot, gr, ch, mode_ext, ath_adjust, ch == 0 ? targ0 : targ1, ch == 0 ? seed0 : seed1,
-                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q);
+                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q, cs);
             if (u.active) { if (ch == 0) seed0 = u.next; else seed1 = u.next; }
             if (!PAIR) ResvSize = uni(ResvSize - u.bits);
             else if (lane == 0) mbox[2 * gr + ch] = u.bits;
             if (gr == 0) { if (ch == 0) gr0_bt0 = u.block_type; else gr0_bt1 = u.block_type; }
         }
         if (PAIR) {                                   // both waves have published this granule: take the other channel's bits
+            if (cs) wg_store(&cs->state, CS_BARRIER, lane);     // (this wave's count helper keeps the barrier's count)
             wg_barrier();
             ResvSize = uni(ResvSize - (mbox[2 * gr] + mbox[2 * gr + 1]));
         }

@@ -287,7 +287,7 @@ template <int RESV> LHIP_DEV bool frame_stage_empty(int stage, const Tables& T) 
 // two waves (kb_quant<1>, which meets once per granule at a workgroup barrier: the other waves keep the barrier count).
 template <int RESV, int PAIRQ>
 LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO,
-                             int st, int wv, int nw, int lane, unsigned char* lds, QuantTabs& Q, int* mbox) {
+                             int st, int wv, int nw, int lane, unsigned char* lds, QuantTabs& Q, int* mbox, CountShare* cshare = nullptr) {
     const int C = T.channels_out, Cp = T.psy_channels, GR = T.mode_gr;
     const StreamDesc sd = SD[st];
     const bool has = sd.nframes > 0;                          // this launch completes a frame of the stream (else only the state moves)
@@ -320,10 +320,18 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             break;
         case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax); break;
         case FS_QUANT:
+            // waves 0 (1): the channel's search; waves 2 (3): its count helper (q_count_helper: the Huffman count of an evaluation while the owner
+            // runs calc_noise); the one-lane simulation (PAIRQ == 0) has neither
             if (PAIRQ && C == 2) {
-                if (has && wv < 2) kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv);
+                if (has && wv < 2) { kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
+#if LHIP_NL != 1
+                else if (has && cshare && wv < 4) q_count_helper(T, cshare[wv - 2], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
+#endif
                 else for (int gr = 0; gr < GR; gr++) wg_barrier();
-            } else if (has && wv == 0) kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv);
+            } else if (has && wv == 0) { kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
+#if LHIP_NL != 1
+            else if (PAIRQ && has && cshare && wv == 2) q_count_helper(T, cshare[0], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
+#endif
             break;
         case FS_BITS_SAVE:   // the state record's reservoir part belongs to the bit packer, everything else to the save: disjoint words
             if (wv == 0) { if (has) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds, rv, W.out_bytes + st); }
@@ -644,12 +652,18 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     if (threadIdx.x == 0) A->W.out_bytes[st] = nout;
 }
 // one workgroup of FR_WAVES waves per stream, one frame per stream (see kb_frame_stage)
+#ifndef LHIP_FRAME_PIPE
+#define LHIP_FRAME_PIPE 1      /* 0: the Huffman counts of the outer loop on the searching wave itself (A/B builds) */
+#endif
+static constexpr bool g_frame_pipe = LHIP_FRAME_PIPE != 0;
 template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QArgs a_unused, const StreamIO* IO) {
     __shared__ QuantTabs Q;
     __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
     __shared__ int mbox[4];
+    __shared__ CountShare CS[2];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < 2) CS[threadIdx.x].state = CS_IDLE;
 #ifdef LHIP_PHASE_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES + 1] = wall_clock64(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 3] = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -661,7 +675,7 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
         if (stage == FS_QUANT) ((QuantLds*)U[wv])->prof[lane] = 0;
 #endif
         if (frame_stage_empty<RESV>(stage, A->T)) continue;
-        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox);
+        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr);
 #ifdef LHIP_PHASE_PROF
         if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0) A->W.prof[lane] = ((QuantLds*)U[wv])->prof[lane];
 #endif
@@ -1315,14 +1329,15 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = FR_WAVES;
-            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[4];
+            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[4]; static thread_local CountShare fcs[2];
+            fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;
             for (int s = 0; s < S; s++) {
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {
                     for (int stage = 0; stage < FR_STAGES; stage++) {
                         if (resv ? frame_stage_empty<1>(stage, T) : frame_stage_empty<0>(stage, T)) continue;
-                        if (resv) kb_frame_stage<1, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox);
-                        else kb_frame_stage<0, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox);
+                        if (resv) kb_frame_stage<1, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox, fcs);
+                        else kb_frame_stage<0, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox, fcs);
                         wg_barrier();
                     }
                 });

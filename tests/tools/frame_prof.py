@@ -1,6 +1,6 @@
 """DEV TOOL (GPU, profiling build tools/build_prof.sh): where ONE 1152-sample encodeBuffer() call -- the reference's documented call
 pattern -- spends its time.  Per call: wall time seen by the caller; the host side of the library (plan / enqueue inputs / enqueue kernels
-/ copy-out + synchronisation); inside the single launch (g_frame) the cycles of each of its fourteen stages; inside its quantization
+/ copy-out + synchronisation); inside the single launch (g_frame) the cycles of each of its stages (a|b: a and b side by side on different waves); inside its quantization
 stage the phases of wave 0 (one channel).  usage: python tests/tools/frame_prof.py [calls]"""
 import ctypes, sys, time
 from pathlib import Path
@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import lamejs_amd, pcm
 lib = lamejs_amd.load_library(ROOT / "lamejs_amd" / "lib" / "liblamejs_hip_prof.so")
-STAGES = ["load", "prep", "psyA", "psyA_ms", "scan_raw", "scan_attack", "scan_bt+ath", "psyB0", "psyB1", "poly", "mdct", "quant", "bits", "save"]
+STAGES = ["load", "prep", "psyA|poly", "psyA_ms", "scan_raw", "scan_attack", "scan_bt+ath", "psyB0|mdct", "psyB1", "quant", "bits|save"]
 PH = ["init", "xrpow", "xmin", "quantize", "count", "noise", "balance", "sfstore", "huffdiv", "publish", "copy", "total",
       "c_load", "c_quads", "c_max", "c_sums", "c_fin", "n_walk", "n_terms", "n_sums", "q_mask", "q_lines"]
 BASE = 64 + 2 * 8192
