@@ -533,7 +533,7 @@ def main():
     kern = wl.kernel_times() if not sim else {}
 
     # ---- N > 1: verdicts of all ranks; RCCL gather of the MP3 bytes to rank 0 (untimed), re-hashed there ----
-    verdicts = [(rank, md5s, full, prefix, wl.nbytes)]
+    verdicts = [(rank, md5s, full, prefix, wl.nbytes, wl.seeds)]
     gathered_ok = None
     if use_dist:
         allv = [None] * world
@@ -572,7 +572,9 @@ def main():
                        "bit_exact_prefix_vs_oracle": (None if any(v[3] is None for v in verdicts) else all(v[3] for v in verdicts)),
                        "seed_repaired_frames": wl.repaired, "repair_iterations": wl.repair_iters,
                        "output_md5_per_rank": [v[1][0] if len(v[1]) == 1 else hashlib.md5("".join(v[1]).encode()).hexdigest() for v in verdicts],
-                       "rccl_gather_of_outputs_rehashed_ok": gathered_ok},
+                       "rccl_gather_of_outputs_rehashed_ok": gathered_ok,
+                       "stream_seeds_per_rank": [[v[5][0], v[5][-1], len(v[5])] for v in verdicts],       # [first, last, count]: ranks encode disjoint streams
+                       "distinct_streams": len({s_ for v in verdicts for s_ in v[5]})},
             "kernels_ms": kern,
         }
         dom = max(kern, key=lambda k_: kern[k_]["ms"]) if kern else None

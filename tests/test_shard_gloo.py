@@ -154,3 +154,26 @@ def test_bench_py_refuses_a_launcher_with_another_world_size():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--frames", "4"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.parametrize("cfg,extra,ch,kbps", [("4", ["--frames", "4"], 2, 320), ("5", ["--streams", "128", "--frames", "3"], 1, 128)])
+def test_bench_py_plain_launch_world8(cfg, extra, ch, kbps):
+    """The shape of the first 8-GPU run (BASELINE configs[3] and configs[4]: 8 x one stereo 320 k stream, 8 x 128 = 1024 mono streams), started
+    PLAINLY as the driver starts it -- `python bench.py --gpus 8 --config N` -- on gloo + the host simulation with a few frames per stream:
+    eight ranks come up, every rank encodes its own streams (8 distinct seeds / 1024 distinct stream ids), the gathered bytes re-hash on rank 0,
+    and every stream equals the oracle's."""
+    if not HOSTSIM.exists():
+        pytest.skip("host simulation not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LAMEJS_HIP_LIB=str(HOSTSIM), LAMEJS_BENCH_HOSTSIM="1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--config", cfg, "--cpu-seconds", "0", "--check-frames", "3"] + extra,
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ns = int(extra[extra.index("--streams") + 1]) if "--streams" in extra else 1
+    c = line["config"]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert c["distinct_streams"] == 8 * ns
+    seed0 = 12345 if cfg != "5" else 1000
+    assert c["stream_seeds_per_rank"] == [[seed0 + rk * ns, seed0 + rk * ns + ns - 1, ns] for rk in range(8)]
+    _check_streams(line, cfg, ch, kbps, ns, int(extra[extra.index("--frames") + 1]), 8)
