@@ -1295,8 +1295,16 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
 // CountShare::state: CS_REQ request posted (owner), CS_DONE reply posted (helper), CS_BARRIER the owner is about to wait at a workgroup
 // barrier and the helper must keep the count, CS_QUIT the owner's frame is finished.
 // ---------------------------------------------------------------------------------------------
-struct CountShare { int state, block_type, max_nonzero_coeff, cnt1_in, r0, r1, t0, t1, t2, c1sel, c1bits;          // request (the fields the count may leave as they are)
-                    int bits, count1, big_values, o_c1sel, o_c1bits, o_r0, o_r1, o_t0, o_t1, o_t2, cnt1, amask, pad_[9]; };
+// The hand-over is on the search's critical path, so it is three LDS words each way: the request is the state word itself (CS_REQ | block
+// type << 8 -- the count reads nothing else of the granule's state: the quantized values are in the owner's record), the reply packs what
+// noquant_count_bits assigns (w[0] bits | count1 << 17; w[1] big_values | count1bits << 10 | count1table_select << 23 | region0_count << 24 |
+// region1_count << 28; w[2] table_select[0..2] + 1 at 6 bits each | sfb_count1 << 18 | the mask of conditionally assigned fields << 24: the
+// owner takes the region counts and table_select[r] only where the reference's count assigns them, Takehiro.js:566-612).
+struct CountShare { int state; uint32_t w[3];
+#ifdef LHIP_PHASE_PROF
+    unsigned long long t_post, t_reply; unsigned int acc[8];      // profiling builds: the hand-over's legs (q_count_helper)
+#endif
+};
 enum { CS_IDLE = 0, CS_REQ = 1, CS_DONE = 2, CS_BARRIER = 8, CS_QUIT = 9 };
 #if defined(LHIP_WAVESIM)
 // how often each way was taken (printed at exit with LAMEJS_PIPE_STATS=1: the simulation must exercise both)
@@ -1309,21 +1317,20 @@ inline PipeStats& pipe_stats() { static PipeStats t; return t; }
 #if LHIP_NL != 1
 // the helper: serves one owner's requests until it is told to leave.  Lo = the owner's LDS record (the quantized values), L = this wave's own (scratch).
 LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo, QuantLds& L, const QuantTabs& Q, int lane) {
-    long spins = 0;
     for (;;) {
-        const int s = wg_load(&cs.state, lane);
+        const int s = wg_wait_not(&cs.state, CS_IDLE, CS_DONE, lane);       // a request, a barrier to keep, or the end
         if (s == CS_QUIT) break;
         if (s == CS_BARRIER) { wg_store(&cs.state, CS_IDLE, lane); wg_barrier(); continue; }     // (the owner posts again only after the barrier)
-        if (s != CS_REQ) { wg_idle(); LHIP_SPIN_GUARD(spins); continue; }
+#ifdef LHIP_PHASE_PROF
+        const unsigned long long hp_seen_ = __builtin_amdgcn_s_memtime();
+#endif
         wg_acquire();
-        spins = 0;
         lane = lane_anew(lane);
         GI g;
-        g.block_type = uni(cs.block_type); g.max_nonzero_coeff = uni(cs.max_nonzero_coeff);
-        g.region0_count = uni(cs.r0); g.region1_count = uni(cs.r1);
-        g.table_select[0] = uni(cs.t0); g.table_select[1] = uni(cs.t1); g.table_select[2] = uni(cs.t2);
-        g.count1table_select = uni(cs.c1sel); g.count1bits = uni(cs.c1bits); g.count1 = 0; g.big_values = 0;
-        int cnt1 = uni(cs.cnt1_in), amask = 0;
+        g.block_type = uni(s >> 8); g.max_nonzero_coeff = 0;
+        g.region0_count = 0; g.region1_count = 0; g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
+        g.count1table_select = 0; g.count1bits = 0; g.count1 = 0; g.big_values = 0;
+        int cnt1 = 0, amask = 0;
         int vx[NPL], vy[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
@@ -1331,12 +1338,22 @@ LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo
             const uint32_t w = i < 288 ? ((const uint32_t*)Lo.ixw)[i] : 0u;
             vx[j] = (int)(w & 0xffffu); vy[j] = (int)(w >> 16);
         }
-        const int bits = q_noquant_count_bits(T, g, Lo.ixw, vx, vy, 1, &cnt1, &amask, lane, L, Q);
-        if (lane == 0) {
-            cs.bits = bits; cs.count1 = g.count1; cs.big_values = g.big_values; cs.o_c1sel = g.count1table_select; cs.o_c1bits = g.count1bits;
-            cs.o_r0 = g.region0_count; cs.o_r1 = g.region1_count; cs.o_t0 = g.table_select[0]; cs.o_t1 = g.table_select[1]; cs.o_t2 = g.table_select[2];
-            cs.cnt1 = cnt1; cs.amask = amask;
-        }
+#ifdef LHIP_PHASE_PROF
+        const unsigned long long hp_start_ = __builtin_amdgcn_s_memtime();
+#endif
+        const int bits = uni(q_noquant_count_bits(T, g, Lo.ixw, vx, vy, 1, &cnt1, &amask, lane, L, Q));
+#ifdef LHIP_PHASE_PROF
+        const unsigned long long hp_end_ = __builtin_amdgcn_s_memtime();
+#endif
+        uni_gi(g);
+        const uint32_t w0 = (uint32_t)bits | ((uint32_t)g.count1 << 17);
+        const uint32_t w1 = (uint32_t)g.big_values | ((uint32_t)g.count1bits << 10) | ((uint32_t)g.count1table_select << 23) | ((uint32_t)g.region0_count << 24) | ((uint32_t)g.region1_count << 28);
+        const uint32_t w2 = (uint32_t)(g.table_select[0] + 1) | ((uint32_t)(g.table_select[1] + 1) << 6) | ((uint32_t)(g.table_select[2] + 1) << 12) | ((uint32_t)uni(cnt1) << 18) | ((uint32_t)uni(amask) << 24);
+        if (lane == 0) { cs.w[0] = w0; cs.w[1] = w1; cs.w[2] = w2; }
+#ifdef LHIP_PHASE_PROF
+        if (lane == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cs.acc[0] += (unsigned int)(hp_seen_ - cs.t_post); cs.acc[1] += (unsigned int)(hp_start_ - hp_seen_);
+                         cs.acc[2] += (unsigned int)(hp_end_ - hp_start_); cs.acc[3] += (unsigned int)(now_ - hp_end_); cs.acc[7] += 1; cs.t_reply = now_; }
+#endif
         wg_store(&cs.state, CS_DONE, lane);
     }
 }
@@ -1357,24 +1374,32 @@ LHIP_DEV int q_count_bits_piped(const Tables& T, GI& g, const int32_t* scalefac,
         PH_BEGIN(); q_quantize(T, g, scalefac, ix, 1, pn.gain, pn.sfb_count1, vx, vy, lane, L, Q); PH_END(L, PH_QUANTIZE);
         (void)vx; (void)vy;                          // the helper reads the pairs back from LDS
     }
-    if (lane == 0) {
-        cs.block_type = g.block_type; cs.max_nonzero_coeff = g.max_nonzero_coeff; cs.cnt1_in = pn.sfb_count1;
-        cs.r0 = g.region0_count; cs.r1 = g.region1_count; cs.t0 = g.table_select[0]; cs.t1 = g.table_select[1]; cs.t2 = g.table_select[2];
-        cs.c1sel = g.count1table_select; cs.c1bits = g.count1bits;
-    }
-    wg_store(&cs.state, CS_REQ, lane);
+#ifdef LHIP_PHASE_PROF
+    if (lane == 0) cs.t_post = __builtin_amdgcn_s_memtime();
+#endif
+    wg_store(&cs.state, CS_REQ | (g.block_type << 8), lane);
     LHIP_PIPE_COUNT(piped);
     { PH_BEGIN(); q_calc_noise_(T, g, scalefac, ix, ni, 1, pn, need_max, lane, L, Q, nc); PH_END(L, PH_NOISE); }
     *spec = 1;
     PH_BEGIN();
-    { long spins = 0; while (wg_load(&cs.state, lane) != CS_DONE) { wg_idle(); LHIP_SPIN_GUARD(spins); } }
+#ifdef LHIP_PHASE_PROF
+    const unsigned long long op_wait0_ = __builtin_amdgcn_s_memtime();
+#endif
+    (void)wg_wait_not(&cs.state, CS_REQ | (g.block_type << 8), CS_REQ | (g.block_type << 8), lane);       // the only thing it can become is CS_DONE
+#ifdef LHIP_PHASE_PROF
+    if (lane == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cs.acc[4] += (unsigned int)(now_ - cs.t_reply); cs.acc[5] += (unsigned int)(op_wait0_ - cs.t_post); cs.acc[6] += (unsigned int)(now_ - op_wait0_); }
+#endif
     wg_acquire();
-    const int bits = uni(cs.bits);
-    g.count1 = uni(cs.count1); g.big_values = uni(cs.big_values); g.count1table_select = uni(cs.o_c1sel); g.count1bits = uni(cs.o_c1bits);
-    g.region0_count = uni(cs.o_r0); g.region1_count = uni(cs.o_r1);
-    g.table_select[0] = uni(cs.o_t0); g.table_select[1] = uni(cs.o_t1); g.table_select[2] = uni(cs.o_t2);
-    *asg = pack_cond_fields(g, uni(cs.amask));
-    pn.sfb_count1 = uni(cs.cnt1);
+    const uint32_t w0 = (uint32_t)uni((int)cs.w[0]), w1 = (uint32_t)uni((int)cs.w[1]), w2 = (uint32_t)uni((int)cs.w[2]);
+    const int bits = (int)(w0 & 0x1ffffu), amask = (int)((w2 >> 24) & 15u);
+    static_assert(LARGE_BITS < (1 << 17), "the reply packs the bit count in 17 bits");
+    g.count1 = (int)(w0 >> 17); g.big_values = (int)(w1 & 1023u); g.count1bits = (int)((w1 >> 10) & 0x1fffu); g.count1table_select = (int)((w1 >> 23) & 1u);
+    if (amask & 8) { g.region0_count = (int)((w1 >> 24) & 15u); g.region1_count = (int)(w1 >> 28); }       // (region1_count is 13 for start / stop blocks: four bits)
+    if (amask & 1) g.table_select[0] = (int)(w2 & 63u) - 1;
+    if (amask & 2) g.table_select[1] = (int)((w2 >> 6) & 63u) - 1;
+    if (amask & 4) g.table_select[2] = (int)((w2 >> 12) & 63u) - 1;
+    *asg = pack_cond_fields(g, amask);
+    pn.sfb_count1 = (int)((w2 >> 18) & 63u);
     PH_END(L, PH_COUNT);                             // (profiling builds: the part of the count the owner still had to wait for)
     return bits;
 }
@@ -2379,7 +2404,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
         active = 1;
         { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
         int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-        q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs);
+        { PH_BEGIN(); q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs); PH_END(L, PH_XRPOW); }   // (profiling builds: the whole search in the otherwise unused slot)
         uni_gi(g); bs_gain = uni(bs_gain);
         lane = lane_anew(lane);
         wave_sync();                                    // the kept spectrum was written by other lanes of this wave

@@ -665,6 +665,9 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 2) CS[threadIdx.x].state = CS_IDLE;
 #ifdef LHIP_PHASE_PROF
+    if (threadIdx.x < 8) CS[0].acc[threadIdx.x] = 0;
+#endif
+#ifdef LHIP_PHASE_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES + 1] = wall_clock64(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 3] = __builtin_amdgcn_s_memtime(); }
 #endif
     q_copy_tabs(A->T, Q, threadIdx.x, 64 * FR_WAVES);       // (first read by the quantization stage: the barriers in between order it)
@@ -678,6 +681,10 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
         kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr);
 #ifdef LHIP_PHASE_PROF
         if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0) A->W.prof[lane] = ((QuantLds*)U[wv])->prof[lane];
+        if (stage == FS_QUANT && blockIdx.x == 0 && wv == 2 && lane < 5) {     // the count helper of wave 0: its five count phases (cycles, calls)
+            A->W.prof[FRAME_PROF_BASE + 16 + lane] = ((QuantLds*)U[wv])->prof[PH_C_LOAD + lane]; A->W.prof[FRAME_PROF_BASE + 24 + lane] = ((QuantLds*)U[wv])->prof[32 + PH_C_LOAD + lane];
+        }
+        if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0 && lane < 8) A->W.prof[FRAME_PROF_BASE + 32 + lane] = CS[0].acc[lane];      // the hand-over's legs
 #endif
         __syncthreads();
     }

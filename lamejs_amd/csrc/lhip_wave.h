@@ -377,6 +377,7 @@ LHIP_DEV int wg_load(const int* p, int lane) { (void)lane; return *p; }
 LHIP_DEV void wg_store(int* p, int v, int lane) { (void)lane; *p = v; }
 LHIP_DEV void wg_add(int* p, int v, int lane) { (void)lane; *p += v; }
 LHIP_DEV void wg_idle() {}
+LHIP_DEV void wg_spin() {}
 LHIP_DEV void wg_acquire() {}
 #elif defined(LHIP_HOSTSIM)
 // lane fibers run one at a time and only switch at wave primitives: plain accesses are atomic; wave_bcast is the switch point that lets the
@@ -386,6 +387,7 @@ LHIP_DEV int wg_load(const int* p, int lane) { int r = 0; if (lane == 0) r = *(c
 LHIP_DEV void wg_store(int* p, int v, int lane) { wave_sync(); if (lane == 0) *(volatile int*)p = v; wave_sync(); }
 LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) *p += v; wave_sync(); }
 LHIP_DEV void wg_idle() { wave_sync(); }
+LHIP_DEV void wg_spin() { wave_sync(); }
 LHIP_DEV void wg_acquire() { wave_sync(); }
 #else
 LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (lane == 0) r = atomicCAS(p, expect, desired); return __builtin_amdgcn_readfirstlane(r); }
@@ -396,8 +398,27 @@ LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wa
 }
 LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
 LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
+#ifndef LHIP_SPIN_SLEEP
+#define LHIP_SPIN_SLEEP 0
+#endif
+LHIP_DEV void wg_spin() { if (LHIP_SPIN_SLEEP) __builtin_amdgcn_s_sleep(LHIP_SPIN_SLEEP); }     // polls that sit on a frame's critical path (the count helper's hand-overs): no pause between looks (wg_idle: 512 clocks)
 LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #endif
+// Spin until the word is neither a nor b; returns what it is then.  For hand-overs on a frame's critical path (the count helper): nothing in
+// the loop but the load, the two compares and a 32-bit guard -- a round is one LDS latency.
+LHIP_DEV int wg_wait_not(const int* p, int a, int b, int lane) {
+    unsigned n = 0;
+    for (;;) {
+        const int s = wg_load(p, lane);
+        if (s != a && s != b) return s;
+        wg_spin();
+#if defined(LHIP_HOSTSIM)
+        if (++n == 0u) abort();
+#else
+        if (++n > (1u << 27)) __builtin_trap();       // seconds: a protocol or compiler bug -- fault instead of hanging the device
+#endif
+    }
+}
 // A poll loop that has gone round this often (seconds; a launch's tail is milliseconds) is a protocol or compiler bug: fault instead of
 // hanging the device (lhip_api.cpp, g_fixup: a dispenser loop nested in another loop has been miscompiled into an exec-masked loop on this
 // toolchain before).

@@ -10,7 +10,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import lamejs_amd, pcm
 lib = lamejs_amd.load_library(ROOT / "lamejs_amd" / "lib" / "liblamejs_hip_prof.so")
 STAGES = ["load", "prep", "psyA|poly", "psyA_ms", "scan_raw", "scan_attack", "scan_bt+ath", "psyB0|mdct", "psyB1", "quant", "bits|save"]
-PH = ["init", "xrpow", "xmin", "quantize", "count", "noise", "balance", "sfstore", "huffdiv", "publish", "copy", "total",
+PH = ["init", "search", "xmin", "quantize", "count", "noise", "balance", "sfstore", "huffdiv", "publish", "copy", "total",
       "c_load", "c_quads", "c_max", "c_sums", "c_fin", "n_walk", "n_terms", "n_sums", "q_mask", "q_lines"]
 BASE = 64 + 2 * 8192
 NW = (512 + 16 * 8192 + 512) // 8
@@ -23,7 +23,7 @@ for corpus in ("sine", "bursts"):
             enc.encodeBuffer(L[1152 * w:1152 * (w + 1)], None if R is None else R[1152 * w:1152 * (w + 1)])
         h0 = (ctypes.c_double * 8)(); lib.lhip_debug_read(9, h0, 64)
         buf = (ctypes.c_uint64 * NW)()
-        st = np.zeros(len(STAGES) + 1); ph = np.zeros(64); wall = 0.0; kern_ticks = 0.0; kern_cyc = 0.0
+        st = np.zeros(len(STAGES) + 1); ph = np.zeros(64); hp = np.zeros(16); ho = np.zeros(8); wall = 0.0; kern_ticks = 0.0; kern_cyc = 0.0
         t_calls = []
         for c in range(3, 3 + ncalls):
             a = L[1152 * c:1152 * (c + 1)]; b = None if R is None else R[1152 * c:1152 * (c + 1)]
@@ -43,6 +43,7 @@ for corpus in ("sine", "bursts"):
             st[:len(STAGES)] += np.diff(s[:len(STAGES) + 1]); st[len(STAGES)] += s[0] - s[len(STAGES) + 3]
             kern_ticks += s[len(STAGES) + 2] - s[len(STAGES) + 1]; kern_cyc += s[len(STAGES)] - s[len(STAGES) + 3]
             ph += np.array([buf[i] for i in range(64)], dtype=np.float64)
+            hp += np.array([buf[BASE + 16 + i] for i in range(16)], dtype=np.float64); ho += np.array([buf[BASE + 32 + i] for i in range(8)], dtype=np.float64)
             ns += 1
         t_calls = np.array(t_calls)
         hz = kern_cyc / (kern_ticks / 1e8)
@@ -60,4 +61,9 @@ for corpus in ("sine", "bursts"):
         for i, n in ((30, "n_lines"), (31, "n_fold")):
             if ph[32 + i]:
                 print(f"      {n:9s} {100.0 * ph[i] / tot:5.1f}%  calls/frame {ph[32 + i] / ns:7.2f}  cycles/call {ph[i] / ph[32 + i]:9.0f}")
+        if hp[8:13].sum():
+            print(f"   count helper of wave 0: {hp[8] / ns:.2f} counts per frame, {hp[:5].sum() / max(hp[8], 1):.0f} cycles each (quads {hp[1] / max(hp[9], 1):.0f} | maxima {hp[2] / max(hp[10], 1):.0f} | sums {hp[3] / max(hp[11], 1):.0f} | finish {hp[4] / max(hp[12], 1):.0f})")
+        if ho[7]:
+            n_ = ho[7]
+            print(f"   hand-over per counted evaluation (cycles): request posted -> seen by the helper {ho[0] / n_:.0f} | acquire + pairs loaded {ho[1] / n_:.0f} | count {ho[2] / n_:.0f} | pack + reply {ho[3] / n_:.0f} | reply -> seen by the owner {ho[4] / n_:.0f};  owner: posted -> starts waiting {ho[5] / n_:.0f} (calc_noise), waits {ho[6] / n_:.0f}")
         enc.close(); enc2.close()
