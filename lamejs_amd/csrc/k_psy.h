@@ -21,74 +21,92 @@ namespace lhip {
 // ---------------------------------------------------------------------------------------------
 // The i == 0 butterfly of block m (no twiddles) and the i >= 1 butterflies are separate work lists, so that a
 // wave never executes both code paths for one batch of items.
-LHIP_DEV void fht_item0(float* fz, int k1, int kx, int m) {
+// LDS layout of a transform buffer while the passes run: one pad word after every 32 (index a lives at a + a / 32).  The butterflies of the
+// first passes touch, lane after lane, addresses 16 (k1 = 4) or 64 (k1 = 16) words apart: in a plain array that is 2 resp. 7 of the 32 LDS
+// banks for a whole wave -- 72 % of g_psyA's LDS cycles were bank conflicts (profiles/r03_pmc_lds_config3.json) -- with the pad the 64 lanes
+// of the k1 = 4 pass spread over all 32 banks.  Everything that reads or writes transform DATA goes through fzp(): the windowing's outputs,
+// the passes, the energies' operands, the joint-stereo copies; the other phases use the same memory as plain scratch, and every transition
+// between the two views already goes through registers and a wave_sync.
+#ifdef LHIP_NO_FZ_PAD      /* A/B builds: the plain layout */
+LHIP_DEV int fzp(int a) { return a; }
+LHIP_DEV int fzo(int c) { return c; }
+#else
+LHIP_DEV int fzp(int a) { return a + (a >> 5); }
+// offsets inside an item: index + c lands at fzp(index) + c + c / 32 because (index & 31) + (c & 31) < 32 for every operand of every pass
+// (k1 = 4: a 16-aligned group; k1 = 16: i < 16 and c & 31 is 0 or 16; k1 >= 64: c is a multiple of 32)
+LHIP_DEV int fzo(int c) { return c + (c >> 5); }
+#endif
+LHIP_DEV void fht_item0(float* fz, int base, int k1, int kx, int m) {
     const int k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
-    float* fi = fz + m * k4;
-    float* gi = fi + kx;
+    const int K1 = fzo(k1), K2 = fzo(k2), K3 = fzo(k3);
+    float* fi = fz + fzp(base + m * k4);
+    float* gi = fz + fzp(base + m * k4 + kx);
     double f0, f1, f2, f3;
-    f1 = (double)fi[0] - (double)fi[k1];
-    f0 = (double)fi[0] + (double)fi[k1];
-    f3 = (double)fi[k2] - (double)fi[k3];
-    f2 = (double)fi[k2] + (double)fi[k3];
-    fi[k2] = (float)(f0 - f2);
+    f1 = (double)fi[0] - (double)fi[K1];
+    f0 = (double)fi[0] + (double)fi[K1];
+    f3 = (double)fi[K2] - (double)fi[K3];
+    f2 = (double)fi[K2] + (double)fi[K3];
+    fi[K2] = (float)(f0 - f2);
     fi[0] = (float)(f0 + f2);
-    fi[k3] = (float)(f1 - f3);
-    fi[k1] = (float)(f1 + f3);
-    f1 = (double)gi[0] - (double)gi[k1];
-    f0 = (double)gi[0] + (double)gi[k1];
-    f3 = LHIP_SQRT2 * (double)gi[k3];
-    f2 = LHIP_SQRT2 * (double)gi[k2];
-    gi[k2] = (float)(f0 - f2);
+    fi[K3] = (float)(f1 - f3);
+    fi[K1] = (float)(f1 + f3);
+    f1 = (double)gi[0] - (double)gi[K1];
+    f0 = (double)gi[0] + (double)gi[K1];
+    f3 = LHIP_SQRT2 * (double)gi[K3];
+    f2 = LHIP_SQRT2 * (double)gi[K2];
+    gi[K2] = (float)(f0 - f2);
     gi[0] = (float)(f0 + f2);
-    gi[k3] = (float)(f1 - f3);
-    gi[k1] = (float)(f1 + f3);
+    gi[K3] = (float)(f1 - f3);
+    gi[K1] = (float)(f1 + f3);
 }
-LHIP_DEV void fht_item1(float* fz, int k1, int kx, int m, int i, const double* tw) {
+LHIP_DEV void fht_item1(float* fz, int base, int k1, int kx, int m, int i, const double* tw) {
     const int k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
-    float* fi = fz + m * k4 + i;
-    float* gi = fz + m * k4 + k1 - i;
+    const int K1 = fzo(k1), K2 = fzo(k2), K3 = fzo(k3);
+    (void)kx;
+    float* fi = fz + fzp(base + m * k4 + i);
+    float* gi = fz + fzp(base + m * k4 + k1 - i);
     const double c1 = tw[4 * (i - 1) + 0], s1 = tw[4 * (i - 1) + 1], c2 = tw[4 * (i - 1) + 2], s2 = tw[4 * (i - 1) + 3];
     double a, b, g0, f0, f1, g1, f2, g2, f3, g3;
-    b = s2 * (double)fi[k1] - c2 * (double)gi[k1];
-    a = c2 * (double)fi[k1] + s2 * (double)gi[k1];
+    b = s2 * (double)fi[K1] - c2 * (double)gi[K1];
+    a = c2 * (double)fi[K1] + s2 * (double)gi[K1];
     f1 = (double)fi[0] - a;
     f0 = (double)fi[0] + a;
     g1 = (double)gi[0] - b;
     g0 = (double)gi[0] + b;
-    b = s2 * (double)fi[k3] - c2 * (double)gi[k3];
-    a = c2 * (double)fi[k3] + s2 * (double)gi[k3];
-    f3 = (double)fi[k2] - a;
-    f2 = (double)fi[k2] + a;
-    g3 = (double)gi[k2] - b;
-    g2 = (double)gi[k2] + b;
+    b = s2 * (double)fi[K3] - c2 * (double)gi[K3];
+    a = c2 * (double)fi[K3] + s2 * (double)gi[K3];
+    f3 = (double)fi[K2] - a;
+    f2 = (double)fi[K2] + a;
+    g3 = (double)gi[K2] - b;
+    g2 = (double)gi[K2] + b;
     b = s1 * f2 - c1 * g3;
     a = c1 * f2 + s1 * g3;
-    fi[k2] = (float)(f0 - a);
+    fi[K2] = (float)(f0 - a);
     fi[0] = (float)(f0 + a);
-    gi[k3] = (float)(g1 - b);
-    gi[k1] = (float)(g1 + b);
+    gi[K3] = (float)(g1 - b);
+    gi[K1] = (float)(g1 + b);
     b = c1 * g2 - s1 * f3;
     a = s1 * g2 + c1 * f3;
-    gi[k2] = (float)(g0 - a);
+    gi[K2] = (float)(g0 - a);
     gi[0] = (float)(g0 + a);
-    fi[k3] = (float)(f1 - b);
-    fi[k1] = (float)(f1 + b);
+    fi[K3] = (float)(f1 - b);
+    fi[K1] = (float)(f1 + b);
 }
 // one radix-4 pass over n points: the n/8 work items are the n/(8 kx) twiddle-free ones and the rest
 LHIP_DEV void fht_pass(float* fz, int n, int k1, int kx, int lane, int nl, int base, const double* tw) {
     const int items = n / 8, nz = items / kx, kx1 = kx - 1;
-    for (int t = lane - base; t < nz; t += nl) if (t >= 0) fht_item0(fz, k1, kx, t);
-    for (int t = lane - base; t < items - nz; t += nl) if (t >= 0) { const int m = t / kx1; fht_item1(fz, k1, kx, m, 1 + t - m * kx1, tw); }
+    for (int t = lane - base; t < nz; t += nl) if (t >= 0) fht_item0(fz, 0, k1, kx, t);
+    for (int t = lane - base; t < items - nz; t += nl) if (t >= 0) { const int m = t / kx1; fht_item1(fz, 0, k1, kx, m, 1 + t - m * kx1, tw); }
 }
 
-// the same pass over `nb` equally long transforms stored back to back, as ONE work list: three 256-point transforms have 32 items
-// each per pass -- one list of 96 fills the lanes where three lists of 32 leave half of them idle
+// the same pass over `nb` equally long transforms stored back to back (ONE padded buffer), as ONE work list: three 256-point transforms have
+// 32 items each per pass -- one list of 96 fills the lanes where three lists of 32 leave half of them idle
 LHIP_DEV void fht_pass_blocks(float* fz, int nb, int n, int k1, int kx, int lane, int nl, const double* tw) {
     const int items = n / 8, nz = items / kx, kx1 = kx - 1, n1 = items - nz;
-    for (int t = lane; t < nb * nz; t += nl) { const int b = t / nz; fht_item0(fz + b * n, k1, kx, t - b * nz); }
+    for (int t = lane; t < nb * nz; t += nl) { const int b = t / nz; fht_item0(fz, b * n, k1, kx, t - b * nz); }
     for (int t = lane; t < nb * n1; t += nl) {
         const int b = t / n1, r = t - b * n1, m = r / kx1;
-        fht_item1(fz + b * n, k1, kx, m, 1 + r - m * kx1, tw);
+        fht_item1(fz, b * n, k1, kx, m, 1 + r - m * kx1, tw);
     }
 }
 
@@ -96,9 +114,11 @@ LHIP_DEV void fht_pass_blocks(float* fz, int nb, int n, int k1, int kx, int lane
 // (fe = fz[0..512], fes[b] = fs[b][0..128]) and the partition arrays live in the then-dead upper half of fz:
 // 7.2 KB instead of 12.3 KB per wave, i.e. LDS no longer caps the kernel at 3 waves per SIMD.
 struct PsyALds {
-    float fz[BLKSIZE];              // long FHT buffer; after the energies: [0..512] fe, [516..] eb/mx/av/ebs
-    float fs[3][BLKSIZE_s];         // short FHT buffers; after the energies: [b][0..128] fes
+    float fz[BLKSIZE + BLKSIZE / 32];              // long FHT buffer (padded layout, fzp); after the energies: [0..512] fe, [516..] eb/mx/av/ebs
+    float fs[3][BLKSIZE_s];                        // short FHT buffers: one padded buffer of 3 x 256 points (fzp over the flat index b * 256 + j) ...
+    float fs_pad[3 * BLKSIZE_s / 32];              // ... which therefore extends into this; after the energies: fs[b][0..128] = fes
 };
+static_assert(offsetof(PsyALds, fs_pad) == offsetof(PsyALds, fs) + sizeof(float) * 3 * BLKSIZE_s, "the short transform buffer is one flat padded array");
 #define PSYA_FE(L) ((L).fz)
 #define PSYA_FES(L, b) ((L).fs[b])
 #define PSYA_EB(L) ((L).fz + 516)
@@ -240,7 +260,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         for (int i = lane; i < FHT_STRIDE; i += LHIP_NL) {
             const double l = fl[i], r = fl[FHT_STRIDE + i];
             const float v = (ch == 2) ? (float)((l + r) * LHIP_SQRT2 * 0.5) : (float)((l - r) * LHIP_SQRT2 * 0.5);
-            if (i < BLKSIZE) L.fz[i] = v; else (&L.fs[0][0])[i - BLKSIZE] = v;
+            if (i < BLKSIZE) L.fz[fzp(i)] = v; else (&L.fs[0][0])[fzp(i - BLKSIZE)] = v;
         }
         wave_sync();
     } else {
@@ -249,7 +269,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         const int b = it / (BLKSIZE_s / 8), j = it - b * (BLKSIZE_s / 8);
         const int k = (576 / 3) * (b + 1);
         const int i = T.fft_rv_tbl[j << 2] & 0xff;
-        float* x = L.fs[b] + 4 * j;
+        float* x = &L.fs[0][0] + fzp(b * BLKSIZE_s + 4 * j);        // padded layout: x[0..3] stay together, the second group sits 128 + 4 words on
         double f0, f1, f2, f3, w;
         f0 = (double)T.window_s[i] * (double)buf(i + k);
         w = (double)T.window_s[0x7f - i] * (double)buf(i + k + 0x80);
@@ -264,8 +284,8 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         f2 = (double)T.window_s[i + 0x41] * (double)buf(i + k + 0x41);
         w = (double)T.window_s[0x3e - i] * (double)buf(i + k + 0xc1);
         f3 = f2 - w; f2 = f2 + w;
-        x[BLKSIZE_s / 2 + 0] = (float)(f0 + f2); x[BLKSIZE_s / 2 + 2] = (float)(f0 - f2);
-        x[BLKSIZE_s / 2 + 1] = (float)(f1 + f3); x[BLKSIZE_s / 2 + 3] = (float)(f1 - f3);
+        x[fzo(BLKSIZE_s / 2) + 0] = (float)(f0 + f2); x[fzo(BLKSIZE_s / 2) + 2] = (float)(f0 - f2);
+        x[fzo(BLKSIZE_s / 2) + 1] = (float)(f1 + f3); x[fzo(BLKSIZE_s / 2) + 3] = (float)(f1 - f3);
     }
     {   // long window, in place: all samples of the lane's items first, then -- after everybody has read -- the butterflies
         enum { KL = (BLKSIZE / 8 + LHIP_NL - 1) / LHIP_NL };
@@ -285,7 +305,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             const int jj = lane + LHIP_NL * u;
             if (jj < BLKSIZE / 8) {
                 const int i = T.fft_rv_tbl[jj] & 0xff;
-                float* x = L.fz + 4 * jj;
+                float* x = L.fz + fzp(4 * jj);
                 double f0, f1, f2, f3, w;
                 f0 = (double)T.window[i] * (double)xin[u][0];
                 w = (double)T.window[i + 0x200] * (double)xin[u][1];
@@ -300,8 +320,8 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
                 f2 = (double)T.window[i + 0x101] * (double)xin[u][6];
                 w = (double)T.window[i + 0x301] * (double)xin[u][7];
                 f3 = f2 - w; f2 = f2 + w;
-                x[BLKSIZE / 2 + 0] = (float)(f0 + f2); x[BLKSIZE / 2 + 2] = (float)(f0 - f2);
-                x[BLKSIZE / 2 + 1] = (float)(f1 + f3); x[BLKSIZE / 2 + 3] = (float)(f1 - f3);
+                x[fzo(BLKSIZE / 2) + 0] = (float)(f0 + f2); x[fzo(BLKSIZE / 2) + 2] = (float)(f0 - f2);
+                x[fzo(BLKSIZE / 2) + 1] = (float)(f1 + f3); x[fzo(BLKSIZE / 2) + 3] = (float)(f1 - f3);
             }
         }
     }
@@ -321,7 +341,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     if (Cp == 4) {                                    // joint stereo: the spectra the mid / side waves combine
         float* fo = W.fht + ((int64_t)gslot * 2 + ch) * FHT_STRIDE;
-        for (int i = lane; i < FHT_STRIDE; i += LHIP_NL) fo[i] = (i < BLKSIZE) ? L.fz[i] : (&L.fs[0][0])[i - BLKSIZE];
+        for (int i = lane; i < FHT_STRIDE; i += LHIP_NL) fo[i] = (i < BLKSIZE) ? L.fz[fzp(i)] : (&L.fs[0][0])[fzp(i - BLKSIZE)];
     }
     }   // ch < 2
 
@@ -335,7 +355,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             const int j = lane + LHIP_NL * u;
             el[u] = 0.f;
             if (j == 0) { const float e0 = L.fz[0]; el[u] = (float)((double)e0 * (double)e0); }
-            else if (j <= BLKSIZE / 2) { const double re = L.fz[j], im = L.fz[BLKSIZE - j]; el[u] = (float)((re * re + im * im) * 0.5); }
+            else if (j <= BLKSIZE / 2) { const double re = L.fz[fzp(j)], im = L.fz[fzp(BLKSIZE - j)]; el[u] = (float)((re * re + im * im) * 0.5); }
         }
 #pragma unroll
         for (int u = 0; u < KS; u++) {
@@ -343,8 +363,9 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             es[u] = 0.f;
             if (it < 3 * (BLKSIZE_s / 2 + 1)) {
                 const int b = it / (BLKSIZE_s / 2 + 1), j = it - b * (BLKSIZE_s / 2 + 1);
-                if (j == 0) { const float e0 = L.fs[b][0]; es[u] = (float)((double)e0 * (double)e0); }
-                else { const double re = L.fs[b][j], im = L.fs[b][BLKSIZE_s - j]; es[u] = (float)((re * re + im * im) * 0.5); }
+                const float* fsf = &L.fs[0][0];
+                if (j == 0) { const float e0 = fsf[fzp(b * BLKSIZE_s)]; es[u] = (float)((double)e0 * (double)e0); }
+                else { const double re = fsf[fzp(b * BLKSIZE_s + j)], im = fsf[fzp(b * BLKSIZE_s + BLKSIZE_s - j)]; es[u] = (float)((re * re + im * im) * 0.5); }
             }
         }
         wave_sync();                                  // every lane has read its operands before anything is overwritten

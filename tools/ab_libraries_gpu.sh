@@ -5,7 +5,8 @@ cd $R
 line() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']
-print('$1', 'step_ms', d['ms_per_step'], 'quant_ms', d['kernels_ms']['quant']['ms'], 'validate_ms', d['kernels_ms']['validate']['ms'], 'repaired', c['seed_repaired_frames'], 'bit_exact_full', c['bit_exact_full'])"; }
+k=d['kernels_ms']
+print('$1', 'step_ms', d['ms_per_step'], 'quant_ms', k['quant']['ms'], 'psyA_ms', k['psyA']['ms'], 'psyB_ms', k['psyB']['ms'], 'poly+mdct_ms', round(k['polyphase']['ms'] + k['mdct']['ms'], 4), 'validate_ms', k['validate']['ms'], 'bits_ms', k['bits']['ms'], 'repaired', c['seed_repaired_frames'], 'bit_exact_full', c['bit_exact_full'])"; }
 B="python bench.py --no-extras --cpu-seconds 0 --steps 6 --warmup 1 --check-frames 0"
 {
 for rep in 1 2; do
