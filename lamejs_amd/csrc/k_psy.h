@@ -796,10 +796,19 @@ LHIP_DEV void kb_scan_ath(const Tables& T, const Workspace& W, const StreamDesc*
 // NCH = psy channels the instantiation can hold: 2 (mono / stereo), or 4 for joint stereo (L, R, mid, side) -- a separate kernel so that
 // the usual configurations keep their 3.5 KB of LDS per wave
 struct PsyBTabs { double mt1[25], mt2[10], mt3[14], mtab[9]; };     // mask_add tables: looked up inside a serially dependent chain
+// The long-block spreading is a chain per partition (lane) whose every step needs three operands of ANOTHER partition k -- its energy times
+// its tonality factor, its ATH share -- and one entry of the lane's own spreading row.  Fetched from global memory inside the chain (one step
+// ahead) they left the wave in s_waitcnt for 70 % of its cycles: a step computes for ~150 cycles, a load from L2 takes several hundred.  They are
+// staged in LDS before the chains start: ebm[k] = eb_l[k] * mtab[mask_idx[k]] and athc[k] = ATH_cb_l[k] * ATH.adjust (the products the chain
+// formed at every use: same operands, same operation) and the spreading rows s3_ll, which overlay the arrays only the later phases use.
+enum { PSYB_S3_LDS = 1024 };
 template <int NCH> struct PsyBLdsT : PsyBTabs {
+    double ebm[CBANDS], athc[CBANDS];
     float thr_l[NCH][CBANDS + 2];
-    float thr_s[NCH][3][CBANDS + 2];
-    float E[NCH][E_STRIDE];
+    union {
+        struct { float thr_s[NCH][3][CBANDS + 2]; float E[NCH][E_STRIDE]; };     // short limiting onwards
+        float s3[PSYB_S3_LDS];                                                   // long spreading: T.s3_ll
+    };
 };
 typedef PsyBLdsT<2> PsyBLds;
 typedef PsyBLdsT<4> PsyBLds4;
@@ -894,23 +903,21 @@ template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, c
     }
     wave_sync();
 
+    for (int i = lane; i < T.n_s3_ll; i += LHIP_NL) L.s3[i] = T.s3_ll[i];
+    LHIP_LANE_ONCE(k, 0, T.npart_l) L.athc[k] = (double)T.ATH_cb_l[k] * ath_adjust;
     for (int ch = 0; ch < Cp; ch++) {
         const int64_t o = (int64_t)gslot * Cp + ch;
         const float* eb_l = W.eb_l + o * EBL_STRIDE;
         const int32_t* midx = W.mask_idx + o * EBL_STRIDE;
+        LHIP_LANE_ONCE(k, 0, T.npart_l) L.ebm[k] = (double)eb_l[k] * L.mtab[midx[k]];
+        wave_sync();
         // long-block spreading with additive masking (PsyModel.js:1274-1320); thr = ecb (pcfact == 0)
-        // The additive-masking chain is serial in the partition's spreading row; the operands of step u + 1 are
-        // fetched while step u is evaluated (one mask_add instance, software-pipelined loads).
+        // The additive-masking chain is serial in the partition's spreading row; all of its operands are in LDS (see PsyBLdsT).
         LHIP_LANE_ONCE(b, 0, T.npart_l) {                        // npart_l < CBANDS = 64
             const int k0 = T.s3ind[2 * b], k1 = T.s3ind[2 * b + 1], j0 = T.s3off_l[b];
-            double ecb = (double)T.s3_ll[j0] * ((double)eb_l[k0] * L.mtab[midx[k0]]);
-            double tn = 0.0, an = 0.0;
-            if (k0 + 1 <= k1) { tn = (double)T.s3_ll[j0 + 1] * ((double)eb_l[k0 + 1] * L.mtab[midx[k0 + 1]]); an = (double)T.ATH_cb_l[k0 + 1] * ath_adjust; }
-            for (int kk = k0 + 1; kk <= k1; kk++) {
-                const double tc = tn, acur = an;
-                if (kk + 1 <= k1) { tn = (double)T.s3_ll[j0 + (kk + 1 - k0)] * ((double)eb_l[kk + 1] * L.mtab[midx[kk + 1]]); an = (double)T.ATH_cb_l[kk + 1] * ath_adjust; }
-                ecb = mask_add_l(T, L, acur, ecb, tc, kk - b);
-            }
+            double ecb = (double)L.s3[j0] * L.ebm[k0];
+            for (int kk = k0 + 1; kk <= k1; kk++)
+                ecb = mask_add_l(T, L, L.athc[kk], ecb, (double)L.s3[j0 + (kk - k0)] * L.ebm[kk], kk - b);
             ecb *= 0.158489319246111;
             float thr = (float)ecb;
             if (!T.disable_reservoir) {   // long-block pre-echo control (PsyModel.js:1300-1318): dead with the reservoir disabled (pcfact == 0)
@@ -924,6 +931,11 @@ template <int NCH> LHIP_DEV void kb_psyB(const Tables& T, const PowBase& pb10, c
             }
             L.thr_l[ch][b] = thr;
         }
+        wave_sync();                                  // the next channel refills ebm
+    }
+    // (the spreading rows are dead: their LDS is thr_s / E from here on)
+    for (int ch = 0; ch < Cp; ch++) {
+        const int64_t o = (int64_t)gslot * Cp + ch;
         // short-block limiting by the two previous sub-blocks (compute_masking_s, 762-775)
         const int pshort = W.prev_short[(int64_t)gslot * C + (ch & 1)];      // blocktype_old[chn & 1] (PsyModel.js:767)
         for (int it = lane; it < 3 * T.npart_s; it += LHIP_NL) {

@@ -884,6 +884,8 @@ static bool build_tables(TableSet& ts, const void* blob, size_t nbytes, const lh
     int k = 0, j = 0;
     for (int p = 0; p < T.npart_l; p++) { extra[p] = k; k += h_s3ind[2 * p + 1] - h_s3ind[2 * p] + 1; extra[2 * CBANDS + p] = j; j += h_nl[p]; }
     if (j != HBLKSIZE) { set_err("long partitions do not cover 513 lines"); return false; }
+    T.n_s3_ll = k;
+    if (k > PSYB_S3_LDS) { set_err("configuration outside the supported envelope (spreading table larger than g_psyB's LDS copy)"); return false; }
     k = 0; j = 0;
     for (int p = 0; p < T.npart_s; p++) { extra[CBANDS + p] = k; k += h_s3ind_s[2 * p + 1] - h_s3ind_s[2 * p] + 1; extra[3 * CBANDS + p] = j; j += h_ns[p]; }
     if (j != HBLKSIZE_s) { set_err("short partitions do not cover 129 lines"); return false; }

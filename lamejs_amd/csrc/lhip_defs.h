@@ -83,6 +83,8 @@ struct Tables {
         use_best_huffman, full_outer_loop, substep_shaping, sfb21_extra, quant_comp, quant_comp_short,
         short_blocks_coupled, useTemporal, ATH_useAdjust, athaa_loudapprox, copyright, original, emphasis,
         extension, error_protection, npart_l, npart_s, n_version_bytes,
+        n_s3_ll,                            // entries of s3_ll (the long-block spreading rows back to back): g_psyB stages them in LDS
+       
         in_samplerate, rs_filter_l, rs_bpc,
         rs_ratio,                           // integer decimation factor (1 = no resampling), derived at create time
         psy_channels,                       // channels the psychoacoustic model analyses: channels_out, or 4 (L, R, mid, side) in joint stereo (mode == 1)
