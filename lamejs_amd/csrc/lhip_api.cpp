@@ -356,14 +356,17 @@ enum { RS_PSYB0, RS_PSYB1, RS_QUANT, RS_STAGES, RS_WAVES = 4,
        RS_LDS_PER_WAVE = ((sizeof(QuantLds) > sizeof(PsyBLds4) ? (sizeof(QuantLds) > sizeof(BitsLds) ? sizeof(QuantLds) : sizeof(BitsLds))
                                                                 : (sizeof(PsyBLds4) > sizeof(BitsLds) ? sizeof(PsyBLds4) : sizeof(BitsLds))) + 15) & ~15 };
 // stage `stage` of frame k (of F) of stream st for wave wv; k == F: only the tail (bit packing of the last frame)
+// cshare (device, wave simulation): the count helpers' records -- while a frame is quantized the psyB and the bit-packing wave have nothing to do
+// and take the Huffman counts of waves 0 / 1 (q_count_helper, k_quant.h)
 template <int PAIRQ>
 LHIP_DEV void kb_resv_stage(int stage, const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, int st, int k, int F,
-                            int wv, int lane, unsigned char* lds, QuantTabs& Q, int* mbox, ResvState& RV, int32_t* nout) {
+                            int wv, int lane, unsigned char* lds, QuantTabs& Q, int* mbox, ResvState& RV, int32_t* nout, CountShare* cshare = nullptr) {
     const int C = T.channels_out, GR = T.mode_gr;
     const StreamDesc sd = SD[st];
     const int g1 = sd.gslot0 + 1 + GR * k, fslot = sd.fslot0 + 1 + k, fidx = sd.out_slot0 + k;
     switch (stage) {
         case RS_PSYB0:
+            if (cshare && wv < 2 && lane == 0) cshare[wv].state = CS_IDLE;      // (the helpers look at it two barriers from here)
             if (wv == 2 && k < F) {       // the reservoir as frame k - 1 left it: decided by that frame's quantization (the packer may still be committing it)
                 const int rs = k == 0 ? RV.ResvSize : W.fr[fidx - 1].ResvSize, rm = k == 0 ? RV.ResvMax : W.fr[fidx - 1].ResvMax;
                 kb_psyB<4>(T, pb, W, SD, g1, lane, *(PsyBLds4*)lds, -1, rs, rm);
@@ -379,9 +382,15 @@ LHIP_DEV void kb_resv_stage(int stage, const Tables& T, const PowBase& pb, const
         case RS_QUANT:
             if (k >= F) break;
             if (PAIRQ && C == 2) {
-                if (wv < 2) kb_quant<1, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, wv, mbox, &RV);
+                if (wv < 2) { kb_quant<1, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, wv, mbox, &RV, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
+#if LHIP_NL != 1
+                else if (cshare) q_count_helper(T, cshare[wv - 2], *(const QuantLds*)(lds - 2 * RS_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
+#endif
                 else for (int gr = 0; gr < GR; gr++) wg_barrier();
-            } else if (wv == 0) kb_quant<0, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, -1, nullptr, &RV);
+            } else if (wv == 0) { kb_quant<0, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, -1, nullptr, &RV, nullptr, PAIRQ ? cshare : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
+#if LHIP_NL != 1
+            else if (PAIRQ && cshare && wv == 2) q_count_helper(T, cshare[0], *(const QuantLds*)(lds - 2 * RS_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
+#endif
             break;
         default: break;
     }
@@ -623,6 +632,10 @@ __global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W, const 
     __shared__ BitsLds L;
     if (SD[blockIdx.x].flush) kb_resv_flush(T, W, blockIdx.x, threadIdx.x, L, W.io[blockIdx.x].state->rv, W.out_bytes + blockIdx.x);
 }
+#ifndef LHIP_FRAME_PIPE
+#define LHIP_FRAME_PIPE 1      /* 0: the Huffman counts of the outer loop on the searching wave itself (A/B builds) */
+#endif
+static constexpr bool g_frame_pipe = LHIP_FRAME_PIPE != 0;
 // the per-stream reservoir program (kb_resv_stage): one workgroup of RS_WAVES waves per stream
 // (two waves per SIMD: 256 registers instead of the 264 an unbounded build takes -- the second workgroup per CU is what lets 512 streams
 //  run side by side; the mode's throughput is streams in flight x one frame per 184 us)
@@ -632,6 +645,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     __shared__ ResvState RV;
     __shared__ int mbox[4];
     __shared__ int32_t nout;
+    __shared__ CountShare CS[2];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, st = blockIdx.x;
     q_copy_tabs(A->T, Q, threadIdx.x, 64 * RS_WAVES);
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     const int F = __builtin_amdgcn_readfirstlane(A->SD[st].nframes);
     for (int k = 0; k <= F; k++)
         for (int stage = 0; stage < RS_STAGES; stage++) {
-            kb_resv_stage<1>(stage, A->T, A->pb, A->W, A->SD, st, k, F, wv, lane, U[wv], Q, mbox, RV, &nout);
+            kb_resv_stage<1>(stage, A->T, A->pb, A->W, A->SD, st, k, F, wv, lane, U[wv], Q, mbox, RV, &nout, g_frame_pipe ? CS : nullptr);
             __syncthreads();
         }
     if (wv == 3 && A->SD[st].flush) kb_resv_flush(A->T, A->W, st, lane, *(BitsLds*)U[3], RV, &nout);
@@ -652,10 +666,6 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     if (threadIdx.x == 0) A->W.out_bytes[st] = nout;
 }
 // one workgroup of FR_WAVES waves per stream, one frame per stream (see kb_frame_stage)
-#ifndef LHIP_FRAME_PIPE
-#define LHIP_FRAME_PIPE 1      /* 0: the Huffman counts of the outer loop on the searching wave itself (A/B builds) */
-#endif
-static constexpr bool g_frame_pipe = LHIP_FRAME_PIPE != 0;
 template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QArgs a_unused, const StreamIO* IO) {
     __shared__ QuantTabs Q;
     __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
@@ -1377,7 +1387,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         for (int b = 0; b < ngs; b++) WAVE_RUN(kb_mdct(T, W, dSD, b, lane_, LM));
         if (resv) {
             // the per-stream reservoir program (kb_resv_stage), as g_resv_stream runs it; the wave simulation as a real workgroup of four waves
-            alignas(16) static thread_local unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static thread_local int rmbox[4];
+            alignas(16) static thread_local unsigned char RU[RS_WAVES][RS_LDS_PER_WAVE]; static thread_local int rmbox[4]; static thread_local CountShare rcs[2];
             for (int s = 0; s < S; s++) {
                 ResvState RV = dIO[s].state->rv;
                 int32_t nout = 0;
@@ -1385,7 +1395,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #ifdef LHIP_WAVESIM
                 wsim::run_block(RS_WAVES, [&](int wave_, int lane_) {
                     for (int k = 0; k <= F; k++)
-                        for (int stage = 0; stage < RS_STAGES; stage++) { kb_resv_stage<1>(stage, T, ts.pb10, W, dSD, s, k, F, wave_, lane_, RU[wave_], QT, rmbox, RV, &nout); wg_barrier(); }
+                        for (int stage = 0; stage < RS_STAGES; stage++) { kb_resv_stage<1>(stage, T, ts.pb10, W, dSD, s, k, F, wave_, lane_, RU[wave_], QT, rmbox, RV, &nout, rcs); wg_barrier(); }
                     if (wave_ == 3 && sd[s].flush) kb_resv_flush(T, W, s, lane_, *(BitsLds*)RU[3], RV, &nout);
                 });
 #else
