@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     const int F = __builtin_amdgcn_readfirstlane(A->SD[st].nframes);
     for (int k = 0; k <= F; k++)
         for (int stage = 0; stage < RS_STAGES; stage++) {
-            kb_resv_stage<1>(stage, A->T, A->pb, A->W, A->SD, st, k, F, wv, lane, U[wv], Q, mbox, RV, &nout, g_frame_pipe ? CS : nullptr);
+            kb_resv_stage<1>(stage, A->T, A->pb, A->W, A->SD, st, k, F, wv, lane, U[wv], Q, mbox, RV, &nout, (g_frame_pipe && A->ctr) ? CS : nullptr);     // A->ctr: the host's verdict on count helpers (run_batch)
             __syncthreads();
         }
     if (wv == 3 && A->SD[st].flush) kb_resv_flush(A->T, A->W, st, lane, *(BitsLds*)U[3], RV, &nout);
@@ -1516,7 +1516,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     if (forked) { HIPCK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ws.ev_join, 0)); aux_guard.aux = nullptr; }
     if (resv) {
         // bit reservoir: psyB -> quantization -> bit packing of a stream's frames are a serial chain: one workgroup per stream walks them
-        QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 2; qa.nfs = nfs; qa.ctr = 0;
+        // (qa.ctr = 1: the idle waves of a workgroup count for the quantizing ones -- only while every workgroup has a CU to itself: with two
+        //  per CU a helper shares its SIMD with the other workgroup's searching wave and the speculative work costs more than it hides --
+        //  512 streams: 2.37 M frames/s without helpers, 2.21 M with, profiles/r05_pass4_* / r05_pass5_*)
+        QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 2; qa.nfs = nfs; qa.ctr = S <= ctx->num_cus ? 1 : 0;
         LAUNCHB(KT_QUANT, g_resv_stream, S, 64 * RS_WAVES, st, qa);
     } else {
     if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, -1);

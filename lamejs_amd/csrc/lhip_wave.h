@@ -399,9 +399,9 @@ LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wa
 LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
 LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
 #ifndef LHIP_SPIN_SLEEP
-#define LHIP_SPIN_SLEEP 0
+#define LHIP_SPIN_SLEEP 2
 #endif
-LHIP_DEV void wg_spin() { if (LHIP_SPIN_SLEEP) __builtin_amdgcn_s_sleep(LHIP_SPIN_SLEEP); }     // polls that sit on a frame's critical path (the count helper's hand-overs): no pause between looks (wg_idle: 512 clocks)
+LHIP_DEV void wg_spin() { if (LHIP_SPIN_SLEEP) __builtin_amdgcn_s_sleep(LHIP_SPIN_SLEEP); }     // polls that sit on a frame's critical path (the count helper's hand-overs): 128 clocks between looks (wg_idle: 512) -- a helper that spins without a pause takes issue slots from another workgroup's searching wave on the same SIMD (bit reservoir, 512 streams: -11 %, profiles/r05_pass4_*)
 LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #endif
 // Spin until the word is neither a nor b; returns what it is then.  For hand-overs on a frame's critical path (the count helper): nothing in
