@@ -1084,6 +1084,7 @@ struct Context {
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     WorkSet ws;
     int num_cus = 256;
+    int fixup_wg_per_cu = 0;    // resident g_fixup workgroups per CU (occupancy query at the first cooperative launch)
     // large host-buffer calls (the drop-in's encodeBuffer with a long Int16Array): chunks of the call are copied in on this stream
     // while the chunk before is being encoded and the one before that is copied out (encode_host_chunked)
     void* copy_stream = nullptr; void* ev_in[2] = {nullptr, nullptr}; void* ev_done[2] = {nullptr, nullptr};
@@ -1160,7 +1161,9 @@ static_assert(FX_STATS_OFF == FX_STATS * 4, "counter block layout");
 #else
 static inline bool g_kt_on_() { return false; }
 #endif
-static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync) {
+// fx_dst (device, optional): where this batch's repair verdict (three words: repaired frames, iterations, "did not converge") is copied on the launch
+// stream while ctx->mu is still held -- the chunked host path logs one per unit, and another thread's batch on the same device must not get in between
+static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool want_sync, int32_t* fx_dst = nullptr) {
     if (jobs.empty()) return true;
 #ifdef LHIP_PHASE_PROF
     auto cp_t_ = std::chrono::steady_clock::now();
@@ -1421,7 +1424,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
 #if defined(LHIP_WAVESIM)
         if (!pair) {   // the persistent kernel as a real 8-wave workgroup: frames drawn from a shared counter (kb_quant_th, what g_quant runs for one- and
                         // two-channel streams alike), then -- two channels -- the waves help each other (k_quant_tail.h)
-            static QuantLds LQ8[8]; static TailShare TS;
+            static thread_local QuantLds LQ8[8]; static thread_local TailShare TS;
             int ctr = 0;
             TS.drawing = 8; for (int w = 0; w < 8; w++) TS.offer[w].state = 0;
             wsim::run_block(8, [&](int wave_, int lane_) {
@@ -1545,7 +1548,12 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         // as many workgroups as can be resident (two per CU): the memo-miss re-validation (a quarter to a third of the frames of steady
         // material) is spread over all of them -- a quarter-chip grid was tried and doubled this stage's time
         int fgrid = (nfs + 63) / 64;
-        if (fgrid > ctx->num_cus * (LHIP_FIXUP_OCC / 2)) fgrid = ctx->num_cus * (LHIP_FIXUP_OCC / 2);
+        if (ctx->fixup_wg_per_cu == 0) {      // once per context: how many of this build's g_fixup workgroups a CU really holds (a grid barrier needs them all resident)
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)g_fixup, 64 * QWAVES, 0) != hipSuccess || nb < 1) nb = 1;
+            ctx->fixup_wg_per_cu = nb < LHIP_FIXUP_OCC / 2 ? nb : LHIP_FIXUP_OCC / 2;
+        }
+        if (fgrid > ctx->num_cus * ctx->fixup_wg_per_cu) fgrid = ctx->num_cus * ctx->fixup_wg_per_cu;
         if (fgrid < 1) fgrid = 1;
         if (fgrid == 1) LAUNCHB(KT_VALIDATE, g_fixup, 1, 64 * QWAVES, st, qa);
         else {
@@ -1567,6 +1575,10 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
     // when somebody asks (lhip_last_batch_stats)
     int32_t fx[3] = {0, 0, 0};
     const bool fetch_fx = nfr > 0 && (!dev_io || want_sync || g_kt_on_());
+    if (fx_dst) {
+        if (nfr > 0) { if (!rt::d2d(fx_dst, (const uint8_t*)W.nflagged + FX_STATS_OFF, 12, st)) return false; }
+        else if (!rt::dzero(fx_dst, 12, st)) return false;
+    }
     // ---- outputs ----
     if (small) {
         // one copy out: [output bytes | counters | out_bytes], then the callers' buffers are filled from the pinned mirror
@@ -1898,16 +1910,13 @@ static int encode_host_pipelined(Context* ctx, const std::vector<lhip_stream*>& 
         }
         if (!rt::event_record(ctx->ev_in[par], cs) || !rt::stream_wait_event(ks, ctx->ev_in[par])) return fail(nullptr);
         const double t_b = trace_chunks ? ms_now() : 0.0;
-        if (!run_batch(ctx, jobs, true, false)) { int64_t code = LHIP_ERR_INTERNAL; for (const Job& j : jobs) if (j.written < 0) { code = j.written; break; } return fail(nullptr, code); }
+        // (this unit's repair verdict stays on the device until the call ends: run_batch copies it into the call's log -- stream-ordered, under the context's
+        //  lock -- and the log is read back once after the last unit)
+        if (!run_batch(ctx, jobs, true, false, (int32_t*)ctx->chunk_fx.p + 4 * k)) { int64_t code = LHIP_ERR_INTERNAL; for (const Job& j : jobs) if (j.written < 0) { code = j.written; break; } return fail(nullptr, code); }
 #ifdef LHIP_HOSTSIM
         // tests: a failure injected after unit k has been consumed (the streams must come back as the call found them)
         if (const char* e = getenv("LHIP_HOSTSIM_FAIL_CHUNK")) if (e[0] && (size_t)atoi(e) == k) return fail("injected failure (LHIP_HOSTSIM_FAIL_CHUNK)");
         repaired_all += g_stat_repaired; iters_all += g_stat_iters;
-#else
-        // this unit's repair verdict (g_fixup: repaired frames, iterations, "did not converge") stays on the device until the call ends:
-        // a stream-ordered copy into the call's log, read back once after the last unit
-        if (g_stat_frames > 0 && !rt::d2d((int32_t*)ctx->chunk_fx.p + 4 * k, (const int32_t*)ctx->ws.nflagged.p + FX_STATS, 12, ks)) return fail(nullptr);
-        if (g_stat_frames == 0 && !rt::dzero((int32_t*)ctx->chunk_fx.p + 4 * k, 12, ks)) return fail(nullptr);
 #endif
         if (!rt::event_record(ctx->ev_done[par], ks)) return fail(nullptr);
         const double t_c = trace_chunks ? ms_now() : 0.0;

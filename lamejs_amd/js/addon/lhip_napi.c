@@ -121,6 +121,16 @@ static napi_value encode_into_new_array(napi_env env, lhip_stream* s, const int1
     static uint8_t none[16];
     const int64_t want = p_out_bytes(s, nl);
     const size_t cap = want > 0 ? (size_t)want : 0;
+    if (cap > 0 && cap == p_max_out(s, nl)) {
+        /* the count is an upper bound, not the count (bit-reservoir extension): encode into scratch memory and hand out an exact copy -- a
+         * zero-filled ArrayBuffer of the bound per call would be allocated only to be thrown away */
+        uint8_t* tmp = (uint8_t*)malloc(cap);
+        if (!tmp) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+        const int64_t m = p_encode(s, dl, dr, nl, tmp, cap);
+        napi_value r = make_i8(env, tmp, m > 0 ? (size_t)m : 0);
+        free(tmp);
+        return r;
+    }
     napi_value ab, ta; void* data = NULL;
     if (napi_create_arraybuffer(env, cap, &data, &ab) != napi_ok || (cap && !data)) { napi_throw_error(env, NULL, "could not allocate the output buffer"); return NULL; }
     const int64_t n = p_encode(s, dl, dr, nl, cap ? (uint8_t*)data : none, cap);
@@ -204,6 +214,11 @@ static napi_value batch_common(napi_env env, napi_callback_info info, int is_flu
             const int64_t want = p_out_bytes(hs[i], ns[i]);
             void* data = NULL;
             caps[i] = want > 0 ? (size_t)want : 0;
+            if (caps[i] > 0 && caps[i] == p_max_out(hs[i], ns[i])) {      /* an upper bound only (bit reservoir): scratch memory, exact copy afterwards */
+                outs[i] = (uint8_t*)malloc(caps[i]);
+                if (!outs[i]) { err = "out of memory"; break; }
+                continue;
+            }
             if (napi_create_arraybuffer(env, caps[i], &data, &abs_[i]) != napi_ok || (caps[i] && !data)) { err = "could not allocate an output buffer"; break; }
             outs[i] = caps[i] ? (uint8_t*)data : none;
         }
@@ -214,10 +229,10 @@ static napi_value batch_common(napi_env env, napi_callback_info info, int is_flu
     }
     if (!err) for (uint32_t i = 0; i < n; i++) {
         napi_value ta;
-        if (!is_flush && wr[i] == (int64_t)caps[i] && napi_create_typedarray(env, napi_int8_array, caps[i], abs_[i], 0, &ta) == napi_ok) napi_set_element(env, result, i, ta);
+        if (!is_flush && abs_[i] && wr[i] == (int64_t)caps[i] && napi_create_typedarray(env, napi_int8_array, caps[i], abs_[i], 0, &ta) == napi_ok) napi_set_element(env, result, i, ta);
         else napi_set_element(env, result, i, make_i8(env, outs[i], wr[i] > 0 ? (size_t)wr[i] : 0));
     }
-    if (is_flush) for (uint32_t i = 0; i < n; i++) free(outs[i]);
+    for (uint32_t i = 0; i < n; i++) if (outs[i] && outs[i] != none && (is_flush || !abs_[i])) free(outs[i]);      /* scratch buffers (flush; bit-reservoir streams) */
     free(hs); free(L); free(R); free(ns); free(caps); free(outs); free(wr); free(abs_);
     if (err) { napi_throw_error(env, NULL, err); return NULL; }
     return result;

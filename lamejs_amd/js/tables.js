@@ -651,10 +651,21 @@ function buildBlob(channels, samplerate, kbps, opts) {
     /* ancillary "version" bytes as the reference emits them: string chars coerced by >> (BitStream.js:180-204) */
     push('version_bytes', I(C.lame_short_version.split('').map(ch => (ch >> 0) & 0xff)));
     huffmanEntries().forEach(e => entries.push(e));
+    /* what the blob was generated FROM: the first 8 bytes of sha256(tables.js ++ constants.json) -- a cached blob is stale when its generator
+     * has changed, whatever the files' modification times say after a checkout (lamejs_amd/__init__.py tables_blob, __graft_entry__.py) */
+    push('src_sha256_64', sourceHash());
     return { blob: packBlob(entries), params: p, tables: T };
 }
 
-module.exports = { buildBlob, resolveParams, buildTables, packBlob };
+function sourceHash() {
+    const fs = require('fs'), path = require('path');
+    const h = require('crypto').createHash('sha256');
+    h.update(fs.readFileSync(__filename)); h.update(fs.readFileSync(path.join(__dirname, 'constants.json')));
+    const d = h.digest();
+    return Int32Array.from([d.readInt32LE(0), d.readInt32LE(4)]);
+}
+
+module.exports = { buildBlob, resolveParams, buildTables, packBlob, sourceHash };
 
 if (require.main === module) {
     /* CLI: node tables.js <channels> <samplerate> <kbps> <out.bin> [joint] [reservoir] */
