@@ -2478,7 +2478,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
 template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
                        int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr,
-                       int* hint = nullptr, CountShare* cs = nullptr) {
+                       int* hint = nullptr, CountShare* cs = nullptr, const int* later_granules_ready = nullptr) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -2550,6 +2550,9 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
     q_ath_pseudo(T, pb10, ath_adjust, lane, L, Q);          // the frame's analog-silence thresholds, both block kinds
     for (int gr = 0; gr < T.mode_gr; gr++) {
         const int gslot = sd.gslot0 + 1 + T.mode_gr * k + gr;
+        // one-frame launch: the thresholds granule 1 quantizes against (psyB of granule 0) are computed by other waves WHILE granule 0 is
+        // quantized; a one-channel frame has no workgroup barrier between its granules to order that, so it waits for their flag here
+        if (gr > 0 && later_granules_ready) { (void)wg_wait_not(later_granules_ready, 0, 0, lane); wg_acquire(); }
         int targ[2] = {0, 0};
         const double max_bits = resv ? q_on_pe_resv(T, pe_use[gr], targ, mean_bits, gr, ResvSize, ResvMax) : (double)targ_bits_for(T, mean_bits, gr, ResvSize, targ);
         if (mode_ext == 2) {

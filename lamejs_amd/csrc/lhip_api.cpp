@@ -294,6 +294,7 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
     const int g1 = sd.gslot0 + 1, fslot = sd.fslot0 + 1;
     ResvState* rv = RESV ? &IO[st].state->rv : nullptr;       // one-frame launches work on the record in global memory
     const int side0 = nw - 2;                                 // the two waves that run the filterbank beside the psychoacoustics
+    const bool psyb_late = !RESV && T.mode != 1;              // psyB beside the quantization of granule 0 (FS_QUANT) instead of in front of it
     switch (stage) {
         case FS_LOAD: kb_load(T, W, SD, IO, st, lane, wv, nw); break;
         case FS_PREP: if (T.rs_ratio != 1) kb_prep_stream(T, W, SD, IO, st, (int64_t)wv * LHIP_NL + lane, (int64_t)nw * LHIP_NL); break;
@@ -314,24 +315,40 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
                 }
             }
             break;
-        case FS_PSYB0_MDCT:   // bit reservoir: the frame's granules one after the other (FS_PSYB1 takes the second); the MDCT needs the block types (scans) and the polyphase output
-            if (has && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
+        case FS_PSYB0_MDCT:   // the MDCT needs the block types (scans) and the polyphase output.  Bit reservoir: psyB here too, the frame's granules one after
+                              // the other (FS_PSYB1 takes the second) -- their thresholds depend on the reservoir; joint stereo: psyB here as well (the frame's M/S
+                              // decision reads granule 0's thresholds before anything is quantized); otherwise psyB runs beside the quantization (psyb_late)
+            if (has && !psyb_late && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
             else if (has && wv >= side0 && wv - side0 < GR) kb_mdct(T, W, SD, g1 + (wv - side0), lane, *(MdctLds*)lds);
+            if (wv == 0 && lane == 0) mbox[3] = 0;                 // "psyB of this frame is done" (FS_QUANT, one-channel frames)
             break;
         case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax); break;
         case FS_QUANT:
             // waves 0 (1): the channel's search; waves 2 (3): its count helper (q_count_helper: the Huffman count of an evaluation while the owner
             // runs calc_noise); the one-lane simulation (PAIRQ == 0) has neither
+            // Without the reservoir (and outside joint stereo) psyB is not on the frame's critical path: granule 0 is quantized against the thresholds the PREVIOUS call left
+            // (the carry slot), granule 1 against psyB(granule 0)'s, and psyB(granule 1)'s are only saved for the next call.  Waves 4 (5) run psyB
+            // while granule 0 is quantized; a two-channel frame's granules are separated by a workgroup barrier anyway (the channels exchange their
+            // bits), a one-channel frame's second granule waits for mbox[3].  The one-lane simulation (PAIRQ == 0, waves one after the other) runs
+            // psyB first.
+            if (!PAIRQ && psyb_late && has && wv == 0) for (int g = 0; g < GR; g++) kb_psyB<4>(T, pb, W, SD, g1 + g, lane, *(PsyBLds4*)lds, -1, 0, 0);
             if (PAIRQ && C == 2) {
                 if (has && wv < 2) { kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
                 else if (has && cshare && wv < 4) q_count_helper(T, cshare[wv - 2], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
-                else for (int gr = 0; gr < GR; gr++) wg_barrier();
-            } else if (has && wv == 0) { kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
+                else {
+                    if (psyb_late && has && wv >= 4 && wv - 4 < GR) kb_psyB<4>(T, pb, W, SD, g1 + (wv - 4), lane, *(PsyBLds4*)lds, -1, 0, 0);
+                    for (int gr = 0; gr < GR; gr++) wg_barrier();
+                }
+            } else if (has && wv == 0) { kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr, (PAIRQ && psyb_late) ? mbox + 3 : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
             else if (PAIRQ && has && cshare && wv == 2) q_count_helper(T, cshare[0], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
+            else if (PAIRQ && psyb_late && has && wv == 4) {           // one-channel frame: both granules' psyB on this wave, then the flag granule 1 waits for
+                for (int g = 0; g < GR; g++) kb_psyB<4>(T, pb, W, SD, g1 + g, lane, *(PsyBLds4*)lds, -1, 0, 0);
+                wg_store(mbox + 3, 1, lane);
+            }
             break;
         case FS_BITS_SAVE:   // the state record's reservoir part belongs to the bit packer, everything else to the save: disjoint words
             if (wv == 0) { if (has) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds, rv, W.out_bytes + st); }
