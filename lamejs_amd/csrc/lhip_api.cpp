@@ -1077,7 +1077,8 @@ struct PinBuf {
         if (!p) { cap = 0; return false; }
         return true;
     }
-    ~PinBuf() { rt::host_free_pinned(p); }
+    // (not freed by a destructor: the contexts live in a process-wide map, so that would run during static destruction, after the HIP runtime --
+    //  and a profiler hooked into it -- has begun to shut down: `rocprofv3 -- python bench.py` ended in a segmentation fault at exit)
 };
 
 // Everything a batch in flight owns: the workspace arrays, the descriptor / host-I/O staging, and the side stream + events of the ATH scan.
