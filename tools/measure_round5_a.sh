@@ -1,6 +1,6 @@
-# DEV TOOL (GPU box): round 4's counter pass -- issue microbenchmark + PMC traffic / instruction counts / mix of configs 3 and 2 -> gpurun_out/r04m/pmc_config{3,2}.json
-# (copied to profiles/r04_pmc_config{3,2}.json, which bench.py's roofline lines read: run BEFORE the final bench pass, tools/measure_round4_b.sh).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04m; mkdir -p $O
+# DEV TOOL (GPU box): round 5's counter pass -- issue microbenchmark + PMC traffic / instruction counts / mix of configs 3 and 2 -> gpurun_out/r05m/pmc_config{3,2}.json
+# (copied to profiles/r05_pmc_config{3,2}.json, which bench.py's roofline lines read: run BEFORE the final bench pass, tools/measure_round5_b.sh).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05m; mkdir -p $O
 cd $R
 timeout 60 tools/_build/ubench_issue $O/ubench_issue.json > $O/ubench_issue.txt 2>&1; tail -3 $O/ubench_issue.txt
 cd /tmp && export TMPDIR=/tmp
