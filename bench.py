@@ -279,6 +279,14 @@ def node_dropin_lines(table):
         e["bit_exact_full"] = None if not want or want[0] is None else bool(want[0] == e["md5"] and want[1] == e["bytes"])
         e["note"] = "own Node process, alone on the GPU; every call returns before the next is made (the reference's API is synchronous)"
         out[nm] = e
+    # the same pattern with the host-side extension { pendingFrames: 64 } (input held back until 64 frames are pending: same byte stream, later calls)
+    for nm, ch_ in (("dropin_node_1152_pending64", 2), ("dropin_node_1152_pending64_mono", 1)):
+        e = run_node(nm, ["calls", str(ch_), "128", "sine", "2000", "3", "64"], 120)
+        if e is None:
+            continue
+        want = calls.get(ch_, (None, None))[:2]
+        e["bit_exact_full"] = None if not want or want[0] is None else bool(want[0] == e["md5"] and want[1] == e["bytes"])
+        out[nm] = e
     e = run_node("dropin_node_1152_batch64", ["callsbatch", "64", "1000", "1000", "3"], 180)
     if e is not None:
         ents = [table.get(("sine", 1, 128, 1000, sd_, False, False)) for sd_ in e["seeds"]]

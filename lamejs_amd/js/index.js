@@ -15,6 +15,11 @@
  * mid/side or left/right), which the reference's own wrapper never selects (index.js:105 hard-codes MPEGMode.STEREO); { reservoir: true }
  * uses the bit reservoir (index.js:108 switches it off).  With the reservoir the frames of a stream are a serial chain -- a launch
  * encodes one frame per stream -- so that mode only uses the GPU well through encodeBatch() over many streams.
+ * Extension for callers that feed 1152 samples per call (every usage the reference documents): { pendingFrames: N } lets the encoder
+ * hold back up to N frames' worth of input and encode them in ONE launch -- a frame alone is one wavefront's serial search (0.2 - 0.8 ms),
+ * sixty-four together take hardly longer.  The BYTE STREAM is the reference's (any chunking of the samples gives the same bytes); only
+ * WHICH call returns which bytes changes: calls return empty arrays until N frames are pending, then all their frames at once, and
+ * flush() returns the rest.  Off by default: without it every call returns exactly the bytes the reference's call returns.
  */
 'use strict';
 const path = require('path');
@@ -32,7 +37,7 @@ function loadAddon() {
  * between streams with identical blobs as well).  Configurations outside the envelope throw in buildBlob and are not cached. */
 const blobCache = new Map();
 function tablesBlob(channels, samplerate, kbps, opts) {
-    const key = [channels, samplerate, kbps, opts && opts.jointStereo ? 1 : 0, opts && opts.reservoir ? 1 : 0].join('|');
+    const key = [channels, samplerate, kbps, opts && opts.jointStereo ? 1 : 0, opts && opts.reservoir ? 1 : 0].join('|');     /* (pendingFrames is host-side only) */
     let blob = blobCache.get(key);
     if (!blob) { blob = tables.buildBlob(channels, samplerate, kbps, opts).blob; blobCache.set(key, blob); }
     return blob;
@@ -49,13 +54,36 @@ function Mp3Encoder(channels, samplerate, kbps, opts) {
     const handle = native.create(blob, channels, samplerate, kbps, defaultDevice);
     Object.defineProperty(this, '_lhip', { value: { handle: handle, channels: channels }, enumerable: false });
 
+    /* { pendingFrames: N }: input held back until N frames' worth has accumulated (see the header comment) */
+    const pendMax = opts && opts.pendingFrames > 1 ? 1152 * (opts.pendingFrames | 0) : 0;
+    let pendL = pendMax ? new Int16Array(pendMax + 1152) : null, pendR = pendMax && channels == 2 ? new Int16Array(pendMax + 1152) : null, pendN = 0;
+    const EMPTY = () => new Int8Array(0);
+    function drain() {
+        if (pendN == 0) return EMPTY();
+        const out = native.encode(handle, pendL.subarray(0, pendN), pendR ? pendR.subarray(0, pendN) : null);
+        pendN = 0;
+        return out;
+    }
     this.encodeBuffer = function (left, right) {
         if (channels == 1) right = null;
         if (!(left instanceof Int16Array)) left = Int16Array.from(left);
         if (right && !(right instanceof Int16Array)) right = Int16Array.from(right);
-        return native.encode(handle, left, right || null);
+        if (!pendMax) return native.encode(handle, left, right || null);
+        if (left.length > pendL.length - pendN) {                /* does not fit beside what is pending: encode that first, then this */
+            const a = drain(), b = left.length >= pendMax ? native.encode(handle, left, right || null) : null;
+            if (b) { const r = new Int8Array(a.length + b.length); r.set(a, 0); r.set(b, a.length); return r; }
+            pendL.set(left, 0); if (pendR) pendR.set(right || left, 0); pendN = left.length;
+            return a;
+        }
+        pendL.set(left, pendN); if (pendR) pendR.set(right || left, pendN); pendN += left.length;
+        return pendN >= pendMax ? drain() : EMPTY();
     };
-    this.flush = function () { return native.flush(handle); };
+    this.flush = function () {
+        if (!pendMax || pendN == 0) return native.flush(handle);
+        const a = drain(), b = native.flush(handle);
+        const r = new Int8Array(a.length + b.length); r.set(a, 0); r.set(b, a.length);
+        return r;
+    };
     /* Extension -- frame-range sharding of ONE stream (include/lamejs_hip.h, lhip_seek ...; DESIGN.md 7): a fresh encoder is put
      * at input sample `samplePos` (a whole number >= 2 of frames) with the seekTailSamples() samples in front of it, encodes a few
      * warm-up frames whose bytes are thrown away, and its getState() at the cut is compared with the getState() of the encoder that

@@ -158,3 +158,30 @@ def test_js_frame_range_shards_hostsim():
 def test_js_frame_range_shards_gpu():
     got = _shard(None, "sine", 2, 128, 300, 8, [100, 200])
     assert got["whole"] == got["pieces"] and got["missed"] == 0 and got["devices_allowed"] >= 1, got
+
+
+def _pending(env_lib, corpus, ch):
+    env = dict(os.environ)
+    if env_lib:
+        env["LAMEJS_HIP_LIB"] = str(env_lib)
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_pending_check.js"), corpus, str(ch), "128", "150"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("pending64", "pending7", "pending5_odd_chunks", "pending3_big_chunks"):
+        assert d[k]["md5"] == d["plain"]["md5"] and d[k]["bytes"] == d["plain"]["bytes"] and d[k]["second_flush_bytes"] == 0, (k, d)
+    assert d["pending64"]["nonempty"] <= 3 < d["plain"]["nonempty"]
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_pending_frames_extension_hostsim():
+    """{ pendingFrames: N } (extension): the 1152-sample call pattern with input held back until N frames are pending -- same byte stream as
+    without it, whatever N and whatever the call sizes; flush() returns the rest and a second flush() nothing."""
+    for corpus, ch in (("bursts", 2), ("sine", 1)):
+        _pending(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", corpus, ch)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_pending_frames_extension_gpu():
+    for corpus, ch in (("bursts", 2), ("sine", 1)):
+        _pending(None, corpus, ch)

@@ -9,7 +9,7 @@
  *       BASELINE configs[4]'s shape through the batch extension: <streams> mono 128 kbps encoders (seeds seed0 ...), ONE
  *       encodeBatch(encoders, lefts) call; the constructors are timed separately (the table blob is built once per configuration).
  *
- *   node bench_dropin.js calls <channels> <kbps> fixture|sine [frames] [reps]
+ *   node bench_dropin.js calls <channels> <kbps> fixture|sine [frames] [reps] [pendingFrames]
  *       THE REFERENCE'S DOCUMENTED CALL PATTERN (README.md:69-74, 103-108; Tests.js:19-33): one Mp3Encoder, 1152 samples per encodeBuffer()
  *       call (left.subarray(i, i + 1152)), every non-empty return collected, flush() at the end.  `fixture`: the reference's own test
  *       material (testdata/Left44100.wav [+ Right44100.wav] = tests/golden/*44100_full.s16, 287 calls; the md5 of the collected bytes is the
@@ -33,7 +33,7 @@ const median = (v) => { const s = v.slice().sort((a, b) => a - b); return s.leng
 
 if (process.argv[2] == 'calls') {
     const fs = require('fs');
-    const [ch, kbps, src, nfrArg, reps] = [+(process.argv[3] || 2), +(process.argv[4] || 128), process.argv[5] || 'fixture', +(process.argv[6] || 2000), +(process.argv[7] || 3)];
+    const [ch, kbps, src, nfrArg, reps, pending] = [+(process.argv[3] || 2), +(process.argv[4] || 128), process.argv[5] || 'fixture', +(process.argv[6] || 2000), +(process.argv[7] || 3), +(process.argv[8] || 0)];
     let L, R = null;
     if (src == 'fixture') {
         const rd = (f) => { const b = fs.readFileSync(path.join(__dirname, '..', 'golden', f)); return new Int16Array(b.buffer, b.byteOffset, b.length >> 1); };
@@ -41,7 +41,7 @@ if (process.argv[2] == 'calls') {
     } else [L, R] = gen.sine(1152 * nfrArg, ch, 12345);
     const ncalls = Math.ceil(L.length / 1152);
     const run = () => {
-        const enc = new lamejs.Mp3Encoder(ch, 44100, kbps);
+        const enc = pending > 1 ? new lamejs.Mp3Encoder(ch, 44100, kbps, { pendingFrames: pending }) : new lamejs.Mp3Encoder(ch, 44100, kbps);
         const parts = [], per = new Float64Array(ncalls);
         const t0 = now();
         for (let i = 0, c = 0; i < L.length; i += 1152, c++) {
@@ -59,7 +59,7 @@ if (process.argv[2] == 'calls') {
     for (let r = 0; r < reps; r++) { last = run(); times.push(last.dt); }
     const dt = median(times), bytes = last.parts.reduce((a, b) => a + b.length, 0);
     const per = Array.from(last.per.slice(2)).sort((a, b) => a - b);
-    console.log(JSON.stringify({ what: 'the reference\'s documented call pattern: one Mp3Encoder, 1152 samples per encodeBuffer() call, flush() at the end (node ' + process.version + ', N-API addon); median of ' + reps + ' runs after a warm-up run',
+    console.log(JSON.stringify({ what: 'the reference\'s documented call pattern: one Mp3Encoder, 1152 samples per encodeBuffer() call, flush() at the end' + (pending > 1 ? ' -- with the extension { pendingFrames: ' + pending + ' }: input held back until that many frames are pending, then ONE launch (same byte stream; the bytes arrive in later calls)' : '') + ' (node ' + process.version + ', N-API addon); median of ' + reps + ' runs after a warm-up run',
         source: src == 'fixture' ? 'the reference\'s own testdata/Left44100.wav' + (ch == 2 ? ' + Right44100.wav' : '') : 'sine, seed 12345', channels: ch, kbps, calls: ncalls, frames: ncalls + 1,
         seconds: +dt.toFixed(5), samples_s: times.map((t) => +t.toFixed(5)), frames_per_s: +((ncalls + 1) / dt).toFixed(1), ms_per_call: +(1000 * dt / ncalls).toFixed(4),
         call_us_median: +(1e6 * per[per.length >> 1]).toFixed(1), call_us_p95: +(1e6 * per[Math.floor(per.length * 0.95)]).toFixed(1), call_us_min: +(1e6 * per[0]).toFixed(1),
