@@ -594,7 +594,7 @@ def main():
             # gfx950 FETCH_SIZE x2 correction) and its instruction mix -- measured offline on this exact workload, under profiles/
             traffic = None
             prof = {}
-            cands = [ROOT / "profiles" / f"r0{r}_pmc_config{key}.json" for r in (4, 3, 2)]       # the newest measurement pass that has this workload
+            cands = sorted((ROOT / "profiles").glob(f"r0*_pmc_config{key}.json"), reverse=True)       # the newest measurement pass that has this workload
             pf = next((q for q in cands if q.exists()), cands[0])
             if wl.full and pf.exists():
                 try:

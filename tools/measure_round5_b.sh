@@ -23,5 +23,5 @@ timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt3 -- 
 python $R/tools/pmc_summary.py stats /tmp/kt3 $O/kernel_stats_config3.csv; head -12 $O/kernel_stats_config3.csv | cut -c1-150
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python $R/bench.py --cpu-seconds 0 --no-extras --steps 6 --check-frames 0 --config 2 > $O/kt2.log 2>&1
 python $R/tools/pmc_summary.py stats /tmp/kt2 $O/kernel_stats_config2.csv; head -12 $O/kernel_stats_config2.csv | cut -c1-150
-timeout 200 python tests/tools/frame_prof.py 300 > $O/frame_prof.txt 2>&1; grep -E '^==|g_frame launch|hand-over' $O/frame_prof.txt
+timeout 200 python $R/tests/tools/frame_prof.py 300 > $O/frame_prof.txt 2>&1; grep -E '^==|g_frame launch|hand-over' $O/frame_prof.txt
 ls $O
