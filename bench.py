@@ -595,7 +595,7 @@ def main():
             traffic = None
             prof = {}
             cands = sorted((ROOT / "profiles").glob(f"r0*_pmc_config{key}.json"), reverse=True)       # the newest measurement pass that has this workload
-            pf = next((q for q in cands if q.exists()), cands[0])
+            pf = cands[0] if cands else ROOT / "profiles" / "no_pmc_profile.json"
             if wl.full and pf.exists():
                 try:
                     prof = json.loads(pf.read_text())
