@@ -179,3 +179,29 @@ def test_wavesim_tail_help():
     import re
     m = re.search(r"tail-help: (\d+) granule-channels by helpers, (\d+) offers withdrawn", r.stderr)
     assert m and int(m.group(1)) > 10 and int(m.group(2)) > 10, r.stderr[-500:]
+
+
+def test_wavesim_one_frame_launch_count_helpers():
+    """The one-frame launch as a real eight-wave workgroup (csrc/lhip_api.cpp kb_frame_stage, k_quant.h q_count_helper / q_count_bits_piped; round 5): 1152
+    samples per call -- the reference's documented call pattern -- on one- and two-channel streams, MPEG-1 and MPEG-2, joint stereo and the bit reservoir
+    (whose multi-frame calls run the per-stream kernel with the same helpers).  Every call's bytes against the oracle, and both fates of a calc_noise made
+    beside the helper's count -- committed, dropped because the evaluation did not fit -- must have occurred; so must a one-channel frame's wait for the
+    psyB wave (MPEG-1 mono) and the two-channel barrier path."""
+    import sys
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    code = ("import sys; sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s'); import numpy as np, lamejs_amd, fuzz_gpu\n"
+            "from oracle_py import oracle_encode\n"
+            "lib = lamejs_amd.load_library(r'%s')\n"
+            "rng = np.random.default_rng(5150); bad = []\n"
+            "for (ch, sr, kb, joint, resv, chunk) in ((2, 44100, 128, False, False, 1152), (1, 44100, 128, False, False, 1152), (2, 22050, 64, False, False, 576), (1, 16000, 32, False, False, 576),\n"
+            "                                       (2, 44100, 128, True, False, 1152), (2, 44100, 192, False, True, 1152), (1, 44100, 64, False, True, 4000)):\n"
+            "    L, R = fuzz_gpu.material(rng, 1152 * 9 + 301, ch)\n"
+            "    enc = lamejs_amd.Mp3Encoder(ch, sr, kb, lib=lib, joint=joint, reservoir=resv)\n"
+            "    got = b''.join(enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk]) for p in range(0, len(L), chunk)) + enc.flush()\n"
+            "    if got != oracle_encode(ch, sr, kb, L, R, joint=joint, reservoir=resv): bad.append((ch, sr, kb, joint, resv))\n"
+            "print('BAD', bad)\n") % (ROOT, ROOT / "tests", ROOT / "tests" / "tools", ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LAMEJS_PIPE_STATS="1"), timeout=900)
+    assert r.returncode == 0 and "BAD []" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+    import re
+    m = re.search(r"count helper: (\d+) evaluations counted on the helper wave, (\d+) of the calc_noise calls made beside them committed", r.stderr)
+    assert m and int(m.group(2)) > 100 and int(m.group(1)) - int(m.group(2)) > 100, r.stderr[-500:]
