@@ -206,7 +206,18 @@ def run_frame_range_shards(args, lib, dist, torch, np, dev, dev_ord, world, rank
                            "bit_exact_full": (None if ent is None else bool(ent[0] == md5 and ent[1] == len(whole))), "output_md5": md5,
                            "cut_state_mismatches": sum(s_["state_mismatches"] for s_ in allstats) // max(world, 1),
                            "ranges_encoded_again": sum(s_["ranges_encoded_again"] for s_ in allstats)}}
-        print(json.dumps(line))
+        _print_line(line)
+
+
+def _print_line(line):
+    """The ONE JSON line, as the last line of stdout: RCCL writes a version banner through C stdio, which -- stdout being a pipe or a file -- sits in
+    libc's buffer until the process exits and would land BEHIND a line Python has already flushed; so libc's buffers are flushed first."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 def alg_bytes_per_frame(ch, kbps):
@@ -759,11 +770,11 @@ def main():
                     continue
                 shapes[f"{'mono' if e.get('channels') == 1 else 'stereo'}{e.get('kbps')}"] = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": False, "frames": e.get("frames"), "host": e.get("host")}
             line["cpu_baseline"]["reference_node_build_container"] = shapes
-    if rank == 0:
-        print(json.dumps(line))
     wl.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        _print_line(line)          # after the process group is gone: nothing of RCCL's can follow it on stdout
 
 
 if __name__ == "__main__":
