@@ -55,7 +55,7 @@ RESAMPLE_CFGS = [(1, 44100, 32), (2, 44100, 48), (1, 48000, 24), (2, 48000, 64),
                  (1, 48000, 40), (1, 48000, 8), (2, 48000, 40), (2, 32000, 40), (1, 32000, 24), (2, 16000, 24)]
 
 
-def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False, max_frames=260, stereo_only=False, whole=False):
+def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=False, max_frames=260, stereo_only=False, whole=False, frame_calls=False):
     """Returns the list of mismatching case descriptions (empty = parity).  joint: the joint-stereo extension on the two-channel
     configurations; the material (same draws as tests/tools/fuzz_ref.py joint) has strongly correlated channels in half of the cases."""
     rng = np.random.default_rng(seed)
@@ -79,6 +79,8 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
         chunk = int(rng.choice([len(L), 1152, 4096, 7777]))
         if whole:
             chunk = len(L)
+        if frame_calls:                       # one frame's worth of samples per call: the one-launch path (g_frame) with its count helpers
+            chunk = 576 * (2 if sr >= 32000 else 1) if rng.integers(0, 4) else int(rng.integers(300, 1200))
         got = b"".join(enc.encodeBuffer(L[p:p + chunk], None if R is None else R[p:p + chunk]) for p in range(0, len(L), chunk)) + enc.flush()
         enc.close()
         want = oracle_encode(ch, sr, kbps, L, R, joint=joint, reservoir=reservoir)
@@ -94,7 +96,8 @@ def run(ncases, seed, lib=None, verbose=True, cfgs=None, joint=False, reservoir=
 
 
 def main():
-    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim|wavesim] [joint] [reservoir] [short] [stereo] [whole]
+    """usage: fuzz_gpu.py [ncases] [seed] [mpeg1|lsf|resample|lowrate] [hostsim|wavesim] [joint] [reservoir] [short] [stereo] [whole] [framecalls]
+    framecalls: every case fed one frame's worth of samples (or a little less) per call -- the reference's documented call pattern, the one-launch path
     stereo: two-channel configurations only; whole: every case in ONE encodeBuffer call (one batch of all its frames)
     wavesim: the 64-lane wave programs as fibers on the CPU (slow: use `short`, at most 40 frames per case)"""
     cfgs = LSF_CFGS if "lsf" in sys.argv[3:] else RESAMPLE_CFGS if "resample" in sys.argv[3:] else LOWRATE_CFGS if "lowrate" in sys.argv[3:] else MPEG1_CFGS
@@ -104,7 +107,7 @@ def main():
     if "wavesim" in sys.argv[3:]:
         lib = lamejs_amd.load_library(str(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_wavesim.so"))
     bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024, lib=lib, cfgs=cfgs, joint="joint" in sys.argv[3:], reservoir="reservoir" in sys.argv[3:],
-              max_frames=40 if "short" in sys.argv[3:] else 260, stereo_only="stereo" in sys.argv[3:], whole="whole" in sys.argv[3:])
+              max_frames=40 if "short" in sys.argv[3:] else 260, stereo_only="stereo" in sys.argv[3:], whole="whole" in sys.argv[3:], frame_calls="framecalls" in sys.argv[3:])
     sys.exit(1 if bad else 0)
 
 
