@@ -205,33 +205,31 @@ LHIP_DEV void kb_resv_flush(const Tables& T, const Workspace& W, int st, int lan
     if (lane == 0) { rv.ancillary_flag = flag; *nout = n; rv.ResvSize = 0; rv.main_data_begin = 0; }
 }
 
-LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L, ResvState* rvp = nullptr, int32_t* nout = nullptr) {
-    const int C = T.channels_out;
+// ---- the pieces of a frame (kb_bits: one wave does them in order; kb_bits_mw_*: the granule-channels side by side on several waves) ----
+struct BitsFrame { StreamDesc sd; int k, fidx, frame_bits; };
+LHIP_DEV bool bits_frame(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, BitsFrame& F) {
     const int st = W.fslot_stream[fslot];
-    const StreamDesc sd = SD[st];
-    const int k = fslot - sd.fslot0 - 1;
-    if (k < 0) return;
-    const int fidx = sd.out_slot0 + k;
-    const int padding = frame_padding(T, sd, k);
-    const int frame_bits = frame_bits_of(T, padding);
+    F.sd = SD[st];
+    F.k = fslot - F.sd.fslot0 - 1;
+    if (F.k < 0) return false;
+    F.fidx = F.sd.out_slot0 + F.k;
+    F.frame_bits = frame_bits_of(T, frame_padding(T, F.sd, F.k));
+    return true;
+}
+// header + side info (BitStream.js:259-426) at bit 0 of w; the main data starts at 8 * T.sideinfo_len
+LHIP_DEV void bits_header(const Tables& T, const Workspace& W, const BitsFrame& F, const GrSide* side, uint32_t* w, int lane) {
+    const int C = T.channels_out, GR = T.mode_gr;
     const bool resv = !T.disable_reservoir;
-    const int nwords = resv ? BITS_LDS_WORDS - 1 : (frame_bits + 31) >> 5;      // reservoir: a frame's data may exceed its nominal size
-    for (int i = lane; i < nwords + 1; i += LHIP_NL) L.w[i] = 0;
-    const int GR = T.mode_gr;
-    static_assert(sizeof(GrSide) % 4 == 0, "side records are staged as words");
-    stage_words((uint32_t*)L.side, (const uint32_t*)(W.side + (int64_t)fidx * 2 * C), GR * C * (int)(sizeof(GrSide) / 4), lane);
-    wave_sync();
-    const GrSide* side = L.side;
+    const int padding = frame_padding(T, F.sd, F.k);
     int pos = 0;
     if (lane == 0) {
-        uint32_t* w = L.w;
 #define PUT(v, n) { put_bits(w, pos, (uint32_t)(v), (n)); pos += (n); }
         PUT(T.out_samplerate < 16000 ? 0xffe : 0xfff, 12) PUT(T.version, 1)       // BitStream.js:262-267
         PUT(4 - 3, 2) PUT(!T.error_protection ? 1 : 0, 1)
         PUT(T.bitrate_index, 4) PUT(T.samplerate_index, 2) PUT(padding, 1) PUT(T.extension, 1)
         PUT(T.mode, 2) PUT(T.mode == 1 ? side[0].mode_ext : 0, 2)                  // mode_ext: the frame's M/S decision in joint stereo (BitStream.js:279)
         PUT(T.copyright, 1) PUT(T.original, 1) PUT(T.emphasis, 2)
-        const int mdb = resv ? js_toint32(W.fr[fidx].main_data_begin) : 0;         // writeheader shifts the number: ToInt32 of a possibly fractional value
+        const int mdb = resv ? js_toint32(W.fr[F.fidx].main_data_begin) : 0;       // writeheader shifts the number: ToInt32 of a possibly fractional value
         if (GR == 2) {
             PUT(mdb, 9)
             PUT(0, C == 2 ? 3 : 5)
@@ -247,19 +245,129 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
     // per-granule-channel side info (BitStream.js:296-350 / 367-405): lane = (granule-channel, field); the widths are
     // turned into bit positions by an exclusive scan (lane order == the reference's gr, ch, field order)
-    {
-        pos = uni_bits_pos(pos);
-        for (int base = 0; base < 16 * GR * C; base += LHIP_NL) {
-            const int it = base + lane, gc = it >> 4, f = it & 15;
-            int n = 0; uint32_t v = 0;
-            if (gc < GR * C) side_field(side[gc], f, GR, &v, &n);
+    pos = uni_bits_pos(pos);
+    for (int base = 0; base < 16 * GR * C; base += LHIP_NL) {
+        const int it = base + lane, gc = it >> 4, f = it & 15;
+        int n = 0; uint32_t v = 0;
+        if (gc < GR * C) side_field(side[gc], f, GR, &v, &n);
+        int tot;
+        const int off = wave_excl_scan(n, lane, &tot);
+        put_bits(w, pos + off, v, n);
+        pos += tot;
+    }
+}
+// main data of one granule-channel (scalefactors + Huffman data, BitStream.js:600-689) from bit `pos` of w; qbuf: 288 words of this wave's LDS.  Returns the
+// position behind it (pos + part2_length + part2_3_length of the record: what the side info announces)
+// (fetch = false: the caller has staged the spectrum in qbuf already)
+LHIP_DEV int bits_main_gc(const Tables& T, const Workspace& W, const BitsFrame& F, const GrSide& gi, int gr, int ch, uint32_t* w, uint32_t* qbuf, int pos, int lane, bool fetch = true) {
+    const int C = T.channels_out, GR = T.mode_gr;
+    wave_sync();                                                 // the previous granule-channel's spectrum is no longer read
+    if (fetch) stage_words(qbuf, (const uint32_t*)(W.l3 + (((int64_t)F.fidx * 2 + gr) * C + ch) * 576), 288, lane);
+    wave_sync();
+    const int16_t* q = (const int16_t*)qbuf;
+    if (GR == 2) {
+        // scalefactors: at most 36 short fields
+        const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];
+        // lane = band: field widths turned into positions by an exclusive scan (bands shared through scfsi are -1: no field)
+        for (int base = 0; base < gi.sfbmax; base += LHIP_NL) {
+            const int sfb = base + lane;
+            int n = 0, v = 0;
+            if (sfb < gi.sfbmax) { v = gi.scalefac[sfb]; if (v != -1) n = sfb < gi.sfbdivide ? slen1 : slen2; }
             int tot;
             const int off = wave_excl_scan(n, lane, &tot);
-            put_bits(L.w, pos + off, v, n);
+            put_bits(w, pos + off, (uint32_t)v, n);
+            pos += tot;
+        }
+    } else {
+        // MPEG-2/2.5: four partitions with their own field widths (BitStream.js:645-686).  The widths and the
+        // partition sizes are what a decoder derives from scalefac_compress (scale_bitcount_lsf packed them):
+        // table 0 (no preflag) = slen1*80 + slen2*16 + slen3*4 + slen4 over {6,5,5,5} / {9,9,9,9} entries,
+        // table 2 (preflag)    = 500 + slen1*3 + slen2 over {11,10,0,0} / {18,18,0,0} entries.
+        const bool pre = gi.preflag != 0, sh = gi.block_type == SHORT_TYPE;
+        const int sc = gi.scalefac_compress - (pre ? 500 : 0);
+        const int sl0 = pre ? sc / 3 : (sc >> 4) / 5, sl1 = pre ? sc % 3 : (sc >> 4) % 5;
+        const int sl2 = pre ? 0 : (sc >> 2) & 3, sl3 = pre ? 0 : sc & 3;
+        const int n0 = pre ? (sh ? 18 : 11) : (sh ? 9 : 6), n1 = pre ? (sh ? 18 : 10) : (sh ? 9 : 5);
+        const int n2 = pre ? 0 : (sh ? 9 : 5);
+        const int b1 = n0, b2 = n0 + n1, b3 = b2 + n2, end = b3 + n2;
+        for (int base = 0; base < end; base += LHIP_NL) {
+            const int i = base + lane;
+            int n = 0, v = 0;
+            if (i < end) { n = i < b1 ? sl0 : i < b2 ? sl1 : i < b3 ? sl2 : sl3; v = gi.scalefac[i]; }
+            int tot;
+            const int off = wave_excl_scan(n, lane, &tot);
+            put_bits(w, pos + off, (uint32_t)(v > 0 ? v : 0), n);
             pos += tot;
         }
     }
-    pos = 8 * T.sideinfo_len;
+    int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
+    if (ts0 == 14) ts0 = 16;
+    if (ts1 == 14) ts1 = 16;
+    if (ts2 == 14) ts2 = 16;
+    if (gi.block_type == SHORT_TYPE) {
+        int r1 = 3 * T.sfb_s[3];
+        if (r1 > gi.big_values) r1 = gi.big_values;
+        pos += huff_region(T, w, pos, ts0, 0, r1, q, lane);
+        pos += huff_region(T, w, pos, ts1, r1, gi.big_values, q, lane);
+    } else {
+        const int bigv = gi.big_values;
+        int i = gi.region0_count + 1;
+        int r1 = T.sfb_l[i];
+        i += gi.region1_count + 1;
+        int r2 = T.sfb_l[i];
+        if (r1 > bigv) r1 = bigv;
+        if (r2 > bigv) r2 = bigv;
+        pos += huff_region(T, w, pos, ts0, 0, r1, q, lane);
+        pos += huff_region(T, w, pos, ts1, r1, r2, q, lane);
+        pos += huff_region(T, w, pos, ts2, r2, bigv, q, lane);
+    }
+    pos += count1_region(T, w, pos, gi, q, lane);
+    return pos;
+}
+// ancillary stuffing of a frame without the reservoir (drain_into_ancillary): "LAME", coerced version chars, then zero bits; one lane
+LHIP_DEV void bits_stuffing(const Tables& T, uint32_t* w, int pos, int frame_bits) {
+    int remaining = frame_bits - pos;
+    const uint32_t lame[4] = {0x4c, 0x41, 0x4d, 0x45};
+    int p2 = pos;
+    for (int i = 0; i < 4; i++) if (remaining >= 8) { put_bits(w, p2, lame[i], 8); p2 += 8; remaining -= 8; }
+    if (remaining >= 32)
+        for (int i = 0; i < T.n_version_bytes && remaining >= 8; ++i) { remaining -= 8; put_bits(w, p2, (uint32_t)T.version_bytes[i], 8); p2 += 8; }
+}
+// the finished frame's bytes to the stream's output (thread tid of nthr); frames of a stream are consecutive
+LHIP_DEV void bits_copy_out(const Tables& T, const Workspace& W, const BitsFrame& F, const uint32_t* w, int tid, int nthr) {
+    const int nbytes = F.frame_bits >> 3, k = F.k;
+    // frame k starts after the k frames before it (sizes differ by the padding slot): k * base + (number of padded frames among them), the
+    // paddings counted in closed form: the lag before frame j is (lag0 - j*frac) mod sr, a padding happens when that value < frac
+    const int base = frame_bits_of(T, 0) >> 3;
+    int64_t npad = 0;
+    if (T.frac_SpF != 0) {
+        const int64_t sr = T.out_samplerate;
+        int64_t m0 = (int64_t)F.sd.slot_lag % sr; if (m0 < 0) m0 += sr;
+        // after k decrements the unwrapped value is m0 - k*frac; each wrap adds sr; wraps = ceil((k*frac - m0)/sr) clipped at 0
+        const int64_t need = (int64_t)k * T.frac_SpF - m0;
+        npad = need > 0 ? (need + sr - 1) / sr : 0;
+    }
+    uint8_t* out = W.out + F.sd.out_off + (int64_t)k * base + npad;
+    for (int i = tid; i < nbytes; i += nthr) out[i] = (uint8_t)(w[i >> 2] >> (24 - 8 * (i & 3)));
+    if (tid == 0) W.frame_bytes[F.fidx] = nbytes;
+}
+
+LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L, ResvState* rvp = nullptr, int32_t* nout = nullptr) {
+    const int C = T.channels_out;
+    BitsFrame F;
+    if (!bits_frame(T, W, SD, fslot, F)) return;
+    const int st = W.fslot_stream[fslot];
+    const int fidx = F.fidx, frame_bits = F.frame_bits;
+    const bool resv = !T.disable_reservoir;
+    const int nwords = resv ? BITS_LDS_WORDS - 1 : (frame_bits + 31) >> 5;      // reservoir: a frame's data may exceed its nominal size
+    for (int i = lane; i < nwords + 1; i += LHIP_NL) L.w[i] = 0;
+    const int GR = T.mode_gr;
+    static_assert(sizeof(GrSide) % 4 == 0, "side records are staged as words");
+    stage_words((uint32_t*)L.side, (const uint32_t*)(W.side + (int64_t)fidx * 2 * C), GR * C * (int)(sizeof(GrSide) / 4), lane);
+    wave_sync();
+    const GrSide* side = L.side;
+    bits_header(T, W, F, side, L.w, lane);
+    int pos = 8 * T.sideinfo_len;
     wave_sync();
     int anc_flag = 0;
     if (resv) {                                                  // drain_into_ancillary(resvDrain_pre) precedes the frame's main data
@@ -270,70 +378,7 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
         wave_sync();
     }
     for (int gr = 0; gr < GR; gr++)
-        for (int ch = 0; ch < C; ch++) {
-            const GrSide& gi = side[gr * C + ch];
-            wave_sync();                                                 // the previous granule-channel's spectrum is no longer read
-            stage_words(L.q, (const uint32_t*)(W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576), 288, lane);
-            wave_sync();
-            const int16_t* q = (const int16_t*)L.q;
-            if (GR == 2) {
-                // scalefactors: at most 36 short fields
-                const int slen1 = T.slen1_tab[gi.scalefac_compress], slen2 = T.slen2_tab[gi.scalefac_compress];
-                // lane = band: field widths turned into positions by an exclusive scan (bands shared through scfsi are -1: no field)
-                for (int base = 0; base < gi.sfbmax; base += LHIP_NL) {
-                    const int sfb = base + lane;
-                    int n = 0, v = 0;
-                    if (sfb < gi.sfbmax) { v = gi.scalefac[sfb]; if (v != -1) n = sfb < gi.sfbdivide ? slen1 : slen2; }
-                    int tot;
-                    const int off = wave_excl_scan(n, lane, &tot);
-                    put_bits(L.w, pos + off, (uint32_t)v, n);
-                    pos += tot;
-                }
-            } else {
-                // MPEG-2/2.5: four partitions with their own field widths (BitStream.js:645-686).  The widths and the
-                // partition sizes are what a decoder derives from scalefac_compress (scale_bitcount_lsf packed them):
-                // table 0 (no preflag) = slen1*80 + slen2*16 + slen3*4 + slen4 over {6,5,5,5} / {9,9,9,9} entries,
-                // table 2 (preflag)    = 500 + slen1*3 + slen2 over {11,10,0,0} / {18,18,0,0} entries.
-                const bool pre = gi.preflag != 0, sh = gi.block_type == SHORT_TYPE;
-                const int sc = gi.scalefac_compress - (pre ? 500 : 0);
-                const int sl0 = pre ? sc / 3 : (sc >> 4) / 5, sl1 = pre ? sc % 3 : (sc >> 4) % 5;
-                const int sl2 = pre ? 0 : (sc >> 2) & 3, sl3 = pre ? 0 : sc & 3;
-                const int n0 = pre ? (sh ? 18 : 11) : (sh ? 9 : 6), n1 = pre ? (sh ? 18 : 10) : (sh ? 9 : 5);
-                const int n2 = pre ? 0 : (sh ? 9 : 5);
-                const int b1 = n0, b2 = n0 + n1, b3 = b2 + n2, end = b3 + n2;
-                for (int base = 0; base < end; base += LHIP_NL) {
-                    const int i = base + lane;
-                    int n = 0, v = 0;
-                    if (i < end) { n = i < b1 ? sl0 : i < b2 ? sl1 : i < b3 ? sl2 : sl3; v = gi.scalefac[i]; }
-                    int tot;
-                    const int off = wave_excl_scan(n, lane, &tot);
-                    put_bits(L.w, pos + off, (uint32_t)(v > 0 ? v : 0), n);
-                    pos += tot;
-                }
-            }
-            int ts0 = gi.table_select[0], ts1 = gi.table_select[1], ts2 = gi.table_select[2];
-            if (ts0 == 14) ts0 = 16;
-            if (ts1 == 14) ts1 = 16;
-            if (ts2 == 14) ts2 = 16;
-            if (gi.block_type == SHORT_TYPE) {
-                int r1 = 3 * T.sfb_s[3];
-                if (r1 > gi.big_values) r1 = gi.big_values;
-                pos += huff_region(T, L.w, pos, ts0, 0, r1, q, lane);
-                pos += huff_region(T, L.w, pos, ts1, r1, gi.big_values, q, lane);
-            } else {
-                const int bigv = gi.big_values;
-                int i = gi.region0_count + 1;
-                int r1 = T.sfb_l[i];
-                i += gi.region1_count + 1;
-                int r2 = T.sfb_l[i];
-                if (r1 > bigv) r1 = bigv;
-                if (r2 > bigv) r2 = bigv;
-                pos += huff_region(T, L.w, pos, ts0, 0, r1, q, lane);
-                pos += huff_region(T, L.w, pos, ts1, r1, r2, q, lane);
-                pos += huff_region(T, L.w, pos, ts2, r2, bigv, q, lane);
-            }
-            pos += count1_region(T, L.w, pos, gi, q, lane);
-        }
+        for (int ch = 0; ch < C; ch++) pos = bits_main_gc(T, W, F, side[gr * C + ch], gr, ch, L.w, L.q, pos, lane);
     if (resv) {
         // bit reservoir: [drain_pre | main data | drain_post] joins the continuous stream, this frame's header + side info joins the
         // queue of headers waiting for the stream to reach their frame start; the reservoir state is committed (format_bitstream,
@@ -366,39 +411,41 @@ LHIP_DEV void kb_bits(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
         return;
     }
-    // ancillary stuffing (drain_into_ancillary): "LAME", coerced version chars, then zero bits
-    if (lane == 0) {
-        int remaining = frame_bits - pos;
-        const uint32_t lame[4] = {0x4c, 0x41, 0x4d, 0x45};
-        int p2 = pos;
-        for (int i = 0; i < 4; i++) if (remaining >= 8) { put_bits(L.w, p2, lame[i], 8); p2 += 8; remaining -= 8; }
-        if (remaining >= 32)
-            for (int i = 0; i < T.n_version_bytes && remaining >= 8; ++i) { remaining -= 8; put_bits(L.w, p2, (uint32_t)T.version_bytes[i], 8); p2 += 8; }
-    }
+    if (lane == 0) bits_stuffing(T, L.w, pos, frame_bits);
     wave_sync();
-    const int nbytes = frame_bits >> 3;
-    uint8_t* out = W.out + sd.out_off + (int64_t)0;
-    // frames of a stream are consecutive; frame k starts after the k frames before it (sizes differ by the padding slot)
-    int64_t start = 0;
-    {
-        // bytes of frames 0..k-1 = k * base + (number of padded frames among them)
-        const int base = frame_bits_of(T, 0) >> 3;
-        // count paddings in closed form: floor((lag0_shift + k*frac)/out_samplerate) style accumulation
-        // lag before frame j is (lag0 - j*frac) mod sr; a padding happens when that value < frac
-        int64_t npad = 0;
-        if (T.frac_SpF != 0) {
-            // number of wraps of the accumulator over k steps
-            const int64_t sr = T.out_samplerate;
-            int64_t m0 = (int64_t)sd.slot_lag % sr; if (m0 < 0) m0 += sr;
-            // after k decrements the unwrapped value is m0 - k*frac; each wrap adds sr; wraps = ceil((k*frac - m0)/sr) clipped at 0
-            const int64_t need = (int64_t)k * T.frac_SpF - m0;
-            npad = need > 0 ? (need + sr - 1) / sr : 0;
-        }
-        start = (int64_t)k * base + npad;
+    bits_copy_out(T, W, F, L.w, lane, LHIP_NL);
+}
+
+// ---- one frame, no reservoir, the granule-channels side by side (one-frame launches: a wave alone waits out every table look-up of the packer,
+// 5 us per granule-channel; g_frame has idle waves).  Wave `part` of `nparts` = GR * C packs granule-channel `part` at the bit position the side
+// records announce (8 sideinfo_len + the lengths of the granule-channels before it) into the ONE frame image wsh (wave 0's; put_bits is an atomic OR);
+// wave 0 also writes header, side info and the stuffing.  The packing waves meet twice (image cleared | packed | copied out) on the counters meet[0], meet[1]
+// (LDS, zero on entry) -- not at the workgroup's barrier: the other waves of the workgroup are busy saving the state and must not hold the packers up.
+LHIP_DEV void kb_bits_mw(const Tables& T, const Workspace& W, const StreamDesc* SD, int fslot, int lane, BitsLds& L, uint32_t* wsh, int part, int nparts, int* meet) {
+    BitsFrame F;
+    bool ok = bits_frame(T, W, SD, fslot, F);
+    const int C = T.channels_out, NGC = T.mode_gr * C;
+    if (ok) {
+        // everything this wave will read from memory is fetched before the first barrier: the side records and its own granule-channel's spectrum
+        const int nwords = (F.frame_bits + 31) >> 5;
+        for (int i = part * LHIP_NL + lane; i < nwords + 1; i += nparts * LHIP_NL) wsh[i] = 0;
+        stage_words((uint32_t*)L.side, (const uint32_t*)(W.side + (int64_t)F.fidx * 2 * C), NGC * (int)(sizeof(GrSide) / 4), lane);
+        if (part < NGC) stage_words(L.q, (const uint32_t*)(W.l3 + (((int64_t)F.fidx * 2 + part / C) * C + part % C) * 576), 288, lane);
     }
-    out += start;
-    for (int i = lane; i < nbytes; i += LHIP_NL) out[i] = (uint8_t)(L.w[i >> 2] >> (24 - 8 * (i & 3)));
-    if (lane == 0) W.frame_bytes[fidx] = nbytes;
+    wg_meet(meet, nparts, lane);
+    if (ok) {
+        const GrSide* side = L.side;
+        int pos = 8 * T.sideinfo_len, end = pos;
+        for (int gc = 0; gc < NGC; gc++) { const int n = side[gc].part2_3_length + side[gc].part2_length; if (gc < part) pos += n; end += n; }
+        if (part == 0) bits_header(T, W, F, side, wsh, lane);
+        for (int gc = part; gc < NGC; gc += nparts) {
+            (void)bits_main_gc(T, W, F, side[gc], gc / C, gc % C, wsh, L.q, pos, lane, gc != part);
+            for (int g2 = gc; g2 < gc + nparts && g2 < NGC; g2++) pos += side[g2].part2_3_length + side[g2].part2_length;
+        }
+        if (part == 0 && lane == 0) bits_stuffing(T, wsh, end, F.frame_bits);
+    }
+    wg_meet(meet + 1, nparts, lane);
+    if (ok) bits_copy_out(T, W, F, wsh, part * LHIP_NL + lane, nparts * LHIP_NL);
 }
 
 }  // namespace lhip

@@ -128,7 +128,7 @@ static_assert(offsetof(PsyALds, fs_pad) == offsetof(PsyALds, fs) + sizeof(float)
 
 #if defined(LHIP_PHASE_PROF) && !defined(LHIP_HOSTSIM)
 #define PSY_STAMP(i) psy_t_[i] = __builtin_amdgcn_s_memtime()      /* stamp 2 sits inside the `ch < 2` branch: the mid / side waves keep stamp 1's time there */
-#define PSY_FLUSH() do { if (lane == 0 && (gslot & 63) == 0) {   /* a sample of the waves: a flush per wave congests what it measures */ if (psy_t_[2] == 0) psy_t_[2] = psy_t_[1]; \
+#define PSY_FLUSH() do { if (lane == 0 && ((gslot & 63) == 0 || (W.ngslots <= 4 && ch == 0 && gslot - sd.gslot0 == 1))) {   /* a sample of the waves: a flush per wave congests what it measures */ if (psy_t_[2] == 0) psy_t_[2] = psy_t_[1]; \
     for (int i_ = 0; i_ < 7; i_++) atomicAdd((unsigned long long*)W.prof + 22 + i_, psy_t_[i_ + 1] - psy_t_[i_]); atomicAdd((unsigned long long*)W.prof + 54, 1ull); } } while (0)
 #define PSY_DECL() unsigned long long psy_t_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #else
@@ -165,6 +165,9 @@ template <int K> LHIP_DEV int guarded_f32_of_sum(const double (&p)[K], double sc
 // one wave per (granule slot >= 1 of a stream, psy channel).  ch = 0, 1: L, R.  Joint stereo adds ch = 2, 3 (mid, side) in a second
 // launch: their high-passed samples and their spectra are linear combinations of the L / R ones (PsyModel.js:1113-1121, 258-273),
 // which the L / R waves leave in W.hpf / W.fht; everything from the energies on is the same code for all four.
+// PART (one-frame launches, where a wave is alone with its latencies and other waves of the workgroup idle): 1 = only the high-pass + sub-block peaks
+// (they need the samples and nothing else, and nothing below needs them), 2 = everything else; 0 = all of it on one wave (the batched kernel).
+template <int PART = 0>
 LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int gslot, int ch, int lane, PsyALds& L) {
     const int C = T.channels_out, Cp = T.psy_channels;
     const int st = W.gslot_stream[gslot];
@@ -196,7 +199,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     PSY_STAMP(0);
 
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
-    {
+    if (PART != 2) {
         const float* fir = L.fz + 397;                // 576 - 350 - 21 + 192
         // Each lane filters NINE CONSECUTIVE outputs: they share 30 input samples, read and widened once (a lane that took
         // output lane + 64 k of each sub-block instead would read 198).  The magnitudes go through LDS (the short FHT buffers are
@@ -252,6 +255,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
             for (int sbk = 0; sbk < 9; sbk++) W.peaks[o * PK_STRIDE + sbk] = pk[sbk];
         }
     }
+    if (PART == 1) return;
 
     PSY_STAMP(1);
     if (ch >= 2) {

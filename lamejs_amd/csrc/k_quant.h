@@ -1301,10 +1301,20 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
 // region1_count << 28; w[2] table_select[0..2] + 1 at 6 bits each | sfb_count1 << 18 | the mask of conditionally assigned fields << 24: the
 // owner takes the region counts and table_select[r] only where the reference's count assigns them, Takehiro.js:566-612).
 struct CountShare { int state; uint32_t w[3];
-#ifdef LHIP_PHASE_PROF
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_HANDOFF_PROF)
     unsigned long long t_post, t_reply; unsigned int acc[8];      // profiling builds: the hand-over's legs (q_count_helper)
 #endif
 };
+// -DLHIP_HANDOFF_PROF (without LHIP_PHASE_PROF): the production code with four clock reads per counted evaluation and fire-and-forget LDS adds --
+// what the hand-over costs when nothing else is instrumented (tests/tools/handoff_prof.py).  acc: 0 owner: posted -> calc_noise finished, 1 owner: waited,
+// 2 evaluations, 3 helper: request seen -> reply written, 4 helper's evaluations, 5 posted -> seen by the helper, 6 reply written -> seen by the owner
+#if defined(LHIP_HANDOFF_PROF) && !defined(LHIP_PHASE_PROF)
+#define HO_NOW() __builtin_amdgcn_s_memtime()
+#define HO_ADD(CS_, I_, V_) do { if (lane == 0) __hip_atomic_fetch_add(&(CS_).acc[I_], (unsigned int)(V_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define HO_ON 1
+#else
+#define HO_ON 0
+#endif
 enum { CS_IDLE = 0, CS_REQ = 1, CS_DONE = 2, CS_BARRIER = 8, CS_QUIT = 9 };
 #if defined(LHIP_WAVESIM)
 // how often each way was taken (printed at exit with LAMEJS_PIPE_STATS=1: the simulation must exercise both)
@@ -1323,6 +1333,9 @@ LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo
         if (s == CS_BARRIER) { wg_store(&cs.state, CS_IDLE, lane); wg_barrier(); continue; }     // (the owner posts again only after the barrier)
 #ifdef LHIP_PHASE_PROF
         const unsigned long long hp_seen_ = __builtin_amdgcn_s_memtime();
+#endif
+#if HO_ON
+        const unsigned long long ho_h0_ = HO_NOW();
 #endif
         wg_acquire();
         lane = lane_anew(lane);
@@ -1354,7 +1367,14 @@ LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo
         if (lane == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cs.acc[0] += (unsigned int)(hp_seen_ - cs.t_post); cs.acc[1] += (unsigned int)(hp_start_ - hp_seen_);
                          cs.acc[2] += (unsigned int)(hp_end_ - hp_start_); cs.acc[3] += (unsigned int)(now_ - hp_end_); cs.acc[7] += 1; cs.t_reply = now_; }
 #endif
+#if HO_ON
+        const unsigned long long ho_h1_ = HO_NOW();
+        if (lane == 0) cs.t_reply = ho_h1_;
+#endif
         wg_store(&cs.state, CS_DONE, lane);
+#if HO_ON
+        HO_ADD(cs, 3, ho_h1_ - ho_h0_); HO_ADD(cs, 4, 1); HO_ADD(cs, 5, ho_h0_ - cs.t_post);
+#endif
     }
 }
 // the owner's side: q_count_bits (use_pn = 1) with the count on the helper and calc_noise run beside it.  *spec = 1: `ni` / `nc` hold a calc_noise
@@ -1377,10 +1397,17 @@ LHIP_DEV int q_count_bits_piped(const Tables& T, GI& g, const int32_t* scalefac,
 #ifdef LHIP_PHASE_PROF
     if (lane == 0) cs.t_post = __builtin_amdgcn_s_memtime();
 #endif
+#if HO_ON
+    const unsigned long long ho_t0_ = HO_NOW();
+    if (lane == 0) cs.t_post = ho_t0_;
+#endif
     wg_store(&cs.state, CS_REQ | (g.block_type << 8), lane);
     LHIP_PIPE_COUNT(piped);
     { PH_BEGIN(); q_calc_noise_(T, g, scalefac, ix, ni, 1, pn, need_max, lane, L, Q, nc); PH_END(L, PH_NOISE); }
     *spec = 1;
+#if HO_ON
+    const unsigned long long ho_t1_ = HO_NOW();
+#endif
     PH_BEGIN();
 #ifdef LHIP_PHASE_PROF
     const unsigned long long op_wait0_ = __builtin_amdgcn_s_memtime();
@@ -1389,8 +1416,14 @@ LHIP_DEV int q_count_bits_piped(const Tables& T, GI& g, const int32_t* scalefac,
 #ifdef LHIP_PHASE_PROF
     if (lane == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cs.acc[4] += (unsigned int)(now_ - cs.t_reply); cs.acc[5] += (unsigned int)(op_wait0_ - cs.t_post); cs.acc[6] += (unsigned int)(now_ - op_wait0_); }
 #endif
+#if HO_ON
+    const unsigned long long ho_t2_ = HO_NOW();
+#endif
     wg_acquire();
     const uint32_t w0 = (uint32_t)uni((int)cs.w[0]), w1 = (uint32_t)uni((int)cs.w[1]), w2 = (uint32_t)uni((int)cs.w[2]);
+#if HO_ON
+    HO_ADD(cs, 0, ho_t1_ - ho_t0_); HO_ADD(cs, 1, ho_t2_ - ho_t1_); HO_ADD(cs, 2, 1); HO_ADD(cs, 6, ho_t2_ - cs.t_reply);
+#endif
     const int bits = (int)(w0 & 0x1ffffu), amask = (int)((w2 >> 24) & 15u);
     static_assert(LARGE_BITS < (1 << 17), "the reply packs the bit count in 17 bits");
     g.count1 = (int)(w0 >> 17); g.big_values = (int)(w1 & 1023u); g.count1bits = (int)((w1 >> 10) & 0x1fffu); g.count1table_select = (int)((w1 >> 23) & 1u);

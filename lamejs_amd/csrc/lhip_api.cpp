@@ -164,7 +164,7 @@ LHIP_DEV void kb_prep_stream(const Tables& T, const Workspace& W, const StreamDe
     const int64_t off = SD[st].pcm_off + io.mf_size;
     for (int ch = 0; ch < C; ch++) {
         float* dst = W.pcm + (int64_t)ch * W.pcm_plane + off;
-        for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, io.src[ch], io.state->rs_old[ch], io.rs_p0, i);
+        for (int64_t i = tid; i < io.n_new; i += nthreads) kb_resample_elem(T, dst, (ch ? io.src[1] : io.src[0]), io.state->rs_old[ch], io.rs_p0, i);
     }
 }
 LHIP_DEV void kb_prep(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int nstreams, int64_t tid, int64_t nthreads) {
@@ -235,7 +235,7 @@ LHIP_DEV void kb_save(const Tables& T, const Workspace& W, const StreamDesc* SD,
                 if (i < RS_TAPS - 1) {
                     const int64_t q = (int64_t)io.n_in - (RS_TAPS - 1) + i;
                     if (q < 0) v = S->rs_old[ch][(RS_TAPS - 1) + q];
-                    else { v = (float)io.src[ch][q]; if (do_scale) v = (float)((double)v * T.scale); }
+                    else { v = (float)(ch ? io.src[1] : io.src[0])[q]; if (do_scale) v = (float)((double)v * T.scale); }
                 }
                 wave_sync();
                 if (i < RS_TAPS - 1) S->rs_old[ch][i] = v;
@@ -299,6 +299,20 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
         case FS_LOAD: kb_load(T, W, SD, IO, st, lane, wv, nw); break;
         case FS_PREP: if (T.rs_ratio != 1) kb_prep_stream(T, W, SD, IO, st, (int64_t)wv * LHIP_NL + lane, (int64_t)nw * LHIP_NL); break;
         case FS_PSYA_POLY:
+            // One-frame launches on the device: waves [0, GR C) take the spectra and everything after them (kb_psyA<2>, the stage's longest chain); wave GR C + j
+            // takes (granule, channel) pair j's polyphase filterbank and then its high-pass + sub-block peaks (kb_psyA<1>: a fifth of psyA, needed by the scans
+            // only) -- on one wave per channel the filterbank of both granules was as long as all of psyA
+            if (PAIRQ && nw >= 2 * GR * C) {
+                const int np = GR * C;
+                if (has && wv < np) kb_psyA<2>(T, W, SD, IO, g1 + wv / C, wv % C, lane, *(PsyALds*)lds);
+                else if (has && wv < 2 * np) {
+                    const int j = wv - np;
+                    kb_poly_run(T, W, SD, IO, g1 + j / C, j % C, 1, lane, *(PolyLds*)lds);
+                    wave_sync();                                  // (the wave's LDS changes its meaning)
+                    kb_psyA<1>(T, W, SD, IO, g1 + j / C, j % C, lane, *(PsyALds*)lds);
+                }
+                break;
+            }
             if (has && wv < GR * C) kb_psyA(T, W, SD, IO, g1 + wv / C, wv % C, lane, *(PsyALds*)lds);
             else if (has && wv >= side0 && wv - side0 < C) kb_poly_run(T, W, SD, IO, g1, wv - side0, GR, lane, *(PolyLds*)lds);
             break;
@@ -320,7 +334,7 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
                               // decision reads granule 0's thresholds before anything is quantized); otherwise psyB runs beside the quantization (psyb_late)
             if (has && !psyb_late && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
             else if (has && wv >= side0 && wv - side0 < GR) kb_mdct(T, W, SD, g1 + (wv - side0), lane, *(MdctLds*)lds);
-            if (wv == 0 && lane == 0) mbox[3] = 0;                 // "psyB of this frame is done" (FS_QUANT, one-channel frames)
+            if (wv == 0 && lane == 0) { mbox[3] = 0; mbox[4] = mbox[5] = 0; }   // "psyB of this frame is done" (FS_QUANT, one-channel frames); the bit packers' meeting points (FS_BITS_SAVE)
             break;
         case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax); break;
         case FS_QUANT:
@@ -351,6 +365,15 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             }
             break;
         case FS_BITS_SAVE:   // the state record's reservoir part belongs to the bit packer, everything else to the save: disjoint words
+            if (PAIRQ && !RESV && nw > GR * C) {
+                // no reservoir: a frame's granule-channels are packed side by side by waves [0, GR C) into wave 0's frame image (kb_bits_mw), the other
+                // waves save the state
+                const int nb = GR * C;
+                uint32_t* wsh = ((BitsLds*)(lds - (size_t)wv * FR_LDS_PER_WAVE))->w;
+                if (wv >= nb) kb_save(T, W, SD, IO, st, lane, wv - nb, nw - nb);
+                else if (has) kb_bits_mw(T, W, SD, fslot, lane, *(BitsLds*)lds, wsh, wv, nb, mbox + 4);
+                break;
+            }
             if (wv == 0) { if (has) kb_bits(T, W, SD, fslot, lane, *(BitsLds*)lds, rv, W.out_bytes + st); }
             else kb_save(T, W, SD, IO, st, lane, wv - 1, nw - 1);
             break;
@@ -686,12 +709,12 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
 template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QArgs a_unused, const StreamIO* IO) {
     __shared__ QuantTabs Q;
     __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
-    __shared__ int mbox[4];
+    __shared__ int mbox[8];
     __shared__ CountShare CS[2];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 2) CS[threadIdx.x].state = CS_IDLE;
-#ifdef LHIP_PHASE_PROF
+#if defined(LHIP_PHASE_PROF) || defined(LHIP_HANDOFF_PROF)
     if (threadIdx.x < 8) CS[0].acc[threadIdx.x] = 0;
 #endif
 #ifdef LHIP_PHASE_PROF
@@ -707,7 +730,10 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
         if (frame_stage_empty<RESV>(stage, A->T)) continue;
         kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr);
 #ifdef LHIP_PHASE_PROF
-        if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0) A->W.prof[lane] = ((QuantLds*)U[wv])->prof[lane];
+        // when each wave finished its part of the two stages whose work is dealt over waves (cycles after the stage's start)
+        if ((stage == FS_PSYA_POLY || stage == FS_BITS_SAVE) && blockIdx.x == 0 && lane == 0)
+            A->W.prof[FRAME_PROF_BASE + (stage == FS_PSYA_POLY ? 40 : 48) + wv] = __builtin_amdgcn_s_memtime() - A->W.prof[FRAME_PROF_BASE + stage];
+        if (stage == FS_QUANT && blockIdx.x == 0 && wv == 0 && (lane < 22 || (lane > 28 && lane != 54))) A->W.prof[lane] = ((QuantLds*)U[wv])->prof[lane];      // (22 .. 28, 54: psyA's phases, PSY_FLUSH)
         if (stage == FS_QUANT && blockIdx.x == 0 && wv == 2 && lane < 5) {     // the count helper of wave 0: its five count phases (cycles, calls)
             A->W.prof[FRAME_PROF_BASE + 16 + lane] = ((QuantLds*)U[wv])->prof[PH_C_LOAD + lane]; A->W.prof[FRAME_PROF_BASE + 24 + lane] = ((QuantLds*)U[wv])->prof[32 + PH_C_LOAD + lane];
         }
@@ -717,6 +743,9 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
     }
 #ifdef LHIP_PHASE_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES] = __builtin_amdgcn_s_memtime(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 2] = wall_clock64(); }
+#elif defined(LHIP_HANDOFF_PROF)
+    // (tests/tools/handoff_prof.py: the legs of wave 0's hand-overs, summed over the calls of the process; the product never zeroes or reads these words)
+    if (blockIdx.x == 0 && threadIdx.x < 8) atomicAdd(A->W.prof + 32 + threadIdx.x, (unsigned long long)CS[0].acc[threadIdx.x]);
 #endif
 }
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
@@ -1369,7 +1398,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = FR_WAVES;
-            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[4]; static thread_local CountShare fcs[2];
+            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[8]; static thread_local CountShare fcs[2];
             fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;
             for (int s = 0; s < S; s++) {
 #ifdef LHIP_WAVESIM

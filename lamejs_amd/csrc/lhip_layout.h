@@ -178,7 +178,7 @@ LHIP_DEV int vd_step(uint32_t h) { return (int)((h >> 16) & 255u); }
 LHIP_DEV PcmSrc pcm_source(const Tables& T, const Workspace& W, const StreamDesc& sd, const StreamIO& io, int ch) {
     PcmSrc P;
     P.plane = T.rs_ratio != 1 ? W.pcm + (int64_t)ch * W.pcm_plane + sd.pcm_off : nullptr;
-    P.tail = io.state->pcm_tail[ch]; P.src = io.src[ch]; P.mf = io.mf_size;
+    P.tail = io.state->pcm_tail[ch]; P.src = ch ? io.src[1] : io.src[0]; P.mf = io.mf_size;       // (not io.src[ch]: a dynamic index into a by-value copy of the record makes the copy a private array)
     P.do_scale = !(T.scale == 0.0) && !(T.scale == 1.0); P.scale = T.scale;
     return P;
 }

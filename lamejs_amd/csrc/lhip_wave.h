@@ -399,25 +399,59 @@ LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wa
 LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
 LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
 #ifndef LHIP_SPIN_SLEEP
-#define LHIP_SPIN_SLEEP 2
+#define LHIP_SPIN_SLEEP 0
 #endif
-LHIP_DEV void wg_spin() { if (LHIP_SPIN_SLEEP) __builtin_amdgcn_s_sleep(LHIP_SPIN_SLEEP); }     // polls that sit on a frame's critical path (the count helper's hand-overs): 128 clocks between looks (wg_idle: 512) -- a helper that spins without a pause takes issue slots from another workgroup's searching wave on the same SIMD (bit reservoir, 512 streams: -11 %, profiles/r05_pass4_*)
+// Pause between the looks of a poll that sits on a frame's critical path (the count helper's hand-overs).  None: the helpers only run while every workgroup
+// has a CU to itself (g_frame always -- its LDS fills the CU --, g_resv_stream when the host says so, run_batch), so a spinning wave takes issue slots from
+// nobody but idle waves of its own workgroup.  (With two workgroups per CU a helper spinning without a pause cost the other workgroup's searching wave
+// 11 %, profiles/r05_pass4_*; -DLHIP_SPIN_SLEEP=2 is the 128-clock pause that cured it before the host stopped enabling helpers there.)
+LHIP_DEV void wg_spin() { if (LHIP_SPIN_SLEEP) __builtin_amdgcn_s_sleep(LHIP_SPIN_SLEEP); }
 LHIP_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #endif
-// Spin until the word is neither a nor b; returns what it is then.  For hand-overs on a frame's critical path (the count helper): nothing in
-// the loop but the load, the two compares and a 32-bit guard -- a round is one LDS latency.
+// Spin until the word is neither a nor b; returns what it is then.  For hand-overs on a frame's critical path (the count helper).  A counted loop
+// with nothing in it but the load and the compares: the compiler unrolls it into read / wait / compare / branch groups, one LDS latency per look
+// (tools/ubench_handoff.hip: what a hand-over costs).  A poll that has gone round 2^27 times (seconds) is a protocol or compiler bug: fault instead of
+// hanging the device.
 LHIP_DEV int wg_wait_not(const int* p, int a, int b, int lane) {
-    unsigned n = 0;
-    for (;;) {
+#if defined(LHIP_HOSTSIM)
+    for (unsigned long n = 0; n < (1ul << 34); n++) {
+#else
+    for (unsigned n = 0; n < (1u << 27); n++) {
+#endif
         const int s = wg_load(p, lane);
         if (s != a && s != b) return s;
         wg_spin();
-#if defined(LHIP_HOSTSIM)
-        if (++n == 0u) abort();
-#else
-        if (++n > (1u << 27)) __builtin_trap();       // seconds: a protocol or compiler bug -- fault instead of hanging the device
-#endif
     }
+#if defined(LHIP_HOSTSIM)
+    abort();
+#else
+    __builtin_trap();
+#endif
+}
+// A meeting point of SOME waves of a workgroup (the hardware barrier is all or nothing): every participant announces itself on a counter in LDS that
+// the caller has zeroed behind an earlier workgroup barrier, then waits until `n` have.  Everything a participant wrote to LDS before is visible after.
+LHIP_DEV void wg_meet(int* p, int n, int lane) {
+#if defined(LHIP_HOSTSIM) && LHIP_NL == 1
+    (void)p; (void)n; (void)lane;
+#else
+#if !defined(LHIP_HOSTSIM)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+    wg_add(p, 1, lane);
+#if defined(LHIP_HOSTSIM)
+    for (unsigned long k = 0; k < (1ul << 34); k++) {
+#else
+    for (unsigned k = 0; k < (1u << 27); k++) {
+#endif
+        if (wg_load(p, lane) >= n) { wg_acquire(); return; }
+        wg_spin();
+    }
+#if defined(LHIP_HOSTSIM)
+    abort();
+#else
+    __builtin_trap();
+#endif
+#endif
 }
 // A poll loop that has gone round this often (seconds; a launch's tail is milliseconds) is a protocol or compiler bug: fault instead of
 // hanging the device (lhip_api.cpp, g_fixup: a dispenser loop nested in another loop has been miscompiled into an exec-masked loop on this

@@ -23,7 +23,7 @@ for corpus in ("sine", "bursts"):
             enc.encodeBuffer(L[1152 * w:1152 * (w + 1)], None if R is None else R[1152 * w:1152 * (w + 1)])
         h0 = (ctypes.c_double * 8)(); lib.lhip_debug_read(9, h0, 64)
         buf = (ctypes.c_uint64 * NW)()
-        st = np.zeros(len(STAGES) + 1); ph = np.zeros(64); hp = np.zeros(16); ho = np.zeros(8); wall = 0.0; kern_ticks = 0.0; kern_cyc = 0.0
+        st = np.zeros(len(STAGES) + 1); wvend = np.zeros(16); ph = np.zeros(64); hp = np.zeros(16); ho = np.zeros(8); wall = 0.0; kern_ticks = 0.0; kern_cyc = 0.0
         t_calls = []
         for c in range(3, 3 + ncalls):
             a = L[1152 * c:1152 * (c + 1)]; b = None if R is None else R[1152 * c:1152 * (c + 1)]
@@ -44,6 +44,7 @@ for corpus in ("sine", "bursts"):
             kern_ticks += s[len(STAGES) + 2] - s[len(STAGES) + 1]; kern_cyc += s[len(STAGES)] - s[len(STAGES) + 3]
             ph += np.array([buf[i] for i in range(64)], dtype=np.float64)
             hp += np.array([buf[BASE + 16 + i] for i in range(16)], dtype=np.float64); ho += np.array([buf[BASE + 32 + i] for i in range(8)], dtype=np.float64)
+            wvend += np.array([buf[BASE + 40 + i] for i in range(16)], dtype=np.float64)
             ns += 1
         t_calls = np.array(t_calls)
         hz = kern_cyc / (kern_ticks / 1e8)
@@ -53,6 +54,11 @@ for corpus in ("sine", "bursts"):
         print(f"   g_frame launch: {kern_ticks / ns / 100:.1f} us on the device ({kern_cyc / ns:.0f} cycles, clock {hz / 1e9:.2f} GHz); table copy to LDS {st[len(STAGES)] / ns / hz * 1e6:.1f} us")
         for i, n in enumerate(STAGES):
             print(f"      {n:12s} {st[i] / ns:10.0f} cycles {st[i] / ns / hz * 1e6:8.1f} us  {100 * st[i] / kern_cyc:5.1f}%")
+        print("      waves' finish times inside psyA|poly, us after its start: " + " ".join(f"{wvend[i] / ns / hz * 1e6:.1f}" for i in range(8)) +
+              "   inside bits|save: " + " ".join(f"{wvend[8 + i] / ns / hz * 1e6:.1f}" for i in range(8)))
+        if ph[54]:
+            names = ["hpf_peaks", "window+r4", "fht", "energies", "loudness", "partitions", "tonal+spread"]
+            print("      psyA (granule 0, channel 0) after its samples are in LDS, us: " + " | ".join(f"{n} {ph[22 + i] / ph[54] / hz * 1e6:.1f}" for i, n in enumerate(names)))
         tot = ph[11] if ph[11] else 1
         print(f"   quantization stage, wave 0 (channel 0, both granules): {ph[11] / ns:.0f} cycles")
         for i, n in enumerate(PH):
