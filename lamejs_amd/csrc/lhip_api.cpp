@@ -281,7 +281,7 @@ static_assert(sizeof(PsyALds) <= FR_LDS_PER_WAVE && sizeof(PsyBLds4) <= FR_LDS_P
               sizeof(QuantLds) <= FR_LDS_PER_WAVE && sizeof(BitsLds) <= FR_LDS_PER_WAVE, "frame kernel: the per-wave LDS union is sized by PolyLds");
 // a stage nobody has work in for this configuration (wave-uniform: a function of the tables and the instantiation) -- skipped with its barrier
 template <int RESV> LHIP_DEV bool frame_stage_empty(int stage, const Tables& T) {
-    return (stage == FS_PREP && T.rs_ratio == 1) || (stage == FS_PSYA_MS && T.psy_channels != 4) || (stage == FS_PSYB1 && !(RESV && T.mode_gr == 2));
+    return (stage == FS_PREP && T.rs_ratio == 1) || (stage == FS_PSYA_MS && T.psy_channels != 4) || stage == FS_PSYB1;
 }
 // stage `stage` of the frame program for wave `wv` (of `nw` >= 6) of the workgroup that owns stream `st`.  PAIRQ: stereo quantization by
 // two waves (kb_quant<1>, which meets once per granule at a workgroup barrier: the other waves keep the barrier count).
@@ -336,7 +336,7 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             else if (has && wv >= side0 && wv - side0 < GR) kb_mdct(T, W, SD, g1 + (wv - side0), lane, *(MdctLds*)lds);
             if (wv == 0 && lane == 0) { mbox[3] = 0; mbox[4] = mbox[5] = 0; }   // "psyB of this frame is done" (FS_QUANT, one-channel frames); the bit packers' meeting points (FS_BITS_SAVE)
             break;
-        case FS_PSYB1: if (has && RESV && GR == 2 && wv == 0) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax); break;
+        case FS_PSYB1: break;     // (the reservoir's second psyB runs beside the quantization now: FS_QUANT)
         case FS_QUANT:
             // waves 0 (1): the channel's search; waves 2 (3): its count helper (q_count_helper: the Huffman count of an evaluation while the owner
             // runs calc_noise); the one-lane simulation (PAIRQ == 0) has neither
@@ -346,6 +346,9 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             // bits), a one-channel frame's second granule waits for mbox[3].  The one-lane simulation (PAIRQ == 0, waves one after the other) runs
             // psyB first.
             if (!PAIRQ && psyb_late && has && wv == 0) for (int g = 0; g < GR; g++) kb_psyB<4>(T, pb, W, SD, g1 + g, lane, *(PsyBLds4*)lds, -1, 0, 0);
+            // Bit reservoir: psyB of the SECOND granule beside the quantization, on wave 4 -- nothing of this frame reads what it leaves (granule 1 is quantized against
+            // psyB(granule 0)'s thresholds, the frame's entropies are those of the maskings in use), the next call does (kb_resv_stage, RS_QUANT: the same)
+            if (RESV && GR == 2 && has && wv == 4) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax);
             if (PAIRQ && C == 2) {
                 if (has && wv < 2) { kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
@@ -386,13 +389,14 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
 // second half of its psychoacoustics depend on the bits every earlier frame spent: the frames of a stream are a
 // serial chain.  What does NOT depend on the reservoir (load, resampling, psyA, the scans, the ATH recurrence, polyphase, MDCT) runs
 // batched over all frames of all streams like any other batch; then ONE workgroup per stream walks the stream's frames in order:
-//     psyB(granule 0) | psyB(granule 1) | quantization | bit packing        (workgroup barriers in between)
-// with the stream's reservoir record in LDS for the whole walk and the bit packing of frame k - 1 running beside psyB(granule 0) of
-// frame k on another wave (the packer commits the record; psyB takes the reservoir fill from what the quantization of frame k - 1
-// decided, W.fr, so the two do not touch the same words).  No launch and no read-back per frame: the byte counts stay on the device
-// until the call ends.  Waves: 0 (and 1: second channel, kb_quant<1>) quantize, 2 runs psyB, 3 packs bits.
+//     psyB(granule 0) | quantization        (a workgroup barrier after each)
+// with the stream's reservoir record in LDS for the whole walk, the bit packing of frame k - 1 beside psyB(granule 0) of frame k on another
+// wave (the packer commits the record; psyB takes the reservoir fill from what the quantization of frame k - 1 decided, W.fr, so the two do
+// not touch the same words), and psyB(granule 1) beside the quantization (only the NEXT frame reads what it leaves; round 5: it was a stage of
+// its own, 11 us of a frame's 183).  No launch and no read-back per frame: the byte counts stay on the device until the call ends.
+// Waves: 0 (and 1: second channel, kb_quant<1>) quantize, 2 runs psyB, 3 packs bits.
 // ===========================================================================================
-enum { RS_PSYB0, RS_PSYB1, RS_QUANT, RS_STAGES, RS_WAVES = 4,
+enum { RS_PSYB0, RS_QUANT, RS_STAGES, RS_WAVES = 4,
        RS_LDS_PER_WAVE = ((sizeof(QuantLds) > sizeof(PsyBLds4) ? (sizeof(QuantLds) > sizeof(BitsLds) ? sizeof(QuantLds) : sizeof(BitsLds))
                                                                 : (sizeof(PsyBLds4) > sizeof(BitsLds) ? sizeof(PsyBLds4) : sizeof(BitsLds))) + 15) & ~15 };
 // stage `stage` of frame k (of F) of stream st for wave wv; k == F: only the tail (bit packing of the last frame)
@@ -406,21 +410,23 @@ LHIP_DEV void kb_resv_stage(int stage, const Tables& T, const PowBase& pb, const
     const int g1 = sd.gslot0 + 1 + GR * k, fslot = sd.fslot0 + 1 + k, fidx = sd.out_slot0 + k;
     switch (stage) {
         case RS_PSYB0:
-            if (cshare && wv < 2 && lane == 0) cshare[wv].state = CS_IDLE;      // (the helpers look at it two barriers from here)
+            if (cshare && wv < 2 && lane == 0) cshare[wv].state = CS_IDLE;      // (the helpers look at it one barrier from here)
             if (wv == 2 && k < F) {       // the reservoir as frame k - 1 left it: decided by that frame's quantization (the packer may still be committing it)
                 const int rs = k == 0 ? RV.ResvSize : W.fr[fidx - 1].ResvSize, rm = k == 0 ? RV.ResvMax : W.fr[fidx - 1].ResvMax;
                 kb_psyB<4>(T, pb, W, SD, g1, lane, *(PsyBLds4*)lds, -1, rs, rm);
             }
             if (wv == 3 && k > 0) kb_bits(T, W, SD, fslot - 1, lane, *(BitsLds*)lds, &RV, nout);
             break;
-        case RS_PSYB1:
-            if (wv == 2 && k < F && GR == 2) {
+        case RS_QUANT:
+            if (k >= F) break;
+            // psyB of the frame's SECOND granule runs beside the quantization: nothing of frame k reads what it leaves (the psychoacoustics are one
+            // granule ahead of their use: granule 1 is quantized against psyB(granule 0)'s thresholds, and the frame's entropies -- q_frame_pe -- are
+            // those of the maskings in use), frame k + 1 does, two barriers from here.  Two-channel frames: on wave 2 before it turns count helper (the
+            // searches post their first request after their bin searches, which take longer than this); one-channel frames: on wave 3, which has nothing else to do.
+            if (GR == 2 && ((PAIRQ && wv == (C == 2 ? 2 : 3)) || (!PAIRQ && wv == 2))) {
                 const int rs = k == 0 ? RV.ResvSize : W.fr[fidx - 1].ResvSize, rm = k == 0 ? RV.ResvMax : W.fr[fidx - 1].ResvMax;
                 kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rs, rm);
             }
-            break;
-        case RS_QUANT:
-            if (k >= F) break;
             if (PAIRQ && C == 2) {
                 if (wv < 2) { kb_quant<1, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, wv, mbox, &RV, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
