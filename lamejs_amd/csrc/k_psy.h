@@ -166,7 +166,9 @@ template <int K> LHIP_DEV int guarded_f32_of_sum(const double (&p)[K], double sc
 // launch: their high-passed samples and their spectra are linear combinations of the L / R ones (PsyModel.js:1113-1121, 258-273),
 // which the L / R waves leave in W.hpf / W.fht; everything from the energies on is the same code for all four.
 // PART (one-frame launches, where a wave is alone with its latencies and other waves of the workgroup idle): 1 = only the high-pass + sub-block peaks
-// (they need the samples and nothing else, and nothing below needs them), 2 = everything else; 0 = all of it on one wave (the batched kernel).
+// (they need the samples and nothing else, and nothing below needs them), 2 = everything else; 0 = all of it on one wave (the batched kernel);
+// 3 = everything else up to the loudness (what the scans and the search of the frame's first granule need), 4 = the rest -- partition energies, tonality,
+// short spreading: psyB's inputs -- later, on the same wave and the same LDS record (nothing but LDS carries over).
 template <int PART = 0>
 LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int gslot, int ch, int lane, PsyALds& L) {
     const int C = T.channels_out, Cp = T.psy_channels;
@@ -177,7 +179,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     // The call's 1024-sample window (segment index 576 q + 304 onwards) is converted ONCE into the long FHT buffer: the high-pass,
     // the short windowing and the long windowing all read it from LDS; the long windowing then runs in place (every lane takes its
     // samples into registers before anybody writes).  The caller's Int16 is read coalesced, 2 bytes per sample, exactly once.
-    if (ch < 2) {
+    if (PART != 4 && ch < 2) {
         const PcmSrc P = pcm_source(T, W, sd, IO[st], ch);
         const int b0 = 576 * q + 304;
         if (!P.plane && b0 >= P.mf) {
@@ -198,8 +200,9 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     PSY_DECL();
     PSY_STAMP(0);
 
+    if (PART == 4) goto psya_tail;
     // --- fs/4 high-pass, 9 sub-block peaks (PsyModel.js:1051-1069, 1122-1132) ---
-    if (PART != 2) {
+    if (PART == 0 || PART == 1) {
         const float* fir = L.fz + 397;                // 576 - 350 - 21 + 192
         // Each lane filters NINE CONSECUTIVE outputs: they share 30 input samples, read and widened once (a lane that took
         // output lane + 64 k of each sub-block instead would read 198).  The magnitudes go through LDS (the short FHT buffers are
@@ -412,6 +415,8 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
     }
 
     PSY_STAMP(5);
+    if (PART == 3) return;
+psya_tail:
     // --- long partitions: energy, max, average (calc_energy, PsyModel.js:906-928) ---
 #if LHIP_NL == 1
     LHIP_LANE_ONCE(b, 0, T.npart_l) {                        // npart_l < CBANDS = 64
@@ -546,7 +551,7 @@ LHIP_DEV void kb_psyA(const Tables& T, const Workspace& W, const StreamDesc* SD,
         }
     }
     PSY_STAMP(7);
-    PSY_FLUSH();
+    if (PART == 0 || PART == 2) PSY_FLUSH();
 #undef buf
 }
 

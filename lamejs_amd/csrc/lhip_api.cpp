@@ -281,7 +281,39 @@ static_assert(sizeof(PsyALds) <= FR_LDS_PER_WAVE && sizeof(PsyBLds4) <= FR_LDS_P
               sizeof(QuantLds) <= FR_LDS_PER_WAVE && sizeof(BitsLds) <= FR_LDS_PER_WAVE, "frame kernel: the per-wave LDS union is sized by PolyLds");
 // a stage nobody has work in for this configuration (wave-uniform: a function of the tables and the instantiation) -- skipped with its barrier
 template <int RESV> LHIP_DEV bool frame_stage_empty(int stage, const Tables& T) {
-    return (stage == FS_PREP && T.rs_ratio == 1) || (stage == FS_PSYA_MS && T.psy_channels != 4) || stage == FS_PSYB1;
+    return (stage == FS_PREP && T.rs_ratio == 1) || (stage == FS_PSYA_MS && T.psy_channels != 4) || stage == FS_PSYB1 ||
+           ((stage == FS_SCAN_RAW || stage == FS_SCAN_ATTACK) && !RESV && T.mode != 1);      // (the flow of kb_frame_stage runs these two scans inside FS_PSYA_POLY)
+}
+// What a one-frame launch does BESIDE the search of the frame's first granule (FS_QUANT, waves 4 .. 7; no reservoir, no joint stereo): wave 4 + j holds the
+// energies of (granule, channel) pair j in its LDS (kb_psyA<3>, FS_PSYA_POLY) and finishes that pair's psyA (partitions, tonality, short spreading); when both
+// channels of a granule are done the first channel's wave runs the granule's psyB.  The second granule's filterbank and MDCT follow on waves that are free by then
+// (two channels: 5 and 7 after their psyA parts; one channel: 6).  Meeting points are counters in LDS among the waves concerned (wg_meet; mbox[6 ..], zeroed in
+// FS_PSYB0_MDCT).  The second granule's search needs psyB(granule 0) and its own MDCT: a two-channel frame's waves arrive at the workgroup barrier between the
+// granules only after all of this; a one-channel frame's second granule waits for mbox[3], set here once both are done.
+LHIP_DEV void frame_flow_tail(const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int g1, int wv, int lane,
+                              unsigned char* lds, int* mbox) {
+    const int C = T.channels_out, GR = T.mode_gr, np = GR * C, j = wv - 4;
+    if (j >= 0 && j < np) {
+        const int g = j / C;
+        kb_psyA<4>(T, W, SD, IO, g1 + g, j % C, lane, *(PsyALds*)lds);
+        if (C == 2) wg_meet(mbox + 6 + g, 2, lane);
+        wave_sync();                                          // (the wave's LDS changes its meaning)
+        if (j % C == 0) kb_psyB<4>(T, pb, W, SD, g1 + g, lane, *(PsyBLds4*)lds, -1, 0, 0);
+    }
+    if (GR == 2) {
+        const bool fb = C == 2 ? (wv == 5 || wv == 7) : wv == 6;      // the second granule's filterbank: channel 0 on wave 5 (6), channel 1 on wave 7
+        if (fb) {
+            wave_sync();
+            kb_poly_run(T, W, SD, IO, g1 + 1, C == 2 ? (wv - 5) / 2 : 0, 1, lane, *(PolyLds*)lds);
+            if (C == 2) wg_meet(mbox + 8, 2, lane);
+            wave_sync();
+            if (wv != 7) kb_mdct(T, W, SD, g1 + 1, lane, *(MdctLds*)lds);
+        }
+        if (C == 1 && (wv == 4 || wv == 6)) {
+            wg_meet(mbox + 9, 2, lane);
+            if (wv == 4) wg_store(mbox + 3, 1, lane);
+        }
+    }
 }
 // stage `stage` of the frame program for wave `wv` (of `nw` >= 6) of the workgroup that owns stream `st`.  PAIRQ: stereo quantization by
 // two waves (kb_quant<1>, which meets once per granule at a workgroup barrier: the other waves keep the barrier count).
@@ -295,10 +327,34 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
     ResvState* rv = RESV ? &IO[st].state->rv : nullptr;       // one-frame launches work on the record in global memory
     const int side0 = nw - 2;                                 // the two waves that run the filterbank beside the psychoacoustics
     const bool psyb_late = !RESV && T.mode != 1;              // psyB beside the quantization of granule 0 (FS_QUANT) instead of in front of it
+    const bool flow = PAIRQ && psyb_late && nw == 8;          // ... and with it everything else the first granule's search does not need (frame_flow_tail)
     switch (stage) {
-        case FS_LOAD: kb_load(T, W, SD, IO, st, lane, wv, nw); break;
+        case FS_LOAD: kb_load(T, W, SD, IO, st, lane, wv, nw); if (wv == 0 && lane == 0) mbox[10] = 0; break;      // ([10]: FS_PSYA_POLY's meeting point)
         case FS_PREP: if (T.rs_ratio != 1) kb_prep_stream(T, W, SD, IO, st, (int64_t)wv * LHIP_NL + lane, (int64_t)nw * LHIP_NL); break;
         case FS_PSYA_POLY:
+            // Without the reservoir and outside joint stereo (psyb_late) only what the search of the frame's FIRST granule needs stays in front of it:
+            //   here      waves 4 + j: pair j's spectra up to the loudness (kb_psyA<3>);  waves 0 (1): granule 0's filterbank;  waves 2, 3: the high-passes
+            //   FS_SCAN_* wave 0;   FS_PSYB0_MDCT  wave 1: granule 0's MDCT
+            //   FS_QUANT  beside the search (frame_flow_tail): psyA's partitions / tonality (kb_psyA<4>, on the waves that hold the energies) -> psyB; the
+            //             second granule's filterbank -> its MDCT, which the second granule's search waits for
+            // (measured: a polyphase granule is 17 us of ONE lane's arithmetic whatever else the wave does, psyA's tail 8.7 us: 25.7 -> 17 us for this stage)
+            if (flow) {
+                const int np = GR * C;
+                if (!has) break;
+                if (wv >= 4 && wv - 4 < np) kb_psyA<3>(T, W, SD, IO, g1 + (wv - 4) / C, (wv - 4) % C, lane, *(PsyALds*)lds);
+                else if (wv < C) kb_poly_run(T, W, SD, IO, g1, wv, 1, lane, *(PolyLds*)lds);
+                else if (wv == 2 || wv == 3) {
+                    for (int j = wv - 2; j < np; j += 2) { kb_psyA<1>(T, W, SD, IO, g1 + j / C, j % C, lane, *(PsyALds*)lds); wave_sync(); }
+                    // the first two scans (attack flags from the peaks) right behind the high-passes, well inside the stage: FS_SCAN_RAW / _ATTACK are empty then
+                    wg_meet(mbox + 10, 2, lane);
+                    if (wv == 2) {
+                        for (int g = lane; g < GR; g += LHIP_NL) kb_scan_raw(T, W, SD, g1 + g);
+                        wave_sync_global();
+                        for (int g = lane; g < GR; g += LHIP_NL) kb_scan_attack(T, W, SD, g1 + g);
+                    }
+                }
+                break;
+            }
             // One-frame launches on the device: waves [0, GR C) take the spectra and everything after them (kb_psyA<2>, the stage's longest chain); wave GR C + j
             // takes (granule, channel) pair j's polyphase filterbank and then its high-pass + sub-block peaks (kb_psyA<1>: a fifth of psyA, needed by the scans
             // only) -- on one wave per channel the filterbank of both granules was as long as all of psyA
@@ -317,8 +373,8 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             else if (has && wv >= side0 && wv - side0 < C) kb_poly_run(T, W, SD, IO, g1, wv - side0, GR, lane, *(PolyLds*)lds);
             break;
         case FS_PSYA_MS: if (has && Cp == 4 && wv < GR * 2) kb_psyA(T, W, SD, IO, g1 + wv / 2, 2 + wv % 2, lane, *(PsyALds*)lds); break;
-        case FS_SCAN_RAW: if (has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_raw(T, W, SD, g1 + g); break;
-        case FS_SCAN_ATTACK: if (has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_attack(T, W, SD, g1 + g); break;
+        case FS_SCAN_RAW: if (!flow && has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_raw(T, W, SD, g1 + g); break;
+        case FS_SCAN_ATTACK: if (!flow && has && wv == 0) for (int g = lane; g < GR; g += LHIP_NL) kb_scan_attack(T, W, SD, g1 + g); break;
         case FS_SCAN_BT:
             if (has && wv == 0) {
                 for (int g = lane; g < GR; g += LHIP_NL) kb_scan_blocktype(T, W, SD, g1 + g);
@@ -332,9 +388,10 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
         case FS_PSYB0_MDCT:   // the MDCT needs the block types (scans) and the polyphase output.  Bit reservoir: psyB here too, the frame's granules one after
                               // the other (FS_PSYB1 takes the second) -- their thresholds depend on the reservoir; joint stereo: psyB here as well (the frame's M/S
                               // decision reads granule 0's thresholds before anything is quantized); otherwise psyB runs beside the quantization (psyb_late)
-            if (has && !psyb_late && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
+            if (flow) { if (has && wv == 1) kb_mdct(T, W, SD, g1, lane, *(MdctLds*)lds); }       // granule 0 only (waves 4 .. 7 keep psyA's energies in their LDS)
+            else if (has && !psyb_late && (RESV ? wv == 0 : wv < GR)) kb_psyB<4>(T, pb, W, SD, g1 + (RESV ? 0 : wv), lane, *(PsyBLds4*)lds, -1, RESV ? rv->ResvSize : 0, RESV ? rv->ResvMax : 0);
             else if (has && wv >= side0 && wv - side0 < GR) kb_mdct(T, W, SD, g1 + (wv - side0), lane, *(MdctLds*)lds);
-            if (wv == 0 && lane == 0) { mbox[3] = 0; mbox[4] = mbox[5] = 0; }   // "psyB of this frame is done" (FS_QUANT, one-channel frames); the bit packers' meeting points (FS_BITS_SAVE)
+            if (wv == 0 && lane == 0) for (int i = 0; i < 12; i++) mbox[i] = 0;     // [3] "granule 1 may be searched" (FS_QUANT, one-channel frames); [4], [5] the bit packers' meeting points (FS_BITS_SAVE); [6 ..] frame_flow_tail's
             break;
         case FS_PSYB1: break;     // (the reservoir's second psyB runs beside the quantization now: FS_QUANT)
         case FS_QUANT:
@@ -355,13 +412,15 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
                 else if (has && cshare && wv < 4) q_count_helper(T, cshare[wv - 2], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
                 else {
-                    if (psyb_late && has && wv >= 4 && wv - 4 < GR) kb_psyB<4>(T, pb, W, SD, g1 + (wv - 4), lane, *(PsyBLds4*)lds, -1, 0, 0);
+                    if (flow && has) frame_flow_tail(T, pb, W, SD, IO, g1, wv, lane, lds, mbox);
+                    else if (psyb_late && has && wv >= 4 && wv - 4 < GR) kb_psyB<4>(T, pb, W, SD, g1 + (wv - 4), lane, *(PsyBLds4*)lds, -1, 0, 0);
                     for (int gr = 0; gr < GR; gr++) wg_barrier();
                 }
             } else if (has && wv == 0) { kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr, (PAIRQ && psyb_late) ? mbox + 3 : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
             else if (PAIRQ && has && cshare && wv == 2) q_count_helper(T, cshare[0], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
+            else if (flow && has && wv >= 4) frame_flow_tail(T, pb, W, SD, IO, g1, wv, lane, lds, mbox);      // (sets the flag granule 1 waits for)
             else if (PAIRQ && psyb_late && has && wv == 4) {           // one-channel frame: both granules' psyB on this wave, then the flag granule 1 waits for
                 for (int g = 0; g < GR; g++) kb_psyB<4>(T, pb, W, SD, g1 + g, lane, *(PsyBLds4*)lds, -1, 0, 0);
                 wg_store(mbox + 3, 1, lane);
@@ -715,7 +774,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
 template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QArgs a_unused, const StreamIO* IO) {
     __shared__ QuantTabs Q;
     __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
-    __shared__ int mbox[8];
+    __shared__ int mbox[12];
     __shared__ CountShare CS[2];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1404,7 +1463,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = FR_WAVES;
-            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[8]; static thread_local CountShare fcs[2];
+            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[12]; static thread_local CountShare fcs[2];
             fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;
             for (int s = 0; s < S; s++) {
 #ifdef LHIP_WAVESIM

@@ -425,6 +425,23 @@ def test_gpu_random_material(lib):
     assert fuzz_gpu.run(70, 5, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS) == []           # integer-ratio resampling in front
 
 
+def test_gpu_one_frame_calls_random(lib):
+    """The reference's documented call pattern -- a frame's worth of samples per encodeBuffer() -- on random material over all families and both extensions: every
+    call is ONE launch of the eight-wave frame program (g_frame: polyphase + high-pass on side waves, psyB and the count helpers beside the search, the granule-
+    channels packed side by side; bit reservoir: its second psyB beside the search).  Bytes against the oracle."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import fuzz_gpu
+    bad = []
+    bad += fuzz_gpu.run(48, 90210, verbose=False, max_frames=40, frame_calls=True)
+    bad += fuzz_gpu.run(32, 90211, verbose=False, cfgs=fuzz_gpu.LSF_CFGS, max_frames=40, frame_calls=True)
+    bad += fuzz_gpu.run(16, 90212, verbose=False, cfgs=fuzz_gpu.RESAMPLE_CFGS, max_frames=40, frame_calls=True)
+    bad += fuzz_gpu.run(20, 90213, verbose=False, joint=True, max_frames=40, frame_calls=True)
+    bad += fuzz_gpu.run(24, 90214, verbose=False, cfgs=fuzz_gpu.MPEG1_CFGS + fuzz_gpu.LSF_CFGS, reservoir=True, max_frames=40, frame_calls=True)
+    bad += fuzz_gpu.run(12, 90215, verbose=False, joint=True, reservoir=True, max_frames=40, frame_calls=True)
+    assert bad == [], bad[:5]
+
+
 def test_gpu_random_material_fresh_seed(lib):
     """The randomised sweep of tests/tools/fuzz_gpu.py with a seed nobody has seen before (taken from the clock, printed, and part of
     the failure message): device-only code -- DPP reductions, readfirstlane uniformity, the rounding-mode asm -- is exercised on
