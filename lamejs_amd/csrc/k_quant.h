@@ -1301,6 +1301,8 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
 // region1_count << 28; w[2] table_select[0..2] + 1 at 6 bits each | sfb_count1 << 18 | the mask of conditionally assigned fields << 24: the
 // owner takes the region counts and table_select[r] only where the reference's count assigns them, Takehiro.js:566-612).
 struct CountShare { int state; uint32_t w[3];
+    int16_t kept[576];          // the search's kept copy of the quantized spectrum (q_outer_loop's `kept`): in LDS where a wave is alone with its memory latencies
+                                // (the batched kernel keeps it in HBM -- the granule-channel's slot of W.l3 -- and reads it back once per search)
 #if defined(LHIP_PHASE_PROF) || defined(LHIP_HANDOFF_PROF)
     unsigned long long t_post, t_reply; unsigned int acc[8];      // profiling builds: the hand-over's legs (q_count_helper)
 #endif
@@ -2436,7 +2438,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
     if (q_init_xrpow(g, lane, L, Q)) {
         active = 1;
         { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
-        int16_t* kept = W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
+        int16_t* kept = cs ? cs->kept : W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
         { PH_BEGIN(); q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs); PH_END(L, PH_XRPOW); }   // (profiling builds: the whole search in the otherwise unused slot)
         uni_gi(g); bs_gain = uni(bs_gain);
         lane = lane_anew(lane);
