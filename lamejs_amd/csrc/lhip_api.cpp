@@ -786,6 +786,10 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
     if (blockIdx.x == 0 && threadIdx.x == 0) { A->W.prof[FRAME_PROF_BASE + FR_STAGES + 1] = wall_clock64(); A->W.prof[FRAME_PROF_BASE + FR_STAGES + 3] = __builtin_amdgcn_s_memtime(); }
 #endif
     q_copy_tabs(A->T, Q, threadIdx.x, 64 * FR_WAVES);       // (first read by the quantization stage: the barriers in between order it)
+    // Unrolled: every stage runs once, and as a loop the compiler hoisted the constants and addresses of ALL stage bodies in front of it and carried them across
+    // the stages -- 60 to 150 values parked in scratch memory (308 - 1264 bytes of scratch per lane as the bodies grew; past ~0.5 KB the launch itself got 20 us
+    // slower: the runtime allocates scratch that large afresh per dispatch).  Unrolled, g_frame<1> needs no scratch at all.
+#pragma clang loop unroll(full)
     for (int stage = 0; stage < FR_STAGES; stage++) {
 #ifdef LHIP_PHASE_PROF
         // profiling build (tests/tools/frame_prof.py): when every stage of stream 0's frame starts, and the quantization phases of its wave 0
