@@ -1468,8 +1468,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = FR_WAVES;
             alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[12]; static thread_local CountShare fcs[2];
-            fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;
             for (int s = 0; s < S; s++) {
+                fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;       // per workgroup, as g_frame does (a stream's owners leave CS_QUIT behind)
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {
                     for (int stage = 0; stage < FR_STAGES; stage++) {

@@ -205,3 +205,21 @@ def test_wavesim_one_frame_launch_count_helpers():
     import re
     m = re.search(r"count helper: (\d+) evaluations counted on the helper wave, (\d+) of the calc_noise calls made beside them committed", r.stderr)
     assert m and int(m.group(2)) > 100 and int(m.group(1)) - int(m.group(2)) > 100, r.stderr[-500:]
+
+
+@pytest.mark.parametrize("ch,nstreams", [(1, 3), (2, 2)])
+def test_wavesim_one_frame_batch_of_streams(wsim, ch, nstreams):
+    """`encodeBatch` over several streams fed 1152 samples per call: the eight-wave one-frame launch once per stream of the batch.  (Round 5's
+    simulation set the count helpers' records to idle once per batch instead of once per workgroup and hung on the second stream; the device
+    kernel initialises them per workgroup.)"""
+    import lamejs_amd, pcm
+    mats = [pcm.bursts(1152 * 4 + 100 * i, ch, seed=3100 + 10 * ch + i) for i in range(nstreams)]
+    encs = [lamejs_amd.Mp3Encoder(ch, 44100, 128, lib=wsim) for _ in mats]
+    got = [b""] * nstreams
+    n = max(len(m[0]) for m in mats)
+    for p in range(0, n, 1152):
+        outs = lamejs_amd.encode_streams(encs, [m[0][p:p + 1152] for m in mats], None if ch == 1 else [m[1][p:p + 1152] for m in mats], flush=False)
+        got = [g + o for g, o in zip(got, outs)]
+    got = [g + e.flush() for g, e in zip(got, encs)]
+    for m, g in zip(mats, got):
+        assert g == oracle_encode(ch, 44100, 128, m[0], m[1])
