@@ -396,6 +396,29 @@ def main():
         if not sim:
             torch.cuda.synchronize()
 
+    def device_identity():
+        """What tells two GPUs apart, per rank: PCI bus id and UUID of the HIP device this rank encodes on (the first multi-GPU run validates itself:
+        N ranks must report N distinct devices).  The host simulation (gloo tests) reports a stand-in per rank."""
+        if sim:
+            return {"hip_device_pci_bus_id": f"hostsim:{rank}", "hip_device_uuid": f"hostsim-{rank}", "hip_device_ordinal": dev_ord}
+        ident = {"hip_device_pci_bus_id": None, "hip_device_uuid": None, "hip_device_ordinal": dev_ord}
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, dev_ord) == 0:
+                ident["hip_device_pci_bus_id"] = buf.value.decode()
+            ub = ctypes.create_string_buffer(16)
+            if hasattr(hip, "hipDeviceGetUuid") and hip.hipDeviceGetUuid(ub, dev_ord) == 0:
+                ident["hip_device_uuid"] = ub.raw.hex()
+        except Exception as ex:
+            ident["error"] = str(ex)[:120]
+        if ident["hip_device_uuid"] is None:
+            try:
+                ident["hip_device_uuid"] = str(torch.cuda.get_device_properties(dev_ord).uuid)
+            except Exception:
+                pass
+        return ident
+
     import lamejs_amd
     import pcm
 
@@ -552,8 +575,13 @@ def main():
     kern = wl.kernel_times() if not sim else {}
 
     # ---- N > 1: verdicts of all ranks; RCCL gather of the MP3 bytes to rank 0 (untimed), re-hashed there ----
-    verdicts = [(rank, md5s, full, prefix, wl.nbytes, wl.seeds)]
+    dom_ms = None           # this rank's dominant kernel: (name, ms per launch) -- at N > 1 the roofline is computed from the slowest rank's
+    if kern:
+        dn_ = max(kern, key=lambda k_: kern[k_]["ms"])
+        dom_ms = (dn_, kern[dn_]["ms"] / max(kern[dn_]["launches"], 1))
+    verdicts = [(rank, md5s, full, prefix, wl.nbytes, wl.seeds, device_identity(), dom_ms)]
     gathered_ok = None
+    rccl_world = dist.get_world_size() if use_dist else None          # as the process group reports it (backend "nccl" = RCCL), beside n_gpus
     if use_dist:
         allv = [None] * world
         dist.all_gather_object(allv, verdicts[0])
@@ -593,12 +621,22 @@ def main():
                        "output_md5_per_rank": [v[1][0] if len(v[1]) == 1 else hashlib.md5("".join(v[1]).encode()).hexdigest() for v in verdicts],
                        "rccl_gather_of_outputs_rehashed_ok": gathered_ok,
                        "stream_seeds_per_rank": [[v[5][0], v[5][-1], len(v[5])] for v in verdicts],       # [first, last, count]: ranks encode disjoint streams
-                       "distinct_streams": len({s_ for v in verdicts for s_ in v[5]})},
+                       "distinct_streams": len({s_ for v in verdicts for s_ in v[5]}),
+                       # which GPU every rank really sat on (a multi-GPU line validates itself: N ranks, N distinct devices)
+                       "devices_per_rank": [v[6] for v in verdicts],
+                       "distinct_devices": len({(v[6].get("hip_device_pci_bus_id"), v[6].get("hip_device_uuid")) for v in verdicts}),
+                       "rccl_world_size": rccl_world, "collective_backend": (None if not use_dist else "gloo (host simulation)" if sim else "nccl (RCCL)")},
             "kernels_ms": kern,
         }
+        if world > 1 and line["config"]["distinct_devices"] != world:
+            raise SystemExit(f"bench.py: {world} ranks report {line['config']['distinct_devices']} distinct devices: {line['config']['devices_per_rank']}")
         dom = max(kern, key=lambda k_: kern[k_]["ms"]) if kern else None
         if dom:
             kt = kern[dom]["ms"] / max(kern[dom]["launches"], 1) / 1000.0
+            # N > 1: every rank runs the same launch on its own GPU; the line's roofline is the SLOWEST rank's (max kernel time over ranks), all of them listed
+            per_rank = [v[7][1] for v in verdicts if v[7] is not None and v[7][0] == dom]
+            if world > 1 and per_rank:
+                kt = max(per_rank) / 1000.0
             alg = alg_bytes_per_frame(wl.ch, wl.kbps) * wl.frames_per_step
             ach = alg / kt / 1e9
             # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
@@ -615,7 +653,8 @@ def main():
                     traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_unit": "bytes/launch",
-                                "algorithmic_bytes_per_launch": int(alg),
+                                "algorithmic_bytes_per_launch": int(alg), "kernel_ms_per_launch": round(kt * 1000.0, 4),
+                                "kernel_ms_per_launch_per_rank": [round(x, 4) for x in per_rank], "per_gpu": True,
                                 "note": "neither HBM nor MFMA bounds this path (SURVEY.md 8d): the HBM fraction is small by construction; "
                                         "see roofline_compute for the limiter (VALU issue)"}
             rc = prof.get("compute", {}).get("g_" + dom)
@@ -631,6 +670,7 @@ def main():
                 line["roofline_compute"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(ach, 1), "peak": ce[8], "unit": "G VALU wave-instructions/s",
                                             "frac": round(ach / ce[8], 4), "peak_at_kernel_occupancy": ce[occ], "frac_at_kernel_occupancy": round(ach / ce[occ], 4),
                                             "occupancy_waves_per_simd": occ, "valu_insts_per_launch": insts, "salu_insts_per_launch": rc["salu_insts_per_launch"],
+                                            "source_head": prof.get("head"),
                                             "source": f"profiles/{pf.name} (PMC counts of this workload on the code of that measurement pass: they go stale with every kernel change) + the issue microbenchmark in it (ceiling of that mix)"}
 
     # ---- the other configurations (N = 1 only): each is its own short run, md5-checked like the main one ----
@@ -758,6 +798,20 @@ def main():
                         line["cpu_baseline"]["reference_node"]["aggregate"] = {
                             "value": round(sum(f for f, _ in res) / tmax, 1), "unit": "frames/s", "cores": len(res), "processes": len(res), "usable_cores": usable, "same_box": True,
                             "sample": f"{len(res)} Node.js processes (one per usable core), 1500 frames each of the same stream, clocks started together; longest {tmax:.2f} s"}
+                # the other shapes the 1152-sample lines are measured on: same box, same call pattern (3000 frames each, a few seconds)
+                shapes = {}
+                for ch_, kb_, mat_, nfr_ in ((1, 128, "sine", 3000), (2, 128, "sine", 3000), (2, 320, "sine", 3000), (2, 128, "fixture", 1435), (1, 128, "fixture", 1435)):
+                    nm_ = f"{'mono' if ch_ == 1 else 'stereo'}{kb_}_{mat_}"
+                    if (ch_, kb_, mat_) == (wl.ch, wl.kbps, "sine"):
+                        shapes[nm_] = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": True, "frames": e["frames"]}
+                        continue
+                    try:
+                        r2_ = subprocess.run([node, tool, str(ch_), str(kb_), str(nfr_), "0", mat_], capture_output=True, text=True, timeout=120, env=env)
+                        e2 = json.loads(r2_.stdout.strip().splitlines()[-1])
+                        shapes[nm_] = {"value": e2["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": True, "frames": e2["frames"]}
+                    except Exception as ex2:
+                        shapes[nm_] = {"error": str(ex2)[:200]}
+                line["cpu_baseline"]["reference_node"]["shapes"] = shapes
             except Exception as ex:
                 line["cpu_baseline"]["reference_node"] = {"error": str(ex)[:300]}
         rn = ROOT / "profiles" / "r02_reference_node_cpu.jsonl"
@@ -770,6 +824,27 @@ def main():
                     continue
                 shapes[f"{'mono' if e.get('channels') == 1 else 'stereo'}{e.get('kbps')}"] = {"value": e["frames_per_s"], "unit": "frames/s", "cores": 1, "same_box": False, "frames": e.get("frames"), "host": e.get("host")}
             line["cpu_baseline"]["reference_node_build_container"] = shapes
+        # ---- what north_star names as the baseline -- "the reference's single-threaded Node.js path timed on the same box's host cores" -- is the line's
+        # cpu_baseline; the plain-C port (three times faster than the thing it stands in for) is nested beside it
+        cb = line["cpu_baseline"]
+        rn_ = cb.get("reference_node")
+        if rn_ and "value" in rn_:
+            port = {k_: cb[k_] for k_ in ("value", "unit", "cores", "kind", "same_box", "sample", "aggregate") if k_ in cb}
+            new_cb = dict(rn_)
+            new_cb["port"] = port
+            if "reference_node_build_container" in cb:
+                new_cb["reference_node_build_container"] = cb["reference_node_build_container"]
+            new_cb["reference_node"] = {k_: rn_[k_] for k_ in ("value", "unit", "cores", "same_box", "kind") if k_ in rn_}      # (older readers of the line look here)
+            line["cpu_baseline"] = new_cb
+            # every 1152-sample line beside the reference on the same box, same material, same call pattern
+            sh = rn_.get("shapes", {})
+            for nm_, ref_ in (("dropin_node_1152", "stereo128_fixture"), ("dropin_node_1152_mono", "mono128_fixture"), ("dropin_node_1152_sine", "stereo128_sine"),
+                              ("dropin_node_1152_sine_mono", "mono128_sine")):
+                e_ = line.get("other_configs", {}).get(nm_)
+                r_ = sh.get(ref_, {}).get("value")
+                if e_ and r_ and "frames_per_s" in e_:
+                    e_["reference_same_pattern_frames_per_s"] = r_
+                    e_["speedup_vs_reference_same_pattern"] = round(e_["frames_per_s"] / r_, 3)
     wl.close()
     if use_dist:
         dist.destroy_process_group()

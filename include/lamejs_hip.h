@@ -112,6 +112,9 @@ size_t lhip_max_output_bytes(const lhip_stream* s, size_t nsamples);
  * library write into it -- no second buffer, no copy (the reference allocates a fresh exact-size Int8Array per call, index.js:129).
  * With the bit reservoir (extension) the count is data-dependent and this returns lhip_max_output_bytes().  < 0: bad handle. */
 int64_t lhip_encode_output_bytes(const lhip_stream* s, size_t nsamples);
+/* 1: lhip_encode_output_bytes(s, n) is the exact byte count of the next call (CBR without the bit reservoir); 0: it is only an upper bound (bit-reservoir
+ * extension: the count is data-dependent) -- a binding then encodes into scratch memory and hands out an exact copy; < 0: bad handle. */
+int lhip_output_bytes_is_exact(const lhip_stream* s);
 
 /* Batch extension (BASELINE config 5: many independent streams, one launch): stream i receives
  * nsamples[i] samples from left[i]/right[i] and its frames are written to out[i] (capacity

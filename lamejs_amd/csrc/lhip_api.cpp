@@ -72,8 +72,13 @@ static void host_free_pinned(void* p) { free(p); }
 #else
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(std::string(#x) + ": " + hipGetErrorString(e_)); return false; } } while (0)
 namespace rt {
-static int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-static bool set_device(int d) { HIPCK(hipSetDevice(d)); return true; }
+// LHIP_ALIAS_DEVICES=n (tests only, 2 <= n <= 8): ordinals 0 .. n-1 are n SEPARATE library contexts -- own mutex, own HIP stream, own workspaces, own table
+// uploads -- on physical device 0, so that a box with one GPU runs the multi-device paths (lhip_set_devices' round-robin placement, host threads batching
+// on two contexts at the same time) against real HIP (tests/test_gpu_parity.py::test_gpu_two_devices_*).  Read at every call: a test sets it for its own duration.
+static int alias_n() { const char* e = getenv("LHIP_ALIAS_DEVICES"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 8 ? v : 0; }
+static int phys(int d) { return alias_n() ? 0 : d; }
+static int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; const int a = alias_n(); return (a && n >= 1) ? a : n; }
+static bool set_device(int d) { HIPCK(hipSetDevice(phys(d))); return true; }
 static void* dmalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; return p; }
 static void dfree(void* p) { if (p) (void)hipFree(p); }
 static bool h2d(void* d, const void* s, size_t n, void* st) { if (n) HIPCK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); return true; }
@@ -647,7 +652,8 @@ LHIP_DEV void grid_barrier(int32_t* bar, int nblocks) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+            // (bounded: 2^26 looks of ~0.12 us = 8 s -- two hundred times the longest launch this can stand behind; a grid that is not co-resident faults instead of hanging the device)
+            for (int n = 0; __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen; n++) { if (n > (1 << 26)) __builtin_trap(); __builtin_amdgcn_s_sleep(4); }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // this CU's L1 must not serve stale records
     }
@@ -1175,8 +1181,10 @@ struct PinBuf {
         if (!p) { cap = 0; return false; }
         return true;
     }
+    void release() { rt::host_free_pinned(p); p = nullptr; cap = 0; }
     // (not freed by a destructor: the contexts live in a process-wide map, so that would run during static destruction, after the HIP runtime --
-    //  and a profiler hooked into it -- has begun to shut down: `rocprofv3 -- python bench.py` ended in a segmentation fault at exit)
+    //  and a profiler hooked into it -- has begun to shut down: `rocprofv3 -- python bench.py` ended in a segmentation fault at exit.  The orderly
+    //  way out releases them: lhip_destroy of a context's last stream, while the runtime is certainly still up.)
 };
 
 // Everything a batch in flight owns: the workspace arrays, the descriptor / host-I/O staging, and the side stream + events of the ATH scan.
@@ -1197,6 +1205,7 @@ struct Context {
     int device = 0;
     void* stream = nullptr;
     std::mutex mu;
+    int live_streams = 0;       // streams created on this context and not yet destroyed (guarded by mu): the last one out releases the pinned staging buffers
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     WorkSet ws;
     int num_cus = 256;
@@ -1218,7 +1227,9 @@ static Context* get_context(int device) {
     std::unique_ptr<Context> c(new Context());
     c->device = device;
 #ifndef LHIP_HOSTSIM
-    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->num_cus = n; }
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, rt::phys(device)) == hipSuccess && n > 0) c->num_cus = n; }
+    // an aliased context (LHIP_ALIAS_DEVICES) gets a HIP stream of its own: on the null stream two contexts of one physical device would simply queue up
+    if (rt::alias_n() && device > 0 && hipSetDevice(0) == hipSuccess) { void* st = nullptr; if (rt::stream_create(&st)) c->stream = st; }
 #endif
     Context* r = c.get();
     g_ctx[device] = std::move(c);
@@ -1844,6 +1855,7 @@ int lhip_create(const lhip_config* cfg, const void* tables, size_t tables_bytes,
     s->d_state = (StreamState*)rt::dmalloc(sizeof(StreamState));
     if (!s->d_state) { set_err("hipMalloc(stream state) failed"); return LHIP_ERR_INTERNAL; }
     if (!rt::h2d(s->d_state, h.get(), sizeof(StreamState), ctx->stream) || !rt::sync(ctx->stream)) return LHIP_ERR_INTERNAL;
+    ctx->live_streams++;
     *out = s.release();
     return 0;
 }
@@ -1855,6 +1867,7 @@ void lhip_destroy(lhip_stream* s) {
     rt::set_device(ctx->device);
     std::shared_ptr<TableSet> ts = s->ts;
     delete s;
+    if (--ctx->live_streams == 0) { (void)rt::sync(ctx->stream); ctx->ws.pin_in.release(); ctx->ws.pin_out.release(); }      // (grow-only while streams live; a later stream allocates them again)
     // the cache entry goes with the last stream that uses it (one reference is the map's, one is `ts` here)
     if (ts.use_count() == 2)
         for (auto it = ctx->tables.begin(); it != ctx->tables.end(); ++it) if (it->second == ts) { ctx->tables.erase(it); break; }
@@ -1871,6 +1884,11 @@ int64_t lhip_encode_output_bytes(const lhip_stream* s, size_t nsamples) {
     if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
     if (!s->ts->T.disable_reservoir) return (int64_t)lhip_max_output_bytes(s, nsamples);      // data-dependent: only a bound exists
     return batch_bytes(*s->ts, s->slot_lag, call_frames(s, nsamples));
+}
+
+int lhip_output_bytes_is_exact(const lhip_stream* s) {
+    if (!s || s->magic != 0x4c484950) { set_err("bad stream handle"); return LHIP_ERR_BAD_HANDLE; }
+    return s->ts->T.disable_reservoir ? 1 : 0;
 }
 
 static int encode_many(lhip_stream* const* streams, size_t n, const int16_t* const* l, const int16_t* const* r,

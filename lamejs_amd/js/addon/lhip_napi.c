@@ -29,6 +29,7 @@ static int64_t (*p_encode)(lhip_stream*, const int16_t*, const int16_t*, size_t,
 static int64_t (*p_flush)(lhip_stream*, uint8_t*, size_t);
 static void (*p_destroy)(lhip_stream*);
 static size_t (*p_max_out)(const lhip_stream*, size_t);
+static int (*p_is_exact)(const lhip_stream*);
 static int64_t (*p_out_bytes)(const lhip_stream*, size_t);
 static int (*p_encode_batch)(lhip_stream* const*, size_t, const int16_t* const*, const int16_t* const*, const size_t*, uint8_t* const*, const size_t*, int64_t*);
 static int (*p_flush_batch)(lhip_stream* const*, size_t, uint8_t* const*, const size_t*, int64_t*);
@@ -56,7 +57,7 @@ static int load_lib(napi_env env) {
     if (!g_lib) { napi_throw_error(env, NULL, "lamejs_amd: cannot load liblamejs_hip.so (no CPU fallback exists)"); return 0; }
 #define SYM(v, n) *(void**)(&v) = dlsym(g_lib, n); if (!v) { napi_throw_error(env, NULL, "lamejs_amd: missing symbol " n); return 0; }
     SYM(p_device_count, "lhip_device_count") SYM(p_create, "lhip_create") SYM(p_encode, "lhip_encode") SYM(p_flush, "lhip_flush")
-    SYM(p_destroy, "lhip_destroy") SYM(p_max_out, "lhip_max_output_bytes") SYM(p_last_error, "lhip_last_error")
+    SYM(p_destroy, "lhip_destroy") SYM(p_max_out, "lhip_max_output_bytes") SYM(p_is_exact, "lhip_output_bytes_is_exact") SYM(p_last_error, "lhip_last_error")
     SYM(p_encode_batch, "lhip_encode_batch") SYM(p_flush_batch, "lhip_flush_batch") SYM(p_set_devices, "lhip_set_devices")
     SYM(p_state_bytes, "lhip_state_bytes") SYM(p_state_get, "lhip_state_get") SYM(p_state_set, "lhip_state_set")
     SYM(p_seek_tail, "lhip_seek_tail_samples") SYM(p_seek, "lhip_seek") SYM(p_out_bytes, "lhip_encode_output_bytes")
@@ -121,7 +122,7 @@ static napi_value encode_into_new_array(napi_env env, lhip_stream* s, const int1
     static uint8_t none[16];
     const int64_t want = p_out_bytes(s, nl);
     const size_t cap = want > 0 ? (size_t)want : 0;
-    if (cap > 0 && cap == p_max_out(s, nl)) {
+    if (cap > 0 && p_is_exact(s) != 1) {
         /* the count is an upper bound, not the count (bit-reservoir extension): encode into scratch memory and hand out an exact copy -- a
          * zero-filled ArrayBuffer of the bound per call would be allocated only to be thrown away */
         uint8_t* tmp = (uint8_t*)malloc(cap);
@@ -214,7 +215,7 @@ static napi_value batch_common(napi_env env, napi_callback_info info, int is_flu
             const int64_t want = p_out_bytes(hs[i], ns[i]);
             void* data = NULL;
             caps[i] = want > 0 ? (size_t)want : 0;
-            if (caps[i] > 0 && caps[i] == p_max_out(hs[i], ns[i])) {      /* an upper bound only (bit reservoir): scratch memory, exact copy afterwards */
+            if (caps[i] > 0 && p_is_exact(hs[i]) != 1) {      /* an upper bound only (bit reservoir): scratch memory, exact copy afterwards */
                 outs[i] = (uint8_t*)malloc(caps[i]);
                 if (!outs[i]) { err = "out of memory"; break; }
                 continue;

@@ -52,7 +52,8 @@ function Mp3Encoder(channels, samplerate, kbps, opts) {
     const native = loadAddon();
     const blob = tablesBlob(channels, samplerate, kbps, opts);
     const handle = native.create(blob, channels, samplerate, kbps, defaultDevice);
-    Object.defineProperty(this, '_lhip', { value: { handle: handle, channels: channels }, enumerable: false });
+    const hooks = { handle: handle, channels: channels, drain: null, pending: () => 0 };
+    Object.defineProperty(this, '_lhip', { value: hooks, enumerable: false });
 
     /* { pendingFrames: N }: input held back until N frames' worth has accumulated (see the header comment) */
     const pendMax = opts && opts.pendingFrames > 1 ? 1152 * (opts.pendingFrames | 0) : 0;
@@ -64,11 +65,16 @@ function Mp3Encoder(channels, samplerate, kbps, opts) {
         pendN = 0;
         return out;
     }
+    /* what is held back belongs in front of anything that reaches the native handle by another way (encodeBatch / flushBatch drain it first and
+     * return its bytes in front of their own; getState / setState / seek refuse while input is pending: the state would not contain it) */
+    if (pendMax) { hooks.drain = drain; hooks.pending = () => pendN; }
+    const noPending = (what) => { if (pendN > 0) throw new Error(what + ': ' + pendN + ' samples are held back by { pendingFrames }; call flush() first'); };
     this.encodeBuffer = function (left, right) {
         if (channels == 1) right = null;
         if (!(left instanceof Int16Array)) left = Int16Array.from(left);
         if (right && !(right instanceof Int16Array)) right = Int16Array.from(right);
         if (!pendMax) return native.encode(handle, left, right || null);
+        if (right && right.length != left.length) throw new TypeError('right must be an Int16Array of the same length');       /* (the native path's own check and message) */
         if (left.length > pendL.length - pendN) {                /* does not fit beside what is pending: encode that first, then this */
             const a = drain(), b = left.length >= pendMax ? native.encode(handle, left, right || null) : null;
             if (b) { const r = new Int8Array(a.length + b.length); r.set(a, 0); r.set(b, a.length); return r; }
@@ -89,9 +95,9 @@ function Mp3Encoder(channels, samplerate, kbps, opts) {
      * warm-up frames whose bytes are thrown away, and its getState() at the cut is compared with the getState() of the encoder that
      * came from the left; equal states = equal futures, otherwise setState() transplants the true one. */
     this.seekTailSamples = function () { return native.seekTailSamples(handle); };
-    this.seek = function (samplePos, tailLeft, tailRight) { native.seek(handle, samplePos, tailLeft, channels == 1 ? null : (tailRight || null)); };
-    this.getState = function () { return native.stateGet(handle); };
-    this.setState = function (state) { native.stateSet(handle, state); };
+    this.seek = function (samplePos, tailLeft, tailRight) { noPending('seek'); native.seek(handle, samplePos, tailLeft, channels == 1 ? null : (tailRight || null)); };
+    this.getState = function () { noPending('getState'); return native.stateGet(handle); };
+    this.setState = function (state) { noPending('setState'); native.stateSet(handle, state); };
 }
 
 /* RIFF/WAVE header reader with the reference's field names (index.js:138-193) */
@@ -134,11 +140,17 @@ module.exports.setDevice = function (d) { defaultDevice = d | 0; };
 /* setDevices(mask): bit d = HIP device d may be used; encoders constructed with the default device (-1) are then dealt round-robin
  * over the allowed GPUs by the library (lhip_set_devices); returns how many devices are allowed.  mask 0 restores the default. */
 module.exports.setDevices = function (mask) { defaultDevice = -1; return loadAddon().setDevices(mask); };
+/* encoders constructed with { pendingFrames }: what they hold back is encoded first and its bytes are returned in front of the batch's own */
+function drainPending(encoders) { return encoders.map((e) => (e._lhip.pending() > 0 ? e._lhip.drain() : null)); }
+function prepend(heads, outs) {
+    return outs.map((b, i) => { const a = heads[i]; if (!a || a.length == 0) return b; const r = new Int8Array(a.length + b.length); r.set(a, 0); r.set(b, a.length); return r; });
+}
 module.exports.encodeBatch = function (encoders, lefts, rights) {
     const hs = encoders.map((e) => e._lhip.handle);
     const L = lefts.map((a) => (a instanceof Int16Array ? a : Int16Array.from(a)));
     const stereo = encoders.length > 0 && encoders[0]._lhip.channels == 2;
     const R = stereo && rights ? rights.map((a) => (a instanceof Int16Array ? a : Int16Array.from(a))) : null;
-    return loadAddon().encodeBatch(hs, L, R);
+    const heads = drainPending(encoders);
+    return prepend(heads, loadAddon().encodeBatch(hs, L, R));
 };
-module.exports.flushBatch = function (encoders) { return loadAddon().flushBatch(encoders.map((e) => e._lhip.handle)); };
+module.exports.flushBatch = function (encoders) { const heads = drainPending(encoders); return prepend(heads, loadAddon().flushBatch(encoders.map((e) => e._lhip.handle))); };

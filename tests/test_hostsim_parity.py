@@ -123,6 +123,13 @@ def test_hostsim_seed_repair_path(sim, sr, kbps):
         sim.lhip_debug_set_spec_seed(180, 4)
 
 
+def test_hostsim_interleaved_live_encoders(sim):
+    """Nine encoders of different configurations (MPEG-1 / MPEG-2 / resampled, joint stereo, bit reservoir) alive at once and called alternately a frame's
+    worth at a time, with calls of 0 and ~3000 samples in between (tests/interleaved.py; the GPU tier runs the same against the device)."""
+    import interleaved
+    assert interleaved.run(sim, 606061) == []
+
+
 def test_hostsim_random_material(sim):
     """Seeded random material (tones, coloured noise, clicks, silence gaps, level steps) at every supported rate:
     this is the sweep that exposed the path-dependent table_select leftovers of the bin search (sparse frames)."""

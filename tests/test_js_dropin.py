@@ -185,3 +185,35 @@ def test_js_pending_frames_extension_hostsim():
 def test_js_pending_frames_extension_gpu():
     for corpus, ch in (("bursts", 2), ("sine", 1)):
         _pending(None, corpus, ch)
+
+
+def _interleaved(env_lib, nfr):
+    """tests/js_interleaved_check.js: seven live encoders of five configurations called in turn (two plain Mp3Encoder objects alternately, an encodeBatch group
+    in between, joint stereo + reservoir, { pendingFrames } incl. its passage through encodeBatch / flushBatch); every stream == itself alone == the oracle."""
+    import hashlib
+    import pcm
+    from oracle_py import oracle_encode
+    env = dict(os.environ)
+    if env_lib:
+        env["LAMEJS_HIP_LIB"] = str(env_lib)
+    r = subprocess.run([NODE, str(ROOT / "tests" / "js_interleaved_check.js"), str(nfr)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["interleaved"] == d["alone"] and len(d["alone"]) == 7, d
+    for name, corpus, ch, kbps, n, seed, kw in (("mono", "sine", 1, 128, 1152 * nfr + 100, 9001, {}), ("stereo", "bursts", 2, 128, 1152 * nfr + 200, 9002, {}),
+                                                ("jr", "bursts", 2, 192, 1152 * nfr + 300, 9006, dict(joint=True, reservoir=True)), ("pend", "sine", 2, 128, 1152 * nfr + 50, 9007, {})):
+        L, R = pcm.CORPORA[corpus](n, ch, seed=seed)
+        want = oracle_encode(ch, 44100, kbps, L, R, **kw)
+        assert d["alone"][name] == hashlib.md5(want).hexdigest() and d["bytes"][name] == len(want), name
+
+
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_interleaved_live_encoders_hostsim():
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "hostsim"), "all"], check=True, capture_output=True)
+    _interleaved(ROOT / "tests" / "hostsim" / "_build" / "liblamejs_hostsim.so", 14)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None or not ADDON.exists(), reason="node / addon not available")
+def test_js_interleaved_live_encoders_gpu():
+    _interleaved(None, 60)

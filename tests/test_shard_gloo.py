@@ -176,4 +176,8 @@ def test_bench_py_plain_launch_world8(cfg, extra, ch, kbps):
     assert c["distinct_streams"] == 8 * ns
     seed0 = 12345 if cfg != "5" else 1000
     assert c["stream_seeds_per_rank"] == [[seed0 + rk * ns, seed0 + rk * ns + ns - 1, ns] for rk in range(8)]
+    # the line validates itself: which device every rank sat on (8 distinct ones -- bench.py refuses to print a line otherwise), the world size
+    # as the process group reports it
+    assert c["distinct_devices"] == 8 and len(c["devices_per_rank"]) == 8 and c["rccl_world_size"] == 8 and "gloo" in c["collective_backend"]
+    assert len({d["hip_device_pci_bus_id"] for d in c["devices_per_rank"]}) == 8 and all(d["hip_device_uuid"] for d in c["devices_per_rank"])
     _check_streams(line, cfg, ch, kbps, ns, int(extra[extra.index("--frames") + 1]), 8)

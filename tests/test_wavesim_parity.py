@@ -223,3 +223,10 @@ def test_wavesim_one_frame_batch_of_streams(wsim, ch, nstreams):
     got = [g + e.flush() for g, e in zip(got, encs)]
     for m, g in zip(mats, got):
         assert g == oracle_encode(ch, 44100, 128, m[0], m[1])
+
+
+def test_wavesim_interleaved_live_encoders(wsim):
+    """The interleaved live encoders of tests/interleaved.py on the 64-lane simulation (eight-wave one-frame launches of different configurations
+    in turn: g_frame<0> / g_frame<1>, helpers on and off), a shorter run."""
+    import interleaved
+    assert interleaved.run(wsim, 606062, nframes=6) == []
