@@ -171,6 +171,12 @@ int lhip_debug_math(int op, const double* in, double* out, size_t n);
  * validation flag frames, which exercises the repair passes; the output must not change. */
 int lhip_debug_set_spec_seed(int start, int step);
 
+/* Test hook: with LHIP_ALIAS_DEVICES=n in the environment (2 <= n <= 8) the library presents n devices that are n SEPARATE contexts -- own mutex, own HIP
+ * stream, own workspaces, own table uploads -- on physical device 0, so that the multi-device paths (lhip_set_devices' round-robin, host threads batching on
+ * two contexts at once) run against real HIP on a box with one GPU.  lhip_debug_release_context(d) gives back the stream the library created for such a
+ * context (and the side stream of its ATH scan) once no stream lives on it; returns 0 or <0. */
+int lhip_debug_release_context(int device);
+
 const char* lhip_last_error(void);
 const char* lhip_version(void);
 

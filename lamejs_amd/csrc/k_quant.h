@@ -1768,6 +1768,26 @@ LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
 // coalesced form the one-thread-per-frame validation reads
 // `cs` (latency kernels only): the record through which a helper wave takes the Huffman count of the outer loop's evaluations while this wave
 // runs calc_noise beside it (q_count_bits_piped); nullptr: everything on this wave
+#if defined(LHIP_HOSTSIM)
+// LAMEJS_SEARCH_STATS=1 (host simulations; tools/search_stats.py): the shape of the search per granule-channel -- evaluations of the bin search and of the
+// step-up after it, and, per outer-loop round, the length of the `while (bits > huff_bits) gain++` run in front of the evaluation that fits, with how often
+// PrevNoise.sfb_count1 (what the next evaluation's 0/1 shortcut is decided with) changed inside a run.  Prices evaluating the gains of a run side by side.
+struct SearchStats {
+    long bs[40] = {0}, bsup[40] = {0}, run[40] = {0}, run_cnt1_moved[40] = {0}, rounds = 0, evals = 0, searches = 0, run_steps = 0, run_steps_cnt1_moved = 0, run_steps_zo = 0;
+    bool on = getenv("LAMEJS_SEARCH_STATS") != nullptr;
+    ~SearchStats() {
+        if (!on) return;
+        fprintf(stderr, "search stats: %ld granule-channel searches, %ld evaluations, %ld outer-loop rounds; %ld evaluations inside gain++ runs (%ld of them with sfb_count1 moved by the evaluation before, %ld with a live 0/1 shortcut)\n", searches, evals, rounds, run_steps, run_steps_cnt1_moved, run_steps_zo);
+        auto pr = [](const char* nm, const long* h) { fprintf(stderr, "  %s:", nm); for (int i = 0; i < 40; i++) if (h[i]) fprintf(stderr, " %d:%ld", i, h[i]); fprintf(stderr, "\n"); };
+        pr("bin-search evaluations per search", bs); pr("step-up evaluations after it", bsup); pr("gain++ run length per outer-loop round (0 = the first evaluation fits)", run);
+        pr("runs in which sfb_count1 moved, by run length", run_cnt1_moved);
+    }
+};
+inline SearchStats& search_stats() { static SearchStats t; return t; }
+#define LHIP_SS(x) do { if (lane == 0 && search_stats().on) { SearchStats& ss_ = search_stats(); x; } } while (0)
+#else
+#define LHIP_SS(x) do { } while (0)
+#endif
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
                            int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr) {
     lane = fresh_lane(lane);
@@ -1789,6 +1809,8 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     int kept_p23 = g.part2_3_length;                        // cod_info.part2_3_length (the one kept field the loop reads)
     const int search_limit = 3;
     int st = ST_BS, nbs = 0;
+    int ss_nbs = 0, ss_nup = 0, ss_run = 0, ss_moved = 0; (void)ss_nbs; (void)ss_nup; (void)ss_run; (void)ss_moved;
+    LHIP_SS(ss_.searches++);
     for (;;) {
 #ifndef LHIP_NO_FORCE_UNI
         uni_gi(w); kept_p23 = uni(kept_p23); st = uni(st); CurrentStep = uni(CurrentStep); flagGoneOver = uni(flagGoneOver); Direction = uni(Direction);
@@ -1805,6 +1827,8 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         else
 #endif
         nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site (but for the two-wave form above)
+        LHIP_SS(ss_.evals++; if (st == ST_BS) ss_nbs++; else if (st == ST_BSUP) ss_nup++;
+                if (st >= ST_A && ss_run > 0) { ss_.run_steps++; if (ss_moved) ss_.run_steps_cnt1_moved++; if (cnt1_seen > 0) ss_.run_steps_zo++; });
         // memo of the bin search: collected in LDS and written to the side record in one burst when the search ends (a global
         // store per step would sit in front of every later memory wait of the wave -- the VMEM counter retires in order)
         if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) { L.memo.bs_tab[nbs] = (w.global_gain << 24) | nBits; L.memo.bs_asg[nbs] = asg; } nbs++; }
@@ -1832,6 +1856,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         if (st == ST_BSUP) {
             if (nBits > desired_rate && w.global_gain < 255) { w.global_gain++; continue; }
             w.part2_3_length = nBits;
+            LHIP_SS(ss_.bs[ss_nbs < 39 ? ss_nbs : 39]++; ss_.bsup[ss_nup < 39 ? ss_nup : 39]++);
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
             wave_sync();
             LHIP_LANE_ONCE(i, 0, nbs) {
@@ -1854,7 +1879,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             }
         } else if (st == ST_A) {
             w.part2_3_length = nBits;
-            if (nBits > huff_bits && w.global_gain <= maxggain) { w.global_gain++; continue; }
+            if (nBits > huff_bits && w.global_gain <= maxggain) { LHIP_SS(ss_run++; ss_moved = (pn.sfb_count1 != cnt1_seen)); w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
             if (best.over_count == 0) {
                 // The reference's second loop (Quantize.js:1004-1013) starts by counting again at the SAME gain.  That evaluation
@@ -1864,14 +1889,15 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
                 // one again (same bits, same assignments, same spectrum) and is not made.
                 st = ST_B;
                 if (pn.sfb_count1 != cnt1_seen) continue;
-                if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
+                if (nBits > best_part2_3_length && w.global_gain <= maxggain) { LHIP_SS(ss_run++; ss_moved = (pn.sfb_count1 != cnt1_seen)); w.global_gain++; continue; }
                 if (w.global_gain > maxggain) break;
             }
         } else {   // ST_B
             w.part2_3_length = nBits;
-            if (nBits > best_part2_3_length && w.global_gain <= maxggain) { w.global_gain++; continue; }
+            if (nBits > best_part2_3_length && w.global_gain <= maxggain) { LHIP_SS(ss_run++; ss_moved = (pn.sfb_count1 != cnt1_seen)); w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
         }
+        LHIP_SS(if (st >= ST_A) { ss_.rounds++; ss_.run[ss_run < 39 ? ss_run : 39]++; }  ss_run = 0; ss_moved = 0);
         if (spec) { q_noise_commit(w, nc, pn, lane, L); LHIP_PIPE_COUNT(committed); }          // made beside the count, on exactly these inputs: now it counts
         else q_calc_noise(T, w, L.sfw, L.ixw, &ni, 1, pn, best.over_count == 0, lane, L, Q);                 // the only call site
         ni.bits = w.part2_3_length;

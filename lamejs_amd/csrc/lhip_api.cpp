@@ -1205,6 +1205,8 @@ struct Context {
     int device = 0;
     void* stream = nullptr;
     std::mutex mu;
+    void* ev_coop[2] = {nullptr, nullptr};      // aliased contexts: the events that order the cooperative launch (null stream) with the context's own stream
+    bool own_stream = false;    // `stream` was created by the library (aliased contexts only) and is destroyed by lhip_debug_release_context
     int live_streams = 0;       // streams created on this context and not yet destroyed (guarded by mu): the last one out releases the pinned staging buffers
     std::map<std::string, std::shared_ptr<TableSet>> tables;
     WorkSet ws;
@@ -1229,7 +1231,7 @@ static Context* get_context(int device) {
 #ifndef LHIP_HOSTSIM
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, rt::phys(device)) == hipSuccess && n > 0) c->num_cus = n; }
     // an aliased context (LHIP_ALIAS_DEVICES) gets a HIP stream of its own: on the null stream two contexts of one physical device would simply queue up
-    if (rt::alias_n() && device > 0 && hipSetDevice(0) == hipSuccess) { void* st = nullptr; if (rt::stream_create(&st)) c->stream = st; }
+    if (rt::alias_n() && device > 0 && hipSetDevice(0) == hipSuccess) { void* st = nullptr; if (rt::stream_create(&st)) { c->stream = st; c->own_stream = true; } }
 #endif
     Context* r = c.get();
     g_ctx[device] = std::move(c);
@@ -1686,7 +1688,18 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         else {
             kt_begin(KT_VALIDATE, st);
             void* kargs[] = {(void*)&qa};
-            hipError_t e_ = hipLaunchCooperativeKernel((const void*)g_fixup, dim3(fgrid), dim3(64 * QWAVES), kargs, 0, (hipStream_t)st);
+            // An aliased context (tests, LHIP_ALIAS_DEVICES) runs on a stream the library created, and its batches come from worker threads: after a cooperative
+            // launch on such a stream from a thread that has since ended, ROCm 7.2's own exit handler crashes inside the HSA runtime (seen on gfx950: every variant
+            // without the cooperative launch, or on the null stream, or from the main thread, exits cleanly).  So there the launch goes through the null
+            // stream, ordered behind / in front of the context's stream by two events.
+            hipStream_t cst = (hipStream_t)st;
+            if (ctx->own_stream) {
+                if (!ctx->ev_coop[0]) { if (!rt::event_create(&ctx->ev_coop[0]) || !rt::event_create(&ctx->ev_coop[1])) return false; }
+                if (!rt::event_record(ctx->ev_coop[0], st) || !rt::stream_wait_event(nullptr, ctx->ev_coop[0])) return false;
+                cst = nullptr;
+            }
+            hipError_t e_ = hipLaunchCooperativeKernel((const void*)g_fixup, dim3(fgrid), dim3(64 * QWAVES), kargs, 0, cst);
+            if (ctx->own_stream && e_ == hipSuccess) { if (!rt::event_record(ctx->ev_coop[1], nullptr) || !rt::stream_wait_event(st, ctx->ev_coop[1])) return false; }
             kt_end(st);
             TRACE_SYNC(g_fixup_cooperative, st);
             if (e_ != hipSuccess) { set_err(std::string("g_fixup (cooperative launch): ") + hipGetErrorString(e_)); return false; }
@@ -2333,6 +2346,24 @@ int lhip_seek(lhip_stream* s, int64_t sample_pos, const int16_t* tail_left, cons
         if (m < 0) m += T.out_samplerate;
         s->slot_lag = (int)m;
     }
+    return 0;
+}
+
+// Test hook (aliased contexts, LHIP_ALIAS_DEVICES): gives back what context `device` holds beyond its streams' lifetime -- the HIP stream the library created
+// for it, the side stream and events of the ATH scan -- while the runtime is up.  Only with no live stream on the context.
+int lhip_debug_release_context(int device) {
+#ifndef LHIP_HOSTSIM
+    Context* ctx = get_context(device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->live_streams != 0) { set_err("lhip_debug_release_context: the context still has streams"); return LHIP_ERR_INTERNAL; }
+    if (!rt::set_device(ctx->device)) return LHIP_ERR_INTERNAL;
+    (void)hipStreamSynchronize((hipStream_t)ctx->stream);
+    WorkSet& ws = ctx->ws;
+    if (ws.aux_stream) { (void)hipStreamSynchronize((hipStream_t)ws.aux_stream); (void)hipStreamDestroy((hipStream_t)ws.aux_stream); (void)hipEventDestroy((hipEvent_t)ws.ev_fork); (void)hipEventDestroy((hipEvent_t)ws.ev_join); ws.aux_stream = ws.ev_fork = ws.ev_join = nullptr; }
+    if (ctx->own_stream) { (void)hipStreamDestroy((hipStream_t)ctx->stream); ctx->stream = nullptr; ctx->own_stream = false; }
+#else
+    (void)device;
+#endif
     return 0;
 }
 

@@ -754,6 +754,7 @@ def test_gpu_two_devices_round_robin_and_concurrent_batches(lib):
     finally:
         lib.lhip_set_devices(0)
         if aliased:
+            assert lib.lhip_debug_release_context(1) == 0        # the stream the library created for the aliased context
             del os.environ["LHIP_ALIAS_DEVICES"]
             assert lib.lhip_device_count() == 1
 
