@@ -896,8 +896,12 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
 #define LP_(r) lp1
 #define PV_(r) pv1
 #endif
-    LHIP_LANE_ONCE(r, 0, 3) {
-        const int m = (r == 0) ? m0 : (r == 1) ? m1 : m2;
+#ifndef LHIP_EXP_UNCOND
+#define LHIP_EXP_UNCOND 0      /* 1 (A/B builds, round 6): no exec-masked code around per-pair / per-line work in the hot loops -- every lane works, lanes
+                                  without work write to a slot nobody reads (profiles/r06_ab_gquant_scalar_side.txt) */
+#endif
+    LHIP_LANE_ONCE(r, 0, LHIP_EXP_UNCOND ? 4 : 3) {
+        const int m = (r == 0) ? m0 : (r == 1) ? m1 : (r == 2) ? m2 : 0;       // (region "3" = beyond big_values: the empty plan, all-zero descriptor)
         const QuantTabs::PlanEnt pe = Q.plan[plan_index(m)];          // the whole plan is a function of the maximum: one look-up
         L.rdesc[r][0] = pe.d0;
         L.rdesc[r][1] = pe.d1;
@@ -940,7 +944,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
     if (any_esc) {
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
-            if (rj[j] < 3) {
+            if (LHIP_EXP_UNCOND || rj[j] < 3) {
                 const int r = rj[j];
                 const uint64_t d = *(const uint64_t*)L.rdesc[r];
                 const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
@@ -957,7 +961,7 @@ LHIP_DEV int q_noquant_count_bits(const Tables& T, GI& g, const int16_t* ix, int
         // no region holds a value above 15 (three calls in four at stereo 128 kbps): nothing to clamp, no escapes to count
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
-            if (rj[j] < 3) {
+            if (LHIP_EXP_UNCOND || rj[j] < 3) {
                 const int r = rj[j];
                 const uint64_t d = *(const uint64_t*)L.rdesc[r];
                 const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
@@ -1205,7 +1209,11 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
             for (int k = 0; k < NLN; k++) { sacc = __builtin_fma(sacc, keep[k], tq[k]); tq[k] = sacc; }   // tq := running sums of the last step
         }
 #pragma unroll
+#if LHIP_EXP_UNCOND
+        for (int k = 0; k < NLN; k++) L.nsum[((marks >> (16 + k)) & 1u) ? lastb[k] : SFBMAX] = tq[k];      // nsum[SFBMAX]: no band
+#else
         for (int k = 0; k < NLN; k++) if ((marks >> (16 + k)) & 1u) L.nsum[lastb[k]] = tq[k];
+#endif
         wave_sync();
         PH_MARK(L, PH_N_FOLD, tm_);
     }

@@ -177,12 +177,22 @@ template <int N> LHIP_DEV void q_floor_fma(const float (&xa)[N], const float (&x
 // of its short series (|f| < 2^-20 after range reduction; the f == 0 returns are the short-series expressions with R = 0, bit
 // for bit) -- selected per lane.  Zero, negative and subnormal operands are NOT handled (callers clamp: calc_noise passes
 // max(noise, 1e-20)).  Bit-identical to v8_log10 on its domain (tests: device math op 7, 60 M operands on the host).
+#if defined(LHIP_EXP_CONSTBLOCK) && !defined(LHIP_HOSTSIM)
+// A/B build (round 6): the routine's twelve f64 constants as one block in constant memory -- a scalar load of the block instead of two s_mov_b32 literals per constant
+__constant__ double LHIP_LOG10_K[12] = {4.34294481903251816668e-01, 3.01029995663611771306e-01, 3.69423907715893078616e-13, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01, 1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01};
+#endif
 LHIP_DEV double v8_log10_pos(double x) {
+#if defined(LHIP_EXP_CONSTBLOCK) && !defined(LHIP_HOSTSIM)
+    const double* K_ = LHIP_LOG10_K;
+    const double ivln10 = K_[0], log10_2hi = K_[1], log10_2lo = K_[2], ln2_hi = K_[3], ln2_lo = K_[4], Lg1 = K_[5], Lg2 = K_[6], Lg3 = K_[7], Lg4 = K_[8], Lg5 = K_[9], Lg6 = K_[10], Lg7 = K_[11];
+#else
     const double ivln10 = 4.34294481903251816668e-01, log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                  Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
+#endif
     int32_t hx = (int32_t)d_hi(x);
     const bool infnan = hx >= 0x7ff00000;
     // log10: x = 2^k10 * m, operand of log in [0.5, 2)
