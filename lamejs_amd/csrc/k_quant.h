@@ -552,12 +552,19 @@ LHIP_DEV void q_calc_xmin(const Tables& T, double ath_adjust, double masking_low
 // xrpow comes in as one 8-byte load and ix goes out as one 32-bit store per pair, and the quantized values stay in
 // registers (vx, vy) for the Huffman bit count that follows -- no LDS round trip between the two.
 enum { NPL = (288 + LHIP_NL - 1) / LHIP_NL };
+// ix_old (candidate helpers, q_cand_helper): where the kept values of cached bands are read from when that is not `ix` itself; `safe`: the record may be
+// changing under this wave (a helper working on a request its owner has already left behind): every table index is clamped, whatever the lines hold
 LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, int16_t* ix, int use_prev,
-                         int pn_gain, int pn_sfb_count1, int (&vx)[NPL], int (&vy)[NPL], int lane, QuantLds& L, const QuantTabs& Q) {
+                         int pn_gain, int pn_sfb_count1, int (&vx)[NPL], int (&vy)[NPL], int lane, QuantLds& L, const QuantTabs& Q,
+                         const int16_t* ix_old = nullptr, int safe = 0) {
     lane = fresh_lane(lane);
+    if (!ix_old) ix_old = ix;
     const double istep = ipow20(Q, g.global_gain);
     // every truncated product is <= xrpow_max * istep: below QT_N no lane can need the part of adj43 that is not staged in LDS
     const int may_big = !(g.xrpow_max * istep < (double)QT_N);
+    // (safe: where no legitimate value reaches QT_N, a clamp into the staged part of the tables is all that lines changing under this wave need -- it never
+    //  changes a legitimate result; where big values are possible the clamp is IXMAX_VAL, the end of the tables in global memory)
+    const int clamp_hi = may_big ? (int)IXMAX_VAL : QT_N - 1;
     const int sfbmax = (g.block_type == SHORT_TYPE) ? 38 : 21;
     const int prev_data_use = use_prev && (g.global_gain == pn_gain);
     // per-band decision as wave-uniform bit masks: cached (keep old values) / 0-1 shortcut; the first
@@ -599,6 +606,10 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     // truncations of every line are q_floor_prod / q_floor_fma (lhip_math.h)
     int ra[NPL], rb[NPL];
     q_floor_prod(xa, xb, istep_f, ra, rb);                                 // 0 <= x <= 8206: truncation == ToInt32
+    if (safe) {
+#pragma unroll
+        for (int j = 0; j < NPL; j++) { ra[j] = ra[j] < 0 ? 0 : (ra[j] > clamp_hi ? clamp_hi : ra[j]); rb[j] = rb[j] < 0 ? 0 : (rb[j] > clamp_hi ? clamp_hi : rb[j]); }
+    }
     float aa[NPL], ab[NPL];
     if (!may_big) {                                                        // every product is below QT_N (see may_big): nothing to clamp
 #pragma unroll
@@ -608,12 +619,16 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
         for (int j = 0; j < NPL; j++) { aa[j] = Q.adj43[ra[j] < QT_N ? ra[j] : QT_N - 1]; ab[j] = Q.adj43[rb[j] < QT_N ? rb[j] : QT_N - 1]; }
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
-            if (ra[j] >= QT_N) aa[j] = T.adj43[ra[j]];
+            if (ra[j] >= QT_N) aa[j] = T.adj43[ra[j]];      // (safe: clamped above)
             if (rb[j] >= QT_N) ab[j] = T.adj43[rb[j]];
         }
     }
     // no masking at the end of the spectrum: zero xrpow quantizes to (int)(0 + adj43[0]) = 0 (see above)
     q_floor_fma(xa, xb, istep_f, aa, ab, vx, vy);
+    if (safe) {
+#pragma unroll
+        for (int j = 0; j < NPL; j++) { vx[j] = vx[j] < 0 ? 0 : (vx[j] > clamp_hi + 1 ? clamp_hi + 1 : vx[j]); vy[j] = vy[j] < 0 ? 0 : (vy[j] > clamp_hi + 1 ? clamp_hi + 1 : vy[j]); }      // (a product just below QT_N may round up to QT_N: legitimate)
+    }
     if (!need_old && m_zo == 0) {
         // the common round (every bin-search round and most others): no cached band, no 0/1 shortcut
 #pragma unroll
@@ -627,7 +642,7 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
         for (int j = 0; j < NPL; j++) {
             const int p = 2 * (lane + LHIP_NL * j);
             int sf = 0; uint32_t oldw = 0;
-            if (p < 576) { sf = l2s[p]; oldw = *(const uint32_t*)(ix + p); }
+            if (p < 576) { sf = l2s[p]; oldw = *(const uint32_t*)(ix_old + p); }
             const int cached = (int)((m_cached >> sf) & 1);
             const int va = cached ? (int)(oldw & 0xffffu) : vx[j], vb = cached ? (int)(oldw >> 16) : vy[j];
             vx[j] = va; vy[j] = vb;
@@ -645,7 +660,7 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
         for (int j = 0; j < NPL; j++) {
             const int p = 2 * (lane + LHIP_NL * j);
             int sf = 0; uint32_t oldw = 0;
-            if (p < 576) { sf = l2s[p]; if (need_old) oldw = *(const uint32_t*)(ix + p); }
+            if (p < 576) { sf = l2s[p]; if (need_old) oldw = *(const uint32_t*)(ix_old + p); }
             const int cached = (int)((m_cached >> sf) & 1), zo = (int)((m_zo >> sf) & 1);
             int va = vx[j], vb = vy[j];
             if (zo) { va = (xa[j] < zo_thr) ? 0 : 1; vb = (xb[j] < zo_thr) ? 0 : 1; }
@@ -658,6 +673,7 @@ LHIP_DEV void q_quantize(const Tables& T, const GI& g, const int32_t* scalefac, 
     }
     wave_sync();
     PH_MARK(L, PH_Q_LINES, tm_);
+    (void)safe;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1062,8 +1078,12 @@ LHIP_DEV void q_noise_commit(const GI& g, const NoiseCommit& nc, PrevNoise& pn, 
     pn.gain = g.global_gain;
     wave_sync();
 }
+// Sp (candidate helpers): the record that receives what the call WRITES (bstep, nsum, distort) when `L` -- the spectrum, the thresholds, the noise cache --
+// belongs to another wave; `safe`: see q_quantize
 LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefac, const int16_t* ix, NoiseRes* res,
-                           int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q, NoiseCommit* defer = nullptr) {
+                           int use_pn, PrevNoise& pn, int need_max, int lane, QuantLds& L, const QuantTabs& Q, NoiseCommit* defer = nullptr,
+                           QuantLds* Sp = nullptr, int safe = 0) {
+    QuantLds& S = Sp ? *Sp : L;
     lane = fresh_lane(lane);
     unsigned long long tm_ = PH_NOW(); (void)tm_;
     // 1) per band: its step and whether the cache answers for it.  The reference walks a start line from band to band and sums the
@@ -1078,6 +1098,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     const int is_short = g.block_type == SHORT_TYPE;
     // quantized values are <= xrpow_max * ipow20(gain) + 1 (the working copy was quantized at this gain): below QT_N - 1
     // no line can need the part of pow43 that is not staged in LDS
+    // (safe: the lines are the helper's own, clamped by its quantization to QT_N - 1 unless big values are possible, in which case this test says so too)
     const int may_big = !(g.xrpow_max * ipow20(Q, g.global_gain) < (double)(QT_N - 1));
 #if LHIP_NL == 1
     // one-lane build: the same band by band (a band next to a step of the class function takes the logarithm by itself; where the
@@ -1085,7 +1106,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     const uint8_t* l2s = line2sfb(Q, g.block_type);
     int over = 0, ssd = 0;
     uint64_t m_fresh = 0;
-    (void)may_big; (void)is_short;
+    (void)may_big; (void)is_short; (void)S;
     for (int sfb = 0; sfb < g.psymax; sfb++) {
         const int s = sf_step(Q, g, scalefac, L.window, sfb);
         if (!(use_pn && L.pn_step[sfb] == s)) m_fresh |= 1ull << sfb;
@@ -1143,7 +1164,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     LHIP_LANE_ONCE(sfb, 0, g.psymax) {
         my_step = sf_step(Q, g, scalefac, L.window, sfb);
         my_fresh = !(use_pn && L.pn_step[sfb] == my_step);
-        L.bstep[sfb] = Q.pow20[my_step + Q_MAX2];
+        S.bstep[sfb] = Q.pow20[my_step + Q_MAX2];
     }
     // the longest chain the fold must carry: the widest evaluated band (an upper bound -- the widest band up to the highest evaluated one)
     const uint64_t m_fresh = wave_ballot(my_fresh);
@@ -1173,7 +1194,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
 #define NOISE_TERMS(IDX) _Pragma("unroll") for (int k = 0; k < NLN; k++) { \
             const int j = NLN * lane + k; \
             const int bnd = l2s[j]; \
-            const float bstep = L.bstep[bnd]; \
+            const float bstep = S.bstep[bnd]; \
             const float xa = L.xr[j]; const int iv = ix[j]; \
             const float pw = Q.pow43[IDX]; \
             const double x = __builtin_fma(-(double)pw, (double)bstep, d_abs((double)xa)); \
@@ -1189,7 +1210,7 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
                 const int j = NLN * lane + k;
                 const int iv = ix[j];
                 if (iv >= QT_N) {
-                    const double x = __builtin_fma(-(double)T.pow43[iv], (double)L.bstep[lastb[k]], d_abs((double)L.xr[j]));
+                    const double x = __builtin_fma(-(double)T.pow43[(!safe || iv <= IXMAX_VAL) ? iv : IXMAX_VAL], (double)S.bstep[lastb[k]], d_abs((double)L.xr[j]));
                     tq[k] = x * x;
                 }
             }
@@ -1210,9 +1231,9 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
         }
 #pragma unroll
 #if LHIP_EXP_UNCOND
-        for (int k = 0; k < NLN; k++) L.nsum[((marks >> (16 + k)) & 1u) ? lastb[k] : SFBMAX] = tq[k];      // nsum[SFBMAX]: no band
+        for (int k = 0; k < NLN; k++) S.nsum[((marks >> (16 + k)) & 1u) ? lastb[k] : SFBMAX] = tq[k];      // nsum[SFBMAX]: no band
 #else
-        for (int k = 0; k < NLN; k++) if ((marks >> (16 + k)) & 1u) L.nsum[lastb[k]] = tq[k];
+        for (int k = 0; k < NLN; k++) if ((marks >> (16 + k)) & 1u) S.nsum[lastb[k]] = tq[k];
 #endif
         wave_sync();
         PH_MARK(L, PH_N_FOLD, tm_);
@@ -1228,16 +1249,16 @@ LHIP_DEV void q_calc_noise_(const Tables& T, const GI& g, const int32_t* scalefa
     const int fresh = my_fresh;
     LHIP_LANE_ONCE(sfb, 0, g.psymax) {
         if (!fresh) {
-            L.distort[sfb] = L.pn_dist[sfb];
+            S.distort[sfb] = L.pn_dist[sfb];
             x = L.pn_x[sfb];
             cls = L.pn_cls[sfb];
         } else {
-            const double noise = L.nsum[sfb], b = (double)L.xmin[sfb], rb = L.rxmin[sfb];
+            const double noise = S.nsum[sfb], b = (double)L.xmin[sfb], rb = L.rxmin[sfb];
             const double nf = (double)(float)noise;
             x = div_by_f32(noise, b, rb);
             double xf = div_by_f32(nf, b, rb);
             if (rb == 0.0) { x = noise / b; xf = nf / b; }         // never on sane material: an xmin outside div_by_f32's proof
-            L.distort[sfb] = (float)x;
+            S.distort[sfb] = (float)x;
             if (defer) { defer->step = my_step; defer->dist = (float)xf; }
             else if (use_pn) { L.pn_step[sfb] = my_step; L.pn_dist[sfb] = (float)xf; }
             cls = need_max ? -1 : noise_class(x);          // the logarithm will be formed anyway: no shortcut
@@ -1328,11 +1349,181 @@ struct CountShare { int state; uint32_t w[3];
 enum { CS_IDLE = 0, CS_REQ = 1, CS_DONE = 2, CS_BARRIER = 8, CS_QUIT = 9 };
 #if defined(LHIP_WAVESIM)
 // how often each way was taken (printed at exit with LAMEJS_PIPE_STATS=1: the simulation must exercise both)
-struct PipeStats { long piped = 0, committed = 0; ~PipeStats() { if (getenv("LAMEJS_PIPE_STATS")) fprintf(stderr, "count helper: %ld evaluations counted on the helper wave, %ld of the calc_noise calls made beside them committed\n", piped, committed); } };
+struct PipeStats { long piped = 0, committed = 0, posted = 0, taken = 0; ~PipeStats() { if (getenv("LAMEJS_PIPE_STATS")) fprintf(stderr, "count helper: %ld evaluations counted on the helper wave, %ld of the calc_noise calls made beside them committed\ncandidate helpers: %ld next-gain evaluations posted, %ld taken\n", piped, committed, posted, taken); } };
 inline PipeStats& pipe_stats() { static PipeStats t; return t; }
 #define LHIP_PIPE_COUNT(f) do { if (lane == 0) pipe_stats().f++; } while (0)
 #else
 #define LHIP_PIPE_COUNT(f) do { } while (0)
+#endif
+// ---------------------------------------------------------------------------------------------
+// The NEXT gain of an outer-loop evaluation, evaluated beside it (one-frame launches, round 6).
+// After balance_noise has amplified bands, the first evaluation of a round often does not fit its budget and the reference steps the gain up until one does
+// (`while (bits > huff_bits) gain++`, Quantize.js:986-1013): on the bench materials 39 - 44 % of the rounds of a two-channel frame make exactly one such step,
+// 3 - 6 % more (tools/search_stats.py).  Every step is a full evaluation -- quantize, count, calc_noise -- behind the one before it, because the 0/1 shortcut of
+// quantize_xrpow at gain g + 1 is steered by PrevNoise.sfb_count1 as the count at gain g left it.  Two otherwise idle waves make that second evaluation WHILE the
+// owner makes the first: each repeats the owner's quantization at g on its own (a pure function of what the owner posts and of arrays nobody writes during a
+// round), derives sfb_count1 from it (q_cnt1_after: big_values is a matter of two ballots), quantizes at g + 1 and then -- role 0 -- counts the Huffman bits
+// or -- role 1 -- runs calc_noise with the cache writes held back (NoiseCommit, left in its own record).  If the owner's evaluation fits, nothing of this is
+// looked at; if it does not, the evaluation at g + 1 is already there: the owner takes the count's reply exactly as it takes its count helper's, the quantized
+// lines and the noise results from role 1's record, and goes on as if it had made the evaluation itself.  Same values, same order of the reference's
+// decisions.  A request the owner has left behind (its round fitted) is finished on arrays that may be changing under the helper: `safe` mode clamps every
+// table index, and nobody reads the result.
+// state[role]: CS_IDLE / CS_REQ | gain << 8 | sfb_count1 << 16 | need_max << 22 | pn.gain << 23 (owner) / CS_DONE (helper) / CS_BARRIER / CS_QUIT as for CountShare.
+// ---------------------------------------------------------------------------------------------
+struct alignas(8) CandShare {
+    int state[2], present[2];   // (state: one 8-byte word for the owner -- both helpers get the same request, and "are both free" is one look)
+    int32_t gi[14];             // the owner's granule state that changes at most once per round (q_cand_sync): see q_cand_helper
+    uint32_t cw[4];             // role 0's reply: CountShare::w[0 .. 2] of the evaluation at gain + 1; [3] sfb_count1 after the evaluation at gain (cross-check)
+    int32_t nres[4];            // role 1's reply: max_noise (two words), over_count, over_SSD
+#if defined(LHIP_HANDOFF_PROF)
+    unsigned int acc[8];        // profiling build (tests/tools/handoff_prof.py): 0 posted, 1 taken, 2 helpers not free when a post was due, 3 cycles waited for a taken evaluation,
+                                // 4 / 5 role 0's busy cycles / requests, 6 role 1's busy cycles, 7 cycles from post to take
+    unsigned long long t_post;
+#endif
+};
+#if defined(LHIP_HANDOFF_PROF) && !defined(LHIP_HOSTSIM)
+#define CD_ADD(CD_, I_, V_) do { if (lane == 0) __hip_atomic_fetch_add(&(CD_).acc[I_], (unsigned int)(V_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define CD_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define CD_ADD(CD_, I_, V_) do { } while (0)
+#define CD_NOW() 0ull
+#endif
+#ifndef LHIP_CAND_SLEEP
+#define LHIP_CAND_SLEEP 2       /* x 64 clocks */
+#endif
+#if LHIP_NL != 1
+LHIP_DEV int q_cnt1_after(const GI& g, const int (&vx)[NPL], const int (&vy)[NPL], const QuantTabs& Q) {
+    // PrevNoise.sfb_count1 as noquant_count_bits leaves it (Takehiro.js:521-560, 618-628): 0 unless the block is a long one with big_values > 0
+    if (g.block_type != NORM_TYPE) return 0;
+    int tp = -1, bp = -1;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const uint64_t nz = wave_ballot((vx[j] | vy[j]) != 0), bg = wave_ballot((vx[j] | vy[j]) > 1);
+        if (nz) tp = 64 * j + 63 - (int)__builtin_clzll(nz);
+        if (bg) bp = 64 * j + 63 - (int)__builtin_clzll(bg);
+    }
+    int i = 2 * tp + 2;
+    const int P = tp + 1, nq = i >> 2;
+    int firstbig = (P - 1 - bp) >> 1;
+    if (firstbig > nq) firstbig = nq;
+    i -= 4 * firstbig;
+    return i == 0 ? 0 : (int)(Q.bvtab[i >> 1] >> 27);
+}
+// the owner's side: the part of its state a helper needs and that only balance_noise changes
+LHIP_DEV void q_cand_sync(CandShare& cd, const GI& w, int lane) {
+    lane = lane_anew(lane);
+    if (lane == 0) {
+        int32_t* k = cd.gi;
+        k[0] = w.block_type; k[1] = w.preflag; k[2] = w.scalefac_scale; k[3] = w.subblock_gain[0]; k[4] = w.subblock_gain[1]; k[5] = w.subblock_gain[2]; k[6] = w.subblock_gain[3];
+        k[7] = w.max_nonzero_coeff; k[8] = w.firstcut; k[9] = w.psymax; k[10] = w.sfbmax;
+        union { double d; int32_t i[2]; } u; u.d = w.xrpow_max; k[11] = u.i[0]; k[12] = u.i[1];
+    }
+}
+LHIP_DEV int q_cand_present(const CandShare& cd, int lane) { int a, b; wg_load2(cd.present, &a, &b, lane); return a & b; }       // both helpers have arrived (they never leave before CS_QUIT)
+LHIP_DEV int q_cand_free(const CandShare& cd, int lane) {       // ... and both are waiting for work: one look at the pair of state words
+    int s0, s1;
+    wg_load2(cd.state, &s0, &s1, lane);
+    return (s0 == CS_IDLE || s0 == CS_DONE) && (s1 == CS_IDLE || s1 == CS_DONE);
+}
+LHIP_DEV void q_cand_post(CandShare& cd, int gain, int cnt1, int need_max, int pn_gain, int lane) {
+    const int req = CS_REQ | (gain << 8) | (cnt1 << 16) | ((need_max != 0) << 22) | (pn_gain << 23);
+    wg_store2(cd.state, req, req, lane);
+}
+// a word for both helpers (CS_BARRIER / CS_QUIT): only once they are not working on a request -- their CS_DONE would overwrite it
+LHIP_DEV void q_cand_signal(CandShare& cd, int v, int lane) {
+    for (int r = 0; r < 2; r++) {
+        long n = 0;
+        for (;;) { const int s = wg_load(&cd.state[r], lane); if (s == CS_IDLE || s == CS_DONE) break; wg_spin(); LHIP_SPIN_GUARD(n); }
+        wg_store(&cd.state[r], v, lane);
+    }
+}
+// a helper: role 0 counts, role 1 runs calc_noise.  Lo = the owner's record, L = this wave's own.
+// (LHIP_CAND_NOINLINE, experiment: the helper as a real function -- its code then takes no part in the register allocation of the kernel it is called from)
+#if defined(LHIP_CAND_NOINLINE) && !defined(LHIP_HOSTSIM)
+static __device__ __attribute__((noinline)) void q_cand_helper(const Tables& T, CandShare& cd, int role, const QuantLds& Lo, QuantLds& L, const QuantTabs& Q, int lane) {
+#else
+LHIP_DEV void q_cand_helper(const Tables& T, CandShare& cd, int role, const QuantLds& Lo, QuantLds& L, const QuantTabs& Q, int lane) {
+#endif
+    wg_store(&cd.present[role], 1, lane);
+    for (;;) {
+        // (a pause between the looks: an idle helper shares its SIMD with a searching wave or its count helper, and a request picked up ~100 clocks later costs
+        //  nothing -- the owner only asks for the result a whole evaluation later)
+        int s;
+        for (long n = 0;;) { s = wg_load(&cd.state[role], lane); if (s != CS_IDLE && s != CS_DONE) break; wg_pause(LHIP_CAND_SLEEP); LHIP_SPIN_GUARD(n); }
+        if (s == CS_QUIT) break;
+        if (s == CS_BARRIER) { wg_store(&cd.state[role], CS_IDLE, lane); wg_barrier(); continue; }
+        const unsigned long long hb0_ = CD_NOW(); (void)hb0_;
+        wg_acquire();
+        lane = lane_anew(lane);
+        GI g;
+        const int32_t* k = cd.gi;
+        g.part2_3_length = 0; g.big_values = 0; g.count1 = 0; g.scalefac_compress = 0; g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
+        g.region0_count = 0; g.region1_count = 0; g.count1table_select = 0; g.part2_length = 0; g.sfb_lmax = 0; g.sfb_smin = 0; g.psy_lmax = 0; g.sfbdivide = 0; g.count1bits = 0;
+        g.global_gain = uni((s >> 8) & 255);
+        const int c0 = uni((s >> 16) & 63), need_max = uni((s >> 22) & 1), pn_gain = uni((int)((unsigned)s >> 23));
+        g.block_type = uni(k[0]); g.preflag = uni(k[1]); g.scalefac_scale = uni(k[2]);
+        g.subblock_gain[0] = uni(k[3]); g.subblock_gain[1] = uni(k[4]); g.subblock_gain[2] = uni(k[5]); g.subblock_gain[3] = uni(k[6]);
+        g.max_nonzero_coeff = uni(k[7]); g.firstcut = uni(k[8]); g.psymax = uni(k[9]); g.sfbmax = uni(k[10]);
+        { union { double d; int32_t i[2]; } u; u.i[0] = uni(k[11]); u.i[1] = uni(k[12]); g.xrpow_max = u.d; }
+        QuantLds& Lin = const_cast<QuantLds&>(Lo);        // (read-only use: the functions below only write through `ix`, `L` / `&L`)
+        int vx[NPL], vy[NPL];
+        q_quantize(T, g, Lo.sfw, L.ixw, 1, pn_gain, c0, vx, vy, lane, Lin, Q, Lo.ixw, 1);          // the owner's evaluation at `gain`, repeated
+        const int c1 = uni(q_cnt1_after(g, vx, vy, Q));
+        g.global_gain = g.global_gain < 255 ? g.global_gain + 1 : 255;
+        q_quantize(T, g, Lo.sfw, L.ixw, 1, pn_gain, c1, vx, vy, lane, Lin, Q, L.ixw, 1);           // (gain + 1 > pn.gain: no band is cached)
+        if (role == 0) {
+            int cnt1 = 0, amask = 0;
+            const int bits = uni(q_noquant_count_bits(T, g, L.ixw, vx, vy, 1, &cnt1, &amask, lane, L, Q));
+            uni_gi(g);
+            const uint32_t w0 = (uint32_t)bits | ((uint32_t)g.count1 << 17);
+            const uint32_t w1 = (uint32_t)g.big_values | ((uint32_t)g.count1bits << 10) | ((uint32_t)g.count1table_select << 23) | ((uint32_t)g.region0_count << 24) | ((uint32_t)g.region1_count << 28);
+            const uint32_t w2 = (uint32_t)(g.table_select[0] + 1) | ((uint32_t)(g.table_select[1] + 1) << 6) | ((uint32_t)(g.table_select[2] + 1) << 12) | ((uint32_t)uni(cnt1) << 18) | ((uint32_t)uni(amask) << 24);
+            if (lane == 0) { cd.cw[0] = w0; cd.cw[1] = w1; cd.cw[2] = w2; cd.cw[3] = (uint32_t)c1; }
+        } else {
+            NoiseRes ni; NoiseCommit nc; nc.fresh = 0; nc.step = 0; nc.cls = 0; nc.dist = 0.f; nc.x = 0.0;
+            PrevNoise pn; pn.gain = pn_gain; pn.sfb_count1 = c1;
+            q_calc_noise_(T, g, Lo.sfw, L.ixw, &ni, 1, pn, need_max, lane, Lin, Q, &nc, &L, 1);
+            lane = lane_anew(lane);
+            LHIP_LANE_ONCE(sfb, 0, (SFBMAX) + 1) { L.qmode[sfb] = nc.fresh; L.pn_step[sfb] = nc.step; L.pn_dist[sfb] = nc.dist; L.pn_x[sfb] = nc.x; L.pn_cls[sfb] = (int16_t)nc.cls; }
+            if (lane == 0) { union { double d; int32_t i[2]; } u; u.d = ni.max_noise; cd.nres[0] = u.i[0]; cd.nres[1] = u.i[1]; cd.nres[2] = ni.over_count; cd.nres[3] = ni.over_SSD; }
+        }
+        CD_ADD(cd, role == 0 ? 4 : 6, CD_NOW() - hb0_); if (role == 0) CD_ADD(cd, 5, 1);
+        wg_store(&cd.state[role], CS_DONE, lane);
+    }
+}
+// the owner takes the evaluation at w.global_gain (already stepped up) that the helpers made beside its last one.  Returns the bit count, or -1 if the helpers'
+// view of sfb_count1 is not the owner's (cannot happen: both derive it from the same quantization; the caller then evaluates by itself)
+LHIP_DEV int q_cand_take(CandShare& cd, const QuantLds& Lh, GI& g, PrevNoise& pn, NoiseRes* ni, NoiseCommit* nc, int lane, QuantLds& L) {
+    for (int r = 0; r < 2; r++) {
+        long n = 0;
+        while (wg_load(&cd.state[r], lane) != CS_DONE) { wg_spin(); LHIP_SPIN_GUARD(n); }
+    }
+    wg_acquire();
+    lane = lane_anew(lane);
+    const uint32_t w0 = (uint32_t)uni((int)cd.cw[0]), w1 = (uint32_t)uni((int)cd.cw[1]), w2 = (uint32_t)uni((int)cd.cw[2]);
+    const int c1 = uni((int)cd.cw[3]);
+    if (c1 != pn.sfb_count1) return -1;
+    const int bits = (int)(w0 & 0x1ffffu), amask = (int)((w2 >> 24) & 15u);
+    g.count1 = (int)(w0 >> 17); g.big_values = (int)(w1 & 1023u); g.count1bits = (int)((w1 >> 10) & 0x1fffu); g.count1table_select = (int)((w1 >> 23) & 1u);
+    if (amask & 8) { g.region0_count = (int)((w1 >> 24) & 15u); g.region1_count = (int)(w1 >> 28); }
+    if (amask & 1) g.table_select[0] = (int)(w2 & 63u) - 1;
+    if (amask & 2) g.table_select[1] = (int)((w2 >> 6) & 63u) - 1;
+    if (amask & 4) g.table_select[2] = (int)((w2 >> 12) & 63u) - 1;
+    pn.sfb_count1 = (int)((w2 >> 18) & 63u);
+    { union { double d; int32_t i[2]; } u; u.i[0] = uni(cd.nres[0]); u.i[1] = uni(cd.nres[1]); ni->max_noise = u.d; ni->over_count = uni(cd.nres[2]); ni->over_SSD = uni(cd.nres[3]); ni->bits = 0; }
+    // what calc_noise left for this evaluation: the cache entries it would write (lane = band), the distortions, and the quantized lines themselves
+    nc->fresh = 0; nc->step = 0; nc->cls = 0; nc->dist = 0.f; nc->x = 0.0;
+    LHIP_LANE_ONCE(sfb, 0, (SFBMAX) + 1) { nc->fresh = Lh.qmode[sfb]; nc->step = Lh.pn_step[sfb]; nc->dist = Lh.pn_dist[sfb]; nc->x = Lh.pn_x[sfb]; nc->cls = Lh.pn_cls[sfb]; L.distort[sfb] = Lh.distort[sfb]; }
+    {
+        uint32_t kw[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)Lh.ixw)[i < 288 ? i : 287]; }
+#pragma unroll
+        for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
+    }
+    wave_sync();
+    return bits;
+}
 #endif
 #if LHIP_NL != 1
 // the helper: serves one owner's requests until it is told to leave.  Lo = the owner's LDS record (the quantized values), L = this wave's own (scratch).
@@ -1782,6 +1973,7 @@ LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
 // PrevNoise.sfb_count1 (what the next evaluation's 0/1 shortcut is decided with) changed inside a run.  Prices evaluating the gains of a run side by side.
 struct SearchStats {
     long bs[40] = {0}, bsup[40] = {0}, run[40] = {0}, run_cnt1_moved[40] = {0}, rounds = 0, evals = 0, searches = 0, run_steps = 0, run_steps_cnt1_moved = 0, run_steps_zo = 0;
+    long mfail[24] = {0}, mfit[24] = {0};      // first evaluation of a round by its margin (huff_bits - the last evaluation's bits), buckets of 8 bits
     bool on = getenv("LAMEJS_SEARCH_STATS") != nullptr;
     ~SearchStats() {
         if (!on) return;
@@ -1789,6 +1981,7 @@ struct SearchStats {
         auto pr = [](const char* nm, const long* h) { fprintf(stderr, "  %s:", nm); for (int i = 0; i < 40; i++) if (h[i]) fprintf(stderr, " %d:%ld", i, h[i]); fprintf(stderr, "\n"); };
         pr("bin-search evaluations per search", bs); pr("step-up evaluations after it", bsup); pr("gain++ run length per outer-loop round (0 = the first evaluation fits)", run);
         pr("runs in which sfb_count1 moved, by run length", run_cnt1_moved);
+        fprintf(stderr, "  first evaluation of a round, by margin huff_bits - previous bits (bucket of 8 bits: fails / fits):"); for (int i = 0; i < 24; i++) if (mfail[i] + mfit[i]) fprintf(stderr, " %d:%ld/%ld", 8 * (i - 4), mfail[i], mfit[i]); fprintf(stderr, "\n");
     }
 };
 inline SearchStats& search_stats() { static SearchStats t; return t; }
@@ -1797,7 +1990,12 @@ inline SearchStats& search_stats() { static SearchStats t; return t; }
 #define LHIP_SS(x) do { } while (0)
 #endif
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
-                           int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr) {
+                           int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr,
+                           CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0) {
+    // (candidate helpers: `cd` is the workgroup's array of records and `lds0` its first wave's LDS -- constants of the kernel, not values this loop has to keep alive;
+    //  what depends on the wave is formed from its index where it is needed: record cd[wave], helper record of wave 5 + 2 wave (two channels) / 3 (one))
+#define CAND_REC() (cd[wg_wave_id()])
+#define CAND_LH() (*(const QuantLds*)(lds0 + (size_t)(T.channels_out == 2 ? 5 + 2 * wg_wave_id() : 3) * (size_t)lds_stride))
     lane = fresh_lane(lane);
     enum { ST_BS, ST_BSUP, ST_A, ST_B };
     NoiseRes best, ni;
@@ -1817,8 +2015,15 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     int kept_p23 = g.part2_3_length;                        // cod_info.part2_3_length (the one kept field the loop reads)
     const int search_limit = 3;
     int st = ST_BS, nbs = 0;
-    int ss_nbs = 0, ss_nup = 0, ss_run = 0, ss_moved = 0; (void)ss_nbs; (void)ss_nup; (void)ss_run; (void)ss_moved;
+    int ss_nbs = 0, ss_nup = 0, ss_run = 0, ss_moved = 0, ss_first_ = 0, ss_prev_bits_ = 0; (void)ss_nbs; (void)ss_nup; (void)ss_run; (void)ss_moved; (void)ss_first_; (void)ss_prev_bits_;
     LHIP_SS(ss_.searches++);
+#ifndef LHIP_CAND_MARGIN
+#define LHIP_CAND_MARGIN 32
+#endif
+    // candidate helpers (q_cand_*), one word of loop state: bits 0-8 the gain they are evaluating beside this wave's evaluation + 1 (0: none posted), 9 the slow
+    // state is posted (q_cand_sync), 10 both helpers have arrived, 11 the next evaluation is the first of its round
+    enum { CF_GAIN = 511, CF_SYNCED = 512, CF_HERE = 1024, CF_FIRST = 2048 };
+    int cflags = 0;
     for (;;) {
 #ifndef LHIP_NO_FORCE_UNI
         uni_gi(w); kept_p23 = uni(kept_p23); st = uni(st); CurrentStep = uni(CurrentStep); flagGoneOver = uni(flagGoneOver); Direction = uni(Direction);
@@ -1831,7 +2036,37 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         int nBits, spec = 0;
         NoiseCommit nc; nc.fresh = 0; nc.step = 0; nc.cls = 0; nc.dist = 0.f; nc.x = 0.0;
 #if LHIP_NL != 1
-        if (cs != nullptr && st >= ST_A) nBits = q_count_bits_piped(T, w, L.sfw, L.ixw, pn, &asg, *cs, &ni, &nc, best.over_count == 0, &spec, lane, L, Q);
+        int taken = 0;
+        if (cd != nullptr && st >= ST_A) {
+            cflags = uni(cflags);
+            // the evaluation at this gain was made beside the last one (this iteration was reached by `gain++; continue`: nothing but the gain has changed)
+            if ((cflags & CF_GAIN) == w.global_gain + 1) {
+                CandShare& cdr = CAND_REC();
+                const unsigned long long tk0_ = CD_NOW(); (void)tk0_;
+                const int b = q_cand_take(cdr, CAND_LH(), w, pn, &ni, &nc, lane, L);
+                if (b >= 0) { nBits = b; spec = 1; taken = 1; LHIP_PIPE_COUNT(taken); CD_ADD(cdr, 1, 1); CD_ADD(cdr, 3, CD_NOW() - tk0_); CD_ADD(cdr, 7, CD_NOW() - cdr.t_post); }
+            }
+            // Posted for the FIRST evaluation of a round only, and only when it is likely not to fit: the bits of the last evaluation, which balance_noise's amplification
+            // can only have raised, within LHIP_CAND_MARGIN of the budget (tools/search_stats.py: 85 % of such evaluations fail within 8 bits of it, 40 % at 24 - 32,
+            // under 20 % beyond 56; a request nobody takes costs the owner ~ 1 k cycles of contention, a taken one saves ~ 3 k)
+            const int cand_due = (cflags & CF_FIRST) && (huff_bits - w.part2_3_length) < LHIP_CAND_MARGIN;
+            cflags &= ~(CF_GAIN | CF_FIRST);
+            if (!taken && cand_due && w.global_gain < 255 && !(w.xrpow_max * ipow20(Q, w.global_gain) > (double)IXMAX_VAL * (1.0 - 0x1p-50))) {
+                CandShare& cdr = CAND_REC();
+                if (!(cflags & CF_HERE) && q_cand_present(cdr, lane)) cflags |= CF_HERE;
+                if ((cflags & CF_HERE) && q_cand_free(cdr, lane)) {
+                    if (!(cflags & CF_SYNCED)) { q_cand_sync(cdr, w, lane); cflags |= CF_SYNCED; }
+#if defined(LHIP_HANDOFF_PROF) && !defined(LHIP_HOSTSIM)
+                    if (lane == 0) cdr.t_post = CD_NOW();
+#endif
+                    q_cand_post(cdr, w.global_gain, pn.sfb_count1, best.over_count == 0, pn.gain, lane);
+                    cflags |= w.global_gain + 2;
+                    LHIP_PIPE_COUNT(posted); CD_ADD(cdr, 0, 1);
+                } else CD_ADD(cdr, 2, 1);
+            }
+        }
+        if (taken) { }
+        else if (cs != nullptr && st >= ST_A) nBits = q_count_bits_piped(T, w, L.sfw, L.ixw, pn, &asg, *cs, &ni, &nc, best.over_count == 0, &spec, lane, L, Q);
         else
 #endif
         nBits = q_count_bits(T, w, L.sfw, L.ixw, st >= ST_A, pn, &asg, lane, L, Q);   // the only call site (but for the two-wave form above)
@@ -1887,6 +2122,7 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             }
         } else if (st == ST_A) {
             w.part2_3_length = nBits;
+            LHIP_SS(if (ss_run == 0 && ss_first_) { int b_ = (huff_bits - ss_prev_bits_) / 8 + 4; b_ = b_ < 0 ? 0 : b_ > 23 ? 23 : b_; if (nBits > huff_bits) ss_.mfail[b_]++; else ss_.mfit[b_]++; } ss_first_ = 0);
             if (nBits > huff_bits && w.global_gain <= maxggain) { LHIP_SS(ss_run++; ss_moved = (pn.sfb_count1 != cnt1_seen)); w.global_gain++; continue; }
             if (w.global_gain > maxggain) break;
             if (best.over_count == 0) {
@@ -1929,13 +2165,17 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         int bal_;
         { PH_BEGIN(); bal_ = q_balance_noise(T, w, L.sfw, lane, L, Q); PH_END(L, PH_BALANCE); }       // the only call site
         if (!bal_) break;
+        cflags = (cflags & ~CF_SYNCED) | CF_FIRST;                // (preflag, scalefac_scale, subblock gains, xrpow_max may have moved)
         maxggain = (w.scalefac_scale != 0) ? 254 : 255;
         huff_bits = targ_bits - w.part2_length;
         if (huff_bits <= 0) break;
+        LHIP_SS(ss_first_ = 1; ss_prev_bits_ = w.part2_3_length);
         st = ST_A;
     }
     wave_sync();
     { const GI inv = w; g = inv; gi_keep_load(L, g); }       // the invariant fields are the working copy's, the rest comes back from LDS
+#undef CAND_REC
+#undef CAND_LH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2460,7 +2700,8 @@ LHIP_DEV int targ_bits_for(const Tables& T, int mean_bits, int gr, int ResvSize,
 struct UnitOut { int bits; Seed next; int block_type; int active; };
 // Inlined at every call site: behind a call (one copy of the code for kb_quant's, the owner's and the helper's site) g_quant was a third slower -- spills around the call.
 LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
-                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr) {
+                        double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr,
+                        CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0) {
     lane = lane_anew(lane);        // (here and below: lane-derived LDS / HBM addresses are formed where they are used, not parked in scratch across the search)
     UnitOut u; u.next = used;
     GI g;
@@ -2473,7 +2714,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
         active = 1;
         { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
         int16_t* kept = cs ? cs->kept : W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-        { PH_BEGIN(); q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs); PH_END(L, PH_XRPOW); }   // (profiling builds: the whole search in the otherwise unused slot)
+        { PH_BEGIN(); q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs, cd, lds0, lds_stride); PH_END(L, PH_XRPOW); }   // (profiling builds: the whole search in the otherwise unused slot)
         uni_gi(g); bs_gain = uni(bs_gain);
         lane = lane_anew(lane);
         wave_sync();                                    // the kept spectrum was written by other lanes of this wave
@@ -2547,7 +2788,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
 template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
                        int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr,
-                       int* hint = nullptr, CountShare* cs = nullptr, const int* later_granules_ready = nullptr) {
+                       int* hint = nullptr, CountShare* cs = nullptr, const int* later_granules_ready = nullptr, CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -2635,7 +2876,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         for (int ch = 0; ch < C; ch++) {
             if (PAIR && ch != my_ch) continue;
             const UnitOut u = q_unit(T, pb10, W, C, Cp, fidx, gslot, gr, ch, mode_ext, ath_adjust, ch == 0 ? targ0 : targ1, ch == 0 ? seed0 : seed1,
-                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q, cs);
+                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q, cs, cd, lds0, lds_stride);
             if (u.active) { if (ch == 0) seed0 = u.next; else seed1 = u.next; }
             if (!PAIR) ResvSize = uni(ResvSize - u.bits);
             else if (lane == 0) mbox[2 * gr + ch] = u.bits;
@@ -2643,6 +2884,9 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         }
         if (PAIR) {                                   // both waves have published this granule: take the other channel's bits
             if (cs) wg_store(&cs->state, CS_BARRIER, lane);     // (this wave's count helper keeps the barrier's count)
+#if LHIP_NL != 1
+            if (cd) q_cand_signal(cd[wg_wave_id()], CS_BARRIER, lane);       // (so do its candidate helpers)
+#endif
             wg_barrier();
             ResvSize = uni(ResvSize - (mbox[2 * gr] + mbox[2 * gr + 1]));
         }

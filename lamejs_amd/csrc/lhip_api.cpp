@@ -324,7 +324,8 @@ LHIP_DEV void frame_flow_tail(const Tables& T, const PowBase& pb, const Workspac
 // two waves (kb_quant<1>, which meets once per granule at a workgroup barrier: the other waves keep the barrier count).
 template <int RESV, int PAIRQ>
 LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO,
-                             int st, int wv, int nw, int lane, unsigned char* lds, QuantTabs& Q, int* mbox, CountShare* cshare = nullptr) {
+                             int st, int wv, int nw, int lane, unsigned char* lds, QuantTabs& Q, int* mbox, CountShare* cshare = nullptr, CandShare* cand = nullptr, unsigned char* lds0 = nullptr) {
+    if (!lds0) lds0 = lds - (size_t)wv * FR_LDS_PER_WAVE;       // (the first wave's LDS: the kernel passes the constant)
     const int C = T.channels_out, Cp = T.psy_channels, GR = T.mode_gr;
     const StreamDesc sd = SD[st];
     const bool has = sd.nframes > 0;                          // this launch completes a frame of the stream (else only the state moves)
@@ -411,19 +412,48 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             // Bit reservoir: psyB of the SECOND granule beside the quantization, on wave 4 -- nothing of this frame reads what it leaves (granule 1 is quantized against
             // psyB(granule 0)'s thresholds, the frame's entropies are those of the maskings in use), the next call does (kb_resv_stage, RS_QUANT: the same)
             if (RESV && GR == 2 && has && wv == 4) kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rv->ResvSize, rv->ResvMax);
+            // Candidate helpers (k_quant.h q_cand_helper, round 6; only with count helpers, nw == 8): the evaluation at the NEXT gain beside the owner's.  Two channels: waves
+            // 4 + 2 c (role 0: count) and 5 + 2 c (role 1: calc_noise) for channel c, once they are through with what they do beside the first granule's search
+            // (frame_flow_tail / psyB); one channel: waves 1 and 3, which have nothing else to do.  They keep the workgroup barriers' count like the count helpers.
             if (PAIRQ && C == 2) {
-                if (has && wv < 2) { kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
+                unsigned char* const base = lds0;
+                const bool cands = LHIP_NL != 1 && cand != nullptr && cshare != nullptr && nw == 8;
+                if (has && wv < 2) {
+                    kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv, nullptr, cshare ? cshare + wv : nullptr, nullptr,
+                                      cands ? cand : nullptr, cands ? lds0 : nullptr, (int)FR_LDS_PER_WAVE);
+                    if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane);
+#if LHIP_NL != 1
+                    if (cands) q_cand_signal(cand[wv], CS_QUIT, lane);
+#endif
+                }
 #if LHIP_NL != 1
                 else if (has && cshare && wv < 4) q_count_helper(T, cshare[wv - 2], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
                 else {
                     if (flow && has) frame_flow_tail(T, pb, W, SD, IO, g1, wv, lane, lds, mbox);
                     else if (psyb_late && has && wv >= 4 && wv - 4 < GR) kb_psyB<4>(T, pb, W, SD, g1 + (wv - 4), lane, *(PsyBLds4*)lds, -1, 0, 0);
+#if LHIP_NL != 1
+#ifndef LHIP_CAND_NOHELPERS
+#define LHIP_CAND_NOHELPERS 0       /* 1 (experiment, only together with LHIP_CAND_MARGIN=-1000): the owner's code as with candidate helpers, but no wave plays helper */
+#endif
+                    if (cands && !LHIP_CAND_NOHELPERS && has && wv >= 4) { wave_sync(); q_cand_helper(T, cand[(wv - 4) >> 1], (wv - 4) & 1, *(const QuantLds*)(base + (size_t)((wv - 4) >> 1) * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane); }
+                    else
+#endif
                     for (int gr = 0; gr < GR; gr++) wg_barrier();
                 }
-            } else if (has && wv == 0) { kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr, (PAIRQ && psyb_late) ? mbox + 3 : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
+            } else if (has && wv == 0) {
+                const bool cands = LHIP_NL != 1 && PAIRQ && cand != nullptr && cshare != nullptr && nw == 8;
+                kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr, (PAIRQ && psyb_late) ? mbox + 3 : nullptr,
+                                  cands ? cand : nullptr, cands ? lds0 : nullptr, (int)FR_LDS_PER_WAVE);
+                if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane);
+#if LHIP_NL != 1
+                if (cands) q_cand_signal(cand[0], CS_QUIT, lane);
+#endif
+            }
 #if LHIP_NL != 1
             else if (PAIRQ && has && cshare && wv == 2) q_count_helper(T, cshare[0], *(const QuantLds*)(lds - 2 * FR_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
+            else if (PAIRQ && !LHIP_CAND_NOHELPERS && has && cshare && cand != nullptr && nw == 8 && (wv == 1 || wv == 3))
+                q_cand_helper(T, cand[0], wv >> 1, *(const QuantLds*)lds0, *(QuantLds*)lds, Q, lane);
 #endif
             else if (flow && has && wv >= 4) frame_flow_tail(T, pb, W, SD, IO, g1, wv, lane, lds, mbox);      // (sets the flag granule 1 waits for)
             else if (PAIRQ && psyb_late && has && wv == 4) {           // one-channel frame: both granules' psyB on this wave, then the flag granule 1 waits for
@@ -747,6 +777,14 @@ __global__ __launch_bounds__(64) void g_resv_flush(Tables T, Workspace W, const 
 #define LHIP_FRAME_PIPE 1      /* 0: the Huffman counts of the outer loop on the searching wave itself (A/B builds) */
 #endif
 static constexpr bool g_frame_pipe = LHIP_FRAME_PIPE != 0;
+#ifndef LHIP_FRAME_CAND
+#define LHIP_FRAME_CAND 0      /* 1: candidate helpers (the evaluation at the next gain beside the owner's, k_quant.h q_cand_helper).  Built, bit-exact on the device and in the wave
+                                  simulation (where it is on), and measured in round 6: an evaluation taken from the helpers saves ~ 3 k of 15.6 k cycles and the search of a
+                                  two-channel frame gets 9.5 % shorter when every round posts -- but a launch whose idle waves poll as helpers instead of waiting at the workgroup
+                                  barrier is 3.6 % (two channels) / 3 % (one) slower before the first request is posted, so the net is +- 0 (two channels) / - 2 .. - 4 % (one):
+                                  profiles/r06_cand_*.txt, DESIGN_ONE_FRAME.md.  Off in the shipped library. */
+#endif
+static constexpr bool g_frame_cand = LHIP_FRAME_CAND != 0;
 // the per-stream reservoir program (kb_resv_stage): one workgroup of RS_WAVES waves per stream
 // (two waves per SIMD: 256 registers instead of the 264 an unbounded build takes -- the second workgroup per CU is what lets 512 streams
 //  run side by side; the mode's throughput is streams in flight x one frame per 184 us)
@@ -782,9 +820,14 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
     __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
     __shared__ int mbox[12];
     __shared__ CountShare CS[2];
+    __shared__ CandShare CD[2];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 2) CS[threadIdx.x].state = CS_IDLE;
+    if (threadIdx.x < 4) { CD[threadIdx.x >> 1].state[threadIdx.x & 1] = CS_IDLE; CD[threadIdx.x >> 1].present[threadIdx.x & 1] = 0; }
+#if defined(LHIP_HANDOFF_PROF)
+    if (threadIdx.x < 8) CD[0].acc[threadIdx.x] = 0;
+#endif
 #if defined(LHIP_PHASE_PROF) || defined(LHIP_HANDOFF_PROF)
     if (threadIdx.x < 8) CS[0].acc[threadIdx.x] = 0;
 #endif
@@ -803,7 +846,7 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
         if (stage == FS_QUANT) ((QuantLds*)U[wv])->prof[lane] = 0;
 #endif
         if (frame_stage_empty<RESV>(stage, A->T)) continue;
-        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr);
+        kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr, (g_frame_pipe && g_frame_cand) ? CD : nullptr, U[0]);
 #ifdef LHIP_PHASE_PROF
         // when each wave finished its part of the two stages whose work is dealt over waves (cycles after the stage's start)
         if ((stage == FS_PSYA_POLY || stage == FS_BITS_SAVE) && blockIdx.x == 0 && lane == 0)
@@ -821,6 +864,7 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
 #elif defined(LHIP_HANDOFF_PROF)
     // (tests/tools/handoff_prof.py: the legs of wave 0's hand-overs, summed over the calls of the process; the product never zeroes or reads these words)
     if (blockIdx.x == 0 && threadIdx.x < 8) atomicAdd(A->W.prof + 32 + threadIdx.x, (unsigned long long)CS[0].acc[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < 8) atomicAdd(A->W.prof + 40 + threadIdx.x, (unsigned long long)CD[0].acc[threadIdx.x]);      // the candidate helpers of channel 0
 #endif
 }
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
@@ -1480,15 +1524,17 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (use_frame) {
             // the one-frame-per-stream program (kb_frame_stage), stage by stage; the wave simulation runs it as a real workgroup
             const int NW = FR_WAVES;
-            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[12]; static thread_local CountShare fcs[2];
+            alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[12]; static thread_local CountShare fcs[2]; static thread_local CandShare fcd[2];
+            static const bool sim_cand = []() { const char* e = getenv("LAMEJS_SIM_NO_CAND"); return !(e && e[0] == '1'); }();
             for (int s = 0; s < S; s++) {
                 fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;       // per workgroup, as g_frame does (a stream's owners leave CS_QUIT behind)
+                for (int c = 0; c < 2; c++) for (int r = 0; r < 2; r++) { fcd[c].state[r] = CS_IDLE; fcd[c].present[r] = 0; }
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {
                     for (int stage = 0; stage < FR_STAGES; stage++) {
                         if (resv ? frame_stage_empty<1>(stage, T) : frame_stage_empty<0>(stage, T)) continue;
-                        if (resv) kb_frame_stage<1, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox, fcs);
-                        else kb_frame_stage<0, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox, fcs);
+                        if (resv) kb_frame_stage<1, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox, fcs, sim_cand ? fcd : nullptr);
+                        else kb_frame_stage<0, 1>(stage, T, ts.pb10, W, dSD, dIO, s, wave_, NW, lane_, UL[wave_], QT, fmbox, fcs, sim_cand ? fcd : nullptr);
                         wg_barrier();
                     }
                 });

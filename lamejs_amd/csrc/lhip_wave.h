@@ -376,7 +376,11 @@ LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { (void)lane; con
 LHIP_DEV int wg_load(const int* p, int lane) { (void)lane; return *p; }
 LHIP_DEV void wg_store(int* p, int v, int lane) { (void)lane; *p = v; }
 LHIP_DEV void wg_add(int* p, int v, int lane) { (void)lane; *p += v; }
+LHIP_DEV void wg_load2(const int* p, int* a, int* b, int lane) { (void)lane; *a = p[0]; *b = p[1]; }
+LHIP_DEV void wg_store2(int* p, int a, int b, int lane) { (void)lane; p[0] = a; p[1] = b; }
 LHIP_DEV void wg_idle() {}
+LHIP_DEV int wg_wave_id() { return 0; }
+LHIP_DEV void wg_pause(int) {}
 LHIP_DEV void wg_spin() {}
 LHIP_DEV void wg_acquire() {}
 #elif defined(LHIP_HOSTSIM)
@@ -386,7 +390,11 @@ LHIP_DEV int wg_cas(int* p, int expect, int desired, int lane) { int r = 0; if (
 LHIP_DEV int wg_load(const int* p, int lane) { int r = 0; if (lane == 0) r = *(const volatile int*)p; return wave_bcast(r, 0); }
 LHIP_DEV void wg_store(int* p, int v, int lane) { wave_sync(); if (lane == 0) *(volatile int*)p = v; wave_sync(); }
 LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) *p += v; wave_sync(); }
+LHIP_DEV void wg_load2(const int* p, int* a, int* b, int lane) { int r0 = 0, r1 = 0; if (lane == 0) { r0 = ((const volatile int*)p)[0]; r1 = ((const volatile int*)p)[1]; } *a = wave_bcast(r0, 0); *b = wave_bcast(r1, 0); }
+LHIP_DEV void wg_store2(int* p, int a, int b, int lane) { wave_sync(); if (lane == 0) { ((volatile int*)p)[0] = a; ((volatile int*)p)[1] = b; } wave_sync(); }
 LHIP_DEV void wg_idle() { wave_sync(); }
+LHIP_DEV int wg_wave_id() { return wsim::current()->cur / 64; }       // the calling lane's wave inside its workgroup
+LHIP_DEV void wg_pause(int) { wave_sync(); }
 LHIP_DEV void wg_spin() { wave_sync(); }
 LHIP_DEV void wg_acquire() { wave_sync(); }
 #else
@@ -397,7 +405,19 @@ LHIP_DEV void wg_store(int* p, int v, int lane) {          // everything this wa
     if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 LHIP_DEV void wg_add(int* p, int v, int lane) { if (lane == 0) atomicAdd(p, v); }
+// two adjacent words (8-byte aligned) in one LDS access: a pair of helpers' state words read / posted at once
+LHIP_DEV void wg_load2(const int* p, int* a, int* b, int lane) {
+    (void)lane;
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    *a = __builtin_amdgcn_readfirstlane((int)(unsigned)v); *b = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+}
+LHIP_DEV void wg_store2(int* p, int a, int b, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store((unsigned long long*)p, (unsigned long long)(unsigned)a | ((unsigned long long)(unsigned)b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 LHIP_DEV void wg_idle() { __builtin_amdgcn_s_sleep(8); }
+LHIP_DEV int wg_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#define wg_pause(N_) do { if ((N_) > 0) __builtin_amdgcn_s_sleep(N_); } while (0)       /* (s_sleep takes an immediate) */
 #ifndef LHIP_SPIN_SLEEP
 #define LHIP_SPIN_SLEEP 0
 #endif

@@ -205,6 +205,10 @@ def test_wavesim_one_frame_launch_count_helpers():
     import re
     m = re.search(r"count helper: (\d+) evaluations counted on the helper wave, (\d+) of the calc_noise calls made beside them committed", r.stderr)
     assert m and int(m.group(2)) > 100 and int(m.group(1)) - int(m.group(2)) > 100, r.stderr[-500:]
+    # round 6: the evaluation at the NEXT gain made beside the owner's by two more waves (q_cand_helper; built into the simulation, off in the shipped device library --
+    # measured, it does not pay: profiles/r06_cand_next_gain_helpers_ab.txt): both fates of a posted evaluation -- taken, left behind -- must have occurred
+    m = re.search(r"candidate helpers: (\d+) next-gain evaluations posted, (\d+) taken", r.stderr)
+    assert m and int(m.group(2)) > 100 and int(m.group(1)) - int(m.group(2)) > 50, r.stderr[-500:]
 
 
 @pytest.mark.parametrize("ch,nstreams", [(1, 3), (2, 2)])

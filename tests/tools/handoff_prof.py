@@ -22,7 +22,7 @@ for n in ("left", "right"):
 def read():
     buf = (ctypes.c_uint64 * 64)()
     lib.lhip_debug_read(7, buf, 512)
-    return np.array([buf[32 + i] for i in range(8)], dtype=np.float64)
+    return np.array([buf[32 + i] for i in range(16)], dtype=np.float64)
 
 
 for corpus in ("sine", "fixture"):
@@ -47,3 +47,7 @@ for corpus in ("sine", "fixture"):
         ne, nh = max(d[2], 1), max(d[4], 1)
         print(f"== {corpus} ch={ch} 128k, {n - 3} one-frame calls: wall median {1e6 * np.median(t):.0f} us | counted evaluations per frame (wave 0) {d[2] / (n - 3):.1f} | per evaluation, cycles: "
               f"owner calc_noise beside the count {d[0] / ne:.0f}, then waited {d[1] / ne:.0f} | helper busy {d[3] / nh:.0f} | posted -> seen by the helper {d[5] / nh:.0f} | reply written -> seen by the owner {d[6] / ne:.0f}")
+        c = d[8:]
+        if c[0] or c[2]:        # candidate helpers (the evaluation at the next gain beside the owner's): per frame, wave 0
+            print(f"      candidate helpers per frame: posted {c[0] / (n - 3):.1f}, taken {c[1] / (n - 3):.1f}, helpers busy when a post was due {c[2] / (n - 3):.1f} | per taken evaluation, cycles: waited {c[3] / max(c[1], 1):.0f}, "
+                  f"post -> taken {c[7] / max(c[1], 1):.0f} | per request: count role busy {c[4] / max(c[5], 1):.0f}, noise role busy {c[6] / max(c[5], 1):.0f}")
