@@ -550,10 +550,29 @@ __global__ __launch_bounds__(64) void g_load(Tables T, Workspace W, const Stream
 __global__ __launch_bounds__(64) void g_save(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_save(T, W, SD, IO, blockIdx.x, threadIdx.x); }
 // psy channels chn0 .. chn0 + nch - 1 of every granule slot: (0, C) for L / R; joint stereo then runs (2, 2) for mid / side, which
 // read what the L / R pass left in W.fht / W.hpf
-__global__ __launch_bounds__(64) void g_psyA(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int chn0, int nch) {
-    __shared__ PsyALds L;
-    const int it = xcd_item(blockIdx.x, W.ngslots * nch);
-    if (it >= 0) kb_psyA(T, W, SD, IO, it / nch, chn0 + it % nch, threadIdx.x, L);
+// Waves per workgroup of the two psychoacoustic kernels, whose work item is one wave.  As one-wave workgroups they were partly launch-bound: 2e5 workgroups of ~ 7 us each
+// left 1.2 - 1.4 waves resident per SIMD (SQ_WAVE_CYCLES / (SIMDs x kernel cycles), profiles/r05_pmc_config3.json) with the VALU half idle.  Four waves of consecutive
+// items per workgroup -- they share nothing but the launch; neighbouring items stay on one XCD, now on one CU -- measured (round 6, profiles/r06_ab_waves_per_workgroup.txt):
+// g_psyA 2.78 -> 2.59 ms, g_psyB 1.07 -> 1.01 ms per 1e5 two-channel frames (one channel 1.36 -> 1.28, 0.61 -> 0.58); 2 waves half of that, 8 slower than 1.  The
+// filterbank kernels do not move and the bit packer loses 6 % (its waves end at very different times): they stay one wave per workgroup.
+#ifndef LHIP_WPB
+#define LHIP_WPB 4
+#endif
+enum { WPB = LHIP_WPB };
+#define XCD_GRID_W(n) XCD_GRID(((n) + WPB - 1) / WPB)
+static __device__ __forceinline__ int xcd_wave_item(int n, int* lane) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    *lane = (int)(threadIdx.x & 63);
+    const int g = xcd_item(blockIdx.x, (n + WPB - 1) / WPB);
+    const int it = g * WPB + wv;
+    return (g >= 0 && it < n) ? it : -1;
+}
+#define WAVE_LDS(TYPE, NAME) __shared__ TYPE NAME##_[WPB]; TYPE& NAME = NAME##_[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]
+__global__ __launch_bounds__(64 * WPB) void g_psyA(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int chn0, int nch) {
+    WAVE_LDS(PsyALds, L);
+    int lane;
+    const int it = xcd_wave_item(W.ngslots * nch, &lane);
+    if (it >= 0) kb_psyA(T, W, SD, IO, it / nch, chn0 + it % nch, lane, L);
 }
 __global__ __launch_bounds__(256) void g_prep(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nstreams) {
     kb_prep(T, W, SD, IO, nstreams, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
@@ -562,10 +581,11 @@ __global__ __launch_bounds__(64) void g_scan_raw(Tables T, Workspace W, const St
 __global__ __launch_bounds__(64) void g_scan_attack(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_attack(T, W, SD, g); }
 __global__ __launch_bounds__(64) void g_scan_blocktype(Tables T, Workspace W, const StreamDesc* SD, int ngs) { const int g = blockIdx.x * 64 + threadIdx.x; if (g < ngs) kb_scan_blocktype(T, W, SD, g); }
 __global__ __launch_bounds__(ATH_NT) void g_scan_ath(Tables T, Workspace W, const StreamDesc* SD) { __shared__ AthLds L; kb_scan_ath(T, W, SD, blockIdx.x, threadIdx.x, L); }
-template <int NCH> __global__ __launch_bounds__(64) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int par) {
-    __shared__ PsyBLdsT<NCH> L;
-    const int it = xcd_item(blockIdx.x, W.ngslots);
-    if (it >= 0) kb_psyB<NCH>(T, pb, W, SD, it, threadIdx.x, L, par);
+template <int NCH> __global__ __launch_bounds__(64 * WPB) void g_psyB(Tables T, PowBase pb, Workspace W, const StreamDesc* SD, int par) {
+    WAVE_LDS(PsyBLdsT<NCH>, L);
+    int lane;
+    const int it = xcd_wave_item(W.ngslots, &lane);
+    if (it >= 0) kb_psyB<NCH>(T, pb, W, SD, it, lane, L, par);
 }
 __global__ __launch_bounds__(64, 4) void g_poly(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO, int nitems) {
     __shared__ PolyLds L;
@@ -1661,8 +1681,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         if (nb < 1) nb = 1;
         LAUNCHB(KT_PREP, g_prep, (int)nb, 256, st, T, W, dSD, dIO, S);
     }
-    LAUNCH(KT_PSYA, g_psyA, XCD_GRID(ngs * C), st, T, W, dSD, dIO, 0, C);
-    if (T.psy_channels == 4) LAUNCH(KT_PSYA, g_psyA, XCD_GRID(ngs * 2), st, T, W, dSD, dIO, 2, 2);
+    LAUNCHB(KT_PSYA, g_psyA, XCD_GRID_W(ngs * C), 64 * WPB, st, T, W, dSD, dIO, 0, C);
+    if (T.psy_channels == 4) LAUNCHB(KT_PSYA, g_psyA, XCD_GRID_W(ngs * 2), 64 * WPB, st, T, W, dSD, dIO, 2, 2);
     LAUNCH(KT_SCAN, g_scan_raw, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_attack, (ngs + 63) / 64, st, T, W, dSD, ngs);
     LAUNCH(KT_SCAN, g_scan_blocktype, (ngs + 63) / 64, st, T, W, dSD, ngs);
@@ -1700,8 +1720,8 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
         QArgs qa; qa.T = T; qa.pb = ts.pb10; qa.W = W; qa.SD = dSD; qa.chain = 2; qa.nfs = nfs; qa.ctr = S <= ctx->num_cus ? 1 : 0;
         LAUNCHB(KT_QUANT, g_resv_stream, S, 64 * RS_WAVES, st, qa);
     } else {
-    if (T.psy_channels == 4) LAUNCH(KT_PSYB, g_psyB<4>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, -1);
-    else LAUNCH(KT_PSYB, g_psyB<2>, XCD_GRID(ngs), st, T, ts.pb10, W, dSD, -1);
+    if (T.psy_channels == 4) LAUNCHB(KT_PSYB, g_psyB<4>, XCD_GRID_W(ngs), 64 * WPB, st, T, ts.pb10, W, dSD, -1);
+    else LAUNCHB(KT_PSYB, g_psyB<2>, XCD_GRID_W(ngs), 64 * WPB, st, T, ts.pb10, W, dSD, -1);
     // persistent quantization kernels: as many workgroups as can be resident (2 per CU), frames dispensed dynamically
     int qgrid = (nfs + QWAVES - 1) / QWAVES;
     if (qgrid > ctx->num_cus * 2) qgrid = ctx->num_cus * 2;

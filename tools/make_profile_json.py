@@ -22,5 +22,7 @@ q = res["counters"]["g_quant"]
 res["compute"]["g_quant"] = {"valu_insts_per_launch": q["SQ_INSTS_VALU"], "salu_insts_per_launch": q["SQ_INSTS_SALU"], "lds_insts_per_launch": q["SQ_INSTS_LDS"],
                              "issue_ceiling_ginst_per_s": {"waves_per_simd": ub["waves_per_simd"], "valu_ginst_per_s": qm["ginst_per_s"]},
                              "occupancy_waves_per_simd": 4}
+import os
+res["head"] = os.environ.get("LAMEJS_SOURCE_HEAD")       # the commit whose library was measured (bench.py: roofline_compute.source_head)
 json.dump(res, open(out, "w"), indent=1)
 print(out, "total traffic GB", res["traffic_total_bytes_per_step"] / 1e9)
