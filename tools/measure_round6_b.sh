@@ -25,3 +25,4 @@ timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- 
 python $R/tools/pmc_summary.py stats /tmp/kt2 $O/kernel_stats_config2.csv; head -12 $O/kernel_stats_config2.csv | cut -c1-150
 timeout 200 python $R/tests/tools/frame_prof.py 300 > $O/frame_prof.txt 2>&1; grep -E '^==|g_frame launch|hand-over' $O/frame_prof.txt
 ls $O
+timeout 150 python $R/tests/tools/handoff_prof.py > $O/handoff_prof.txt 2>&1; tail -4 $O/handoff_prof.txt | cut -c1-300
