@@ -399,24 +399,17 @@ def main():
     def device_identity():
         """What tells two GPUs apart, per rank: PCI bus id and UUID of the HIP device this rank encodes on (the first multi-GPU run validates itself:
         N ranks must report N distinct devices).  The host simulation (gloo tests) reports a stand-in per rank."""
-        if sim:
-            return {"hip_device_pci_bus_id": f"hostsim:{rank}", "hip_device_uuid": f"hostsim-{rank}", "hip_device_ordinal": dev_ord}
+        # (through the library's own C ABI: it asks the HIP runtime it is linked against -- loading a runtime by name here could bring a second copy into the process)
         ident = {"hip_device_pci_bus_id": None, "hip_device_uuid": None, "hip_device_ordinal": dev_ord}
         try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            buf = ctypes.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, dev_ord) == 0:
-                ident["hip_device_pci_bus_id"] = buf.value.decode()
-            ub = ctypes.create_string_buffer(16)
-            if hasattr(hip, "hipDeviceGetUuid") and hip.hipDeviceGetUuid(ub, dev_ord) == 0:
-                ident["hip_device_uuid"] = ub.raw.hex()
+            a_, b_ = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+            lib.lhip_device_identity.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+            if lib.lhip_device_identity(dev_ord, a_, b_, 64) == 0:
+                ident["hip_device_pci_bus_id"], ident["hip_device_uuid"] = a_.value.decode(), b_.value.decode()
+                if sim:         # the host simulation knows no ranks: one stand-in device per rank
+                    ident["hip_device_pci_bus_id"], ident["hip_device_uuid"] = f"hostsim:{rank}", f"hostsim-{rank}"
         except Exception as ex:
             ident["error"] = str(ex)[:120]
-        if ident["hip_device_uuid"] is None:
-            try:
-                ident["hip_device_uuid"] = str(torch.cuda.get_device_properties(dev_ord).uuid)
-            except Exception:
-                pass
         return ident
 
     import lamejs_amd

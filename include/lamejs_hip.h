@@ -66,6 +66,9 @@ int lhip_device_count(void);
 int lhip_set_devices(uint64_t mask);
 /* the HIP device a stream was placed on (>= 0), or LHIP_ERR_BAD_HANDLE */
 int lhip_stream_device(const lhip_stream* s);
+/* What tells two GPUs apart: PCI bus id ("0000:a7:00.0") and UUID (32 hex digits) of HIP device `device` (-1 = current), as NUL-terminated strings of at most
+ * `cap` bytes each (40 is enough).  bench.py prints them per rank, so that a multi-GPU line shows N ranks on N distinct devices.  Returns 0 or <0. */
+int lhip_device_identity(int device, char* pci_bus_id, char* uuid_hex, size_t cap);
 
 /* Frame-range sharding of ONE stream (extension; SURVEY.md 8e, second mode).  A long stream can be cut at frame boundaries and the
  * pieces encoded side by side (other GPUs, other processes): the state at a cut is SPECULATED -- lhip_seek puts a fresh stream at an

@@ -1868,6 +1868,25 @@ int lhip_stream_device(const lhip_stream* s) {
     return s->ctx->device;
 }
 
+int lhip_device_identity(int device, char* pci_bus_id, char* uuid_hex, size_t cap) {
+    if (!pci_bus_id || !uuid_hex || cap < 2) { set_err("null argument"); return LHIP_ERR_INTERNAL; }
+    pci_bus_id[0] = 0; uuid_hex[0] = 0;
+#ifdef LHIP_HOSTSIM
+    snprintf(pci_bus_id, cap, "hostsim:%d", device < 0 ? 0 : device); snprintf(uuid_hex, cap, "hostsim-%d", device < 0 ? 0 : device);
+    return 0;
+#else
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) { set_err("hipGetDevice failed"); return LHIP_ERR_INTERNAL; }
+    const int pd = rt::phys(device);
+    if (hipDeviceGetPCIBusId(pci_bus_id, (int)cap, pd) != hipSuccess) { set_err("hipDeviceGetPCIBusId failed"); return LHIP_ERR_INTERNAL; }
+    hipUUID u;
+    if (hipDeviceGetUuid(&u, pd) == hipSuccess) {
+        size_t o = 0;
+        for (int i = 0; i < 16 && o + 3 <= cap; i++) o += (size_t)snprintf(uuid_hex + o, cap - o, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+    }
+    return 0;
+#endif
+}
+
 const char* lhip_last_error(void) { return g_err.c_str(); }
 const char* lhip_version(void) {
 #ifdef LHIP_HOSTSIM
@@ -1946,7 +1965,7 @@ void lhip_destroy(lhip_stream* s) {
     rt::set_device(ctx->device);
     std::shared_ptr<TableSet> ts = s->ts;
     delete s;
-    if (--ctx->live_streams == 0) { (void)rt::sync(ctx->stream); ctx->ws.pin_in.release(); ctx->ws.pin_out.release(); }      // (grow-only while streams live; a later stream allocates them again)
+    if (--ctx->live_streams == 0 && !getenv("LHIP_KEEP_PINNED")) { (void)rt::sync(ctx->stream); ctx->ws.pin_in.release(); ctx->ws.pin_out.release(); }      // (grow-only while streams live; a later stream allocates them again)
     // the cache entry goes with the last stream that uses it (one reference is the map's, one is `ts` here)
     if (ts.use_count() == 2)
         for (auto it = ctx->tables.begin(); it != ctx->tables.end(); ++it) if (it->second == ts) { ctx->tables.erase(it); break; }
