@@ -550,11 +550,11 @@ __global__ __launch_bounds__(64) void g_load(Tables T, Workspace W, const Stream
 __global__ __launch_bounds__(64) void g_save(Tables T, Workspace W, const StreamDesc* SD, const StreamIO* IO) { kb_save(T, W, SD, IO, blockIdx.x, threadIdx.x); }
 // psy channels chn0 .. chn0 + nch - 1 of every granule slot: (0, C) for L / R; joint stereo then runs (2, 2) for mid / side, which
 // read what the L / R pass left in W.fht / W.hpf
-// Waves per workgroup of the two psychoacoustic kernels, whose work item is one wave.  As one-wave workgroups they were partly launch-bound: 2e5 workgroups of ~ 7 us each
-// left 1.2 - 1.4 waves resident per SIMD (SQ_WAVE_CYCLES / (SIMDs x kernel cycles), profiles/r05_pmc_config3.json) with the VALU half idle.  Four waves of consecutive
-// items per workgroup -- they share nothing but the launch; neighbouring items stay on one XCD, now on one CU -- measured (round 6, profiles/r06_ab_waves_per_workgroup.txt):
-// g_psyA 2.78 -> 2.59 ms, g_psyB 1.07 -> 1.01 ms per 1e5 two-channel frames (one channel 1.36 -> 1.28, 0.61 -> 0.58); 2 waves half of that, 8 slower than 1.  The
-// filterbank kernels do not move and the bit packer loses 6 % (its waves end at very different times): they stay one wave per workgroup.
+// Waves per workgroup of the two psychoacoustic kernels, whose work item is one wave: four waves of consecutive items per workgroup (they share nothing but the
+// launch; neighbouring items -- which read the same windows, twiddles and spreading rows, and overlapping PCM -- stay on one XCD, now on one CU and its L1).  Measured
+// (round 6, profiles/r06_ab_waves_per_workgroup.txt): g_psyA 2.78 -> 2.59 ms, g_psyB 1.07 -> 1.01 ms per 1e5 two-channel frames (one channel 1.36 -> 1.28, 0.61 -> 0.58);
+// 2 waves half of that, 8 slower than 1.  The filterbank kernels do not move and the bit packer loses 6 % (its waves end at very different times): they stay one wave per
+// workgroup.  (Occupancy is not what changed: 4 - 5 resident waves per SIMD before and after -- SQ_WAVE_CYCLES counts in units of four clocks, calibrated on g_quant's known 4.)
 #ifndef LHIP_WPB
 #define LHIP_WPB 4
 #endif
