@@ -1330,6 +1330,8 @@ LHIP_DEV void q_calc_noise(const Tables& T, const GI& g, const int32_t* scalefac
 // region1_count << 28; w[2] table_select[0..2] + 1 at 6 bits each | sfb_count1 << 18 | the mask of conditionally assigned fields << 24: the
 // owner takes the region counts and table_select[r] only where the reference's count assigns them, Takehiro.js:566-612).
 struct CountShare { int state; uint32_t w[3];
+    int here;                   // the helper is listening (set when it enters q_count_helper, cleared where the record is reset): look-ahead requests are only posted then
+    int32_t xmax[2];            // the granule's xrpow_max (posted once per search): what a look-ahead evaluation of the bin search needs beside the gain (CS_REQ2)
     int16_t kept[576];          // the search's kept copy of the quantized spectrum (q_outer_loop's `kept`): in LDS where a wave is alone with its memory latencies
                                 // (the batched kernel keeps it in HBM -- the granule-channel's slot of W.l3 -- and reads it back once per search)
 #if defined(LHIP_PHASE_PROF) || defined(LHIP_HANDOFF_PROF)
@@ -1346,10 +1348,17 @@ struct CountShare { int state; uint32_t w[3];
 #else
 #define HO_ON 0
 #endif
-enum { CS_IDLE = 0, CS_REQ = 1, CS_DONE = 2, CS_BARRIER = 8, CS_QUIT = 9 };
+enum { CS_IDLE = 0, CS_REQ = 1, CS_DONE = 2, CS_REQ2 = 3, CS_BARRIER = 8, CS_QUIT = 9 };
+#ifndef LHIP_BS_AHEAD
+#define LHIP_BS_AHEAD 0       /* 1: look-ahead evaluations of the bin search on the count helper (q_outer_loop).  Built in round 6, bit-exact on the device (1050 cases) and in the wave
+                                 simulation (which is compiled with it, tests/hostsim/Makefile); a taken evaluation costs the owner ~ 1.5 k cycles instead of 6.4 k and the predictor is right for
+                                 96 / 78 / 53 - 60 % of the evaluations (steady two-channel / one-channel / moving material) -- but the one-frame kernel with this code in it is 5 - 11 % SLOWER
+                                 on every line: the owner's unchanged calc_noise takes 4 - 8 % longer, the helper's unchanged count 3 - 10 % (tests/tools/handoff_prof.py): the kernel's scalar
+                                 registers are full, and whatever is added to the search loop is paid for in spills by all of it.  profiles/r06_bs_lookahead_ab.txt.  Off. */
+#endif
 #if defined(LHIP_WAVESIM)
 // how often each way was taken (printed at exit with LAMEJS_PIPE_STATS=1: the simulation must exercise both)
-struct PipeStats { long piped = 0, committed = 0, posted = 0, taken = 0; ~PipeStats() { if (getenv("LAMEJS_PIPE_STATS")) fprintf(stderr, "count helper: %ld evaluations counted on the helper wave, %ld of the calc_noise calls made beside them committed\ncandidate helpers: %ld next-gain evaluations posted, %ld taken\n", piped, committed, posted, taken); } };
+struct PipeStats { long piped = 0, committed = 0, posted = 0, taken = 0, bs_posted = 0, bs_taken = 0; ~PipeStats() { if (getenv("LAMEJS_PIPE_STATS")) fprintf(stderr, "count helper: %ld evaluations counted on the helper wave, %ld of the calc_noise calls made beside them committed\ncandidate helpers: %ld next-gain evaluations posted, %ld taken\nbin-search look-ahead: %ld evaluations posted to the count helper, %ld taken\n", piped, committed, posted, taken, bs_posted, bs_taken); } };
 inline PipeStats& pipe_stats() { static PipeStats t; return t; }
 #define LHIP_PIPE_COUNT(f) do { if (lane == 0) pipe_stats().f++; } while (0)
 #else
@@ -1528,6 +1537,7 @@ LHIP_DEV int q_cand_take(CandShare& cd, const QuantLds& Lh, GI& g, PrevNoise& pn
 #if LHIP_NL != 1
 // the helper: serves one owner's requests until it is told to leave.  Lo = the owner's LDS record (the quantized values), L = this wave's own (scratch).
 LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo, QuantLds& L, const QuantTabs& Q, int lane) {
+    wg_store(&cs.here, 1, lane);
     for (;;) {
         const int s = wg_wait_not(&cs.state, CS_IDLE, CS_DONE, lane);       // a request, a barrier to keep, or the end
         if (s == CS_QUIT) break;
@@ -1541,21 +1551,37 @@ LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo
         wg_acquire();
         lane = lane_anew(lane);
         GI g;
-        g.block_type = uni(s >> 8); g.max_nonzero_coeff = 0;
+        const int ahead = LHIP_BS_AHEAD ? uni((s & 255) == CS_REQ2) : 0;
+        g.block_type = uni(ahead ? (s >> 16) & 255 : s >> 8); g.max_nonzero_coeff = 0;
         g.region0_count = 0; g.region1_count = 0; g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
         g.count1table_select = 0; g.count1bits = 0; g.count1 = 0; g.big_values = 0;
         int cnt1 = 0, amask = 0;
         int vx[NPL], vy[NPL];
+        int large = 0;
+        if (ahead) {
+            // a look-ahead evaluation of the owner's bin search (q_outer_loop): count_bits at the requested gain -- a pure function of the gain, the block type
+            // and arrays nobody writes during a bin search (xrpow; no scalefactors, no noise cache yet): the owner's own evaluation, made beside it.  The
+            // quantized lines stay in this wave's record: the owner copies them if this evaluation ends its search.
+            g.global_gain = uni((s >> 8) & 255); g.firstcut = 64; g.max_nonzero_coeff = 575; g.preflag = 0; g.scalefac_scale = 0;
+            g.subblock_gain[0] = g.subblock_gain[1] = g.subblock_gain[2] = g.subblock_gain[3] = 0;
+            { union { double d; int32_t i[2]; } u; u.i[0] = uni(cs.xmax[0]); u.i[1] = uni(cs.xmax[1]); g.xrpow_max = u.d; }
+            const double ip = ipow20(Q, g.global_gain);          // Takehiro.js:635-638, as q_count_bits
+            if (g.xrpow_max * ip > (double)IXMAX_VAL * (1.0 - 0x1p-50)) { const double w = (double)IXMAX_VAL / ip; if (g.xrpow_max > w) large = 1; }
+            if (!large) q_quantize(T, g, Lo.sfw, L.ixw, 0, 0, 0, vx, vy, lane, const_cast<QuantLds&>(Lo), Q);
+        } else {
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             const int i = lane + LHIP_NL * j;
             const uint32_t w = i < 288 ? ((const uint32_t*)Lo.ixw)[i] : 0u;
             vx[j] = (int)(w & 0xffffu); vy[j] = (int)(w >> 16);
         }
+        }
 #ifdef LHIP_PHASE_PROF
         const unsigned long long hp_start_ = __builtin_amdgcn_s_memtime();
 #endif
-        const int bits = uni(q_noquant_count_bits(T, g, Lo.ixw, vx, vy, 1, &cnt1, &amask, lane, L, Q));
+        int bits_ = (int)LARGE_BITS;
+        if (!large) bits_ = q_noquant_count_bits(T, g, ahead ? L.ixw : Lo.ixw, vx, vy, !ahead, &cnt1, &amask, lane, L, Q);      // (one instance of the count for both kinds of request)
+        const int bits = uni(bits_);
 #ifdef LHIP_PHASE_PROF
         const unsigned long long hp_end_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1967,12 +1993,31 @@ LHIP_DEV void gi_keep_load(const QuantLds& L, GI& g) {
 // coalesced form the one-thread-per-frame validation reads
 // `cs` (latency kernels only): the record through which a helper wave takes the Huffman count of the outer loop's evaluations while this wave
 // runs calc_noise beside it (q_count_bits_piped); nullptr: everything on this wave
+// bin_search_StepSize's transition (Quantize.js:340-381) as a pure function: the gain evaluated after `gain`, given whether that evaluation's bits exceeded the
+// budget (`over`; `equal`: they met it exactly); -1: the search ends with this evaluation.  st_bsup: the step-up loop behind the search (Quantize.js:375-379).
+LHIP_DEV int bs_next_gain(int st_bsup, int gain, int CurrentStep, int flagGoneOver, int Direction, int over, int equal) {
+    if (!st_bsup) {
+        if (!(CurrentStep == 1 || equal)) {
+            int step;
+            if (over) { if (Direction == 2) flagGoneOver = 1; if (flagGoneOver) CurrentStep /= 2; step = CurrentStep; }
+            else { if (Direction == 1) flagGoneOver = 1; if (flagGoneOver) CurrentStep /= 2; step = -CurrentStep; }
+            int g = gain + step;
+            if (g < 0) g = 0;
+            if (g > 255) g = 255;
+            return g;
+        }
+    }
+    return (over && gain < 255) ? gain + 1 : -1;
+}
 #if defined(LHIP_HOSTSIM)
 // LAMEJS_SEARCH_STATS=1 (host simulations; tools/search_stats.py): the shape of the search per granule-channel -- evaluations of the bin search and of the
 // step-up after it, and, per outer-loop round, the length of the `while (bits > huff_bits) gain++` run in front of the evaluation that fits, with how often
 // PrevNoise.sfb_count1 (what the next evaluation's 0/1 shortcut is decided with) changed inside a run.  Prices evaluating the gains of a run side by side.
 struct SearchStats {
     long bs[40] = {0}, bsup[40] = {0}, run[40] = {0}, run_cnt1_moved[40] = {0}, rounds = 0, evals = 0, searches = 0, run_steps = 0, run_steps_cnt1_moved = 0, run_steps_zo = 0;
+    int prev_nbs = 3;                  // (rule 3: the length of the previous search decides between "the answer is the seed" and "keep walking")
+    long pred[4][2] = {{0}};            // bin search: predictions of the next gain, rule x (miss, hit): 0 "over iff gain < seed", 1 "over iff the last move was down", 2 "over iff gain <= seed"
+    long bsdir[8][3][2] = {{{0}}};      // bin search: evaluation index (0 .. 7) x direction of the last move (0 none, 1 up, 2 down) x this evaluation's verdict (0: bits <= desired, 1: over)
     long mfail[24] = {0}, mfit[24] = {0};      // first evaluation of a round by its margin (huff_bits - the last evaluation's bits), buckets of 8 bits
     bool on = getenv("LAMEJS_SEARCH_STATS") != nullptr;
     ~SearchStats() {
@@ -1981,17 +2026,20 @@ struct SearchStats {
         auto pr = [](const char* nm, const long* h) { fprintf(stderr, "  %s:", nm); for (int i = 0; i < 40; i++) if (h[i]) fprintf(stderr, " %d:%ld", i, h[i]); fprintf(stderr, "\n"); };
         pr("bin-search evaluations per search", bs); pr("step-up evaluations after it", bsup); pr("gain++ run length per outer-loop round (0 = the first evaluation fits)", run);
         pr("runs in which sfb_count1 moved, by run length", run_cnt1_moved);
+        fprintf(stderr, "  next-gain predictions (miss/hit): over iff gain < seed %ld/%ld | over iff last move down %ld/%ld | over iff gain <= seed %ld/%ld | previous search <= 4 evaluations ? gain < seed : same direction again %ld/%ld\n", pred[0][0], pred[0][1], pred[1][0], pred[1][1], pred[2][0], pred[2][1], pred[3][0], pred[3][1]);
+        fprintf(stderr, "  bin-search evaluations, index / last move (- up down): under/over:"); for (int i = 0; i < 8; i++) for (int d = 0; d < 3; d++) if (bsdir[i][d][0] + bsdir[i][d][1]) fprintf(stderr, " %d%c:%ld/%ld", i, "-ud"[d], bsdir[i][d][0], bsdir[i][d][1]); fprintf(stderr, "\n");
         fprintf(stderr, "  first evaluation of a round, by margin huff_bits - previous bits (bucket of 8 bits: fails / fits):"); for (int i = 0; i < 24; i++) if (mfail[i] + mfit[i]) fprintf(stderr, " %d:%ld/%ld", 8 * (i - 4), mfail[i], mfit[i]); fprintf(stderr, "\n");
     }
 };
 inline SearchStats& search_stats() { static SearchStats t; return t; }
-#define LHIP_SS(x) do { if (lane == 0 && search_stats().on) { SearchStats& ss_ = search_stats(); x; } } while (0)
+#define LHIP_SS(...) do { if (lane == 0 && search_stats().on) { SearchStats& ss_ = search_stats(); __VA_ARGS__; } } while (0)
 #else
-#define LHIP_SS(x) do { } while (0)
+#define LHIP_SS(...) do { } while (0)
 #endif
 LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, int bs_step, int* bs_gain_out,
                            int16_t* kept, GrSide* rec, uint32_t* dig, int64_t dn, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr,
-                           CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0) {
+                           CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0, int cs_stride = 0) {
+    // (cs_stride: the count helper's LDS record lies cs_stride bytes behind this wave's -- where a look-ahead evaluation of the bin search leaves its quantized lines)
     // (candidate helpers: `cd` is the workgroup's array of records and `lds0` its first wave's LDS -- constants of the kernel, not values this loop has to keep alive;
     //  what depends on the wave is formed from its index where it is needed: record cd[wave], helper record of wave 5 + 2 wave (two channels) / 3 (one))
 #define CAND_REC() (cd[wg_wave_id()])
@@ -2015,6 +2063,19 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
     int kept_p23 = g.part2_3_length;                        // cod_info.part2_3_length (the one kept field the loop reads)
     const int search_limit = 3;
     int st = ST_BS, nbs = 0;
+    // Bin search with a look-ahead on the count helper (latency kernels; LHIP_BS_AHEAD): while this wave evaluates a gain, the helper -- idle during the bin search --
+    // evaluates the gain the search is most likely to ask for next (bs_next_gain under a predicted verdict: "the answer is the seed" after a short search, "keep walking"
+    // after a long one; right for 96 % of the evaluations of a steady two-channel stream, 78 % one channel, 53 - 60 % on material whose gains move, tools/search_stats.py).
+    // count_bits during the bin search is a pure function of the gain, so a prediction that comes true IS the reference's evaluation: its reply is taken like a count
+    // helper's, its quantized lines are copied if it ends the search.  ahead: the gain under evaluation on the helper + 1 (0: none); ahead_ix: the last evaluation's lines are the helper's.
+    const bool bs_ahead = LHIP_BS_AHEAD && LHIP_NL != 1 && cs != nullptr && cs_stride != 0;
+    // (one word of loop state -- every scalar this loop carries is paid for in every iteration: bits 0-8 the gain under evaluation on the helper + 1 (0: none), 9 the last
+    //  evaluation's lines are the helper's, 10 the previous search of this wave was a long one ("keep walking"), 11 the helper is listening)
+    enum { AF_GAIN = 511, AF_IX = 512, AF_WALK = 1024, AF_HERE = 2048 };
+    int aflags = 0;
+#if LHIP_NL != 1
+    if (bs_ahead) { if (lane == 0) { union { double d; int32_t i[2]; } u; u.d = w.xrpow_max; cs->xmax[0] = u.i[0]; cs->xmax[1] = u.i[1]; } if (uni(L.gkeep[23]) > 4) aflags |= AF_WALK; }      // (gkeep[23]: the length of this wave's previous search)
+#endif
     int ss_nbs = 0, ss_nup = 0, ss_run = 0, ss_moved = 0, ss_first_ = 0, ss_prev_bits_ = 0; (void)ss_nbs; (void)ss_nup; (void)ss_run; (void)ss_moved; (void)ss_first_; (void)ss_prev_bits_;
     LHIP_SS(ss_.searches++);
 #ifndef LHIP_CAND_MARGIN
@@ -2037,6 +2098,42 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         NoiseCommit nc; nc.fresh = 0; nc.step = 0; nc.cls = 0; nc.dist = 0.f; nc.x = 0.0;
 #if LHIP_NL != 1
         int taken = 0;
+        if (bs_ahead) {
+            aflags = uni(aflags);
+            if (st <= ST_BSUP) {
+                if ((aflags & AF_GAIN) == w.global_gain + 1) {     // the evaluation at this gain was made beside the last one
+                    long n_ = 0;
+                    while (wg_load(&cs->state, lane) != CS_DONE) { wg_spin(); LHIP_SPIN_GUARD(n_); }
+                    wg_acquire();
+                    const uint32_t w0 = (uint32_t)uni((int)cs->w[0]), w1 = (uint32_t)uni((int)cs->w[1]), w2 = (uint32_t)uni((int)cs->w[2]);
+                    const int amask = (int)((w2 >> 24) & 15u);
+                    nBits = (int)(w0 & 0x1ffffu);
+                    aflags &= ~AF_GAIN;
+                    if (nBits != (int)LARGE_BITS) {       // (an evaluation that overflows touches neither the fields nor the lines: this wave makes that one itself, q_count_bits)
+                        w.count1 = (int)(w0 >> 17); w.big_values = (int)(w1 & 1023u); w.count1bits = (int)((w1 >> 10) & 0x1fffu); w.count1table_select = (int)((w1 >> 23) & 1u);
+                        if (amask & 8) { w.region0_count = (int)((w1 >> 24) & 15u); w.region1_count = (int)(w1 >> 28); }
+                        if (amask & 1) w.table_select[0] = (int)(w2 & 63u) - 1;
+                        if (amask & 2) w.table_select[1] = (int)((w2 >> 6) & 63u) - 1;
+                        if (amask & 4) w.table_select[2] = (int)((w2 >> 12) & 63u) - 1;
+                        asg = pack_cond_fields(w, amask);
+                        taken = 1; aflags |= AF_IX;
+                        LHIP_PIPE_COUNT(bs_taken);
+                    }
+                }
+                if (!taken) {
+                    // (a request the search did not come to is finished before the next is posted: the helper's reply words are one set)
+                    if (aflags & AF_GAIN) { long n_ = 0; while (wg_load(&cs->state, lane) != CS_DONE) { wg_spin(); LHIP_SPIN_GUARD(n_); } }
+                    aflags &= ~(AF_GAIN | AF_IX);
+                    const int over_ = st == ST_BSUP ? 1 : ((!(aflags & AF_WALK) || Direction == 0) ? (w.global_gain < bs_start) : (Direction == 1));
+                    const int nx = bs_next_gain(st == ST_BSUP, w.global_gain, CurrentStep, flagGoneOver, Direction, over_, 0);
+                    if (!(aflags & AF_HERE) && wg_load(&cs->here, lane)) aflags |= AF_HERE;       // (a helper still busy with its stage's other work would make this wave wait for it)
+                    if ((aflags & AF_HERE) && nx >= 0 && nx != w.global_gain) { wg_store(&cs->state, CS_REQ2 | (nx << 8) | (w.block_type << 16), lane); aflags |= nx + 1; LHIP_PIPE_COUNT(bs_posted); }
+                }
+            } else if (aflags & AF_GAIN) {        // the first evaluation of the outer loop: the helper must be free before it is asked to count
+                long n_ = 0; while (wg_load(&cs->state, lane) != CS_DONE) { wg_spin(); LHIP_SPIN_GUARD(n_); }
+                aflags &= ~AF_GAIN;
+            }
+        }
         if (cd != nullptr && st >= ST_A) {
             cflags = uni(cflags);
             // the evaluation at this gain was made beside the last one (this iteration was reached by `gain++; continue`: nothing but the gain has changed)
@@ -2075,6 +2172,15 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         // memo of the bin search: collected in LDS and written to the side record in one burst when the search ends (a global
         // store per step would sit in front of every later memory wait of the wave -- the VMEM counter retires in order)
         if (st <= ST_BSUP && nbs < BS_TAB_MAX) { if (lane == 0) { L.memo.bs_tab[nbs] = (w.global_gain << 24) | nBits; L.memo.bs_asg[nbs] = asg; } nbs++; }
+        LHIP_SS(if (st <= ST_BSUP) { const int ov_ = nBits > desired_rate, eq_ = nBits == desired_rate;
+                    const int act_ = bs_next_gain(st == ST_BSUP, w.global_gain, CurrentStep, flagGoneOver, Direction, ov_, eq_);
+                    const int p0_ = bs_next_gain(st == ST_BSUP, w.global_gain, CurrentStep, flagGoneOver, Direction, w.global_gain < bs_start, 0);
+                    const int p1_ = bs_next_gain(st == ST_BSUP, w.global_gain, CurrentStep, flagGoneOver, Direction, Direction == 2, 0);
+                    const int p2_ = bs_next_gain(st == ST_BSUP, w.global_gain, CurrentStep, flagGoneOver, Direction, w.global_gain <= bs_start, 0);
+                    const int ov3_ = (ss_.prev_nbs <= 4 || Direction == 0) ? (w.global_gain < bs_start) : (Direction == 1);
+                    const int p3_ = bs_next_gain(st == ST_BSUP, w.global_gain, CurrentStep, flagGoneOver, Direction, st == ST_BSUP ? 1 : ov3_, 0);
+                    if (act_ >= 0) { ss_.pred[0][p0_ == act_]++; ss_.pred[1][p1_ == act_]++; ss_.pred[2][p2_ == act_]++; ss_.pred[3][p3_ == act_]++; } });
+        LHIP_SS(if (st <= ST_BSUP) { const int i_ = (ss_nbs + ss_nup - 1) < 7 ? (ss_nbs + ss_nup - 1) : 7; ss_.bsdir[i_ < 0 ? 0 : i_][st == ST_BSUP ? 1 : Direction][nBits > desired_rate]++; });
         if (st == ST_BS) {
             if (CurrentStep == 1 || nBits == desired_rate) st = ST_BSUP;
             else {
@@ -2099,7 +2205,21 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         if (st == ST_BSUP) {
             if (nBits > desired_rate && w.global_gain < 255) { w.global_gain++; continue; }
             w.part2_3_length = nBits;
-            LHIP_SS(ss_.bs[ss_nbs < 39 ? ss_nbs : 39]++; ss_.bsup[ss_nup < 39 ? ss_nup : 39]++);
+#if LHIP_NL != 1
+            if (bs_ahead) {
+                if ((aflags & AF_IX) && nBits != (int)LARGE_BITS) {        // the search's last evaluation was the helper's: its quantized lines are what the loop goes on with
+                    const QuantLds& Lh1 = *(const QuantLds*)((const unsigned char*)&L + cs_stride);
+                    uint32_t kw[NPL];
+#pragma unroll
+                    for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; kw[j] = ((const uint32_t*)Lh1.ixw)[i < 288 ? i : 287]; }
+#pragma unroll
+                    for (int j = 0; j < NPL; j++) { const int i = lane + LHIP_NL * j; if (i < 288) ((uint32_t*)L.ixw)[i] = kw[j]; }
+                    wave_sync();
+                }
+                if (lane == 0) L.gkeep[23] = nbs;                   // the next search of this wave: "walk" or "the answer is the seed"
+            }
+#endif
+            LHIP_SS(ss_.bs[ss_nbs < 39 ? ss_nbs : 39]++; ss_.bsup[ss_nup < 39 ? ss_nup : 39]++; ss_.prev_nbs = ss_nbs);
             *bs_gain_out = w.global_gain;                    // OldValue[ch] after this granule
             wave_sync();
             LHIP_LANE_ONCE(i, 0, nbs) {
@@ -2114,6 +2234,9 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
             }
             wave_sync();
             if (0 == T.noise_shaping) {
+#if LHIP_NL != 1
+                if (bs_ahead && (uni(aflags) & AF_GAIN)) { long n_ = 0; while (wg_load(&cs->state, lane) != CS_DONE) { wg_spin(); LHIP_SPIN_GUARD(n_); } }
+#endif
                 g = w;
                 for (int i = lane; i < 288; i += LHIP_NL) ((uint32_t*)kept)[i] = ((const uint32_t*)L.ixw)[i];
                 LHIP_LANE_ONCE(i, 0, (SFBMAX) + 1) L.sfb[i] = L.sfw[i];
@@ -2173,6 +2296,9 @@ LHIP_DEV void q_outer_loop(const Tables& T, GI& g, int targ_bits, int bs_start, 
         st = ST_A;
     }
     wave_sync();
+#if LHIP_NL != 1
+    if (bs_ahead && (uni(aflags) & AF_GAIN)) { long n_ = 0; while (wg_load(&cs->state, lane) != CS_DONE) { wg_spin(); LHIP_SPIN_GUARD(n_); } }      // (nobody may post to a busy helper)
+#endif
     { const GI inv = w; g = inv; gi_keep_load(L, g); }       // the invariant fields are the working copy's, the rest comes back from LDS
 #undef CAND_REC
 #undef CAND_LH
@@ -2701,7 +2827,7 @@ struct UnitOut { int bits; Seed next; int block_type; int active; };
 // Inlined at every call site: behind a call (one copy of the code for kb_quant's, the owner's and the helper's site) g_quant was a third slower -- spills around the call.
 LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W, int C, int Cp, int fidx, int gslot, int gr, int ch, int mode_ext,
                         double ath_adjust, int targ_ch, Seed used, int gr0_bt, int lane, QuantLds& L, const QuantTabs& Q, CountShare* cs = nullptr,
-                        CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0) {
+                        CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0, int cs_stride = 0) {
     lane = lane_anew(lane);        // (here and below: lane-derived LDS / HBM addresses are formed where they are used, not parked in scratch across the search)
     UnitOut u; u.next = used;
     GI g;
@@ -2714,7 +2840,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
         active = 1;
         { PH_BEGIN(); q_calc_xmin(T, ath_adjust, masking_lower, ratio, g, lane, L, Q); PH_END(L, PH_XMIN); }
         int16_t* kept = cs ? cs->kept : W.l3 + (((int64_t)fidx * 2 + gr) * C + ch) * 576;
-        { PH_BEGIN(); q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs, cd, lds0, lds_stride); PH_END(L, PH_XRPOW); }   // (profiling builds: the whole search in the otherwise unused slot)
+        { PH_BEGIN(); q_outer_loop(T, g, targ_ch, used.start, used.step, &bs_gain, kept, W.side + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig + ((int64_t)fidx * 2 + gr) * C + ch, W.vdig_n, lane, L, Q, cs, cd, lds0, lds_stride, cs_stride); PH_END(L, PH_XRPOW); }   // (profiling builds: the whole search in the otherwise unused slot)
         uni_gi(g); bs_gain = uni(bs_gain);
         lane = lane_anew(lane);
         wave_sync();                                    // the kept spectrum was written by other lanes of this wave
@@ -2788,7 +2914,7 @@ LHIP_DEV UnitOut q_unit(const Tables& T, const PowBase& pb10, const Workspace& W
 template <int PAIR = 0, int RESV = 0>
 LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W, const StreamDesc* SD, int fslot,
                        int chain, int lane, QuantLds& L, const QuantTabs& Q, int my_ch = -1, int* mbox = nullptr, const ResvState* rvp = nullptr,
-                       int* hint = nullptr, CountShare* cs = nullptr, const int* later_granules_ready = nullptr, CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0) {
+                       int* hint = nullptr, CountShare* cs = nullptr, const int* later_granules_ready = nullptr, CandShare* cd = nullptr, const unsigned char* lds0 = nullptr, int lds_stride = 0, int cs_stride = 0) {
     const int C = T.channels_out;
     const int st = W.fslot_stream[fslot];
     const StreamDesc sd = SD[st];
@@ -2876,7 +3002,7 @@ LHIP_DEV void kb_quant(const Tables& T, const PowBase& pb10, const Workspace& W,
         for (int ch = 0; ch < C; ch++) {
             if (PAIR && ch != my_ch) continue;
             const UnitOut u = q_unit(T, pb10, W, C, Cp, fidx, gslot, gr, ch, mode_ext, ath_adjust, ch == 0 ? targ0 : targ1, ch == 0 ? seed0 : seed1,
-                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q, cs, cd, lds0, lds_stride);
+                                     ch == 0 ? gr0_bt0 : gr0_bt1, lane, L, Q, cs, cd, lds0, lds_stride, cs_stride);
             if (u.active) { if (ch == 0) seed0 = u.next; else seed1 = u.next; }
             if (!PAIR) ResvSize = uni(ResvSize - u.bits);
             else if (lane == 0) mbox[2 * gr + ch] = u.bits;

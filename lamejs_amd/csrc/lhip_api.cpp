@@ -420,7 +420,7 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
                 const bool cands = LHIP_NL != 1 && cand != nullptr && cshare != nullptr && nw == 8;
                 if (has && wv < 2) {
                     kb_quant<1, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, wv, mbox, rv, nullptr, cshare ? cshare + wv : nullptr, nullptr,
-                                      cands ? cand : nullptr, cands ? lds0 : nullptr, (int)FR_LDS_PER_WAVE);
+                                      cands ? cand : nullptr, cands ? lds0 : nullptr, (int)FR_LDS_PER_WAVE, cshare ? 2 * (int)FR_LDS_PER_WAVE : 0);
                     if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane);
 #if LHIP_NL != 1
                     if (cands) q_cand_signal(cand[wv], CS_QUIT, lane);
@@ -444,7 +444,7 @@ LHIP_DEV void kb_frame_stage(int stage, const Tables& T, const PowBase& pb, cons
             } else if (has && wv == 0) {
                 const bool cands = LHIP_NL != 1 && PAIRQ && cand != nullptr && cshare != nullptr && nw == 8;
                 kb_quant<0, RESV>(T, pb, W, SD, fslot, RESV ? 2 : 0, lane, *(QuantLds*)lds, Q, -1, nullptr, rv, nullptr, PAIRQ ? cshare : nullptr, (PAIRQ && psyb_late) ? mbox + 3 : nullptr,
-                                  cands ? cand : nullptr, cands ? lds0 : nullptr, (int)FR_LDS_PER_WAVE);
+                                  cands ? cand : nullptr, cands ? lds0 : nullptr, (int)FR_LDS_PER_WAVE, (PAIRQ && cshare) ? 2 * (int)FR_LDS_PER_WAVE : 0);
                 if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane);
 #if LHIP_NL != 1
                 if (cands) q_cand_signal(cand[0], CS_QUIT, lane);
@@ -504,7 +504,7 @@ LHIP_DEV void kb_resv_stage(int stage, const Tables& T, const PowBase& pb, const
     const int g1 = sd.gslot0 + 1 + GR * k, fslot = sd.fslot0 + 1 + k, fidx = sd.out_slot0 + k;
     switch (stage) {
         case RS_PSYB0:
-            if (cshare && wv < 2 && lane == 0) cshare[wv].state = CS_IDLE;      // (the helpers look at it one barrier from here)
+            if (cshare && wv < 2 && lane == 0) { cshare[wv].state = CS_IDLE; cshare[wv].here = 0; }      // (the helpers look at it one barrier from here)
             if (wv == 2 && k < F) {       // the reservoir as frame k - 1 left it: decided by that frame's quantization (the packer may still be committing it)
                 const int rs = k == 0 ? RV.ResvSize : W.fr[fidx - 1].ResvSize, rm = k == 0 ? RV.ResvMax : W.fr[fidx - 1].ResvMax;
                 kb_psyB<4>(T, pb, W, SD, g1, lane, *(PsyBLds4*)lds, -1, rs, rm);
@@ -522,12 +522,12 @@ LHIP_DEV void kb_resv_stage(int stage, const Tables& T, const PowBase& pb, const
                 kb_psyB<4>(T, pb, W, SD, g1 + 1, lane, *(PsyBLds4*)lds, -1, rs, rm);
             }
             if (PAIRQ && C == 2) {
-                if (wv < 2) { kb_quant<1, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, wv, mbox, &RV, nullptr, cshare ? cshare + wv : nullptr); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
+                if (wv < 2) { kb_quant<1, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, wv, mbox, &RV, nullptr, cshare ? cshare + wv : nullptr, nullptr, nullptr, nullptr, 0, cshare ? 2 * (int)RS_LDS_PER_WAVE : 0); if (cshare) wg_store(&cshare[wv].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
                 else if (cshare) q_count_helper(T, cshare[wv - 2], *(const QuantLds*)(lds - 2 * RS_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
                 else for (int gr = 0; gr < GR; gr++) wg_barrier();
-            } else if (wv == 0) { kb_quant<0, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, -1, nullptr, &RV, nullptr, PAIRQ ? cshare : nullptr); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
+            } else if (wv == 0) { kb_quant<0, 1>(T, pb, W, SD, fslot, 2, lane, *(QuantLds*)lds, Q, -1, nullptr, &RV, nullptr, PAIRQ ? cshare : nullptr, nullptr, nullptr, nullptr, 0, (PAIRQ && cshare) ? 2 * (int)RS_LDS_PER_WAVE : 0); if (PAIRQ && cshare) wg_store(&cshare[0].state, CS_QUIT, lane); }
 #if LHIP_NL != 1
             else if (PAIRQ && cshare && wv == 2) q_count_helper(T, cshare[0], *(const QuantLds*)(lds - 2 * RS_LDS_PER_WAVE), *(QuantLds*)lds, Q, lane);
 #endif
@@ -843,7 +843,7 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
     __shared__ CandShare CD[2];
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (threadIdx.x < 2) CS[threadIdx.x].state = CS_IDLE;
+    if (threadIdx.x < 2) { CS[threadIdx.x].state = CS_IDLE; CS[threadIdx.x].here = 0; }
     if (threadIdx.x < 4) { CD[threadIdx.x >> 1].state[threadIdx.x & 1] = CS_IDLE; CD[threadIdx.x >> 1].present[threadIdx.x & 1] = 0; }
 #if defined(LHIP_HANDOFF_PROF)
     if (threadIdx.x < 8) CD[0].acc[threadIdx.x] = 0;
@@ -1547,7 +1547,7 @@ static bool run_batch(Context* ctx, std::vector<Job>& jobs, bool dev_io, bool wa
             alignas(16) static thread_local unsigned char UL[FR_WAVES][FR_LDS_PER_WAVE]; static thread_local int fmbox[12]; static thread_local CountShare fcs[2]; static thread_local CandShare fcd[2];
             static const bool sim_cand = []() { const char* e = getenv("LAMEJS_SIM_NO_CAND"); return !(e && e[0] == '1'); }();
             for (int s = 0; s < S; s++) {
-                fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE;       // per workgroup, as g_frame does (a stream's owners leave CS_QUIT behind)
+                fcs[0].state = CS_IDLE; fcs[1].state = CS_IDLE; fcs[0].here = fcs[1].here = 0;      // per workgroup, as g_frame does (a stream's owners leave CS_QUIT behind)
                 for (int c = 0; c < 2; c++) for (int r = 0; r < 2; r++) { fcd[c].state[r] = CS_IDLE; fcd[c].present[r] = 0; }
 #ifdef LHIP_WAVESIM
                 wsim::run_block(NW, [&](int wave_, int lane_) {

@@ -209,6 +209,10 @@ def test_wavesim_one_frame_launch_count_helpers():
     # measured, it does not pay: profiles/r06_cand_next_gain_helpers_ab.txt): both fates of a posted evaluation -- taken, left behind -- must have occurred
     m = re.search(r"candidate helpers: (\d+) next-gain evaluations posted, (\d+) taken", r.stderr)
     assert m and int(m.group(2)) > 100 and int(m.group(1)) - int(m.group(2)) > 50, r.stderr[-500:]
+    # ... and the bin search's look-ahead on the count helper (LHIP_BS_AHEAD: compiled into the simulations, off in the shipped device library -- profiles/r06_bs_lookahead_ab.txt):
+    # predictions that came true and were taken, predictions the search did not come to
+    m = re.search(r"bin-search look-ahead: (\d+) evaluations posted to the count helper, (\d+) taken", r.stderr)
+    assert m and int(m.group(2)) > 100 and int(m.group(1)) - int(m.group(2)) > 100, r.stderr[-500:]
 
 
 @pytest.mark.parametrize("ch,nstreams", [(1, 3), (2, 2)])
