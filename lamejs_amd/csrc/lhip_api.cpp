@@ -1965,7 +1965,7 @@ void lhip_destroy(lhip_stream* s) {
     rt::set_device(ctx->device);
     std::shared_ptr<TableSet> ts = s->ts;
     delete s;
-    if (--ctx->live_streams == 0 && !getenv("LHIP_KEEP_PINNED")) { (void)rt::sync(ctx->stream); ctx->ws.pin_in.release(); ctx->ws.pin_out.release(); }      // (grow-only while streams live; a later stream allocates them again)
+    if (--ctx->live_streams == 0) { (void)rt::sync(ctx->stream); ctx->ws.pin_in.release(); ctx->ws.pin_out.release(); }      // (grow-only while streams live; a later stream allocates them again)
     // the cache entry goes with the last stream that uses it (one reference is the map's, one is `ts` here)
     if (ts.use_count() == 2)
         for (auto it = ctx->tables.begin(); it != ctx->tables.end(); ++it) if (it->second == ts) { ctx->tables.erase(it); break; }

@@ -36,6 +36,13 @@ def run_boundary_checks(lib, oracle_encode):
         small = np.empty(100, dtype=np.uint8)
         r_ = L if R is None else R
         st0 = enc.state_get()
+        # ---- what a binding sizes its result with: exact without the bit reservoir (and said to be), a bound with it; a garbage handle is refused
+        assert lib.lhip_output_bytes_is_exact(h) == (0 if resv else 1)
+        assert lib.lhip_output_bytes_is_exact(ctypes.c_void_p(0)) == ERR_HANDLE
+        if not resv:
+            assert lib.lhip_encode_output_bytes(h, len(L)) == len(oracle_encode(ch, sr, kbps, L, R, flush=False))
+        else:
+            assert lib.lhip_encode_output_bytes(h, len(L)) == lib.lhip_max_output_bytes(h, len(L))
         # ---- -1 from lhip_encode: nothing consumed; the same call with room gives the right bytes
         assert lib.lhip_encode(h, L.ctypes.data, r_.ctypes.data, len(L), small.ctypes.data, len(small)) == ERR_SMALL
         assert b"too small" in lib.lhip_last_error()
