@@ -295,7 +295,14 @@ template <int RESV> LHIP_DEV bool frame_stage_empty(int stage, const Tables& T) 
 // (two channels: 5 and 7 after their psyA parts; one channel: 6).  Meeting points are counters in LDS among the waves concerned (wg_meet; mbox[6 ..], zeroed in
 // FS_PSYB0_MDCT).  The second granule's search needs psyB(granule 0) and its own MDCT: a two-channel frame's waves arrive at the workgroup barrier between the
 // granules only after all of this; a one-channel frame's second granule waits for mbox[3], set here once both are done.
-LHIP_DEV void frame_flow_tail(const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int g1, int wv, int lane,
+// LHIP_FRAME_SPLIT (experiment, round 6): everything of the one-frame kernel that is not the search as real functions -- the search loop then has the kernel's register
+// allocation to itself (its scalar registers are full: code added to it is paid for in spills by all of it, DESIGN_ONE_FRAME.md)
+#if defined(LHIP_FRAME_SPLIT) && !defined(LHIP_HOSTSIM)
+#define LHIP_DEV_COLD static __device__ __attribute__((noinline))
+#else
+#define LHIP_DEV_COLD LHIP_DEV
+#endif
+LHIP_DEV_COLD void frame_flow_tail(const Tables& T, const PowBase& pb, const Workspace& W, const StreamDesc* SD, const StreamIO* IO, int g1, int wv, int lane,
                               unsigned char* lds, int* mbox) {
     const int C = T.channels_out, GR = T.mode_gr, np = GR * C, j = wv - 4;
     if (j >= 0 && j < np) {
@@ -834,6 +841,13 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void g_resv_stream(QArgs a_unused
     for (int i = threadIdx.x; i < (int)(sizeof(ResvState) / 4); i += 64 * RS_WAVES) ((uint32_t*)grv)[i] = ((const uint32_t*)&RV)[i];
     if (threadIdx.x == 0) A->W.out_bytes[st] = nout;
 }
+#if defined(LHIP_FRAME_SPLIT) && !defined(LHIP_HOSTSIM)
+// every stage but the search, one copy behind a call (LHIP_FRAME_SPLIT)
+template <int RESV> static __device__ __attribute__((noinline)) void kb_frame_stage_cold(int stage, const QArgs* A, const StreamIO* IO, int st, int wv, int lane, unsigned char* lds, QuantTabs& Q, int* mbox,
+                                                                                        CountShare* cshare, CandShare* cand, unsigned char* lds0) {
+    kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, st, wv, FR_WAVES, lane, lds, Q, mbox, cshare, cand, lds0);
+}
+#endif
 // one workgroup of FR_WAVES waves per stream, one frame per stream (see kb_frame_stage)
 template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QArgs a_unused, const StreamIO* IO) {
     __shared__ QuantTabs Q;
@@ -866,6 +880,10 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
         if (stage == FS_QUANT) ((QuantLds*)U[wv])->prof[lane] = 0;
 #endif
         if (frame_stage_empty<RESV>(stage, A->T)) continue;
+#if defined(LHIP_FRAME_SPLIT) && !defined(LHIP_HOSTSIM)
+        if (stage != FS_QUANT) kb_frame_stage_cold<RESV>(stage, A, IO, blockIdx.x, wv, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr, (g_frame_pipe && g_frame_cand) ? CD : nullptr, U[0]);
+        else
+#endif
         kb_frame_stage<RESV, 1>(stage, A->T, A->pb, A->W, A->SD, IO, blockIdx.x, wv, FR_WAVES, lane, U[wv], Q, mbox, g_frame_pipe ? CS : nullptr, (g_frame_pipe && g_frame_cand) ? CD : nullptr, U[0]);
 #ifdef LHIP_PHASE_PROF
         // when each wave finished its part of the two stages whose work is dealt over waves (cycles after the stage's start)
