@@ -1537,7 +1537,7 @@ LHIP_DEV int q_cand_take(CandShare& cd, const QuantLds& Lh, GI& g, PrevNoise& pn
 #if LHIP_NL != 1
 // the helper: serves one owner's requests until it is told to leave.  Lo = the owner's LDS record (the quantized values), L = this wave's own (scratch).
 LHIP_DEV void q_count_helper(const Tables& T, CountShare& cs, const QuantLds& Lo, QuantLds& L, const QuantTabs& Q, int lane) {
-    wg_store(&cs.here, 1, lane);
+    if (LHIP_BS_AHEAD) wg_store(&cs.here, 1, lane);
     for (;;) {
         const int s = wg_wait_not(&cs.state, CS_IDLE, CS_DONE, lane);       // a request, a barrier to keep, or the end
         if (s == CS_QUIT) break;

@@ -854,13 +854,19 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
     __shared__ __attribute__((aligned(16))) unsigned char U[FR_WAVES][FR_LDS_PER_WAVE];
     __shared__ int mbox[12];
     __shared__ CountShare CS[2];
+#if LHIP_FRAME_CAND
     __shared__ CandShare CD[2];
+#else
+    CandShare* const CD = nullptr;
+#endif
     const QArgs* A = (const QArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (threadIdx.x < 2) { CS[threadIdx.x].state = CS_IDLE; CS[threadIdx.x].here = 0; }
+    if (threadIdx.x < 2) { CS[threadIdx.x].state = CS_IDLE; if (LHIP_BS_AHEAD) CS[threadIdx.x].here = 0; }
+#if LHIP_FRAME_CAND
     if (threadIdx.x < 4) { CD[threadIdx.x >> 1].state[threadIdx.x & 1] = CS_IDLE; CD[threadIdx.x >> 1].present[threadIdx.x & 1] = 0; }
 #if defined(LHIP_HANDOFF_PROF)
     if (threadIdx.x < 8) CD[0].acc[threadIdx.x] = 0;
+#endif
 #endif
 #if defined(LHIP_PHASE_PROF) || defined(LHIP_HANDOFF_PROF)
     if (threadIdx.x < 8) CS[0].acc[threadIdx.x] = 0;
@@ -902,7 +908,9 @@ template <int RESV> __global__ __launch_bounds__(64 * FR_WAVES) void g_frame(QAr
 #elif defined(LHIP_HANDOFF_PROF)
     // (tests/tools/handoff_prof.py: the legs of wave 0's hand-overs, summed over the calls of the process; the product never zeroes or reads these words)
     if (blockIdx.x == 0 && threadIdx.x < 8) atomicAdd(A->W.prof + 32 + threadIdx.x, (unsigned long long)CS[0].acc[threadIdx.x]);
+#if LHIP_FRAME_CAND
     if (blockIdx.x == 0 && threadIdx.x < 8) atomicAdd(A->W.prof + 40 + threadIdx.x, (unsigned long long)CD[0].acc[threadIdx.x]);      // the candidate helpers of channel 0
+#endif
 #endif
 }
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline accounting)
